@@ -1,0 +1,238 @@
+/*
+ * oracle_ops.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of the integer/byte-level ops of the hot path.  Only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ * The product path (i2vsgg_amd/) never links or calls it.
+ *
+ * Every function cites the reference file:line (under /root/reference/lib/model)
+ * whose arithmetic it restates.  Arithmetic type and evaluation order follow the
+ * reference's CPU path exactly (float vs double promotion, no FMA contraction:
+ * build with -ffp-contract=off).
+ *
+ * Pinning status:
+ *   nms_greedy          pinned  : golden vectors made by the reference nms_cpu.py
+ *   roi_align_*         UNPINNED: roi_align/src/roi_align.c needs <TH/TH.h>, absent
+ *                       from this image (torch 2.10 ships no TH), and its Python
+ *                       wrapper is a torch-0.4 legacy Function; restated line by
+ *                       line from roi_align.c:80-136 / roi_align_kernel.cu:94-143.
+ *   roi_pool_*          UNPINNED: model._C source is absent from the reference tree;
+ *                       restated from roi_pooling_kernel.cu:24-93,128-203.
+ */
+#include <math.h>
+#include <float.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ NMS ---- */
+/* nms/nms_cpu.py:6-34.  dets (n,5) fp32 [x1,y1,x2,y2,score], rows already in
+ * descending score order (the caller sorts; proposal_layer.py:127-146) so the
+ * reference's argsort()[::-1] is the identity on tie-free input.  Keeps i, drops
+ * j>i with IoU > thresh (`ovr <= thresh` survives, nms_cpu.py:31); IoU in fp32,
+ * thresh compared as fp32 (numpy weak-scalar promotion).  Returns count kept. */
+int oracle_nms_sorted(const float* dets, int n, float thresh, int32_t* keep)
+{
+    unsigned char* dead = (unsigned char*)calloc((size_t)(n > 0 ? n : 1), 1);
+    float* area = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+    int nk = 0;
+    for (int i = 0; i < n; ++i) {
+        const float* d = dets + 5 * (size_t)i;
+        area[i] = (d[2] - d[0] + 1.0f) * (d[3] - d[1] + 1.0f);
+    }
+    for (int i = 0; i < n; ++i) {
+        if (dead[i]) continue;
+        keep[nk++] = i;
+        const float* a = dets + 5 * (size_t)i;
+        for (int j = i + 1; j < n; ++j) {
+            if (dead[j]) continue;
+            const float* b = dets + 5 * (size_t)j;
+            float xx1 = fmaxf(a[0], b[0]), yy1 = fmaxf(a[1], b[1]);
+            float xx2 = fminf(a[2], b[2]), yy2 = fminf(a[3], b[3]);
+            float w = fmaxf(0.0f, xx2 - xx1 + 1.0f);
+            float h = fmaxf(0.0f, yy2 - yy1 + 1.0f);
+            float inter = w * h;
+            float ovr = inter / (area[i] + area[j] - inter);
+            if (!(ovr <= thresh)) dead[j] = 1;
+        }
+    }
+    free(dead); free(area);
+    return nk;
+}
+
+/* ------------------------------------------------------------ ROIAlign ---- */
+/* Shared sample-point geometry of roi_align.c:99-118 (fwd) and
+ * roi_align_kernel.cu:103-125 (bwd).  Returns 0 when the sample is outside. */
+static int ra_sample(const float* roi, float scale, int H, int W, int AH, int AW,
+                     int ph, int pw, int* hs, int* ws, float* hr, float* wr)
+{
+    float x1 = roi[1] * scale, y1 = roi[2] * scale;
+    float x2 = roi[3] * scale, y2 = roi[4] * scale;
+    float rw = fmaxf(x2 - x1 + 1., 0.);
+    float rh = fmaxf(y2 - y1 + 1., 0.);
+    float bh = rh / (AH - 1.);
+    float bw = rw / (AW - 1.);
+    float h = (float)(ph) * bh + y1;
+    float w = (float)(pw) * bw + x1;
+    int hstart = fminf(floor(h), H - 2);
+    int wstart = fminf(floor(w), W - 2);
+    if (h < 0 || h >= H || w < 0 || w >= W) return 0;
+    *hs = hstart; *ws = wstart;
+    *hr = h - (float)(hstart);
+    *wr = w - (float)(wstart);
+    return 1;
+}
+
+/* roi_align.c:80-136 (ROIAlignForwardCpu).  feat NCHW (B,C,H,W); rois (R,5);
+ * out (R,C,AH,AW).  Double-precision tap products exactly as the `1.` literals
+ * promote them. */
+void oracle_roi_align_fwd(const float* feat, const float* rois, int R, int C, int H,
+                          int W, int AH, int AW, float scale, float* out)
+{
+    for (int n = 0; n < R; ++n)
+        for (int ph = 0; ph < AH; ++ph)
+            for (int pw = 0; pw < AW; ++pw) {
+                int hs, ws; float hr, wr;
+                int ok = ra_sample(rois + 5 * n, scale, H, W, AH, AW, ph, pw, &hs, &ws, &hr, &wr);
+                int b = (int)rois[5 * n];
+                for (int c = 0; c < C; ++c) {
+                    size_t o = (((size_t)n * C + c) * AH + ph) * AW + pw;
+                    if (!ok) { out[o] = 0.f; continue; }
+                    const float* p = feat + (((size_t)b * C + c) * H + hs) * W + ws;
+                    out[o] = p[0] * (1. - hr) * (1. - wr) + p[1] * (1. - hr) * wr
+                           + p[W] * hr * (1. - wr) + p[W + 1] * hr * wr;
+                }
+            }
+}
+
+/* roi_align_kernel.cu:94-143 (ROIAlignBackward; the CPU twin roi_align.c:138-190
+ * has an inverted bounds test and is not followed).  Serial order replaces the
+ * CUDA atomics: index order (n,c,ph,pw).  grad_in NCHW, pre-zeroed by caller. */
+void oracle_roi_align_bwd(const float* gout, const float* rois, int R, int C, int H,
+                          int W, int AH, int AW, float scale, float* gin)
+{
+    for (int n = 0; n < R; ++n) {
+        int b = (int)rois[5 * n];
+        for (int c = 0; c < C; ++c)
+            for (int ph = 0; ph < AH; ++ph)
+                for (int pw = 0; pw < AW; ++pw) {
+                    int hs, ws; float hr, wr;
+                    if (!ra_sample(rois + 5 * n, scale, H, W, AH, AW, ph, pw, &hs, &ws, &hr, &wr))
+                        continue;
+                    float g = gout[(((size_t)n * C + c) * AH + ph) * AW + pw];
+                    float* p = gin + (((size_t)b * C + c) * H + hs) * W + ws;
+                    p[0]     += (float)(g * (1. - hr) * (1 - wr));
+                    p[1]     += (float)(g * (1. - hr) * wr);
+                    p[W]     += (float)(g * hr * (1 - wr));
+                    p[W + 1] += (float)(g * hr * wr);
+                }
+    }
+}
+
+/* roi_align/modules/roi_align.py:26-29: avg_pool2d(kernel 2, stride 1) over the
+ * (PH+1)x(PW+1) aligned grid; fp32 running sum in window raster order then /4
+ * (torch CPU avg_pool2d contiguous kernel). */
+void oracle_avgpool2x2_fwd(const float* x, int N, int AH, int AW, float* y)
+{
+    int PH = AH - 1, PW = AW - 1;
+    for (int n = 0; n < N; ++n)
+        for (int i = 0; i < PH; ++i)
+            for (int j = 0; j < PW; ++j) {
+                const float* p = x + ((size_t)n * AH + i) * AW + j;
+                float s = 0.f;
+                s += p[0]; s += p[1]; s += p[AW]; s += p[AW + 1];
+                y[((size_t)n * PH + i) * PW + j] = s / 4.f;
+            }
+}
+
+void oracle_avgpool2x2_bwd(const float* gy, int N, int AH, int AW, float* gx)
+{
+    int PH = AH - 1, PW = AW - 1;
+    memset(gx, 0, sizeof(float) * (size_t)N * AH * AW);
+    for (int n = 0; n < N; ++n)
+        for (int i = 0; i < PH; ++i)
+            for (int j = 0; j < PW; ++j) {
+                float d = gy[((size_t)n * PH + i) * PW + j] / 4.f;
+                float* p = gx + ((size_t)n * AH + i) * AW + j;
+                p[0] += d; p[1] += d; p[AW] += d; p[AW + 1] += d;
+            }
+}
+
+/* ------------------------------------------------------------- ROIPool ---- */
+/* roi_pooling_kernel.cu:24-93 (ROIPoolForward), same Caffe algorithm that
+ * model._C.roi_pool_forward implements (roi_layers/roi_pool.py:17).  feat NCHW.
+ * argmax = index inside the (b,c) plane (h*W+w) or -1. */
+void oracle_roi_pool_fwd(const float* feat, const float* rois, int R, int C, int H,
+                         int W, int PH, int PW, float scale, float* out, int32_t* argmax)
+{
+    for (int n = 0; n < R; ++n) {
+        const float* r = rois + 5 * n;
+        int b = (int)r[0];
+        int x1 = (int)roundf(r[1] * scale), y1 = (int)roundf(r[2] * scale);
+        int x2 = (int)roundf(r[3] * scale), y2 = (int)roundf(r[4] * scale);
+        int rw = (int)fmaxf((float)(x2 - x1 + 1), 1.f);
+        int rh = (int)fmaxf((float)(y2 - y1 + 1), 1.f);
+        float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+        for (int c = 0; c < C; ++c) {
+            const float* plane = feat + ((size_t)b * C + c) * H * W;
+            for (int ph = 0; ph < PH; ++ph)
+                for (int pw = 0; pw < PW; ++pw) {
+                    int hs = (int)floorf((float)ph * bh), he = (int)ceilf((float)(ph + 1) * bh);
+                    int ws = (int)floorf((float)pw * bw), we = (int)ceilf((float)(pw + 1) * bw);
+                    hs = (int)fminf(fmaxf((float)(hs + y1), 0.f), (float)H);
+                    he = (int)fminf(fmaxf((float)(he + y1), 0.f), (float)H);
+                    ws = (int)fminf(fmaxf((float)(ws + x1), 0.f), (float)W);
+                    we = (int)fminf(fmaxf((float)(we + x1), 0.f), (float)W);
+                    int empty = (he <= hs) || (we <= ws);
+                    float m = empty ? 0.f : -FLT_MAX;
+                    int mi = -1;
+                    for (int h = hs; h < he; ++h)
+                        for (int w = ws; w < we; ++w)
+                            if (plane[h * W + w] > m) { m = plane[h * W + w]; mi = h * W + w; }
+                    size_t o = (((size_t)n * C + c) * PH + ph) * PW + pw;
+                    out[o] = m;
+                    argmax[o] = mi;
+                }
+        }
+    }
+}
+
+/* roi_pooling_kernel.cu:128-203 computes the same sum in gather form; here in
+ * scatter form over (n,c,ph,pw) order.  gin NCHW pre-zeroed by caller. */
+void oracle_roi_pool_bwd(const float* gout, const float* rois, const int32_t* argmax,
+                         int R, int C, int H, int W, int PH, int PW, float* gin)
+{
+    for (int n = 0; n < R; ++n) {
+        int b = (int)rois[5 * n];
+        for (int c = 0; c < C; ++c) {
+            float* plane = gin + ((size_t)b * C + c) * H * W;
+            for (int k = 0; k < PH * PW; ++k) {
+                size_t o = ((size_t)n * C + c) * PH * PW + k;
+                if (argmax[o] >= 0) plane[argmax[o]] += gout[o];
+            }
+        }
+    }
+}
+
+/* --------------------------------------------------------- RPN decode ---- */
+/* bbox_transform.py:77-103 + :125-133 on one image.  anchors (N,4), deltas (N,4),
+ * each op rounded separately in fp32; exp evaluated in double and rounded once
+ * (<=1 ulp from torch's fp32 exp; see DESIGN.md "decode exp"). */
+void oracle_decode_clip(const float* anchors, const float* deltas, int N,
+                        float im_h, float im_w, float* out)
+{
+    float xmax = im_w - 1.0f, ymax = im_h - 1.0f;
+    for (int i = 0; i < N; ++i) {
+        const float* a = anchors + 4 * (size_t)i;
+        const float* d = deltas + 4 * (size_t)i;
+        float w = a[2] - a[0] + 1.0f, h = a[3] - a[1] + 1.0f;
+        float cx = a[0] + 0.5f * w, cy = a[1] + 0.5f * h;
+        float pcx = d[0] * w + cx, pcy = d[1] * h + cy;
+        float pw = (float)exp((double)d[2]) * w, ph = (float)exp((double)d[3]) * h;
+        float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph;
+        float x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * ph;
+        float* o = out + 4 * (size_t)i;
+        o[0] = fminf(fmaxf(x1, 0.f), xmax); o[1] = fminf(fmaxf(y1, 0.f), ymax);
+        o[2] = fminf(fmaxf(x2, 0.f), xmax); o[3] = fminf(fmaxf(y2, 0.f), ymax);
+    }
+}
