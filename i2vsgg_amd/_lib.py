@@ -1,0 +1,80 @@
+"""ctypes binding of libi2vsgg_hip.so -- the ONLY compute backend of this package.
+
+There is no CPU or eager-PyTorch fallback: if the shared library is missing or an entry
+point is absent, import fails loudly.  Signatures mirror include/i2vsgg_hip.h.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libi2vsgg_hip.so")
+
+LAYOUT_NHWC, LAYOUT_NCHW = 0, 1
+EPI_RELU, EPI_RESIDUAL, EPI_SCALE, EPI_BIAS = 1, 2, 4, 8
+
+_p, _i, _f, _z, _l = C.c_void_p, C.c_int32, C.c_float, C.c_size_t, C.c_int64
+
+# name -> (restype, argtypes); kept in the same order as the header
+SIGNATURES = {
+    "i2v_version": (_i, []),
+    "i2v_last_error": (C.c_char_p, []),
+    "i2v_roi_align_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _p, _i, _p]),
+    "i2v_roi_align_bwd": (_i, [_p, _i, _p, _i, _i, _i, _f, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "i2v_roi_pool_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _f, _p, _p, _i, _p]),
+    "i2v_roi_pool_bwd": (_i, [_p, _p, _i, _p, _i, _i, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "i2v_nms_workspace_bytes": (_z, [_i, _i]),
+    "i2v_nms_sorted": (_i, [_p, _i, _i, _f, _i, _p, _p, _p, _z, _p]),
+    "i2v_rpn_proposal_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
+    "i2v_rpn_proposal": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _z, _p]),
+    "i2v_rpn_decode": (_i, [_p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p]),
+    "i2v_sort_desc_workspace_bytes": (_z, [_i, _i]),
+    "i2v_sort_desc": (_i, [_p, _i, _i, _p, _p, _z, _p]),
+    "i2v_bbox_overlaps": (_i, [_p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p]),
+    "i2v_conv_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "i2v_conv_dgrad_workspace_bytes": (_z, [_i, _i, _i, _i]),
+    "i2v_conv_dgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "i2v_conv_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "i2v_conv_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _z, _p]),
+    "i2v_epilogue_bwd": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _p]),
+    "i2v_maxpool3x3s2_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "i2v_sgd_momentum": (_i, [_p, _p, _p, _l, _f, _f, _f, _p]),
+    "i2v_dstyle_pool_fwd": (_i, [_p, _p, _p, _l, _i, _i, _i, _p]),
+    "i2v_dstyle_pool_bwd": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _i, _p]),
+}
+
+
+class I2VError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "i2vsgg_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise ImportError("i2vsgg_amd: %s does not export %s (stale build?)" % (LIB_PATH, name))
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise I2VError("%s failed (%d): %s" % (what, rc, lib.i2v_last_error().decode()))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,319 @@
+// ROIAlign (legacy aligned-grid variant, optionally fused with the 2x2/s1 average of
+// RoIAlignAvg) and Caffe ROIPool for gfx950.  HBM-bound gather kernels: the channel
+// axis is the lane axis (NHWC), so every tap is a coalesced 16 B/lane read and every
+// gradient atomic wave-instruction covers 256 contiguous bytes.
+//
+// Arithmetic follows roi_align/src/roi_align.c:91-134 exactly (float / double
+// promotion, one rounding per op; this file is built with -ffp-contract=off).
+#include "common.h"
+#include <float.h>
+
+namespace {
+
+struct Strides { long long b, c, h, w; };
+
+__host__ __device__ inline Strides feat_strides(int layout, int C, int H, int W) {
+    Strides s;
+    if (layout == I2V_LAYOUT_NHWC) { s.c = 1; s.w = C; s.h = (long long)W * C; s.b = (long long)H * W * C; }
+    else { s.w = 1; s.h = W; s.c = (long long)H * W; s.b = (long long)C * H * W; }
+    return s;
+}
+
+struct Sample { int ok, hs, ws; float hr, wr; };
+
+// roi_align.c:99-118: geometry of sample point (ph,pw) of the AHxAW aligned grid.
+__device__ inline Sample ra_sample(const float* roi, float scale, int H, int W, int AH, int AW, int ph, int pw) {
+    Sample s;
+    float x1 = roi[1] * scale, y1 = roi[2] * scale, x2 = roi[3] * scale, y2 = roi[4] * scale;
+    float rw = fmaxf((float)((double)(x2 - x1) + 1.), 0.f);
+    float rh = fmaxf((float)((double)(y2 - y1) + 1.), 0.f);
+    float bh = (float)((double)rh / (AH - 1.));
+    float bw = (float)((double)rw / (AW - 1.));
+    float h = (float)ph * bh + y1;
+    float w = (float)pw * bw + x1;
+    s.hs = (int)fminf(floorf(h), (float)(H - 2));
+    s.ws = (int)fminf(floorf(w), (float)(W - 2));
+    s.ok = !(h < 0 || h >= H || w < 0 || w >= W);
+    s.hr = h - (float)s.hs;
+    s.wr = w - (float)s.ws;
+    return s;
+}
+
+__device__ inline float bilinear(float p00, float p01, float p10, float p11, float hr, float wr) {
+    return (float)(p00 * (1. - hr) * (1. - wr) + p01 * (1. - hr) * wr + p10 * hr * (1. - wr) + p11 * hr * wr);
+}
+
+// ---------------------------------------------------------------- forward, NHWC
+// grid = R*PH blocks (one output row of one ROI), 256 threads, 4 channels per thread.
+template <int AVG>
+__global__ void __launch_bounds__(256)
+roi_align_fwd_nhwc(const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
+                   int C, int H, int W, int PH, int PW, float scale, Strides os) {
+    const int r = blockIdx.x / PH, ph = blockIdx.x % PH;
+    const float* roi = rois + 5 * (long long)r;
+    const int b = (int)roi[0];
+    const int AH = PH + AVG, AW = PW + AVG;
+    const float* fb = feat + (long long)b * H * W * C;
+    for (int c = threadIdx.x * 4; c < C; c += blockDim.x * 4) {
+        float4 tp = make_float4(0, 0, 0, 0), bp = tp;   // previous column: top / bottom sample row
+        for (int aw = 0; aw < AW; ++aw) {
+            float4 v[2];
+#pragma unroll
+            for (int k = 0; k <= AVG; ++k) {
+                Sample s = ra_sample(roi, scale, H, W, AH, AW, ph + k, aw);
+                if (s.ok) {
+                    const float* p = fb + ((long long)s.hs * W + s.ws) * C + c;
+                    float4 a = *(const float4*)p, bq = *(const float4*)(p + C);
+                    float4 cq = *(const float4*)(p + (long long)W * C), d = *(const float4*)(p + (long long)W * C + C);
+                    v[k].x = bilinear(a.x, bq.x, cq.x, d.x, s.hr, s.wr);
+                    v[k].y = bilinear(a.y, bq.y, cq.y, d.y, s.hr, s.wr);
+                    v[k].z = bilinear(a.z, bq.z, cq.z, d.z, s.hr, s.wr);
+                    v[k].w = bilinear(a.w, bq.w, cq.w, d.w, s.hr, s.wr);
+                } else {
+                    v[k] = make_float4(0, 0, 0, 0);
+                }
+            }
+            float4 o;
+            int pw;
+            if (AVG) {
+                if (aw == 0) { tp = v[0]; bp = v[1]; continue; }
+                pw = aw - 1;
+                // avg_pool2d(2, stride 1): fp32 running sum in window raster order, then /4
+                o.x = (((tp.x + v[0].x) + bp.x) + v[1].x) / 4.f;
+                o.y = (((tp.y + v[0].y) + bp.y) + v[1].y) / 4.f;
+                o.z = (((tp.z + v[0].z) + bp.z) + v[1].z) / 4.f;
+                o.w = (((tp.w + v[0].w) + bp.w) + v[1].w) / 4.f;
+                tp = v[0]; bp = v[1];
+            } else {
+                pw = aw;
+                o = v[0];
+            }
+            float* q = out + r * os.b + ph * os.h + pw * os.w + c * os.c;
+            if (os.c == 1) {
+                *(float4*)q = o;
+            } else {
+                q[0] = o.x; q[os.c] = o.y; q[2 * os.c] = o.z; q[3 * os.c] = o.w;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- forward, any layout
+// one thread per output element; the reference's own decomposition
+// (roi_align_kernel.cu:15-70).  Used for NCHW features (inner-boundary drop-in).
+template <int AVG>
+__global__ void roi_align_fwd_generic(const float* __restrict__ feat, const float* __restrict__ rois,
+                                      float* __restrict__ out, long long total, int C, int H, int W, int PH,
+                                      int PW, float scale, Strides fs, Strides os) {
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        int pw = idx % PW, ph = (idx / PW) % PH, c = (idx / PW / PH) % C, r = idx / PW / PH / C;
+        const float* roi = rois + 5 * (long long)r;
+        const float* fb = feat + (long long)roi[0] * fs.b + c * fs.c;
+        const int AH = PH + AVG, AW = PW + AVG;
+        float v[2][2];
+#pragma unroll
+        for (int i = 0; i <= AVG; ++i)
+#pragma unroll
+            for (int j = 0; j <= AVG; ++j) {
+                Sample s = ra_sample(roi, scale, H, W, AH, AW, ph + i, pw + j);
+                float val = 0.f;
+                if (s.ok) {
+                    const float* p = fb + s.hs * fs.h + s.ws * fs.w;
+                    val = bilinear(p[0], p[fs.w], p[fs.h], p[fs.h + fs.w], s.hr, s.wr);
+                }
+                v[i][j] = val;
+            }
+        float o = AVG ? (((v[0][0] + v[0][AVG]) + v[AVG][0]) + v[AVG][AVG]) / 4.f : v[0][0];
+        out[r * os.b + c * os.c + ph * os.h + pw * os.w] = o;
+    }
+}
+
+// ---------------------------------------------------------------- backward (atomics)
+// grid = R*AH blocks (one SAMPLE row of one ROI), lane = channel.  Follows
+// roi_align_kernel.cu:94-143 (the CPU twin roi_align.c:175 has an inverted test); the
+// avg_pool2d backward (grad/4 summed over the <=4 windows holding the sample, raster
+// order) is folded in front of the scatter.
+template <int AVG>
+__global__ void __launch_bounds__(256)
+roi_align_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gfeat,
+                     int C, int H, int W, int PH, int PW, float scale, Strides fs, Strides os) {
+    const int AH = PH + AVG, AW = PW + AVG;
+    const int r = blockIdx.x / AH, ah = blockIdx.x % AH;
+    const float* roi = rois + 5 * (long long)r;
+    float* gb = gfeat + (long long)roi[0] * fs.b;
+    for (int aw = 0; aw < AW; ++aw) {
+        Sample s = ra_sample(roi, scale, H, W, AH, AW, ah, aw);
+        if (!s.ok) continue;
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            const float* go = gout + r * os.b + c * os.c;
+            float g;
+            if (AVG) {
+                g = 0.f;
+                for (int ph = ah - 1; ph <= ah; ++ph)
+                    for (int pw = aw - 1; pw <= aw; ++pw)
+                        if (ph >= 0 && ph < PH && pw >= 0 && pw < PW) g += go[ph * os.h + pw * os.w] / 4.f;
+            } else {
+                g = go[ah * os.h + aw * os.w];
+            }
+            float* p = gb + c * fs.c + s.hs * fs.h + s.ws * fs.w;
+            atomicAdd(p, (float)(g * (1. - s.hr) * (1 - s.wr)));
+            atomicAdd(p + fs.w, (float)(g * (1. - s.hr) * s.wr));
+            atomicAdd(p + fs.h, (float)(g * s.hr * (1 - s.wr)));
+            atomicAdd(p + fs.h + fs.w, (float)(g * s.hr * s.wr));
+        }
+    }
+}
+
+// ---------------------------------------------------------------- ROIPool
+// roi_pooling_kernel.cu:24-93.  One wave per (roi, 64-channel chunk); lane = channel.
+// The PHxPW results of the chunk are staged in LDS so that an NCHW output (the
+// flatten order vrd.fc6 expects) is written as one contiguous 64*PH*PW run.
+__global__ void __launch_bounds__(64)
+roi_pool_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
+                    int* __restrict__ argmax, int C, int H, int W, int PH, int PW, float scale, Strides fs,
+                    Strides os, int out_nchw) {
+    extern __shared__ float lds[];
+    const int P = PH * PW;
+    float* sval = lds;
+    int* sarg = (int*)(lds + 64 * P);
+    const int chunks = (C + 63) / 64;
+    const int r = blockIdx.x / chunks, c0 = (blockIdx.x % chunks) * 64;
+    const int c = c0 + threadIdx.x;
+    const float* roi = rois + 5 * (long long)r;
+    const int b = (int)roi[0];
+    const int x1 = (int)roundf(roi[1] * scale), y1 = (int)roundf(roi[2] * scale);
+    const int x2 = (int)roundf(roi[3] * scale), y2 = (int)roundf(roi[4] * scale);
+    const int rw = max(x2 - x1 + 1, 1), rh = max(y2 - y1 + 1, 1);
+    const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+    const bool live = c < C;
+    const float* fb = feat + (long long)b * fs.b + (live ? c : 0) * fs.c;
+    for (int ph = 0; ph < PH; ++ph) {
+        int hs = (int)floorf((float)ph * bh), he = (int)ceilf((float)(ph + 1) * bh);
+        hs = min(max(hs + y1, 0), H); he = min(max(he + y1, 0), H);
+        for (int pw = 0; pw < PW; ++pw) {
+            int ws = (int)floorf((float)pw * bw), we = (int)ceilf((float)(pw + 1) * bw);
+            ws = min(max(ws + x1, 0), W); we = min(max(we + x1, 0), W);
+            bool empty = (he <= hs) || (we <= ws);
+            float m = empty ? 0.f : -FLT_MAX;
+            int mi = -1;
+            if (live)
+                for (int h = hs; h < he; ++h)
+                    for (int w = ws; w < we; ++w) {
+                        float v = fb[h * fs.h + w * fs.w];
+                        if (v > m) { m = v; mi = h * W + w; }
+                    }
+            sval[threadIdx.x * P + ph * PW + pw] = m;
+            sarg[threadIdx.x * P + ph * PW + pw] = mi;
+        }
+    }
+    __syncthreads();
+    const int nch = min(64, C - c0);
+    if (out_nchw) {                      // (r, c0..c0+nch, :, :) is contiguous
+        float* o = out + (long long)r * C * P + (long long)c0 * P;
+        int* a = argmax + (long long)r * C * P + (long long)c0 * P;
+        for (int e = threadIdx.x; e < nch * P; e += 64) { o[e] = sval[e]; a[e] = sarg[e]; }
+    } else {                             // NHWC: (r, p, c) with c contiguous
+        for (int p = 0; p < P; ++p)
+            if (live) {
+                long long o = (long long)r * P * C + (long long)p * C + c;
+                out[o] = sval[threadIdx.x * P + p];
+                argmax[o] = sarg[threadIdx.x * P + p];
+            }
+    }
+}
+
+__global__ void roi_pool_bwd_kernel(const float* __restrict__ gout, const int* __restrict__ argmax,
+                                    const float* __restrict__ rois, float* __restrict__ gfeat, long long total,
+                                    int C, int W, int P, Strides fs, int out_nchw) {
+    for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        int c, r;
+        if (out_nchw) { c = (idx / P) % C; r = idx / P / C; }
+        else { c = idx % C; r = idx / C / P; }
+        int a = argmax[idx];
+        if (a < 0) continue;
+        int b = (int)rois[5 * (long long)r];
+        atomicAdd(gfeat + b * fs.b + c * fs.c + (a / W) * fs.h + (a % W) * fs.w, gout[idx]);
+    }
+}
+
+inline Strides out_strides(int layout, int C, int PH, int PW) {
+    Strides s;
+    if (layout == I2V_LAYOUT_NHWC) { s.c = 1; s.w = C; s.h = (long long)PW * C; s.b = (long long)PH * PW * C; }
+    else { s.w = 1; s.h = PW; s.c = (long long)PH * PW; s.b = (long long)C * PH * PW; }
+    return s;
+}
+
+}  // namespace
+
+extern "C" int32_t i2v_roi_align_fwd(const float* feat, int32_t feat_layout, int32_t B, int32_t C, int32_t H,
+                                     int32_t W, const float* rois, int32_t R, int32_t PH, int32_t PW,
+                                     float scale, int32_t avg, float* out, int32_t out_layout, void* stream) {
+    I2V_CHECK_ARG(feat && rois && out, "roi_align_fwd: null pointer");
+    I2V_CHECK_ARG(B > 0 && C > 0 && H >= 2 && W >= 2 && R >= 0 && PH > 0 && PW > 0, "roi_align_fwd: bad shape");
+    I2V_CHECK_ARG(avg == 0 || avg == 1, "roi_align_fwd: avg must be 0/1");
+    I2V_CHECK_ARG(avg || (PH > 1 && PW > 1), "roi_align_fwd: aligned grid needs >=2 points per side");
+    if (R == 0) return I2V_OK;
+    hipStream_t st = (hipStream_t)stream;
+    Strides os = out_strides(out_layout, C, PH, PW);
+    if (feat_layout == I2V_LAYOUT_NHWC && (C % 4) == 0) {
+        if (avg) roi_align_fwd_nhwc<1><<<R * PH, 256, 0, st>>>(feat, rois, out, C, H, W, PH, PW, scale, os);
+        else roi_align_fwd_nhwc<0><<<R * PH, 256, 0, st>>>(feat, rois, out, C, H, W, PH, PW, scale, os);
+    } else {
+        Strides fs = feat_strides(feat_layout, C, H, W);
+        long long total = (long long)R * C * PH * PW;
+        int grid = (int)fmin((double)i2v_cdiv(total, 256), 65535.0 * 4);
+        if (avg) roi_align_fwd_generic<1><<<grid, 256, 0, st>>>(feat, rois, out, total, C, H, W, PH, PW, scale, fs, os);
+        else roi_align_fwd_generic<0><<<grid, 256, 0, st>>>(feat, rois, out, total, C, H, W, PH, PW, scale, fs, os);
+    }
+    I2V_CHECK_LAUNCH("roi_align_fwd");
+    return I2V_OK;
+}
+
+extern "C" int32_t i2v_roi_align_bwd(const float* gout, int32_t out_layout, const float* rois, int32_t R,
+                                     int32_t PH, int32_t PW, float scale, int32_t avg, float* gfeat,
+                                     int32_t feat_layout, int32_t B, int32_t C, int32_t H, int32_t W,
+                                     void* stream) {
+    I2V_CHECK_ARG(gout && rois && gfeat, "roi_align_bwd: null pointer");
+    I2V_CHECK_ARG(B > 0 && C > 0 && H >= 2 && W >= 2 && R >= 0 && PH > 0 && PW > 0, "roi_align_bwd: bad shape");
+    I2V_CHECK_ARG(avg == 0 || avg == 1, "roi_align_bwd: avg must be 0/1");
+    if (R == 0) return I2V_OK;
+    hipStream_t st = (hipStream_t)stream;
+    Strides os = out_strides(out_layout, C, PH, PW), fs = feat_strides(feat_layout, C, H, W);
+    if (avg) roi_align_bwd_kernel<1><<<R * (PH + 1), 256, 0, st>>>(gout, rois, gfeat, C, H, W, PH, PW, scale, fs, os);
+    else roi_align_bwd_kernel<0><<<R * PH, 256, 0, st>>>(gout, rois, gfeat, C, H, W, PH, PW, scale, fs, os);
+    I2V_CHECK_LAUNCH("roi_align_bwd");
+    return I2V_OK;
+}
+
+extern "C" int32_t i2v_roi_pool_fwd(const float* feat, int32_t feat_layout, int32_t B, int32_t C, int32_t H,
+                                    int32_t W, const float* rois, int32_t R, int32_t PH, int32_t PW, float scale,
+                                    float* out, int32_t* argmax, int32_t out_layout, void* stream) {
+    I2V_CHECK_ARG(feat && rois && out && argmax, "roi_pool_fwd: null pointer");
+    I2V_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && R >= 0 && PH > 0 && PW > 0, "roi_pool_fwd: bad shape");
+    I2V_CHECK_ARG(PH * PW <= 256, "roi_pool_fwd: pooled grid too large for the LDS stage");
+    if (R == 0) return I2V_OK;
+    Strides fs = feat_strides(feat_layout, C, H, W), os = out_strides(out_layout, C, PH, PW);
+    size_t lds = (size_t)64 * PH * PW * 8;
+    roi_pool_fwd_kernel<<<R * ((C + 63) / 64), 64, lds, (hipStream_t)stream>>>(
+        feat, rois, out, argmax, C, H, W, PH, PW, scale, fs, os, out_layout == I2V_LAYOUT_NCHW);
+    I2V_CHECK_LAUNCH("roi_pool_fwd");
+    return I2V_OK;
+}
+
+extern "C" int32_t i2v_roi_pool_bwd(const float* gout, const int32_t* argmax, int32_t out_layout,
+                                    const float* rois, int32_t R, int32_t PH, int32_t PW, float* gfeat,
+                                    int32_t feat_layout, int32_t B, int32_t C, int32_t H, int32_t W,
+                                    void* stream) {
+    I2V_CHECK_ARG(gout && argmax && rois && gfeat, "roi_pool_bwd: null pointer");
+    I2V_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && R >= 0 && PH > 0 && PW > 0, "roi_pool_bwd: bad shape");
+    if (R == 0) return I2V_OK;
+    Strides fs = feat_strides(feat_layout, C, H, W);
+    long long total = (long long)R * C * PH * PW;
+    int grid = (int)fmin((double)i2v_cdiv(total, 256), 65535.0 * 4);
+    roi_pool_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(gout, argmax, rois, gfeat, total, C, W, PH * PW, fs,
+                                                                out_layout == I2V_LAYOUT_NCHW);
+    I2V_CHECK_LAUNCH("roi_pool_bwd");
+    return I2V_OK;
+}

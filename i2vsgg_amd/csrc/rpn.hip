@@ -1,0 +1,449 @@
+// RPN proposal path on the device: anchors + box decode + clip, per-image descending
+// sort (bitonic, 64-bit score|index keys), bitmask NMS whose suppression scan runs in a
+// single workgroup on the device (no host round trip), top-N gather and zero padding.
+// Replaces rpn/proposal_layer.py:49-163 and nms/nms_cpu.py:6-34.
+//
+// Box arithmetic is fp32 with one rounding per operation (built with
+// -ffp-contract=off) so IoU threshold decisions match the reference's CPU path bit
+// for bit on the same boxes.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ decode + clip
+// One thread per anchor (b, y, x, a); NHWC inputs make (y,x,a) the memory order of both
+// the scores and the deltas, which is exactly the reference's permute(0,2,3,1) order
+// (proposal_layer.py:99-104).
+__global__ void rpn_decode_kernel(const float* __restrict__ cls, int is_prob, const float* __restrict__ bbox,
+                                  const float* __restrict__ im_info, const float* __restrict__ base, int B, int H,
+                                  int W, int A, int stride, float* __restrict__ prop, float* __restrict__ score) {
+    const long long n_per = (long long)H * W * A;
+    const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (idx >= n_per * B) return;
+    const int b = idx / n_per;
+    const long long i = idx % n_per;
+    const int a = i % A;
+    const long long cell = i / A;
+    const int x = cell % W, y = cell / W;
+    // fg probability: rpn.py:69-71 reshapes to (B,2,A*H,W) and softmaxes the pair
+    const float* cp = cls + ((long long)b * H * W + cell) * 2 * A;
+    float fg;
+    if (is_prob) {
+        fg = cp[A + a];
+    } else {
+        float s0 = cp[a], s1 = cp[A + a], m = fmaxf(s0, s1);
+        float e0 = expf(s0 - m), e1 = expf(s1 - m);
+        fg = e1 / (e0 + e1);
+    }
+    score[idx] = fg;
+    // anchor = base[a] + (x*stride, y*stride, x*stride, y*stride)   proposal_layer.py:81-95
+    const float sx = (float)(x * stride), sy = (float)(y * stride);
+    const float ax1 = base[4 * a] + sx, ay1 = base[4 * a + 1] + sy;
+    const float ax2 = base[4 * a + 2] + sx, ay2 = base[4 * a + 3] + sy;
+    const float* d = bbox + ((long long)b * H * W + cell) * 4 * A + 4 * a;
+    // bbox_transform.py:77-103
+    const float w = ax2 - ax1 + 1.0f, h = ay2 - ay1 + 1.0f;
+    const float cx = ax1 + 0.5f * w, cy = ay1 + 0.5f * h;
+    const float pcx = d[0] * w + cx, pcy = d[1] * h + cy;
+    const float pw = (float)exp((double)d[2]) * w, ph = (float)exp((double)d[3]) * h;
+    const float xmax = im_info[3 * b + 1] - 1.0f, ymax = im_info[3 * b] - 1.0f;
+    // clip_boxes :125-133
+    float4 o;
+    o.x = fminf(fmaxf(pcx - 0.5f * pw, 0.f), xmax);
+    o.y = fminf(fmaxf(pcy - 0.5f * ph, 0.f), ymax);
+    o.z = fminf(fmaxf(pcx + 0.5f * pw, 0.f), xmax);
+    o.w = fminf(fmaxf(pcy + 0.5f * ph, 0.f), ymax);
+    *(float4*)(prop + 4 * idx) = o;
+}
+
+// ------------------------------------------------------------------ bitonic sort
+// key = (order-preserving u32 of the score) << 32 | (0xFFFFFFFF - index): sorting keys
+// DESCENDING gives descending score with ascending index on ties; padding keys are 0.
+constexpr int SORT_TILE = 4096;     // u64 keys per LDS tile (32 KiB)
+constexpr int SORT_THREADS = 512;
+
+__device__ inline unsigned int f2ord(float f) {
+    unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ void sort_make_keys(const float* __restrict__ keys, int n, int P, unsigned long long* __restrict__ out) {
+    const int seg = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    unsigned long long k = 0;
+    if (i < n) k = ((unsigned long long)f2ord(keys[(long long)seg * n + i]) << 32) | (0xFFFFFFFFu - (unsigned)i);
+    out[(long long)seg * P + i] = k;
+}
+
+__device__ inline void cmpswap_desc(unsigned long long& a, unsigned long long& b, bool desc) {
+    if ((a < b) == desc) { unsigned long long t = a; a = b; b = t; }
+}
+
+// all stages with partner distance < SORT_TILE, for k from k_lo up to k_hi (inclusive)
+__global__ void __launch_bounds__(SORT_THREADS)
+sort_local(unsigned long long* __restrict__ data, int P, int k_lo, int k_hi) {
+    __shared__ unsigned long long s[SORT_TILE];
+    const long long base = (long long)blockIdx.y * P + (long long)blockIdx.x * SORT_TILE;
+    for (int i = threadIdx.x; i < SORT_TILE; i += SORT_THREADS) s[i] = data[base + i];
+    __syncthreads();
+    const int gbase = blockIdx.x * SORT_TILE;
+    for (int k = k_lo; k <= k_hi; k <<= 1) {
+        int j0 = (k >> 1) < SORT_TILE ? (k >> 1) : (SORT_TILE >> 1);
+        for (int j = j0; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < SORT_TILE / 2; t += SORT_THREADS) {
+                int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));     // lower index of the pair
+                bool desc = (((gbase + i) & k) == 0);
+                cmpswap_desc(s[i], s[i | j], desc);
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < SORT_TILE; i += SORT_THREADS) data[base + i] = s[i];
+}
+
+__global__ void sort_global_step(unsigned long long* __restrict__ data, int P, int k, int j) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P / 2) return;
+    unsigned long long* d = data + (long long)blockIdx.y * P;
+    int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+    bool desc = ((i & k) == 0);
+    unsigned long long a = d[i], b = d[i | j];
+    if ((a < b) == desc) { d[i] = b; d[i | j] = a; }
+}
+
+__global__ void sort_emit_order(const unsigned long long* __restrict__ keys, int n, int P, int* __restrict__ order) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long k = keys[(long long)blockIdx.y * P + i];
+    order[(long long)blockIdx.y * n + i] = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
+}
+
+inline int next_pow2(int n) { int p = 1; while (p < n) p <<= 1; return p; }
+inline int sort_padded(int n) { int p = next_pow2(n); return p < SORT_TILE ? SORT_TILE : p; }
+
+int launch_sort(const float* keys, int n_seg, int n, unsigned long long* buf, hipStream_t st) {
+    const int P = sort_padded(n);
+    sort_make_keys<<<dim3(i2v_cdiv(P, 256), n_seg), 256, 0, st>>>(keys, n, P, buf);
+    dim3 tiles(P / SORT_TILE, n_seg);
+    sort_local<<<tiles, SORT_THREADS, 0, st>>>(buf, P, 2, SORT_TILE);
+    for (int k = SORT_TILE * 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j >= SORT_TILE; j >>= 1)
+            sort_global_step<<<dim3(i2v_cdiv(P / 2, 256), n_seg), 256, 0, st>>>(buf, P, k, j);
+        sort_local<<<tiles, SORT_THREADS, 0, st>>>(buf, P, k, k);
+    }
+    return P;
+}
+
+// ------------------------------------------------------------------ gather sorted dets
+__global__ void gather_dets(const unsigned long long* __restrict__ keys, int P, const float* __restrict__ prop,
+                            const float* __restrict__ score, int n_all, int n_top, float* __restrict__ dets,
+                            int* __restrict__ src_idx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (i >= n_top) return;
+    unsigned long long k = keys[(long long)b * P + i];
+    int idx = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
+    float4 p = *(const float4*)(prop + ((long long)b * n_all + idx) * 4);
+    float* d = dets + ((long long)b * n_top + i) * 5;
+    d[0] = p.x; d[1] = p.y; d[2] = p.z; d[3] = p.w; d[4] = score[(long long)b * n_all + idx];
+    src_idx[(long long)b * n_top + i] = idx;
+}
+
+// ------------------------------------------------------------------ NMS
+// (1) mask kernel: 64x64 tiles of the upper triangle; one wave per tile, lane = row.
+//     nms_cpu.py:13,20-29: areas with +1, IoU = inter / (area_i + area_j - inter).
+__global__ void __launch_bounds__(64)
+nms_mask_kernel(const float* __restrict__ dets, int n, int nblk, float thresh,
+                unsigned long long* __restrict__ mask) {
+    const int cb = blockIdx.x, rb = blockIdx.y, img = blockIdx.z;
+    if (cb < rb) return;
+    __shared__ float sb[64 * 5];
+    const float* D = dets + (long long)img * n * 5;
+    const int ccount = min(64, n - cb * 64);
+    if ((int)threadIdx.x < ccount) {
+        const float* p = D + ((long long)cb * 64 + threadIdx.x) * 5;
+        sb[threadIdx.x * 5 + 0] = p[0]; sb[threadIdx.x * 5 + 1] = p[1];
+        sb[threadIdx.x * 5 + 2] = p[2]; sb[threadIdx.x * 5 + 3] = p[3];
+        sb[threadIdx.x * 5 + 4] = (p[2] - p[0] + 1.0f) * (p[3] - p[1] + 1.0f);
+    }
+    __syncthreads();
+    const int row = rb * 64 + threadIdx.x;
+    if (row >= n) return;
+    const float* p = D + (long long)row * 5;
+    const float x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3];
+    const float area = (x2 - x1 + 1.0f) * (y2 - y1 + 1.0f);
+    unsigned long long bits = 0;
+    const int jstart = (cb == rb) ? threadIdx.x + 1 : 0;
+    for (int j = jstart; j < ccount; ++j) {
+        float xx1 = fmaxf(x1, sb[j * 5]), yy1 = fmaxf(y1, sb[j * 5 + 1]);
+        float xx2 = fminf(x2, sb[j * 5 + 2]), yy2 = fminf(y2, sb[j * 5 + 3]);
+        float w = fmaxf(0.0f, xx2 - xx1 + 1.0f), h = fmaxf(0.0f, yy2 - yy1 + 1.0f);
+        float inter = w * h;
+        float ovr = inter / (area + sb[j * 5 + 4] - inter);
+        if (!(ovr <= thresh)) bits |= 1ull << j;       // nms_cpu.py:31 keeps ovr <= thresh
+    }
+    mask[((long long)img * n + row) * nblk + cb] = bits;
+}
+
+// (2) scan kernel: one 1024-thread workgroup per image walks the 64-row blocks in score
+//     order.  Wave 0 resolves the block's diagonal word serially (64 readlane steps);
+//     all 16 waves then OR the mask rows of the rows just kept into the LDS "removed"
+//     bitmap.  Stops after max_keep kept rows.  Replaces the host scan of
+//     nms_cuda_kernel.cu:132-144 and the Python while-loop of nms_cpu.py:18-32.
+constexpr int SCAN_THREADS = 1024;
+constexpr int SCAN_MAX_BLK = 1024;      // n <= 65536
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+nms_scan_kernel(const unsigned long long* __restrict__ mask, int n, int nblk, int max_keep,
+                int* __restrict__ keep_out, int* __restrict__ num_out) {
+    __shared__ unsigned long long removed[SCAN_MAX_BLK];
+    __shared__ unsigned long long s_kept;
+    __shared__ int s_count;
+    const int img = blockIdx.x;
+    const unsigned long long* M = mask + (long long)img * n * nblk;
+    int* keep = keep_out + (long long)img * n;
+    for (int i = threadIdx.x; i < nblk; i += SCAN_THREADS) removed[i] = 0;
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int limit = max_keep > 0 ? max_keep : n;
+    for (int rb = 0; rb < nblk; ++rb) {
+        if (wave == 0) {
+            const int row = rb * 64 + lane;
+            unsigned long long diag = (row < n) ? M[(long long)row * nblk + rb] : 0ull;
+            unsigned long long cur = removed[rb];
+            const int valid = min(64, n - rb * 64);
+            if (valid < 64) cur |= ~0ull << valid;
+            unsigned long long kept = 0;
+            int count = s_count;
+            for (int i = 0; i < valid && count < limit; ++i) {
+                unsigned long long d = __shfl(diag, i);
+                if (!((cur >> i) & 1ull)) { kept |= 1ull << i; cur |= d; ++count; }
+            }
+            if ((kept >> lane) & 1ull) {
+                int pos = s_count + __popcll(kept & ((1ull << lane) - 1ull));
+                keep[pos] = row;
+            }
+            if (lane == 0) { s_kept = kept; s_count = count; }
+        }
+        __syncthreads();
+        const unsigned long long kept = s_kept;
+        const int count = s_count;
+        if (count >= limit) break;
+        // OR the kept rows' masks into the columns to the right of the diagonal
+        for (int i = wave; i < 64; i += SCAN_THREADS / 64) {
+            if (!((kept >> i) & 1ull)) continue;
+            const unsigned long long* mr = M + (long long)(rb * 64 + i) * nblk;
+            for (int j = rb + 1 + lane; j < nblk; j += 64) {
+                unsigned long long v = mr[j];
+                if (v) atomicOr(&removed[j], v);
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) num_out[img] = s_count;
+}
+
+// ------------------------------------------------------------------ emit rois
+__global__ void write_rois(const float* __restrict__ dets, const int* __restrict__ src_idx,
+                           const int* __restrict__ keep, const int* __restrict__ num, int n_top, int post,
+                           float* __restrict__ rois, int* __restrict__ kept_idx, int* __restrict__ num_kept) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (k >= post) return;
+    const int cnt = min(num[b], post);
+    float* r = rois + ((long long)b * post + k) * 5;
+    r[0] = (float)b;
+    int src = -1;
+    if (k < cnt) {
+        const int row = keep[(long long)b * n_top + k];
+        const float* d = dets + ((long long)b * n_top + row) * 5;
+        r[1] = d[0]; r[2] = d[1]; r[3] = d[2]; r[4] = d[3];
+        src = src_idx[(long long)b * n_top + row];
+    } else {
+        r[1] = r[2] = r[3] = r[4] = 0.f;
+    }
+    if (kept_idx) kept_idx[(long long)b * post + k] = src;
+    if (num_kept && k == 0) num_kept[b] = cnt;
+}
+
+// ------------------------------------------------------------------ IoU vs ground truth
+// bbox_transform.py:168-257.  One thread per box row, loops the K gt boxes (K <= 64).
+__global__ void bbox_overlaps_kernel(const float* __restrict__ boxes, int box_stride, int box_off, int batched,
+                                     const float* __restrict__ gt, int N, int K, float* __restrict__ ov,
+                                     float* __restrict__ max_ov, int* __restrict__ arg_ov) {
+    extern __shared__ float sg[];          // K x 6: x1,y1,x2,y2,area,zero
+    const int b = blockIdx.y;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const float* g = gt + ((long long)b * K + k) * 5;
+        float gw = g[2] - g[0] + 1.0f, gh = g[3] - g[1] + 1.0f;
+        sg[k * 6] = g[0]; sg[k * 6 + 1] = g[1]; sg[k * 6 + 2] = g[2]; sg[k * 6 + 3] = g[3];
+        sg[k * 6 + 4] = gw * gh;
+        sg[k * 6 + 5] = (gw == 1.0f && gh == 1.0f) ? 1.f : 0.f;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float* p = boxes + ((long long)(batched ? b : 0) * N + i) * box_stride + box_off;
+    const float x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3];
+    const float bw = x2 - x1 + 1.0f, bh = y2 - y1 + 1.0f;
+    const float area = bw * bh;
+    const bool bzero = (bw == 1.0f && bh == 1.0f);
+    float best = -INFINITY;
+    int besti = 0;
+    for (int k = 0; k < K; ++k) {
+        float iw = fminf(x2, sg[k * 6 + 2]) - fmaxf(x1, sg[k * 6]) + 1.0f;
+        float ih = fminf(y2, sg[k * 6 + 3]) - fmaxf(y1, sg[k * 6 + 1]) + 1.0f;
+        iw = iw < 0.f ? 0.f : iw;
+        ih = ih < 0.f ? 0.f : ih;
+        float inter = iw * ih;
+        float o = inter / (area + sg[k * 6 + 4] - inter);
+        if (sg[k * 6 + 5] != 0.f) o = 0.f;
+        if (bzero) o = -1.f;
+        if (ov) ov[((long long)b * N + i) * K + k] = o;
+        if (o > best) { best = o; besti = k; }
+    }
+    if (max_ov) max_ov[(long long)b * N + i] = best;
+    if (arg_ov) arg_ov[(long long)b * N + i] = besti;
+}
+
+struct ProposalWs {
+    float* prop; float* score; unsigned long long* keys; float* dets; int* src; int* keep; int* num;
+    unsigned long long* mask; size_t total;
+};
+
+ProposalWs carve(void* ws, int B, long long n_all, int n_top) {
+    ProposalWs w;
+    char* p = (char*)ws;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { void* q = p ? (void*)(p + off) : nullptr; off += i2v_align(bytes); return q; };
+    const int P = sort_padded((int)n_all);
+    const int nblk = (n_top + 63) / 64;
+    w.prop = (float*)take((size_t)B * n_all * 16);
+    w.score = (float*)take((size_t)B * n_all * 4);
+    w.keys = (unsigned long long*)take((size_t)B * P * 8);
+    w.dets = (float*)take((size_t)B * n_top * 20);
+    w.src = (int*)take((size_t)B * n_top * 4);
+    w.keep = (int*)take((size_t)B * n_top * 4);
+    w.num = (int*)take((size_t)B * 4);
+    w.mask = (unsigned long long*)take((size_t)B * n_top * nblk * 8);
+    w.total = off;
+    return w;
+}
+
+int launch_nms(const float* dets, int n_img, int n, float thresh, int max_keep, int* keep, int* num,
+               unsigned long long* mask, hipStream_t st) {
+    const int nblk = (n + 63) / 64;
+    nms_mask_kernel<<<dim3(nblk, nblk, n_img), 64, 0, st>>>(dets, n, nblk, thresh, mask);
+    nms_scan_kernel<<<n_img, SCAN_THREADS, 0, st>>>(mask, n, nblk, max_keep, keep, num);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" size_t i2v_nms_workspace_bytes(int32_t n_img, int32_t n) {
+    if (n_img <= 0 || n <= 0) return 256;
+    return i2v_align((size_t)n_img * n * ((n + 63) / 64) * 8);
+}
+
+extern "C" int32_t i2v_nms_sorted(const float* dets, int32_t n_img, int32_t n, float thresh, int32_t max_keep,
+                                  int32_t* keep_out, int32_t* num_out, void* ws, size_t ws_bytes, void* stream) {
+    I2V_CHECK_ARG(n_img > 0 && n >= 0, "nms_sorted: bad shape");
+    I2V_CHECK_ARG(num_out, "nms_sorted: null num_out");
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) {            // nms_wrapper.py:15-16: empty input -> empty keep
+        hipMemsetAsync(num_out, 0, sizeof(int) * n_img, st);
+        return I2V_OK;
+    }
+    I2V_CHECK_ARG(dets && keep_out, "nms_sorted: null pointer");
+    I2V_CHECK_ARG(n <= 64 * SCAN_MAX_BLK, "nms_sorted: n > 65536 unsupported");
+    if (ws_bytes < i2v_nms_workspace_bytes(n_img, n) || !ws) {
+        i2v_set_error("nms_sorted: workspace %zu < %zu", ws_bytes, i2v_nms_workspace_bytes(n_img, n));
+        return I2V_ERR_WORKSPACE;
+    }
+    launch_nms(dets, n_img, n, thresh, max_keep, keep_out, num_out, (unsigned long long*)ws, st);
+    I2V_CHECK_LAUNCH("nms_sorted");
+    return I2V_OK;
+}
+
+extern "C" int32_t i2v_rpn_decode(const float* cls, int32_t is_prob, const float* bbox, const float* im_info,
+                                  const float* base, int32_t B, int32_t H, int32_t W, int32_t A, int32_t stride,
+                                  float* prop, float* score, void* stream) {
+    I2V_CHECK_ARG(cls && bbox && im_info && base && prop && score, "rpn_decode: null pointer");
+    I2V_CHECK_ARG(B > 0 && H > 0 && W > 0 && A > 0 && A <= 64, "rpn_decode: bad shape");
+    long long total = (long long)B * H * W * A;
+    rpn_decode_kernel<<<i2v_cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(cls, is_prob, bbox, im_info, base, B, H,
+                                                                              W, A, stride, prop, score);
+    I2V_CHECK_LAUNCH("rpn_decode");
+    return I2V_OK;
+}
+
+extern "C" size_t i2v_sort_desc_workspace_bytes(int32_t n_seg, int32_t n) {
+    if (n_seg <= 0 || n <= 0) return 256;
+    return i2v_align((size_t)n_seg * sort_padded(n) * 8);
+}
+
+extern "C" int32_t i2v_sort_desc(const float* keys, int32_t n_seg, int32_t n, int32_t* order, void* ws,
+                                 size_t ws_bytes, void* stream) {
+    I2V_CHECK_ARG(n_seg > 0 && n >= 0, "sort_desc: bad shape");
+    if (n == 0) return I2V_OK;
+    I2V_CHECK_ARG(keys && order, "sort_desc: null pointer");
+    I2V_CHECK_ARG(n <= (1 << 24), "sort_desc: n too large");
+    if (!ws || ws_bytes < i2v_sort_desc_workspace_bytes(n_seg, n)) {
+        i2v_set_error("sort_desc: workspace too small");
+        return I2V_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int P = launch_sort(keys, n_seg, n, (unsigned long long*)ws, st);
+    sort_emit_order<<<dim3(i2v_cdiv(n, 256), n_seg), 256, 0, st>>>((unsigned long long*)ws, n, P, order);
+    I2V_CHECK_LAUNCH("sort_desc");
+    return I2V_OK;
+}
+
+extern "C" size_t i2v_rpn_proposal_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t A, int32_t pre) {
+    if (B <= 0 || H <= 0 || W <= 0 || A <= 0) return 256;
+    long long n_all = (long long)H * W * A;
+    // proposal_layer.py:140: truncate only when 0 < pre < B*N (numel of the whole batch)
+    int n_top = (pre > 0 && pre < (long long)B * n_all && pre < n_all) ? pre : (int)n_all;
+    return carve(nullptr, B, n_all, n_top).total;
+}
+
+extern "C" int32_t i2v_rpn_proposal(const float* cls, int32_t is_prob, const float* bbox, const float* im_info,
+                                    const float* base, int32_t B, int32_t H, int32_t W, int32_t A, int32_t stride,
+                                    int32_t pre, int32_t post, float thresh, float* rois, int32_t* kept_idx,
+                                    int32_t* num_kept, void* ws, size_t ws_bytes, void* stream) {
+    I2V_CHECK_ARG(cls && bbox && im_info && base && rois, "rpn_proposal: null pointer");
+    I2V_CHECK_ARG(B > 0 && H > 0 && W > 0 && A > 0 && A <= 64 && post > 0, "rpn_proposal: bad shape");
+    const long long n_all = (long long)H * W * A;
+    I2V_CHECK_ARG(n_all <= 64 * SCAN_MAX_BLK, "rpn_proposal: more than 65536 anchors per image");
+    const int n_top = (pre > 0 && pre < (long long)B * n_all && pre < n_all) ? pre : (int)n_all;
+    if (!ws || ws_bytes < carve(nullptr, B, n_all, n_top).total) {
+        i2v_set_error("rpn_proposal: workspace too small");
+        return I2V_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    ProposalWs w = carve(ws, B, n_all, n_top);
+    rpn_decode_kernel<<<i2v_cdiv(B * n_all, 256), 256, 0, st>>>(cls, is_prob, bbox, im_info, base, B, H, W, A,
+                                                               stride, w.prop, w.score);
+    const int P = launch_sort(w.score, B, (int)n_all, w.keys, st);
+    gather_dets<<<dim3(i2v_cdiv(n_top, 256), B), 256, 0, st>>>(w.keys, P, w.prop, w.score, (int)n_all, n_top,
+                                                               w.dets, w.src);
+    launch_nms(w.dets, B, n_top, thresh, post, w.keep, w.num, w.mask, st);
+    write_rois<<<dim3(i2v_cdiv(post, 256), B), 256, 0, st>>>(w.dets, w.src, w.keep, w.num, n_top, post, rois,
+                                                             kept_idx, num_kept);
+    I2V_CHECK_LAUNCH("rpn_proposal");
+    return I2V_OK;
+}
+
+extern "C" int32_t i2v_bbox_overlaps(const float* boxes, int32_t box_stride, int32_t box_off, int32_t batched,
+                                     const float* gt, int32_t B, int32_t N, int32_t K, float* ov, float* max_ov,
+                                     int32_t* arg_ov, void* stream) {
+    I2V_CHECK_ARG(boxes && gt, "bbox_overlaps: null pointer");
+    I2V_CHECK_ARG(B > 0 && N >= 0 && K > 0 && K <= 1024 && box_stride >= box_off + 4, "bbox_overlaps: bad shape");
+    if (N == 0) return I2V_OK;
+    bbox_overlaps_kernel<<<dim3(i2v_cdiv(N, 256), B), 256, (size_t)K * 24, (hipStream_t)stream>>>(
+        boxes, box_stride, box_off, batched, gt, N, K, ov, max_ov, arg_ov);
+    I2V_CHECK_LAUNCH("bbox_overlaps");
+    return I2V_OK;
+}

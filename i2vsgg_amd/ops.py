@@ -1,0 +1,399 @@
+"""torch-facing wrappers over the C-ABI of libi2vsgg_hip.so.
+
+Conventions
+  * activations are torch tensors with the reference's LOGICAL shape (B,C,H,W) held in
+    ``channels_last`` memory format, i.e. physically NHWC -- the layout the kernels want;
+    ``as_nhwc`` converts (one copy) when a caller hands over a plain NCHW tensor;
+  * conv weights keep the reference's logical shape (Cout,Cin,KH,KW), also channels_last,
+    which is exactly the (Cout,KH,KW,Cin) K-major filter layout of the implicit GEMM;
+  * every function launches on torch's current stream and never synchronises;
+  * no CPU fallback: non-CUDA tensors raise.
+"""
+import torch
+
+from . import _lib
+from ._lib import EPI_BIAS, EPI_RELU, EPI_RESIDUAL, EPI_SCALE, LAYOUT_NCHW, LAYOUT_NHWC, check, lib, ptr, stream
+
+_CL = torch.channels_last
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.I2VError("i2vsgg_amd ops run on the GPU only (got a %s tensor); there is no CPU fallback"
+                                % t.device.type)
+
+
+def as_nhwc(x):
+    """(B,C,H,W) tensor -> same logical tensor, physically NHWC (no copy if already so)."""
+    if x.dim() != 4:
+        raise ValueError("expected a 4-D (B,C,H,W) tensor")
+    if x.dtype != torch.float32:
+        x = x.float()
+    return x.contiguous(memory_format=_CL)
+
+
+def _is_nhwc(x):
+    return x.dim() == 4 and x.is_contiguous(memory_format=_CL)
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag="default"):
+    """Grow-only scratch buffer per (device, tag)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+# ----------------------------------------------------------------------------- ROI ops
+def _rois_f32(rois):
+    if rois.dim() != 2 or rois.size(1) != 5:
+        # roi_align.c:28-31 returns 0 for a malformed roi tensor; here it is an error
+        raise ValueError("rois must be (K,5) [batch_idx,x1,y1,x2,y2]")
+    return rois.contiguous().float()
+
+
+class _RoIAlignFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, rois, ph, pw, scale, avg, out_nchw):
+        _need_cuda(feat, rois)
+        rois = _rois_f32(rois)
+        nhwc = _is_nhwc(feat)
+        if not nhwc:
+            feat = feat.contiguous()
+        B, C, H, W = feat.shape
+        R = rois.size(0)
+        out = torch.empty((R, C, ph, pw), device=feat.device, dtype=torch.float32,
+                          memory_format=torch.contiguous_format if out_nchw else _CL)
+        check(lib.i2v_roi_align_fwd(ptr(feat), LAYOUT_NHWC if nhwc else LAYOUT_NCHW, B, C, H, W, ptr(rois), R, ph, pw,
+                                    scale, int(avg), ptr(out), LAYOUT_NCHW if out_nchw else LAYOUT_NHWC, stream()),
+              "roi_align_fwd")
+        ctx.save_for_backward(rois)
+        ctx.meta = (feat.shape, nhwc, ph, pw, scale, int(avg), out_nchw)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (rois,) = ctx.saved_tensors
+        shape, nhwc, ph, pw, scale, avg, out_nchw = ctx.meta
+        B, C, H, W = shape
+        gout = gout.contiguous() if out_nchw else gout.contiguous(memory_format=_CL)
+        gfeat = torch.zeros(shape, device=gout.device, dtype=torch.float32,
+                            memory_format=_CL if nhwc else torch.contiguous_format)
+        check(lib.i2v_roi_align_bwd(ptr(gout), LAYOUT_NCHW if out_nchw else LAYOUT_NHWC, ptr(rois), rois.size(0), ph, pw,
+                                    scale, avg, ptr(gfeat), LAYOUT_NHWC if nhwc else LAYOUT_NCHW, B, C, H, W, stream()),
+              "roi_align_bwd")
+        return gfeat, None, None, None, None, None, None
+
+
+def roi_align(feat, rois, pooled_h, pooled_w, spatial_scale, avg=True, out_nchw=False):
+    """Legacy ROIAlign (+ fused 2x2/s1 mean when ``avg``); differentiable w.r.t. ``feat`` only."""
+    return _RoIAlignFn.apply(feat, rois, int(pooled_h), int(pooled_w), float(spatial_scale), bool(avg), bool(out_nchw))
+
+
+class _RoIPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, rois, ph, pw, scale, out_nchw):
+        _need_cuda(feat, rois)
+        rois = _rois_f32(rois)
+        nhwc = _is_nhwc(feat)
+        if not nhwc:
+            feat = feat.contiguous()
+        B, C, H, W = feat.shape
+        R = rois.size(0)
+        fmt = torch.contiguous_format if out_nchw else _CL
+        out = torch.empty((R, C, ph, pw), device=feat.device, dtype=torch.float32, memory_format=fmt)
+        arg = torch.empty((R, C, ph, pw), device=feat.device, dtype=torch.int32, memory_format=fmt)
+        check(lib.i2v_roi_pool_fwd(ptr(feat), LAYOUT_NHWC if nhwc else LAYOUT_NCHW, B, C, H, W, ptr(rois), R, ph, pw,
+                                   scale, ptr(out), ptr(arg), LAYOUT_NCHW if out_nchw else LAYOUT_NHWC, stream()),
+              "roi_pool_fwd")
+        ctx.save_for_backward(rois, arg)
+        ctx.meta = (feat.shape, nhwc, ph, pw, out_nchw)
+        ctx.mark_non_differentiable(arg)
+        return out, arg
+
+    @staticmethod
+    def backward(ctx, gout, _garg):
+        rois, arg = ctx.saved_tensors
+        shape, nhwc, ph, pw, out_nchw = ctx.meta
+        B, C, H, W = shape
+        gout = gout.contiguous() if out_nchw else gout.contiguous(memory_format=_CL)
+        gfeat = torch.zeros(shape, device=gout.device, dtype=torch.float32,
+                            memory_format=_CL if nhwc else torch.contiguous_format)
+        check(lib.i2v_roi_pool_bwd(ptr(gout), ptr(arg), LAYOUT_NCHW if out_nchw else LAYOUT_NHWC, ptr(rois),
+                                   rois.size(0), ph, pw, ptr(gfeat), LAYOUT_NHWC if nhwc else LAYOUT_NCHW, B, C, H, W,
+                                   stream()), "roi_pool_bwd")
+        return gfeat, None, None, None, None, None
+
+
+def roi_pool(feat, rois, pooled_h, pooled_w, spatial_scale, out_nchw=True, return_argmax=False):
+    out, arg = _RoIPoolFn.apply(feat, rois, int(pooled_h), int(pooled_w), float(spatial_scale), bool(out_nchw))
+    return (out, arg) if return_argmax else out
+
+
+# ----------------------------------------------------------------------------- NMS / RPN
+def nms_sorted(dets, thresh, max_keep=0):
+    """dets (n,5) or (n_img,n,5), rows in descending score order -> (keep int32 (n_img,n), num int32 (n_img,)),
+    both on the device (no sync)."""
+    _need_cuda(dets)
+    d = dets.contiguous().float()
+    if d.dim() == 2:
+        d = d.unsqueeze(0)
+    n_img, n = d.shape[0], d.shape[1]
+    keep = torch.empty((n_img, max(n, 1)), device=d.device, dtype=torch.int32)
+    num = torch.empty((n_img,), device=d.device, dtype=torch.int32)
+    nb = lib.i2v_nms_workspace_bytes(n_img, n)
+    ws = workspace(nb, d.device, "nms")
+    check(lib.i2v_nms_sorted(ptr(d), n_img, n, float(thresh), int(max_keep), ptr(keep), ptr(num), ptr(ws), ws.numel(),
+                             stream()), "nms_sorted")
+    return keep, num
+
+
+def sort_desc(keys):
+    """(n_seg,n) fp32 -> int32 order (descending, ties by ascending index)."""
+    _need_cuda(keys)
+    k = keys.contiguous().float()
+    if k.dim() == 1:
+        k = k.unsqueeze(0)
+    n_seg, n = k.shape
+    order = torch.empty((n_seg, n), device=k.device, dtype=torch.int32)
+    ws = workspace(lib.i2v_sort_desc_workspace_bytes(n_seg, n), k.device, "sort")
+    check(lib.i2v_sort_desc(ptr(k), n_seg, n, ptr(order), ptr(ws), ws.numel(), stream()), "sort_desc")
+    return order
+
+
+def rpn_decode(cls_nhwc, bbox_nhwc, im_info, base_anchors, feat_stride, is_prob=False):
+    """cls (B,2A,H,W) / bbox (B,4A,H,W) channels_last -> proposals (B,HWA,4), fg scores (B,HWA)."""
+    _need_cuda(cls_nhwc, bbox_nhwc, im_info, base_anchors)
+    cls_nhwc, bbox_nhwc = as_nhwc(cls_nhwc), as_nhwc(bbox_nhwc)
+    B, C2, H, W = cls_nhwc.shape
+    A = C2 // 2
+    prop = torch.empty((B, H * W * A, 4), device=cls_nhwc.device, dtype=torch.float32)
+    score = torch.empty((B, H * W * A), device=cls_nhwc.device, dtype=torch.float32)
+    check(lib.i2v_rpn_decode(ptr(cls_nhwc), int(is_prob), ptr(bbox_nhwc), ptr(im_info.contiguous().float()),
+                             ptr(base_anchors.contiguous().float()), B, H, W, A, int(feat_stride), ptr(prop), ptr(score),
+                             stream()), "rpn_decode")
+    return prop, score
+
+
+def rpn_proposal(cls_nhwc, bbox_nhwc, im_info, base_anchors, feat_stride, pre_nms_top_n, post_nms_top_n, nms_thresh,
+                 is_prob=False, want_index=False):
+    """Whole proposal layer on the device -> rois (B,post,5) [, kept anchor idx (B,post), num (B,)]."""
+    _need_cuda(cls_nhwc, bbox_nhwc, im_info, base_anchors)
+    cls_nhwc, bbox_nhwc = as_nhwc(cls_nhwc), as_nhwc(bbox_nhwc)
+    B, C2, H, W = cls_nhwc.shape
+    A = C2 // 2
+    dev = cls_nhwc.device
+    rois = torch.empty((B, post_nms_top_n, 5), device=dev, dtype=torch.float32)
+    kept = torch.empty((B, post_nms_top_n), device=dev, dtype=torch.int32) if want_index else None
+    num = torch.empty((B,), device=dev, dtype=torch.int32) if want_index else None
+    nb = lib.i2v_rpn_proposal_workspace_bytes(B, H, W, A, int(pre_nms_top_n))
+    ws = workspace(nb, dev, "rpn")
+    info = im_info.contiguous().float()
+    base = base_anchors.contiguous().float()
+    check(lib.i2v_rpn_proposal(ptr(cls_nhwc), int(is_prob), ptr(bbox_nhwc), ptr(info), ptr(base), B, H, W, A,
+                               int(feat_stride), int(pre_nms_top_n), int(post_nms_top_n), float(nms_thresh), ptr(rois),
+                               ptr(kept), ptr(num), ptr(ws), ws.numel(), stream()), "rpn_proposal")
+    return (rois, kept, num) if want_index else rois
+
+
+def bbox_overlaps(boxes, gt, want_matrix=False):
+    """boxes (N,4) shared by all images or (B,N,4|5) [5: col0=batch idx]; gt (B,K,5).
+    Returns (overlaps (B,N,K) or None, max (B,N), argmax (B,N) int32)."""
+    _need_cuda(boxes, gt)
+    gt = gt.contiguous().float()
+    boxes = boxes.contiguous().float()
+    B, K = gt.shape[0], gt.shape[1]
+    batched = boxes.dim() == 3
+    N = boxes.shape[-2]
+    stride = boxes.shape[-1]
+    off = 1 if stride == 5 else 0
+    ov = torch.empty((B, N, K), device=gt.device, dtype=torch.float32) if want_matrix else None
+    mx = torch.empty((B, N), device=gt.device, dtype=torch.float32)
+    am = torch.empty((B, N), device=gt.device, dtype=torch.int32)
+    check(lib.i2v_bbox_overlaps(ptr(boxes), stride, off, int(batched), ptr(gt), B, N, K, ptr(ov), ptr(mx), ptr(am),
+                                stream()), "bbox_overlaps")
+    return ov, mx, am
+
+
+# ----------------------------------------------------------------------------- conv / linear
+def _conv_fwd_raw(x, w, scale, shift, res, stride, pad, flags):
+    B, Cin, H, W = x.shape
+    Cout, _, KH, KW = w.shape
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W + 2 * pad - KW) // stride + 1
+    y = torch.empty((B, Cout, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=_CL)
+    check(lib.i2v_conv_fwd(ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(res), ptr(y), B, H, W, Cin, Cout, KH, KW, stride,
+                           pad, flags, stream()), "conv_fwd")
+    return y
+
+
+def _conv_dgrad_raw(g, w, in_shape, stride, pad):
+    B, Cin, H, W = in_shape
+    Cout, _, KH, KW = w.shape
+    dev = g.device
+    if stride > 1 and not (KH == 1 and KW == 1 and pad == 0):
+        # zero-insertion: a strided conv's dgrad is the stride-1 dgrad of the dilated gradient map
+        Hd, Wd = H + 2 * pad - KH + 1, W + 2 * pad - KW + 1
+        gd = torch.zeros((B, Cout, Hd, Wd), device=dev, dtype=torch.float32, memory_format=_CL)
+        gd[:, :, ::stride, ::stride][:, :, :g.shape[2], :g.shape[3]] = g
+        g, stride = gd, 1
+    gx = torch.empty((B, Cin, H, W), device=dev, dtype=torch.float32, memory_format=_CL)
+    ws = workspace(lib.i2v_conv_dgrad_workspace_bytes(Cin, Cout, KH, KW), dev, "dgrad")
+    check(lib.i2v_conv_dgrad(ptr(g), ptr(w), ptr(gx), B, H, W, Cin, Cout, KH, KW, stride, pad, ptr(ws), ws.numel(),
+                             stream()), "conv_dgrad")
+    return gx
+
+
+def _conv_wgrad_raw(x, g, w_shape, stride, pad):
+    B, Cin, H, W = x.shape
+    Cout, _, KH, KW = w_shape
+    gw = torch.empty(w_shape, device=x.device, dtype=torch.float32, memory_format=_CL)
+    check(lib.i2v_conv_wgrad(ptr(x), ptr(g), ptr(gw), B, H, W, Cin, Cout, KH, KW, stride, pad, 0.0, None, 0, stream()),
+          "conv_wgrad")
+    return gw
+
+
+class _ConvFn(torch.autograd.Function):
+    """y = relu?( conv(x,w)*scale + shift + res ).  scale/shift of a frozen BN get no gradient;
+    a bias (shift without scale) does."""
+
+    @staticmethod
+    def forward(ctx, x, w, scale, shift, res, stride, pad, relu):
+        _need_cuda(x, w)
+        x = as_nhwc(x)
+        w = as_nhwc(w)
+        flags = 0
+        if scale is not None:
+            flags |= EPI_SCALE
+        elif shift is not None:
+            flags |= EPI_BIAS
+        if res is not None:
+            res = as_nhwc(res)
+            flags |= EPI_RESIDUAL
+        if relu:
+            flags |= EPI_RELU
+        y = _conv_fwd_raw(x, w, scale, shift, res, stride, pad, flags)
+        ctx.cfg = (stride, pad, relu, scale is not None, shift is not None, res is not None)
+        ctx.save_for_backward(x, w, scale, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, scale, y = ctx.saved_tensors
+        stride, pad, relu, has_scale, has_shift, has_res = ctx.cfg
+        gy = as_nhwc(gy)
+        M, N = gy.shape[0] * gy.shape[2] * gy.shape[3], gy.shape[1]
+        gres = None
+        need_bias = ctx.needs_input_grad[3] and has_shift and not has_scale
+        need_res = has_res and ctx.needs_input_grad[4]
+        gbias = torch.zeros((N,), device=gy.device, dtype=torch.float32) if need_bias else None
+
+        def epi(src, yy, sc, want_out, bias, rl):
+            out = torch.empty_like(src) if want_out else None
+            check(lib.i2v_epilogue_bwd(ptr(src), ptr(yy), ptr(sc), ptr(out), ptr(bias), M, N, int(rl), stream()),
+                  "epilogue_bwd")
+            return out
+
+        if relu and has_scale and not need_res:
+            g = epi(gy, y, scale, True, None, True)          # mask and BN scale in one pass
+        else:
+            g_pre = gy
+            if relu:
+                g_pre = epi(gy, y, None, True, gbias, True)  # g_pre = gy * (y > 0) [+ bias column sums]
+            elif need_bias:
+                epi(gy, None, None, False, gbias, False)
+            g = epi(g_pre, None, scale, True, None, False) if has_scale else g_pre
+            gres = g_pre if need_res else None
+        gx = _conv_dgrad_raw(g, w, x.shape, stride, pad) if ctx.needs_input_grad[0] else None
+        gw = _conv_wgrad_raw(x, g, w.shape, stride, pad) if ctx.needs_input_grad[1] else None
+        return gx, gw, None, gbias, gres, None, None, None
+
+
+def conv2d(x, w, scale=None, shift=None, res=None, stride=1, pad=0, relu=False):
+    """Implicit-GEMM conv with fused epilogue.  x (B,Cin,H,W), w (Cout,Cin,KH,KW); Cin % 4 == 0."""
+    return _ConvFn.apply(x, w, scale, shift, res, int(stride), int(pad), bool(relu))
+
+
+def linear(x, w, b=None, relu=False):
+    """nn.Linear (+ReLU) as a 1x1 conv over (M,1,1,K): x (M,K), w (N,K) -> (M,N)."""
+    M, K = x.shape
+    y = conv2d(x.contiguous().view(M, K, 1, 1), w.view(w.shape[0], K, 1, 1), None, b, None, 1, 0, relu)
+    return y.view(M, w.shape[0])
+
+
+def maxpool3x3s2(x):
+    """Stem max pool: k3 s2 p0 ceil_mode (resnet_instance_styleD_bilinear.py:228).  No backward:
+    the stem is frozen (RCNN_base[0..1] requires_grad=False, :392-393) and the pool input needs no grad
+    unless layer1 inputs do -- handled by torch autograd through ``_MaxPoolFn``."""
+    return _MaxPoolFn.apply(x)
+
+
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x)
+        x = as_nhwc(x)
+        B, C, H, W = x.shape
+        Ho, Wo = (H - 3 + 1) // 2 + 1, (W - 3 + 1) // 2 + 1
+        if (Ho - 1) * 2 >= H:
+            Ho -= 1
+        if (Wo - 1) * 2 >= W:
+            Wo -= 1
+        y = torch.empty((B, C, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=_CL)
+        arg = torch.empty((B, C, Ho, Wo), device=x.device, dtype=torch.int32, memory_format=_CL) \
+            if x.requires_grad else None
+        check(lib.i2v_maxpool3x3s2_fwd(ptr(x), ptr(y), ptr(arg), B, H, W, C, stream()), "maxpool3x3s2")
+        ctx.shape = x.shape
+        ctx.save_for_backward(arg)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (arg,) = ctx.saved_tensors
+        B, C, H, W = ctx.shape
+        # scatter by saved argmax (plumbing; the stem is frozen on every path the reference trains)
+        gx = torch.zeros((B, H * W, C), device=gy.device, dtype=torch.float32)
+        gyf = gy.permute(0, 2, 3, 1).reshape(B, -1, C)
+        idx = arg.permute(0, 2, 3, 1).reshape(B, -1, C).long()
+        gx.scatter_add_(1, idx, gyf)
+        return gx.view(B, H, W, C).permute(0, 3, 1, 2)
+
+
+def sgd_momentum_(p, g, m, lr, momentum, weight_decay):
+    """In-place fused SGD step on flat fp32 buffers."""
+    _need_cuda(p, g, m)
+    check(lib.i2v_sgd_momentum(ptr(p), ptr(g), ptr(m), p.numel(), float(lr), float(momentum), float(weight_decay),
+                               stream()), "sgd_momentum")
+
+
+class _DStylePoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x1, x2, dim, rank):
+        _need_cuda(x1, x2)
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        n_img, rows, N = x1.shape
+        z = torch.empty((n_img, dim), device=x1.device, dtype=torch.float32)
+        check(lib.i2v_dstyle_pool_fwd(ptr(x1), ptr(x2), ptr(z), rows, n_img, dim, rank, stream()), "dstyle_pool_fwd")
+        ctx.save_for_backward(x1, x2)
+        ctx.dr = (dim, rank)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        x1, x2 = ctx.saved_tensors
+        dim, rank = ctx.dr
+        g1, g2 = torch.empty_like(x1), torch.empty_like(x2)
+        check(lib.i2v_dstyle_pool_bwd(ptr(gz.contiguous()), ptr(x1), ptr(x2), ptr(g1), ptr(g2), x1.shape[1], x1.shape[0],
+                                      dim, rank, stream()), "dstyle_pool_bwd")
+        return g1, g2, None, None
+
+
+def dstyle_pool(x1, x2, dim, rank):
+    """z[b,d] = sum_pos sum_r x1[b,pos,d*rank+r]*x2[b,pos,d*rank+r] (x1,x2: (B,rows,dim*rank))."""
+    return _DStylePoolFn.apply(x1, x2, int(dim), int(rank))

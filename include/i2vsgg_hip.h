@@ -1,0 +1,178 @@
+/*
+ * i2vsgg_hip.h -- the drop-in boundary of libi2vsgg_hip.so (MI355X / gfx950).
+ *
+ * A flat C ABI over raw DEVICE pointers: no torch types, no hidden allocation, no
+ * hidden synchronisation, never exit().  Every entry point
+ *   - returns int32_t: 0 = ok, <0 = error (I2V_ERR_*; text via i2v_last_error()),
+ *   - takes the HIP stream to launch on as an opaque `void*` (hipStream_t),
+ *   - writes only into caller-owned outputs / caller-provided workspace
+ *     (size from the matching *_workspace_bytes() query).
+ *
+ * Each group cites the reference interface it replaces (paths under
+ * /root/reference/lib/model).  INTEGRATION.md shows the ctypes stubs a maintainer of
+ * the reference would add in place of the torch.utils.ffi `_ext` modules / `model._C`.
+ *
+ * Layouts.  Feature maps are NHWC ("channels_last": (B,H,W,C), C contiguous), the
+ * layout the MFMA implicit-GEMM convolutions produce and consume.  ROI outputs can
+ * be written NHWC (R,PH,PW,C) for the HIP heads or NCHW (R,C,PH,PW) for reference
+ * callers (flatten order of vrd.fc6, resnet_SGG_emb.py:146).  rois are (R,5) fp32
+ * [batch_idx, x1, y1, x2, y2] in image coordinates, as in the reference.
+ */
+#ifndef I2VSGG_HIP_H
+#define I2VSGG_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define I2V_OK               0
+#define I2V_ERR_ARG         -1   /* bad shape / null pointer / unsupported size   */
+#define I2V_ERR_LAUNCH      -2   /* hipGetLastError() after a launch               */
+#define I2V_ERR_WORKSPACE   -3   /* workspace too small                            */
+#define I2V_ERR_UNSUPPORTED -4
+
+#define I2V_LAYOUT_NHWC 0
+#define I2V_LAYOUT_NCHW 1
+
+/* epilogue flags of i2v_conv_fwd */
+#define I2V_EPI_RELU      1
+#define I2V_EPI_RESIDUAL  2
+#define I2V_EPI_SCALE     4      /* y = acc*scale[n] + shift[n]  (frozen BN)       */
+#define I2V_EPI_BIAS      8      /* y = acc + shift[n]                             */
+
+int32_t     i2v_version(void);
+const char* i2v_last_error(void);
+
+/* ---- ROIAlign (legacy "aligned grid incl. both ends" variant) ------------------
+ * replaces roi_align/src/roi_align_cuda.h:1-5 (roi_align_forward_cuda /
+ * roi_align_backward_cuda), launchers roi_align_kernel.h:13-27, and -- fused with the
+ * 2x2 stride-1 average -- RoIAlignAvg (roi_align/modules/roi_align.py:18-29).
+ * `pooled_*` is the FINAL grid (7x7); avg=1 samples (pooled+1)^2 points and averages,
+ * avg=0 samples pooled^2 points (plain RoIAlign).  feat is NHWC (feat_layout must be
+ * I2V_LAYOUT_NHWC) or NCHW.  bwd ACCUMULATES into grad_feat (caller zero-fills, as
+ * roi_align/functions/roi_align.py:42-43 does); fp32 atomics, summation order free. */
+int32_t i2v_roi_align_fwd(const float* feat, int32_t feat_layout, int32_t B, int32_t C, int32_t H, int32_t W,
+                          const float* rois, int32_t R, int32_t pooled_h, int32_t pooled_w,
+                          float spatial_scale, int32_t avg, float* out, int32_t out_layout, void* stream);
+int32_t i2v_roi_align_bwd(const float* grad_out, int32_t out_layout, const float* rois, int32_t R,
+                          int32_t pooled_h, int32_t pooled_w, float spatial_scale, int32_t avg,
+                          float* grad_feat, int32_t feat_layout, int32_t B, int32_t C, int32_t H, int32_t W,
+                          void* stream);
+
+/* ---- ROIPool (Caffe max pooling) ----------------------------------------------
+ * replaces roi_pooling/src/roi_pooling_cuda.c:7-8,49-50 and model._C.roi_pool_forward /
+ * roi_pool_backward (roi_layers/roi_pool.py:17,30).  argmax holds h*W+w of the winning
+ * input pixel or -1 (int32, same shape/layout as out).  bwd accumulates into grad_feat. */
+int32_t i2v_roi_pool_fwd(const float* feat, int32_t feat_layout, int32_t B, int32_t C, int32_t H, int32_t W,
+                         const float* rois, int32_t R, int32_t pooled_h, int32_t pooled_w,
+                         float spatial_scale, float* out, int32_t* argmax, int32_t out_layout, void* stream);
+int32_t i2v_roi_pool_bwd(const float* grad_out, const int32_t* argmax, int32_t out_layout,
+                         const float* rois, int32_t R, int32_t pooled_h, int32_t pooled_w,
+                         float* grad_feat, int32_t feat_layout, int32_t B, int32_t C, int32_t H, int32_t W,
+                         void* stream);
+
+/* ---- NMS -----------------------------------------------------------------------
+ * replaces nms/src/nms_cuda.h:4-5 (nms_cuda) / nms_cuda_kernel.h:5-6 (nms_cuda_compute)
+ * and the live CPU path nms/nms_cpu.py:6-34.  dets (n_img, n, 5) fp32 rows
+ * [x1,y1,x2,y2,score] ALREADY in descending score order; one independent problem per
+ * image.  keep_out (n_img, n) int32: kept row indices in order, first num_out[img]
+ * valid.  max_keep>0 stops each scan after that many kept rows (post_nms_topN).
+ * Fully asynchronous: counts stay on the device. */
+size_t  i2v_nms_workspace_bytes(int32_t n_img, int32_t n);
+int32_t i2v_nms_sorted(const float* dets, int32_t n_img, int32_t n, float thresh, int32_t max_keep,
+                       int32_t* keep_out, int32_t* num_out, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* ---- RPN proposal layer ----------------------------------------------------------
+ * replaces rpn/proposal_layer.py:49-163 incl. generate_anchors.py:45-56,
+ * bbox_transform.py:77-103 (bbox_transform_inv), :125-133 (clip_boxes), the sort at
+ * proposal_layer.py:127 and the per-image host NMS at :150.
+ *   cls   (B,H,W,2A) NHWC RPN class scores; fg score of anchor a = 2-way softmax of
+ *         (cls[..,a], cls[..,A+a]) as rpn.py:69-71 (is_prob=1: cls already holds the
+ *         probabilities, fg = cls[..,A+a])
+ *   bbox  (B,H,W,4A) NHWC deltas;  im_info (B,3) [h,w,scale] on the device
+ *   base_anchors (A,4) fp32 on the device (generate_anchors output)
+ *   rois  (B,post_nms_top_n,5) zero padded, col0 = image index
+ *   kept_idx (B,post_nms_top_n) int32 anchor index (y*W+x)*A+a of each roi or -1 (may be NULL)
+ *   num_kept (B) int32 (may be NULL)
+ * Order on exactly tied scores: descending score, then ascending anchor index. */
+size_t  i2v_rpn_proposal_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t A, int32_t pre_nms_top_n);
+int32_t i2v_rpn_proposal(const float* cls, int32_t is_prob, const float* bbox, const float* im_info,
+                         const float* base_anchors, int32_t B, int32_t H, int32_t W, int32_t A,
+                         int32_t feat_stride, int32_t pre_nms_top_n, int32_t post_nms_top_n, float nms_thresh,
+                         float* rois, int32_t* kept_idx, int32_t* num_kept,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* pieces of the above, exported for parity tests and reuse */
+int32_t i2v_rpn_decode(const float* cls, int32_t is_prob, const float* bbox, const float* im_info,
+                       const float* base_anchors, int32_t B, int32_t H, int32_t W, int32_t A, int32_t feat_stride,
+                       float* proposals /* (B,HWA,4) */, float* scores /* (B,HWA) */, void* stream);
+size_t  i2v_sort_desc_workspace_bytes(int32_t n_seg, int32_t n);
+int32_t i2v_sort_desc(const float* keys, int32_t n_seg, int32_t n, int32_t* order_out /* (n_seg,n) */,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* IoU of boxes (B,N,4 | stride_box floats per row, first 4 used after `box_off`) against
+ * gt (B,K,5): bbox_transform.py:168-257 (bbox_overlaps_batch) incl. the zero-area
+ * masks; also emits per-row max/argmax (first max).  overlaps may be NULL. */
+int32_t i2v_bbox_overlaps(const float* boxes, int32_t box_stride, int32_t box_off, int32_t boxes_batched,
+                          const float* gt, int32_t B, int32_t N, int32_t K,
+                          float* overlaps, float* max_ov, int32_t* argmax_ov, void* stream);
+
+/* ---- convolution / linear as MFMA implicit GEMM (fp32 in, fp32 accumulate) --------
+ * replaces the cuDNN-backed nn.Conv2d + frozen nn.BatchNorm2d + ReLU + residual add of
+ * Bottleneck.forward (resnet_instance_styleD_bilinear.py:197-217), the stem (:224-228),
+ * the RPN convs (rpn/rpn.py:27-36), the 1x1 discriminator convs (:41-46) and -- as a
+ * 1x1 conv over (M,1,1,K) -- every nn.Linear of the vrd head (resnet_SGG_emb.py:83-127).
+ *   x   (B,H,W,Cin) NHWC, Cin % 4 == 0        w  (Cout,KH,KW,Cin)  (K-major per filter)
+ *   y   (B,Ho,Wo,Cout) NHWC                    res same shape as y (I2V_EPI_RESIDUAL)
+ *   y = epi(sum_k x*w) with epi per flags: *scale[n] +shift[n], +res, relu.
+ * dgrad: gx (B,H,W,Cin) = conv_transpose(gy, w) (overwrites gx); the workspace holds the
+ *        flipped/transposed filter.  stride>1 is supported for 1x1 filters (all the path needs).
+ * wgrad: gw (Cout,KH,KW,Cin) (+)= gy^T * im2col(x); beta=0 overwrites, beta=1 accumulates. */
+int32_t i2v_conv_fwd(const float* x, const float* w, const float* scale, const float* shift, const float* res,
+                     float* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                     int32_t KH, int32_t KW, int32_t stride, int32_t pad, int32_t flags, void* stream);
+size_t  i2v_conv_dgrad_workspace_bytes(int32_t Cin, int32_t Cout, int32_t KH, int32_t KW);
+int32_t i2v_conv_dgrad(const float* gy, const float* w, float* gx, int32_t B, int32_t H, int32_t W,
+                       int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
+                       void* workspace, size_t workspace_bytes, void* stream);
+size_t  i2v_conv_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                                       int32_t KH, int32_t KW, int32_t stride, int32_t pad);
+int32_t i2v_conv_wgrad(const float* x, const float* gy, float* gw, int32_t B, int32_t H, int32_t W,
+                       int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
+                       float beta, void* workspace, size_t workspace_bytes, void* stream);
+
+/* epilogue backward: g = gy * (y>0) [relu], optional channel scale; optional per-channel
+ * sum of g into gshift (bias gradient).  In-place (g==gy) allowed. */
+int32_t i2v_epilogue_bwd(const float* gy, const float* y, const float* scale, float* g, float* gbias,
+                         int64_t M, int32_t N, int32_t relu, void* stream);
+
+/* 3x3 / stride 2 / pad 0 / ceil_mode max pool of the stem (resnet_instance...:228), NHWC */
+int32_t i2v_maxpool3x3s2_fwd(const float* x, float* y, int32_t* argmax, int32_t B, int32_t H, int32_t W, int32_t C,
+                             void* stream);
+
+/* ---- netD_style factorised-bilinear pooling ------------------------------------------
+ * replaces the x1*x2 product, the rank sum and the spatial sum of netD_style.forward
+ * (resnet_instance_styleD_bilinear.py:131-136) with one streaming pass:
+ *   z[b][d] = sum_{row<rows} sum_{r<rank} x1[b][row][d*rank+r] * x2[b][row][d*rank+r]
+ * x1,x2 (n_img, rows, dim*rank) fp32; z (n_img, dim) (overwritten).  bwd writes
+ * g1 = gz[b][d]*x2 and g2 = gz[b][d]*x1 (same shapes as x1/x2). */
+int32_t i2v_dstyle_pool_fwd(const float* x1, const float* x2, float* z, int64_t rows, int32_t n_img,
+                            int32_t dim, int32_t rank, void* stream);
+int32_t i2v_dstyle_pool_bwd(const float* gz, const float* x1, const float* x2, float* g1, float* g2,
+                            int64_t rows, int32_t n_img, int32_t dim, int32_t rank, void* stream);
+
+/* ---- fused SGD(momentum) step over a flat parameter buffer -------------------------
+ * replaces torch.optim.SGD.step of trainval_net_SGG_emb.py:145-150,255 for one param
+ * group: g' = g + wd*p ; m = mom*m + g' ; p -= lr*m   (m==first step handled by caller
+ * zero-init, which equals torch's "buf = clone(g')" on the first step). */
+int32_t i2v_sgd_momentum(float* p, const float* g, float* m, int64_t n, float lr, float momentum,
+                         float weight_decay, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* I2VSGG_HIP_H */

@@ -1,0 +1,370 @@
+"""Parity of the HIP kernels (called through the C-ABI of libi2vsgg_hip.so) against the CPU
+oracle and the reference-generated golden vectors.  Needs a real MI355X: `pytest -m gpu`."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from i2vsgg_amd import synthetic as syn  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU (torch.cuda.is_available() is False)")
+    from i2vsgg_amd import ops as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import cops, rpn
+    return cops, rpn
+
+
+DEV = "cuda:0"
+
+
+def _rois_cases(rng, B, H, W, scale=16.0, n=24):
+    """ROIs incl. degenerate (x2<x1), sub-pixel, out-of-image and full-image boxes."""
+    bx = syn.boxes(int(rng.integers(1 << 30)), n, H * scale, W * scale, 16, min(H, W) * scale * 0.9)
+    r = np.zeros((n + 6, 5), np.float32)
+    r[:n, 1:] = bx
+    r[:n, 0] = rng.integers(0, B, n)
+    r[n + 0] = [0, 0, 0, W * scale - 1, H * scale - 1]            # full image
+    r[n + 1] = [B - 1, 40.5, 33.25, 41.0, 33.5]                   # sub-pixel
+    r[n + 2] = [0, 120, 90, 60, 30]                               # malformed: x2<x1, y2<y1
+    r[n + 3] = [B - 1, -50, -40, 80, 70]                          # partly outside (negative)
+    r[n + 4] = [0, W * scale - 30, H * scale - 30, W * scale + 90, H * scale + 60]   # beyond the far edge
+    r[n + 5] = [B - 1, 10, 10, 10, 10]                            # single point
+    return r
+
+
+@pytest.mark.parametrize("C,H,W,B", [(4, 9, 11, 2), (64, 19, 32, 2), (1024, 38, 63, 1)])
+@pytest.mark.parametrize("avg", [True, False])
+def test_roi_align_fwd_bit_exact(ops, oracle, C, H, W, B, avg):
+    cops, _ = oracle
+    rng = np.random.default_rng(C + H)
+    feat = rng.standard_normal((B, C, H, W), dtype=np.float32)
+    rois = _rois_cases(rng, B, H, W)
+    ph = pw = 7
+    if avg:
+        ref = cops.roi_align_avg_fwd(feat, rois, ph, pw, 1.0 / 16.0)
+    else:
+        ref = cops.roi_align_fwd(feat, rois, ph, pw, 1.0 / 16.0)
+    ft = torch.from_numpy(feat).to(DEV)
+    rt = torch.from_numpy(rois).to(DEV)
+    for nhwc_in in (True, False):
+        for out_nchw in (True, False):
+            f = ft.contiguous(memory_format=torch.channels_last) if nhwc_in else ft
+            out = ops.roi_align(f, rt, ph, pw, 1.0 / 16.0, avg=avg, out_nchw=out_nchw)
+            assert out.shape == ref.shape
+            got = out.cpu().numpy()
+            assert np.array_equal(got, ref), "nhwc_in=%s out_nchw=%s maxdiff=%g" % (
+                nhwc_in, out_nchw, np.abs(got - ref).max())
+
+
+def test_roi_align_full_image_last_row_is_zero(ops):
+    """Property of the legacy grid: a full-image ROI samples row/col H, W -> 0."""
+    feat = torch.ones((1, 8, 38, 63), device=DEV).contiguous(memory_format=torch.channels_last)
+    rois = torch.tensor([[0, 0, 0, 63 * 16 - 1, 38 * 16 - 1]], device=DEV, dtype=torch.float32)
+    out = ops.roi_align(feat, rois, 8, 8, 1.0 / 16.0, avg=False)
+    assert torch.all(out[0, :, 7, :] == 0) and torch.all(out[0, :, :, 7] == 0)
+    assert torch.all(out[0, :, :7, :7] == 1)
+
+
+@pytest.mark.parametrize("C,H,W,B", [(8, 9, 11, 2), (256, 19, 32, 2)])
+@pytest.mark.parametrize("avg", [True, False])
+def test_roi_align_bwd(ops, oracle, C, H, W, B, avg):
+    cops, _ = oracle
+    rng = np.random.default_rng(7 + C)
+    rois = _rois_cases(rng, B, H, W)
+    gout = rng.standard_normal((rois.shape[0], C, 7, 7), dtype=np.float32)
+    ref = (cops.roi_align_avg_bwd if avg else cops.roi_align_bwd)(gout, rois, (B, C, H, W), 1.0 / 16.0)
+    for nhwc in (True, False):
+        feat = torch.zeros((B, C, H, W), device=DEV, requires_grad=True)
+        f = feat.contiguous(memory_format=torch.channels_last) if nhwc else feat
+        out = ops.roi_align(f, torch.from_numpy(rois).to(DEV), 7, 7, 1.0 / 16.0, avg=avg, out_nchw=not nhwc)
+        out.backward(torch.from_numpy(gout).to(DEV))
+        # atomics: summation order is free -> tolerance, not bit-exactness
+        np.testing.assert_allclose(feat.grad.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("C,H,W,B", [(4, 9, 11, 2), (100, 19, 32, 2), (1024, 38, 63, 1)])
+def test_roi_pool_fwd_bwd(ops, oracle, C, H, W, B):
+    cops, _ = oracle
+    rng = np.random.default_rng(11 + C)
+    feat = rng.standard_normal((B, C, H, W), dtype=np.float32)
+    rois = _rois_cases(rng, B, H, W)
+    ref, refarg = cops.roi_pool_fwd(feat, rois, 7, 7, 1.0 / 16.0)
+    gout = rng.standard_normal(ref.shape, dtype=np.float32)
+    refg = cops.roi_pool_bwd(gout, rois, refarg, feat.shape)
+    for nhwc in (True, False):
+        for out_nchw in (True, False):
+            ft = torch.from_numpy(feat).to(DEV).requires_grad_()
+            f = ft.contiguous(memory_format=torch.channels_last) if nhwc else ft
+            out, arg = ops.roi_pool(f, torch.from_numpy(rois).to(DEV), 7, 7, 1.0 / 16.0, out_nchw=out_nchw,
+                                    return_argmax=True)
+            assert np.array_equal(out.detach().cpu().numpy(), ref)
+            assert np.array_equal(arg.cpu().numpy(), refarg)
+            out.backward(torch.from_numpy(gout).to(DEV))
+            np.testing.assert_allclose(ft.grad.cpu().numpy(), refg, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 300, 1000, 6000, 12000])
+def test_nms_keep_matches_reference_golden(ops, gold, n):
+    g = gold("nms_keep")
+    for clustered in (False, True):
+        dets = syn.tie_free_dets(1000 + n, n, clustered=clustered)
+        dt = torch.from_numpy(dets).to(DEV)
+        for th in (0.7, 0.3):
+            ref = g["n%d_%s_t%02d" % (n, "c" if clustered else "u", int(th * 10))]
+            keep, num = ops.nms_sorted(dt, th)
+            k = int(num.item())
+            assert k == ref.size
+            assert np.array_equal(keep[0, :k].cpu().numpy(), ref)
+
+
+def test_nms_batched_early_exit_and_empty(ops, oracle):
+    cops, _ = oracle
+    dets = np.stack([syn.tie_free_dets(77 + i, 3000, clustered=bool(i % 2)) for i in range(3)])
+    keep, num = ops.nms_sorted(torch.from_numpy(dets).to(DEV), 0.7, max_keep=300)
+    for i in range(3):
+        ref = cops.nms_sorted(dets[i], 0.7)[:300]
+        assert int(num[i]) == ref.size
+        assert np.array_equal(keep[i, :ref.size].cpu().numpy(), ref)
+    keep, num = ops.nms_sorted(torch.zeros((0, 5), device=DEV), 0.7)
+    assert int(num.item()) == 0
+
+
+@pytest.mark.parametrize("n", [5, 4096, 4097, 21546, 40000])
+def test_sort_desc(ops, n):
+    rng = np.random.default_rng(n)
+    keys = rng.standard_normal((2, n)).astype(np.float32)
+    keys[0, : n // 3] = keys[0, n // 3: 2 * (n // 3)][: n // 3]      # force ties
+    order = ops.sort_desc(torch.from_numpy(keys).to(DEV)).cpu().numpy()
+    for s in range(2):
+        ref = np.argsort(-keys[s], kind="stable")
+        assert np.array_equal(order[s], ref)
+
+
+def _rpn_inputs(seed, B, H=38, W=63):
+    rng = np.random.default_rng(seed)
+    n = B * 9 * H * W
+    fg = ((rng.permutation(n).astype(np.float32) + 1.0) / np.float32(n + 2)).reshape(B, 9, H, W)
+    deltas = (rng.standard_normal((B, 36, H, W)) * 0.25).astype(np.float32)
+    return fg, deltas
+
+
+def test_rpn_decode_bit_exact_vs_oracle_and_reference(ops, oracle, gold):
+    _, rpn = oracle
+    g = gold("decode_clip")
+    rng = np.random.default_rng(101)
+    anc = rpn.anchor_grid(38, 63)
+    deltas = (rng.standard_normal((2, anc.shape[0], 4)) * np.array([0.3, 0.3, 0.5, 0.5])).astype(np.float32)
+    # (B,N,4) in (y,x,a) order -> NCHW bbox map (B,36,H,W)
+    bbox = deltas.reshape(2, 38, 63, 36).transpose(0, 3, 1, 2).copy()
+    cls = np.zeros((2, 18, 38, 63), np.float32)
+    base = torch.from_numpy(rpn.base_anchors().astype(np.float32)).to(DEV)
+    prop, _ = ops.rpn_decode(torch.from_numpy(cls).to(DEV), torch.from_numpy(bbox).to(DEV),
+                             torch.from_numpy(g["im_info"]).to(DEV), base, 16, is_prob=True)
+    got = prop.cpu().numpy()
+    for b in range(2):
+        mine = rpn.decode_clip(anc, deltas[b], g["im_info"][b, 0], g["im_info"][b, 1])
+        assert np.array_equal(got[b], mine)                     # bit-exact vs the oracle
+        np.testing.assert_allclose(got[b], g["proposals"][b], rtol=3e-7, atol=2e-4)   # exp ulp vs torch
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_rpn_proposal_layer_vs_reference_golden(ops, oracle, gold, B):
+    _, rpn = oracle
+    g = gold("proposal_layer")
+    fg, deltas = _rpn_inputs(200 + B, B)
+    prob = np.concatenate([1.0 - fg, fg], 1).astype(np.float32)
+    info = np.array([[600, 1000, 1.0]] * B, np.float32)
+    base = torch.from_numpy(rpn.base_anchors().astype(np.float32)).to(DEV)
+    for mode, pre, post in (("train", 12000, 2000), ("test", 6000, 300), ("target", 12000, 32)):
+        rois, kept, num = ops.rpn_proposal(torch.from_numpy(prob).to(DEV), torch.from_numpy(deltas).to(DEV),
+                                           torch.from_numpy(info).to(DEV), base, 16, pre, post, 0.7, is_prob=True,
+                                           want_index=True)
+        ref_rois, ref_kept = rpn.proposal_layer(fg, deltas, info, pre, post, 0.7)
+        got = rois.cpu().numpy()
+        assert np.array_equal(got, ref_rois)                    # bit-exact vs the oracle
+        for b in range(B):                                      # identical kept anchor indices
+            k = int(num[b])
+            assert k == ref_kept[b].size
+            assert np.array_equal(kept[b, :k].cpu().numpy(), ref_kept[b])
+        np.testing.assert_allclose(got, g["rois_B%d_%s" % (B, mode)], rtol=3e-7, atol=2e-4)
+
+
+def test_rpn_proposal_from_logits(ops, oracle):
+    """is_prob=0: the pairwise softmax of rpn.py:69-71 is fused into the decode kernel."""
+    _, rpn = oracle
+    rng = np.random.default_rng(5)
+    cls = rng.standard_normal((1, 18, 38, 63)).astype(np.float32)
+    _, deltas = _rpn_inputs(6, 1)
+    prob = F.softmax(torch.from_numpy(cls).view(1, 2, 9 * 38, 63), 1).view(1, 18, 38, 63).numpy()
+    info = np.array([[600, 1000, 1.0]], np.float32)
+    base = torch.from_numpy(rpn.base_anchors().astype(np.float32)).to(DEV)
+    _, score = ops.rpn_decode(torch.from_numpy(cls).to(DEV), torch.from_numpy(deltas).to(DEV),
+                              torch.from_numpy(info).to(DEV), base, 16, is_prob=False)
+    ref = prob[0, 9:].transpose(1, 2, 0).reshape(-1)
+    np.testing.assert_allclose(score[0].cpu().numpy(), ref, rtol=2e-6, atol=1e-7)
+
+
+def test_bbox_overlaps_vs_reference_golden(ops, oracle, gold):
+    _, rpn = oracle
+    g = gold("box_math")
+    ov, mx, am = ops.bbox_overlaps(torch.from_numpy(g["rois"]).to(DEV), torch.from_numpy(g["gt"]).to(DEV),
+                                   want_matrix=True)
+    assert np.array_equal(ov.cpu().numpy(), g["overlaps_rois"])
+    assert np.array_equal(mx.cpu().numpy(), g["overlaps_rois"].max(2))
+    assert np.array_equal(am.cpu().numpy(), g["overlaps_rois"].argmax(2))
+    anc = torch.from_numpy(rpn.anchor_grid(38, 63)[::7].copy()).to(DEV)
+    ov, _, _ = ops.bbox_overlaps(anc, torch.from_numpy(g["gt"]).to(DEV), want_matrix=True)
+    assert np.array_equal(ov.cpu().numpy(), g["overlaps_anchors"])
+
+
+# --------------------------------------------------------------------------- conv / linear
+CONV_CASES = [
+    # B, Cin, H, W, Cout, K, stride, pad
+    (2, 64, 20, 27, 64, 1, 1, 0),
+    (2, 64, 20, 27, 256, 1, 1, 0),
+    (1, 128, 19, 33, 128, 3, 1, 1),
+    (2, 256, 21, 30, 512, 1, 2, 0),
+    (1, 4, 67, 91, 64, 7, 2, 3),
+    (1, 1024, 38, 63, 512, 3, 1, 1),     # RPN_Conv shape (split-free, 64x64 tiles)
+    (3, 512, 7, 7, 18, 1, 1, 0),         # Cout not a multiple of 4
+    (1, 96, 16, 16, 128, 5, 2, 2),       # vrd.conv_lo.1 (Cin not a power of two)
+    (4, 128, 8, 8, 64, 8, 1, 0),         # vrd.conv_lo.2 -> 1x1 output, deep K (split-K)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_vs_torch_fp32(ops, case):
+    B, Cin, H, W, Cout, K, s, p = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((B, Cin, H, W), dtype=np.float32)
+    w = (rng.standard_normal((Cout, Cin, K, K), dtype=np.float32) / np.sqrt(Cin * K * K)).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, Cout).astype(np.float32)
+    sh = rng.uniform(-0.5, 0.5, Cout).astype(np.float32)
+    xt, wt = torch.from_numpy(x), torch.from_numpy(w)
+    ref = F.conv2d(xt, wt, stride=s, padding=p)
+    res = torch.from_numpy(rng.standard_normal(tuple(ref.shape), dtype=np.float32))
+    xd, wd = xt.to(DEV), wt.to(DEV)
+    scd, shd, resd = torch.from_numpy(sc).to(DEV), torch.from_numpy(sh).to(DEV), res.to(DEV)
+    tol = dict(rtol=2e-5, atol=2e-5)
+    y = ops.conv2d(xd, wd, stride=s, pad=p)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), **tol)
+    y = ops.conv2d(xd, wd, scd, shd, resd, s, p, relu=True)
+    r2 = F.relu(ref * torch.from_numpy(sc).view(1, -1, 1, 1) + torch.from_numpy(sh).view(1, -1, 1, 1) + res)
+    np.testing.assert_allclose(y.cpu().numpy(), r2.numpy(), **tol)
+    y = ops.conv2d(xd, wd, None, shd, None, s, p, relu=False)
+    np.testing.assert_allclose(y.cpu().numpy(), (ref + torch.from_numpy(sh).view(1, -1, 1, 1)).numpy(), **tol)
+
+
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[5] != 7])
+def test_conv_bwd_vs_torch_autograd(ops, case):
+    B, Cin, H, W, Cout, K, s, p = case
+    rng = np.random.default_rng(sum(case) + 1)
+    x = rng.standard_normal((B, Cin, H, W), dtype=np.float32)
+    w = (rng.standard_normal((Cout, Cin, K, K), dtype=np.float32) / np.sqrt(Cin * K * K)).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, Cout).astype(np.float32)
+    xt, wt, bt = (torch.from_numpy(a).requires_grad_() for a in (x, w, b))
+    ref = F.relu(F.conv2d(xt, wt, bt, stride=s, padding=p))
+    gy = torch.from_numpy(rng.standard_normal(tuple(ref.shape), dtype=np.float32))
+    ref.backward(gy)
+    xd, wd, bd = (torch.from_numpy(a).to(DEV).requires_grad_() for a in (x, w, b))
+    y = ops.conv2d(xd, wd, None, bd, None, s, p, relu=True)
+    y.backward(gy.to(DEV))
+    tol = dict(rtol=3e-4, atol=3e-4)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xt.grad.numpy(), **tol)
+    np.testing.assert_allclose(wd.grad.cpu().numpy(), wt.grad.numpy(), **tol)
+    np.testing.assert_allclose(bd.grad.cpu().numpy(), bt.grad.numpy(), **tol)
+
+
+def test_conv_bn_residual_backward(ops):
+    """Bottleneck-style epilogue: frozen-BN scale/shift + residual + ReLU; grads to x, w and res."""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 64, 12, 15), dtype=np.float32)
+    w = (rng.standard_normal((128, 64, 1, 1), dtype=np.float32) / 8).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, 128).astype(np.float32)
+    sh = rng.uniform(-0.5, 0.5, 128).astype(np.float32)
+    r = rng.standard_normal((2, 128, 12, 15), dtype=np.float32)
+    xt, wt, rt = (torch.from_numpy(a).requires_grad_() for a in (x, w, r))
+    ref = F.relu(F.conv2d(xt, wt) * torch.from_numpy(sc).view(1, -1, 1, 1) + torch.from_numpy(sh).view(1, -1, 1, 1) + rt)
+    gy = torch.from_numpy(rng.standard_normal(tuple(ref.shape), dtype=np.float32))
+    ref.backward(gy)
+    xd, wd, rd = (torch.from_numpy(a).to(DEV).requires_grad_() for a in (x, w, r))
+    y = ops.conv2d(xd, wd, torch.from_numpy(sc).to(DEV), torch.from_numpy(sh).to(DEV), rd, 1, 0, relu=True)
+    y.backward(gy.to(DEV))
+    tol = dict(rtol=3e-4, atol=3e-4)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xt.grad.numpy(), **tol)
+    np.testing.assert_allclose(wd.grad.cpu().numpy(), wt.grad.numpy(), **tol)
+    np.testing.assert_allclose(rd.grad.cpu().numpy(), rt.grad.numpy(), **tol)
+
+
+@pytest.mark.parametrize("M,K,N", [(8, 50176, 64), (128, 4096, 300), (32, 600, 256), (62, 300, 1024), (5, 64, 1)])
+def test_linear_fwd_bwd(ops, M, K, N):
+    rng = np.random.default_rng(M + K + N)
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    w = (rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal((N,), dtype=np.float32)
+    xt, wt, bt = (torch.from_numpy(a).requires_grad_() for a in (x, w, b))
+    ref = F.relu(F.linear(xt, wt, bt))
+    gy = torch.from_numpy(rng.standard_normal((M, N), dtype=np.float32))
+    ref.backward(gy)
+    xd, wd, bd = (torch.from_numpy(a).to(DEV).requires_grad_() for a in (x, w, b))
+    y = ops.linear(xd, wd, bd, relu=True)
+    y.backward(gy.to(DEV))
+    tol = dict(rtol=3e-4, atol=3e-4)
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref.detach().numpy(), **tol)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xt.grad.numpy(), **tol)
+    np.testing.assert_allclose(wd.grad.cpu().numpy(), wt.grad.numpy(), **tol)
+    np.testing.assert_allclose(bd.grad.cpu().numpy(), bt.grad.numpy(), **tol)
+
+
+@pytest.mark.parametrize("H,W", [(300, 500), (49, 66), (50, 65)])
+def test_maxpool_ceil_mode(ops, H, W):
+    x = torch.from_numpy(np.random.default_rng(H).standard_normal((2, 64, H, W), dtype=np.float32))
+    ref = F.max_pool2d(x, 3, 2, 0, ceil_mode=True)
+    y = ops.maxpool3x3s2(x.to(DEV))
+    assert y.shape == ref.shape
+    assert torch.equal(y.cpu(), ref)
+
+
+def test_sgd_momentum_matches_torch(ops):
+    rng = np.random.default_rng(9)
+    p0 = rng.standard_normal(100003, dtype=np.float32)
+    pt = torch.from_numpy(p0.copy()).requires_grad_()
+    opt = torch.optim.SGD([pt], lr=0.01, momentum=0.9, weight_decay=5e-4)
+    pd = torch.from_numpy(p0.copy()).to(DEV)
+    md = torch.zeros_like(pd)
+    for it in range(3):
+        g = rng.standard_normal(100003, dtype=np.float32)
+        pt.grad = torch.from_numpy(g.copy())
+        opt.step()
+        ops.sgd_momentum_(pd, torch.from_numpy(g).to(DEV), md, 0.01, 0.9, 5e-4)
+    np.testing.assert_allclose(pd.cpu().numpy(), pt.detach().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_dstyle_pool(ops):
+    rng = np.random.default_rng(4)
+    x1 = torch.from_numpy(rng.standard_normal((2, 300, 2560), dtype=np.float32)).requires_grad_()
+    x2 = torch.from_numpy(rng.standard_normal((2, 300, 2560), dtype=np.float32)).requires_grad_()
+    ref = (x1 * x2).reshape(2, 300, 512, 5).sum(-1).sum(1)
+    gz = torch.from_numpy(rng.standard_normal((2, 512), dtype=np.float32))
+    ref.backward(gz)
+    d1, d2 = (t.detach().to(DEV).requires_grad_() for t in (x1, x2))
+    z = ops.dstyle_pool(d1, d2, 512, 5)
+    z.backward(gz.to(DEV))
+    np.testing.assert_allclose(z.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(d1.grad.cpu().numpy(), x1.grad.numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(d2.grad.cpu().numpy(), x2.grad.numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_cpu_tensor_is_rejected_loudly(ops):
+    with pytest.raises(Exception):
+        ops.roi_align(torch.zeros(1, 4, 8, 8), torch.zeros(1, 5), 7, 7, 1 / 16.0)
