@@ -1,0 +1,152 @@
+"""SGG_emb relation head ``vrd`` and its ``resnet`` wrapper (faster_rcnn/resnet_SGG_emb.py).
+
+The reference pushes the subject/object boxes and the union boxes through ``fc6`` (50176 -> 4096,
+822 MB of fp32 weights) in two separate passes per frame.  Here every row of every frame of the batch
+-- boxes and union boxes alike -- goes through fc6/fc7 in ONE GEMM, so the 822 MB weight is streamed
+once per step (forward) instead of 2 x frames times."""
+import math
+import pickle
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..roi_layers import ROIPool
+from ..utils.config import cfg
+from .faster_rcnn_SGG_emb import _fasterRCNN
+from .layers import C4Base, load_reference_state, make_layer
+from .utils import FC, Conv2d, Linear
+
+RESNET_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
+
+
+def _load_pickle(path):
+    with open(path, "rb") as f:
+        return pickle.load(f, encoding="bytes")
+
+
+class vrd(nn.Module):
+    """resnet_SGG_emb.py:65-221.  ``args`` needs num_relations, num_classes, emb_dim, use_obj_visual,
+    spatial_type (only the reference defaults True / 2 are implemented) and may carry
+    the three pickle paths; synthetic runs assign ``source_gt_rels`` directly."""
+
+    def __init__(self, args, all_obj_vecs=None, all_prd_vecs=None, bn=False):
+        super().__init__()
+        assert not bn
+        self.args = args
+        self.n_rel, self.n_obj, self.emb_dim = args.num_relations, args.num_classes, args.emb_dim
+        self.obj_vecs, self.prd_vecs = all_obj_vecs, all_prd_vecs
+        self._so_prior = None
+        self.source_gt_rels, self.target_gt_rels = {}, {}
+        if getattr(args, "source_so_prior_path", None):
+            self._so_prior = np.array(_load_pickle(args.source_so_prior_path))
+        if getattr(args, "source_gt_rels_path", None):
+            self.source_gt_rels = _load_pickle(args.source_gt_rels_path)
+        if getattr(args, "target_gt_rels_path", None):
+            self.target_gt_rels = _load_pickle(args.target_gt_rels_path)
+        assert getattr(args, "use_obj_visual", True) and getattr(args, "spatial_type", 2) == 2
+
+        self.roi_pool = ROIPool((cfg.POOLING_SIZE, cfg.POOLING_SIZE), 1.0 / 16.0)
+        self.fc6 = FC(1024 * 7 * 7, 4096)
+        self.fc7 = FC(4096, 4096)
+        self.so_vis_embeddings = FC(4096, self.emb_dim, relu=False)
+        self.fc8 = FC(4096, 256)
+        self.criterion = nn.BCEWithLogitsLoss()
+        self.fc_so = FC(300 * 2, 256)
+        self.conv_lo = nn.Sequential(Conv2d(2, 96, 5, same_padding=True, stride=2),
+                                     Conv2d(96, 128, 5, same_padding=True, stride=2),
+                                     Conv2d(128, 64, 8, same_padding=False))
+        self.fc_lov = FC(64, 256)
+        self.fc_fusion = FC(768, 256)
+        self.fc_rel = FC(256, self.emb_dim, relu=False)
+        self.prd_sem_embeddings = nn.Sequential(Linear(300, 1024), nn.LeakyReLU(0.1), Linear(1024, self.emb_dim))
+        self.dropout = True          # F.dropout(training=self.training) of the reference (:149-163)
+        self._prd_dev = None
+
+    def _dev(self, x, dtype=torch.float32):
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(x)
+        return x.to(device=self.fc6.fc.weight.device, dtype=dtype)
+
+    def _drop(self, x):
+        return F.dropout(x, training=self.training) if self.dropout else x
+
+    def forward(self, fmap, boxes, rel_boxes, SpatialFea, classes, ix1, ix2):
+        """Reference signature.  ``fmap`` (B,1024,H,W) (numpy as in the reference, or a device tensor);
+        boxes (nb,5), rel_boxes (nr,5) with the frame index in column 0; ix1/ix2 index rows of ``boxes``.
+        Returns (prd_cls_scores (nr,n_rel), relation feature (nr,emb_dim) as a numpy array)."""
+        scores, x = self.forward_device(self._dev(fmap), self._dev(boxes), self._dev(rel_boxes),
+                                        self._dev(SpatialFea), self._dev(ix1, torch.long), self._dev(ix2, torch.long))
+        return scores, x.detach().cpu().numpy()
+
+    def forward_device(self, fmap, boxes, rel_boxes, spatial, ix1, ix2):
+        nb = boxes.size(0)
+        rois = torch.cat((boxes, rel_boxes), 0)
+        pooled = self.roi_pool(fmap, rois)                       # (nb+nr, 1024, 7, 7), NCHW flatten order
+        h = self.fc6(pooled.view(pooled.size(0), -1))            # one pass over the 822 MB weight
+        h = self.fc7(self._drop(h))
+        h = self._drop(h)
+        obj = self.so_vis_embeddings(h[:nb])
+        x = self.fc8(h[nb:])
+        x_so = self.fc_so(torch.cat((obj.index_select(0, ix1), obj.index_select(0, ix2)), 1))
+        lo = self.conv_lo(spatial)
+        lo = self.fc_lov(lo.reshape(lo.size(0), -1))
+        x = self.fc_rel(self.fc_fusion(torch.cat((x, x_so, lo), 1)))
+        if self._prd_dev is None or self._prd_dev.device != x.device:
+            self._prd_dev = torch.from_numpy(np.asarray(self.prd_vecs, np.float32)).to(x.device)
+        sem = F.normalize(self.prd_sem_embeddings(self._prd_dev), p=2, dim=1)
+        scores = torch.mm(F.normalize(x, p=2, dim=1), sem.t())
+        if not self.training:
+            scores = F.softmax(scores, dim=1)
+        return scores, x
+
+    # ---- host helpers with the reference names (float64 like the reference's numpy) -------------
+    def _getUnionBBox(self, aBB, bBB, ih, iw, margin=10):
+        return [max(0, min(aBB[0], bBB[0]) - margin), max(0, min(aBB[1], bBB[1]) - margin),
+                min(iw, max(aBB[2], bBB[2]) + margin), min(ih, max(aBB[3], bBB[3]) + margin)]
+
+    def _getDualMask(self, ih, iw, bb):
+        rh, rw = 32.0 / ih, 32.0 / iw
+        x1, x2 = max(0, int(math.floor(bb[0] * rw))), min(32, int(math.ceil(bb[2] * rw)))
+        y1, y2 = max(0, int(math.floor(bb[1] * rh))), min(32, int(math.ceil(bb[3] * rh)))
+        mask = np.zeros((32, 32))
+        mask[y1:y2, x1:x2] = 1
+        return mask
+
+
+class resnet(_fasterRCNN):
+    def __init__(self, classes, args, num_layers=101, pretrained=False, class_agnostic=False,
+                 obj_vecs=None, prd_vecs=None):
+        self.dout_base_model = 1024
+        self.pretrained = pretrained
+        self.class_agnostic = class_agnostic
+        self.layers = num_layers
+        self.args = args
+        self.obj_vecs, self.prd_vecs = obj_vecs, prd_vecs      # GloVe rows are an input array here
+        _fasterRCNN.__init__(self, classes, args)
+
+    def _init_modules(self):
+        blocks = RESNET_BLOCKS[self.layers]
+        self.RCNN_base = C4Base(blocks[:3])
+        self.vrd = vrd(self.args, self.obj_vecs, self.prd_vecs)
+        layer4, _ = make_layer(1024, 512, blocks[3], 2)
+        self.RCNN_top = nn.Sequential(layer4)
+        self.RCNN_cls_score = Linear(2048, self.n_classes)
+        self.RCNN_bbox_pred = Linear(2048, 4 if self.class_agnostic else 4 * self.n_classes)
+        for p in self.RCNN_base[0].parameters():
+            p.requires_grad = False
+        if self.pretrained:
+            path = cfg.RESNET_PATH if self.layers == 101 else cfg.RESNET_PATH50
+            sd = torch.load(path, map_location="cpu")
+            names = {"conv1": "RCNN_base.0", "bn1": "RCNN_base.1", "layer1": "RCNN_base.4", "layer2": "RCNN_base.5",
+                     "layer3": "RCNN_base.6", "layer4": "RCNN_top.0"}
+            load_reference_state(self, {names[k.split(".")[0]] + k[len(k.split(".")[0]):]: v for k, v in sd.items()
+                                        if k.split(".")[0] in names}, strict=False)
+
+    def train(self, mode=True):
+        nn.Module.train(self, mode)
+        return self
+
+    def _head_to_tail(self, pool5):
+        return self.RCNN_top(pool5).mean(3).mean(2)

@@ -1,0 +1,105 @@
+"""instance_styleD detector pieces (faster_rcnn/resnet_instance_styleD_bilinear.py): the two
+discriminators and the ``resnet`` wrapper (C4 base, layer4 as ROI head, frozen BN)."""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from i2vsgg_amd import ops
+from ..utils.config import cfg
+from ..utils.net_utils import GradReverse
+from .faster_rcnn_instance_styleD_bilinear import _fasterRCNN
+from .layers import C4Base, ConvParams, load_reference_state, make_layer
+from .utils import Linear, _LinearParams
+
+RESNET_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
+
+
+class netD_pixel(nn.Module):
+    """Instance-level discriminator (:38-83): GRL -> 1x1 1024->512 ReLU -> 512->128 ReLU -> 128->1
+    -> sigmoid, no biases.  Each 1x1 conv is a GEMM over the (K*49) ROI pixels with the ReLU fused."""
+
+    def __init__(self, context=False):
+        super().__init__()
+        self.conv1 = ConvParams(1024, 512, 1, std=0.01)
+        self.conv2 = ConvParams(512, 128, 1, std=0.01)
+        self.conv3 = ConvParams(128, 1, 1, std=0.01)
+        self.context = context
+
+    def forward(self, x, lamb=1.0):
+        x = GradReverse.apply(x, lamb)
+        x = ops.conv2d(x, self.conv1.weight, relu=True)
+        x = ops.conv2d(x, self.conv2.weight, relu=True)
+        d = torch.sigmoid(ops.conv2d(x, self.conv3.weight))
+        if self.context:
+            return d, x.mean((2, 3), keepdim=True)
+        return d
+
+
+class netD_style(nn.Module):
+    """Image-level factorised-bilinear discriminator (:85-146).  The two 512 -> dim*rank projections
+    are GEMMs over the H*W positions; product + rank sum + spatial sum are one streaming kernel
+    (``ops.dstyle_pool``) instead of three full-size passes over a 9375 x 2560 intermediate."""
+
+    def __init__(self, context=False, dim=512, rank=5):
+        super().__init__()
+        self.dim, self.rank, self.context = dim, rank, context
+        self.fc_1 = _LinearParams(512, dim * rank)
+        self.fc_2 = _LinearParams(512, dim * rank)
+        self.fc1 = _LinearParams(dim, 1)
+        for m in (self.fc_1, self.fc_2, self.fc1):         # kaiming_normal_(fan_out, relu) :116-118
+            m.weight.data.normal_(0, math.sqrt(2.0 / m.weight.shape[0]))
+
+    def forward(self, x, lamb=1.0):
+        x = GradReverse.apply(x, lamb)
+        b, c, h, w = x.shape
+        rows = ops.as_nhwc(x).permute(0, 2, 3, 1).reshape(b * h * w, c)            # (positions, 512), a view
+        x1 = ops.linear(rows, self.fc_1.weight, self.fc_1.bias)
+        x2 = ops.linear(rows, self.fc_2.weight, self.fc_2.bias)
+        z = ops.dstyle_pool(x1.view(b, h * w, -1), x2.view(b, h * w, -1), self.dim, self.rank)
+        z = torch.sqrt(F.relu(z)) - torch.sqrt(F.relu(-z))
+        z = F.normalize(z, p=2, dim=1)
+        d = torch.sigmoid(ops.linear(z, self.fc1.weight, self.fc1.bias))
+        return (d, z) if self.context else d
+
+
+class resnet(_fasterRCNN):
+    def __init__(self, classes, num_layers=101, pretrained=False, class_agnostic=False, ic=False, gc=False):
+        self.dout_base_model = 1024
+        self.pretrained = pretrained
+        self.class_agnostic = class_agnostic
+        self.layers = num_layers
+        _fasterRCNN.__init__(self, classes, class_agnostic, ic, gc)
+
+    def _init_modules(self):
+        blocks = RESNET_BLOCKS[self.layers]
+        self.model_path = cfg.RESNET_PATH if self.layers == 101 else cfg.RESNET_PATH50
+        self.RCNN_base = C4Base(blocks[:3])
+        self.netD_pixel = netD_pixel(context=self.ic)
+        self.netD_style = netD_style(context=self.gc)
+        layer4, _ = make_layer(1024, 512, blocks[3], 2)
+        self.RCNN_top = nn.Sequential(layer4)
+        feat_d = 2048 + (512 if self.gc else 0) + (128 if self.ic else 0)
+        self.RCNN_cls_score = Linear(feat_d, self.n_classes)
+        self.RCNN_bbox_pred = Linear(feat_d, 4 if self.class_agnostic else 4 * self.n_classes)
+        for p in self.RCNN_base[0].parameters():       # :392-393 (all BN params are frozen by construction)
+            p.requires_grad = False
+        if self.pretrained:
+            sd = torch.load(self.model_path, map_location="cpu")
+            names = {"conv1": "RCNN_base.0", "bn1": "RCNN_base.1", "layer1": "RCNN_base.4", "layer2": "RCNN_base.5",
+                     "layer3": "RCNN_base.6", "layer4": "RCNN_top.0"}
+            mapped = {names[k.split(".")[0]] + k[len(k.split(".")[0]):]: v for k, v in sd.items()
+                      if k.split(".")[0] in names}
+            load_reference_state(self, mapped, strict=False)
+
+    def extract_feature(self, x):
+        """-> (base_feat (B,1024,H/16,W/16), base_feat1 = layer2 output) (:412-420)."""
+        return self.RCNN_base(x, tap=True)
+
+    def train(self, mode=True):
+        nn.Module.train(self, mode)          # BN is frozen in every mode; nothing else to switch
+        return self
+
+    def _head_to_tail(self, pool5):
+        return self.RCNN_top(pool5).mean(3).mean(2)

@@ -1,0 +1,77 @@
+"""Training helpers with the reference's names (lib/model/utils/net_utils.py)."""
+import torch
+from torch.utils.data.sampler import Sampler
+
+
+class sampler(Sampler):
+    """Contiguous index blocks of ``batch_size`` in random block order, leftovers last
+    (net_utils.py:13-36) -- keeps images of similar aspect ratio (sorted roidb) in one batch."""
+
+    def __init__(self, train_size, batch_size):
+        self.num_data = train_size
+        self.batch_size = batch_size
+        self.num_per_batch = train_size // batch_size
+        self.leftover = torch.arange(self.num_per_batch * batch_size, train_size).long()
+
+    def __iter__(self):
+        starts = torch.randperm(self.num_per_batch).view(-1, 1) * self.batch_size
+        idx = (starts + torch.arange(self.batch_size).view(1, -1)).view(-1)
+        return iter(torch.cat((idx, self.leftover), 0))
+
+    def __len__(self):
+        return self.num_data
+
+
+class GradReverse(torch.autograd.Function):
+    """Gradient reversal layer (net_utils.py:52-61): identity forward, ``-lambd * g`` backward."""
+
+    @staticmethod
+    def forward(ctx, x, lambd):
+        ctx.lambd = lambd
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * -ctx.lambd, None
+
+
+def grad_reverse(x, lambd=1.0):
+    return GradReverse.apply(x, lambd)
+
+
+def _smooth_l1_loss(bbox_pred, bbox_targets, bbox_inside_weights, bbox_outside_weights, sigma=1.0, dim=[1]):
+    """net_utils.py:122-136."""
+    s2 = sigma ** 2
+    d = bbox_inside_weights * (bbox_pred - bbox_targets)
+    ad = d.abs()
+    near = (ad < 1.0 / s2).detach().float()
+    loss = bbox_outside_weights * (d * d * (s2 / 2.0) * near + (ad - 0.5 / s2) * (1.0 - near))
+    for i in sorted(dim, reverse=True):
+        loss = loss.sum(i)
+    return loss.mean()
+
+
+def adjust_learning_rate(optimizer, decay=0.1):
+    for g in optimizer.param_groups:
+        g["lr"] = decay * g["lr"]
+
+
+def clip_gradient(model, clip_norm):
+    sq = [p.grad.norm() ** 2 for p in model.parameters() if p.requires_grad and p.grad is not None]
+    total = torch.sqrt(torch.stack(sq).sum()).item() if sq else 0.0
+    k = clip_norm / max(total, clip_norm)
+    for p in model.parameters():
+        if p.requires_grad and p.grad is not None:
+            p.grad.mul_(k)
+
+
+def save_checkpoint(state, filename):
+    torch.save(state, filename)
+
+
+def weights_normal_init(model, dev=0.01):
+    for m in (model if isinstance(model, list) else [model]):
+        for mod in m.modules():
+            w = getattr(mod, "weight", None)
+            if isinstance(w, torch.nn.Parameter) and w.dim() >= 2:
+                w.data.normal_(0.0, dev)

@@ -83,8 +83,8 @@ class _RoIAlignFn(torch.autograd.Function):
         shape, nhwc, ph, pw, scale, avg, out_nchw = ctx.meta
         B, C, H, W = shape
         gout = gout.contiguous() if out_nchw else gout.contiguous(memory_format=_CL)
-        gfeat = torch.zeros(shape, device=gout.device, dtype=torch.float32,
-                            memory_format=_CL if nhwc else torch.contiguous_format)
+        gfeat = torch.empty(shape, device=gout.device, dtype=torch.float32,
+                            memory_format=_CL if nhwc else torch.contiguous_format).zero_()
         check(lib.i2v_roi_align_bwd(ptr(gout), LAYOUT_NCHW if out_nchw else LAYOUT_NHWC, ptr(rois), rois.size(0), ph, pw,
                                     scale, avg, ptr(gfeat), LAYOUT_NHWC if nhwc else LAYOUT_NCHW, B, C, H, W, stream()),
               "roi_align_bwd")
@@ -123,8 +123,8 @@ class _RoIPoolFn(torch.autograd.Function):
         shape, nhwc, ph, pw, out_nchw = ctx.meta
         B, C, H, W = shape
         gout = gout.contiguous() if out_nchw else gout.contiguous(memory_format=_CL)
-        gfeat = torch.zeros(shape, device=gout.device, dtype=torch.float32,
-                            memory_format=_CL if nhwc else torch.contiguous_format)
+        gfeat = torch.empty(shape, device=gout.device, dtype=torch.float32,
+                            memory_format=_CL if nhwc else torch.contiguous_format).zero_()
         check(lib.i2v_roi_pool_bwd(ptr(gout), ptr(arg), LAYOUT_NCHW if out_nchw else LAYOUT_NHWC, ptr(rois),
                                    rois.size(0), ph, pw, ptr(gfeat), LAYOUT_NHWC if nhwc else LAYOUT_NCHW, B, C, H, W,
                                    stream()), "roi_pool_bwd")
@@ -237,10 +237,16 @@ def _conv_dgrad_raw(g, w, in_shape, stride, pad):
     B, Cin, H, W = in_shape
     Cout, _, KH, KW = w.shape
     dev = g.device
+    if Cout % 4:
+        # the transposed conv reduces over Cout: pad it to a float4 boundary with zero filters
+        padc = 4 - Cout % 4
+        g = torch.nn.functional.pad(g, (0, 0, 0, 0, 0, padc)).contiguous(memory_format=_CL)
+        w = torch.cat([w, w.new_zeros((padc,) + tuple(w.shape[1:]))], 0).contiguous(memory_format=_CL)
+        Cout += padc
     if stride > 1 and not (KH == 1 and KW == 1 and pad == 0):
         # zero-insertion: a strided conv's dgrad is the stride-1 dgrad of the dilated gradient map
         Hd, Wd = H + 2 * pad - KH + 1, W + 2 * pad - KW + 1
-        gd = torch.zeros((B, Cout, Hd, Wd), device=dev, dtype=torch.float32, memory_format=_CL)
+        gd = torch.empty((B, Cout, Hd, Wd), device=dev, dtype=torch.float32, memory_format=_CL).zero_()
         gd[:, :, ::stride, ::stride][:, :, :g.shape[2], :g.shape[3]] = g
         g, stride = gd, 1
     gx = torch.empty((B, Cin, H, W), device=dev, dtype=torch.float32, memory_format=_CL)

@@ -1,0 +1,249 @@
+"""Model-level parity on the GPU: the HIP path (through the reference-named modules) against the
+golden vectors the reference itself produced (tools/gen_golden.py) and against the CPU oracle.
+Tolerance for floating point: 1e-3 relative (BASELINE.json north_star), written per assert."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from i2vsgg_amd import synthetic as syn  # noqa: E402
+
+DEV = "cuda:0"
+REL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def cfg():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    from i2vsgg_amd.model.utils import config as c
+    c.cfg_from_file(c.default_cfg_file("res101"))
+    c.cfg_from_list(["ANCHOR_SCALES", "[8, 16, 32]", "ANCHOR_RATIOS", "[0.5,1,2]", "MAX_NUM_GT_BOXES", "30"])
+    return c.cfg
+
+
+def _rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def _load(module, params, prefix=""):
+    from i2vsgg_amd.model.faster_rcnn.layers import load_reference_state
+    sd = {k[len(prefix):]: v for k, v in params.items() if k.startswith(prefix)}
+    r = load_reference_state(module, sd, strict=False)
+    assert not r.unexpected_keys, r.unexpected_keys
+    return module
+
+
+def test_backbone_and_layer4_vs_reference_golden(cfg, gold):
+    from i2vsgg_amd.model.faster_rcnn.layers import C4Base, make_layer
+    g = gold("backbone_small")
+    p = syn.backbone_params(0, 101)
+    base = _load(C4Base((3, 4, 23)), p, "RCNN_base.").to(DEV)
+    left = [k for k in base.state_dict() if ("RCNN_base." + k) not in p and "num_batches" not in k]
+    assert not left, left                      # every reference key is consumed
+    im, _ = syn.frames(600, 2, 97, 131)
+    with torch.no_grad():
+        feat, feat1 = base(torch.from_numpy(im).to(DEV), tap=True)
+    assert tuple(feat.shape) == tuple(g["after_6_shape"]) and tuple(feat1.shape) == tuple(g["after_5_shape"])
+    assert _rel_err(feat.cpu().numpy(), g["after_6_full"]) < REL
+    assert _rel_err(feat1.contiguous().cpu().numpy().reshape(-1)[::53], g["after_5_sample"]) < REL
+    layer4, _ = make_layer(1024, 512, 3, 2)
+    top = _load(torch.nn.Sequential(layer4), p, "RCNN_top.").to(DEV)
+    pool5 = torch.from_numpy(np.random.default_rng(601).standard_normal((3, 1024, 7, 7), dtype=np.float32)).to(DEV)
+    with torch.no_grad():
+        h2t = top(pool5).mean(3).mean(2)
+    assert _rel_err(h2t.cpu().numpy(), g["head_to_tail_full"]) < REL
+
+
+def test_discriminators_vs_reference_golden(cfg, gold):
+    from i2vsgg_amd.model.faster_rcnn.resnet_instance_styleD_bilinear import netD_pixel, netD_style
+    g = gold("discriminators")
+    p = syn.netd_params(12)
+    dp = _load(netD_pixel(context=True), p, "netD_pixel.").to(DEV)
+    ds = _load(netD_style(context=True), p, "netD_style.").to(DEV)
+    rng = np.random.default_rng(500)
+    x = torch.from_numpy(rng.standard_normal((6, 1024, 7, 7), dtype=np.float32)).to(DEV).requires_grad_()
+    d, feat = dp(x, 0.1)
+    (0.5 * torch.mean(d ** 2) + feat.sum() * 1e-3).backward()
+    assert _rel_err(d.detach().cpu().numpy(), g["pix_d"]) < REL
+    assert _rel_err(feat.detach().cpu().numpy(), g["pix_feat"]) < REL
+    assert _rel_err(x.grad.cpu().numpy()[:, ::16], g["pix_gx"]) < REL          # includes the GRL sign / scale
+    assert _rel_err(dp.conv1.weight.grad.cpu().numpy()[:8], g["pix_gw1"]) < REL
+    assert _rel_err(dp.conv3.weight.grad.cpu().numpy(), g["pix_gw3"]) < REL
+    y = torch.from_numpy(rng.standard_normal((2, 512, 19, 32), dtype=np.float32)).to(DEV).requires_grad_()
+    d, feat = ds(y, 0.01)
+    (0.5 * torch.mean((1 - d) ** 2)).backward()
+    assert _rel_err(d.detach().cpu().numpy(), g["sty_d"]) < REL
+    assert _rel_err(feat.detach().cpu().numpy(), g["sty_feat"]) < REL
+    assert _rel_err(y.grad.cpu().numpy()[:, ::16], g["sty_gx"]) < REL
+    assert _rel_err(ds.fc_1.weight.grad.cpu().numpy()[:16], g["sty_gw1"]) < REL
+    assert _rel_err(ds.fc_2.bias.grad.cpu().numpy(), g["sty_gb2"]) < REL
+    assert _rel_err(ds.fc1.weight.grad.cpu().numpy(), g["sty_gfc1"]) < REL
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_anchor_target_layer_vs_reference_golden(cfg, gold, B):
+    from i2vsgg_amd.model.rpn.anchor_target_layer import _AnchorTargetLayer
+    g = gold("anchor_target")
+    gt, nb = syn.gt_boxes(300 + B, B, 8)
+    layer = _AnchorTargetLayer(16, cfg.ANCHOR_SCALES, cfg.ANCHOR_RATIOS)
+    np.random.seed(3)
+    out = layer((torch.zeros(B, 18, 38, 63, device=DEV), torch.from_numpy(gt).to(DEV),
+                 torch.tensor([[600, 1000, 1.0]] * B, device=DEV), torch.from_numpy(nb).to(DEV)))
+    assert np.array_equal(out[0].cpu().numpy(), g["B%d_labels" % B])            # identical sampled anchors
+    assert np.array_equal(out[2].cpu().numpy(), g["B%d_inw" % B])
+    np.testing.assert_allclose(out[3].cpu().numpy(), g["B%d_outw" % B], rtol=1e-6)
+    np.testing.assert_allclose(out[1].cpu().numpy(), g["B%d_targets" % B], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,R", [(1, 128), (2, 32)])
+def test_proposal_target_layer_vs_reference_golden(cfg, gold, B, R):
+    from i2vsgg_amd.model.rpn.proposal_target_layer_cascade import _ProposalTargetLayer
+    g = gold("proposal_target")
+    cfg.TRAIN.BATCH_SIZE = R
+    try:
+        gt, nb = syn.gt_boxes(400 + B, B, 8)
+        rois = np.zeros((B, 2000, 5), np.float32)
+        for b in range(B):
+            rois[b, :, 0] = b
+            rois[b, :, 1:] = syn.boxes(410 + b, 2000, min_side=24, max_side=380)
+            jit = np.random.default_rng(420 + b).normal(0, 8, (64, 4)).astype(np.float32)
+            rois[b, :64, 1:] = np.clip(gt[b, np.arange(64) % 8, :4] + jit, 0, [999, 599, 999, 599])
+        layer = _ProposalTargetLayer(16)
+        np.random.seed(3)
+        out = layer(torch.from_numpy(rois).to(DEV), torch.from_numpy(gt).to(DEV), torch.from_numpy(nb).to(DEV))
+    finally:
+        cfg.TRAIN.BATCH_SIZE = 128
+    for name, t in zip(("rois", "labels", "targets", "inw", "outw"), out):
+        ref = g["B%d_R%d_%s" % (B, R, name)]
+        if name == "targets":
+            np.testing.assert_allclose(t.cpu().numpy(), ref, rtol=1e-4, atol=1e-5)
+        else:
+            assert np.array_equal(t.cpu().numpy(), ref), name
+
+
+def test_rpn_train_losses_vs_reference_golden(cfg, gold):
+    from i2vsgg_amd.model.rpn.rpn import _RPN
+    g = gold("rpn_train")
+    rpn = _load(_RPN(1024), syn.rpn_params(10), "RCNN_rpn.").to(DEV)
+    rpn.train()
+    feat = torch.from_numpy(np.abs(np.random.default_rng(700).standard_normal((2, 1024, 38, 63), dtype=np.float32)))
+    gt, nb = syn.gt_boxes(701, 2, 8)
+    cfg.TRAIN.RPN_POST_NMS_TOP_N = 2000
+    np.random.seed(3)
+    rois, lc, lb = rpn(feat.to(DEV), torch.tensor([[600, 1000, 1.0]] * 2, device=DEV), torch.from_numpy(gt).to(DEV),
+                       torch.from_numpy(nb).to(DEV))
+    assert abs(lc.item() - float(g["loss_cls"])) / abs(float(g["loss_cls"])) < REL
+    assert abs(lb.item() - float(g["loss_box"])) / abs(float(g["loss_box"])) < REL
+    # proposals: same boxes up to score near-ties (softmax / conv rounding can swap neighbours):
+    # compare as sets of rows per image
+    got, ref = rois.cpu().numpy(), g["rois"]
+    assert got.shape == ref.shape
+    for b in range(2):
+        a = {tuple(np.round(r, 2)) for r in got[b]}
+        c = {tuple(np.round(r, 2)) for r in ref[b]}
+        assert len(a & c) >= 0.98 * len(c)
+    lc.backward()
+    assert rpn.RPN_cls_score.weight.grad is not None and torch.isfinite(rpn.RPN_cls_score.weight.grad).all()
+
+
+def _vrd_args(n_rel=62, n_cls=16):
+    return argparse.Namespace(num_relations=n_rel, num_classes=n_cls, emb_dim=300, use_obj_visual=True,
+                              spatial_type=2, vrd_task="pre_det")
+
+
+def test_vrd_head_vs_reference_golden(cfg, gold):
+    from i2vsgg_amd.model.faster_rcnn.faster_rcnn_SGG_emb import build_pair_tables, rasterize_masks
+    from i2vsgg_amd.model.faster_rcnn.resnet_SGG_emb import vrd
+    g = gold("vrd_head")
+    n_rel, n_cls = 62, 16
+    head = vrd(_vrd_args(), syn.word_vectors(22, n_cls), syn.word_vectors(21, n_rel))
+    _load(head, syn.vrd_params(13), "vrd.").to(DEV)
+    head.train()
+    head.dropout = False                 # fixtures use eval-mode dropout
+    anno = syn.relation_annotation(31, 8, 8, n_rel, n_cls)
+    gt, union, bounds, labels, ixs, ixo = build_pair_tables(anno, 1.0, 600.0, 1000.0, n_rel)
+    assert np.array_equal(union, g["union_boxes"])                                # pair builder, exact
+    masks = rasterize_masks(bounds, DEV)
+    assert np.array_equal(masks[:, 0].cpu().numpy(), g["dual_masks"])
+    fmap = np.abs(np.random.default_rng(32).standard_normal((1, 1024, 38, 63), dtype=np.float32))
+    fm = torch.from_numpy(fmap).to(DEV).contiguous(memory_format=torch.channels_last)
+    boxes = np.zeros((gt.shape[0], 5), np.float32)
+    boxes[:, 1:] = gt
+    relb = np.zeros((union.shape[0], 5), np.float32)
+    relb[:, 1:] = union
+    score, feat = head.forward_device(fm, torch.from_numpy(boxes).to(DEV), torch.from_numpy(relb).to(DEV), masks,
+                                      torch.from_numpy(ixs).to(DEV), torch.from_numpy(ixo).to(DEV))
+    loss = head.criterion(score, torch.from_numpy(labels).to(DEV))
+    loss.backward()
+    assert _rel_err(score.detach().cpu().numpy(), g["scores"]) < REL              # relation logits
+    assert _rel_err(feat.detach().cpu().numpy(), g["rel_feat"]) < REL
+    assert abs(loss.item() - float(g["loss"])) / float(g["loss"]) < REL
+    assert _rel_err(head.fc6.fc.bias.grad.cpu().numpy(), g["g_fc6_b"]) < REL
+    assert _rel_err(head.fc7.fc.bias.grad.cpu().numpy(), g["g_fc7_b"]) < REL
+    assert _rel_err(head.fc_rel.fc.weight.grad.cpu().numpy(), g["g_fc_rel_w"]) < REL
+    assert _rel_err(head.conv_lo[0].conv.weight.grad.cpu().numpy(), g["g_conv0_w"]) < REL
+    assert _rel_err(head.prd_sem_embeddings[0].bias.grad.cpu().numpy(), g["g_sem0_b"]) < REL
+    gw = head.fc6.fc.weight.grad
+    assert _rel_err(gw[:4, ::97].cpu().numpy(), g["g_fc6_w"]) < REL
+    assert abs(gw.double().abs().sum().item() - float(g["g_fc6_w_abs"])) / float(g["g_fc6_w_abs"]) < REL
+
+
+def test_sgg_emb_step_two_frames_equals_mean_of_single_frames(cfg):
+    """Batch semantics: loss(B frames) == mean of the per-frame losses."""
+    from i2vsgg_amd.model.faster_rcnn.resnet_SGG_emb import resnet
+    n_rel, n_cls = 62, 16
+    torch.manual_seed(0)
+    net = resnet(tuple(range(n_cls)), _vrd_args(), 50, obj_vecs=syn.word_vectors(22, n_cls),
+                 prd_vecs=syn.word_vectors(21, n_rel))
+    net.create_architecture()
+    net.vrd.dropout = False
+    net.vrd.source_gt_rels = {"f%d" % i: syn.relation_annotation(40 + i, 6, 5, n_rel, n_cls, 200, 320) for i in range(2)}
+    net.to(DEV).train()
+    im, info = syn.frames(9, 2, 200, 320)
+    imd, infod = torch.from_numpy(im).to(DEV), torch.from_numpy(info).to(DEV)
+    z = torch.zeros(2, 1, 5, device=DEV)
+    both = net(imd, infod, z, z, ["f0", "f1"])
+    one = [net(imd[i:i + 1], infod[i:i + 1], z, z, "f%d" % i) for i in range(2)]
+    assert abs(both.item() - 0.5 * (one[0].item() + one[1].item())) < 1e-5 * abs(both.item())
+    both.backward()
+    assert net.vrd.fc6.fc.weight.grad is not None
+    assert all(p.grad is None for p in net.RCNN_base.parameters())          # backbone gets no gradient (detach)
+
+
+def test_instance_styled_source_and_target_step_runs_and_is_finite(cfg):
+    """One D+G adversarial step (trainval_net_instance_styleD_bilinear.py:271-341) at small size."""
+    from i2vsgg_amd.model.faster_rcnn.resnet_instance_styleD_bilinear import resnet
+    cfg.TRAIN.BATCH_SIZE = 32
+    cfg.TRAIN.RPN_POST_NMS_TOP_N_TARGET = 32
+    try:
+        torch.manual_seed(0)
+        np.random.seed(3)
+        net = resnet(tuple(range(16)), 50)
+        net.create_architecture()
+        net.to(DEV).train()
+        im, info = syn.frames(5, 2, 320, 480)
+        gt, nb = syn.gt_boxes(6, 2, 6, im_h=320, im_w=480)
+        imd, infod = torch.from_numpy(im).to(DEV), torch.from_numpy(info).to(DEV)
+        out = net(imd, infod, torch.from_numpy(gt).to(DEV), torch.from_numpy(nb).to(DEV), target=False, eta=0.1,
+                  eta_style=0.001)
+        rois, cls_prob, bbox_pred, l1, l2, l3, l4, lab, d_inst, d_sty = out
+        assert rois.shape == (2, 32, 5) and cls_prob.shape == (2, 32, 16) and d_inst.shape == (64, 1, 7, 7)
+        loss = l1.mean() + l2.mean() + l3.mean() + l4.mean() + 0.5 * torch.mean(d_inst ** 2) + 0.5 * torch.mean(d_sty ** 2)
+        d_it, d_st = net(imd, infod, torch.zeros(2, 1, 5, device=DEV), torch.zeros(2, device=DEV), target=True,
+                         eta=0.1, eta_style=0.001)
+        loss = loss + 0.5 * torch.mean((1 - d_it) ** 2) + 0.5 * torch.mean((1 - d_st) ** 2)
+        loss.backward()
+        assert torch.isfinite(loss)
+        for name, p in net.named_parameters():
+            if p.requires_grad and not name.startswith("RCNN_base.0"):
+                assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        assert net.RCNN_base[0].weight.grad is None
+    finally:
+        cfg.TRAIN.BATCH_SIZE = 128
+        cfg.TRAIN.RPN_POST_NMS_TOP_N_TARGET = 128
