@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/sec at 600x1000, 32 ROI/frame (BASELINE.json).
+
+A "step" is one pass of the hot path over one batch of synthetic frames already resident in HBM.
+Workload at N=1 = BASELINE.json configs[1]: cfgs/res101.yml, batch = 2 frames, 32 boxes + 32
+relation pairs per frame, SGG_emb forward + backward + SGD update on one MI355X (ResNet-101 C4
+backbone forward under no_grad as the reference detaches it; relation head fwd+bwd; fp32).
+N>1: weak scaling, 2 frames per rank, one RCCL all-reduce of the vrd gradients per step.
+
+Prints ONE JSON line on rank 0 (see the contract in the task brief) with `roofline` for the
+dominant kernel (conv_igemm_f32, MFMA-bound) and `cpu_baseline` (the CPU oracle on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+FRAMES_PER_RANK = 2
+MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def cpu_baseline(threads):
+    """The CPU oracle (a port: oracle/nets.py, torch-CPU fp32) on a bounded sample of the same
+    workload: ONE 600x1000 frame through the ResNet-101 C4 backbone + the relation head forward,
+    backward and SGD update for that frame's 32 boxes + 32 pairs."""
+    import numpy as np
+    from i2vsgg_amd import synthetic as syn, train
+    from i2vsgg_amd.model.faster_rcnn.faster_rcnn_SGG_emb import build_pair_tables
+    from oracle import nets
+    torch.set_num_threads(threads)
+    p = syn.backbone_params(0, 101, top=False)
+    v = {k: t.requires_grad_() for k, t in syn.vrd_params(13).items()}
+    im, info, annos = train.synthetic_sgg_batch(1, 1)
+    gt, union, bounds, labels, ixs, ixo = build_pair_tables(annos["f0"], 1.0, 600.0, 1000.0, 62)
+    boxes = np.zeros((gt.shape[0], 5), np.float32); boxes[:, 1:] = gt
+    relb = np.zeros((union.shape[0], 5), np.float32); relb[:, 1:] = union
+    masks = np.zeros((union.shape[0], 2, 32, 32), np.float32)
+    for i in range(union.shape[0]):
+        for j in range(2):
+            x1, y1, x2, y2 = bounds[i, j]
+            masks[i, j, y1:y2, x1:x2] = 1
+    prd = syn.word_vectors(21, 62)
+    opt = torch.optim.SGD(list(v.values()), lr=1e-4, momentum=0.9, weight_decay=5e-4)
+    times = []
+    for it in range(2):
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            fmap, _ = nets.extract_feature(torch.from_numpy(im), p)
+        sc, _ = nets.vrd_head(fmap, boxes, relb, masks, ixs, ixo, prd, v, training=True)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(sc, torch.from_numpy(labels))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    return 1.0 / min(times), min(times)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", type=int, default=101)
+    a = ap.parse_args()
+
+    from i2vsgg_amd import ops, parallel, train
+    from i2vsgg_amd.model.utils import config as c
+    rank, world, dev = parallel.init_from_env()
+    assert dev.type == "cuda", "bench.py needs a GPU (the product path has no CPU fallback)"
+    assert world == a.gpus or world == 1, "launch with torchrun --nproc-per-node %d" % a.gpus
+    c.cfg_from_file(c.default_cfg_file("res101"))
+    c.cfg_from_list(["ANCHOR_SCALES", "[8, 16, 32]", "ANCHOR_RATIOS", "[0.5,1,2]", "MAX_NUM_GT_BOXES", "30",
+                     "TRAIN.BATCH_SIZE", "32", "TRAIN.RPN_POST_NMS_TOP_N_TARGET", "32"])
+
+    net = train.build_sgg_net(a.layers, device=dev)
+    step = train.SGGEmbStep(net, FRAMES_PER_RANK, seed=1 + rank, device=dev, use_graph=not a.no_graph)
+    graphed = step.capture(warmup=2)
+    for _ in range(a.warmup):
+        step()
+    parallel.barrier(dev)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    parallel.barrier(dev)
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    loss = float(step.loss)
+
+    # ---- roofline of the dominant kernel: HIP events around every implicit-GEMM launch of eager
+    #      steps (events cannot be read back from inside a graph replay), same process, same data
+    ops.PROFILE = []
+    n_prof = 3
+    for _ in range(n_prof):
+        step._body()
+    torch.cuda.synchronize(dev)
+    rec = ops.PROFILE
+    ops.PROFILE = None
+    fwd = [(e0.elapsed_time(e1) * 1e-3, fl) for e0, e1, fl, tag in rec if tag in ("fwd", "dgrad")]
+    t_conv = sum(t for t, _ in fwd)
+    f_conv = sum(f for _, f in fwd)
+    by_tag = {}
+    for e0, e1, fl, tag in rec:
+        d = by_tag.setdefault(tag, [0.0, 0.0, 0])
+        d[0] += e0.elapsed_time(e1) * 1e-3; d[1] += fl; d[2] += 1
+    achieved = f_conv / t_conv / 1e12
+
+    out = {
+        "metric": "frames/sec (600x1000, 32 ROI/frame)", "value": world * FRAMES_PER_RANK * a.steps / elapsed,
+        "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[1]: cfgs/res101.yml, SGG_emb fwd+bwd+SGD, %d frames/GPU "
+                               "600x1000, 32 boxes + 32 pairs/frame, ResNet-%d C4" % (FRAMES_PER_RANK, a.layers),
+                   "frames_per_gpu": FRAMES_PER_RANK, "global_frames": world * FRAMES_PER_RANK,
+                   "hip_graph": bool(graphed), "parallelism": "dp%d (frames sharded, RCCL all-reduce of vrd grads)" % world,
+                   "loss": loss},
+        "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (fwd + dgrad launches)", "achieved": achieved,
+                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+                     "traffic": None, "launches_per_step": len(fwd) // n_prof,
+                     "avg_launch_us": 1e6 * t_conv / max(len(fwd), 1),
+                     "gflop_per_step": f_conv / n_prof / 1e9,
+                     "by_kind": {k: {"ms_per_step": 1e3 * v[0] / n_prof, "tflops": v[1] / max(v[0], 1e-12) / 1e12,
+                                     "launches": v[2] // n_prof} for k, v in by_tag.items()}},
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        # the GPU box grants a CPU share (16 cores per GPU), not the whole host: never oversubscribe
+        threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+        fps, sec = cpu_baseline(threads)
+        out["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": threads, "kind": "port",
+                               "sample": "1 frame 600x1000: ResNet-101 C4 fwd + vrd head fwd/bwd/SGD for 32 boxes + "
+                                         "32 pairs, best of 2 (%.2f s)" % sec}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

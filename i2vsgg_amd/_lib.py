@@ -6,6 +6,10 @@ point is absent, import fails loudly.  Signatures mirror include/i2vsgg_hip.h.
 import ctypes as C
 import os
 
+# torch first: its wheel bundles the HIP runtime (libamdhip64) the process must share; loading our
+# library before torch would bind it to a second copy of the runtime and launches would fail.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libi2vsgg_hip.so")
 

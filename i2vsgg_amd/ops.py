@@ -222,14 +222,36 @@ def bbox_overlaps(boxes, gt, want_matrix=False):
 
 
 # ----------------------------------------------------------------------------- conv / linear
+PROFILE = None      # bench.py sets this to a list: (start_event, end_event, flops, tag) per GEMM launch
+
+
+class _Timed:
+    """HIP events around one launch on the launch stream (torch's current stream) when profiling."""
+
+    def __init__(self, flops, tag):
+        self.on = PROFILE is not None
+        if self.on:
+            self.rec = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), flops, tag)
+
+    def __enter__(self):
+        if self.on:
+            self.rec[0].record()
+
+    def __exit__(self, *a):
+        if self.on:
+            self.rec[1].record()
+            PROFILE.append(self.rec)
+
+
 def _conv_fwd_raw(x, w, scale, shift, res, stride, pad, flags):
     B, Cin, H, W = x.shape
     Cout, _, KH, KW = w.shape
     Ho = (H + 2 * pad - KH) // stride + 1
     Wo = (W + 2 * pad - KW) // stride + 1
     y = torch.empty((B, Cout, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=_CL)
-    check(lib.i2v_conv_fwd(ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(res), ptr(y), B, H, W, Cin, Cout, KH, KW, stride,
-                           pad, flags, stream()), "conv_fwd")
+    with _Timed(2.0 * B * Ho * Wo * Cout * KH * KW * Cin, "fwd"):
+        check(lib.i2v_conv_fwd(ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(res), ptr(y), B, H, W, Cin, Cout, KH, KW,
+                               stride, pad, flags, stream()), "conv_fwd")
     return y
 
 
@@ -251,8 +273,9 @@ def _conv_dgrad_raw(g, w, in_shape, stride, pad):
         g, stride = gd, 1
     gx = torch.empty((B, Cin, H, W), device=dev, dtype=torch.float32, memory_format=_CL)
     ws = workspace(lib.i2v_conv_dgrad_workspace_bytes(Cin, Cout, KH, KW), dev, "dgrad")
-    check(lib.i2v_conv_dgrad(ptr(g), ptr(w), ptr(gx), B, H, W, Cin, Cout, KH, KW, stride, pad, ptr(ws), ws.numel(),
-                             stream()), "conv_dgrad")
+    with _Timed(2.0 * B * g.shape[2] * g.shape[3] * Cout * KH * KW * Cin, "dgrad"):
+        check(lib.i2v_conv_dgrad(ptr(g), ptr(w), ptr(gx), B, H, W, Cin, Cout, KH, KW, stride, pad, ptr(ws), ws.numel(),
+                                 stream()), "conv_dgrad")
     return gx
 
 
@@ -260,8 +283,9 @@ def _conv_wgrad_raw(x, g, w_shape, stride, pad):
     B, Cin, H, W = x.shape
     Cout, _, KH, KW = w_shape
     gw = torch.empty(w_shape, device=x.device, dtype=torch.float32, memory_format=_CL)
-    check(lib.i2v_conv_wgrad(ptr(x), ptr(g), ptr(gw), B, H, W, Cin, Cout, KH, KW, stride, pad, 0.0, None, 0, stream()),
-          "conv_wgrad")
+    with _Timed(2.0 * B * g.shape[2] * g.shape[3] * Cout * KH * KW * Cin, "wgrad"):
+        check(lib.i2v_conv_wgrad(ptr(x), ptr(g), ptr(gw), B, H, W, Cin, Cout, KH, KW, stride, pad, 0.0, None, 0,
+                                 stream()), "conv_wgrad")
     return gw
 
 

@@ -1,0 +1,191 @@
+"""Training steps of the two reference loops, as reusable objects.
+
+``SGGEmbStep``      one step of trainval_net_SGG_emb.py:189-255 (pre_det): backbone forward (no grad,
+                    the reference detaches it), relation head forward + backward, SGD(momentum) update
+                    of the ``vrd.*`` parameters with the reference's param groups (:129-150).
+``InstanceStyleDStep`` one D+G adversarial step of trainval_net_instance_styleD_bilinear.py:262-341.
+
+Both keep their inputs resident on the device, can be captured into a HIP graph (the step is launch
+bound otherwise: ~300 small kernels), and all-reduce gradients over RCCL when world_size > 1.
+"""
+import numpy as np
+import torch
+
+from . import ops, parallel
+from . import synthetic as syn
+from .model.utils.config import cfg
+
+
+class FusedSGD:
+    """SGD(momentum) with the reference's param groups (bias: lr x2 and no weight decay when
+    cfg.TRAIN.DOUBLE_BIAS / not BIAS_DECAY) on the fused HIP kernel; one launch per tensor."""
+
+    def __init__(self, named_params, lr, momentum=None, weight_decay=None):
+        T = cfg.TRAIN
+        self.momentum = T.MOMENTUM if momentum is None else momentum
+        wd = T.WEIGHT_DECAY if weight_decay is None else weight_decay
+        self.items = []
+        for name, p in named_params:
+            if not p.requires_grad:
+                continue
+            is_bias = "bias" in name
+            self.items.append(dict(
+                name=name, p=p, m=torch.zeros_like(p),
+                lr=lr * ((T.DOUBLE_BIAS + 1) if is_bias else 1),
+                wd=(wd if T.BIAS_DECAY else 0.0) if is_bias else wd))
+
+    def params(self):
+        return [it["p"] for it in self.items]
+
+    def zero_grad(self):
+        for it in self.items:
+            it["p"].grad = None
+
+    def scale_lr(self, k):
+        for it in self.items:
+            it["lr"] *= k
+
+    @torch.no_grad()
+    def step(self):
+        for it in self.items:
+            p, g = it["p"], it["p"].grad
+            if g is None:
+                continue
+            if g.stride() != p.stride():
+                g = torch.empty_like(p).copy_(g)
+            ops.sgd_momentum_(p, g, it["m"], it["lr"], self.momentum, it["wd"])
+
+
+def synthetic_sgg_batch(seed, n_frames, n_boxes=32, n_pairs=32, n_rel=62, n_cls=16, h=600, w=1000):
+    """frames + per-frame annotation dicts (keys ``f0..``) + im_info."""
+    im, info = syn.frames(seed, n_frames, h, w)
+    annos = {"f%d" % i: syn.relation_annotation(seed * 1000 + i, n_boxes, n_pairs, n_rel, n_cls, h, w)
+             for i in range(n_frames)}
+    return im, info, annos
+
+
+class SGGEmbStep:
+    def __init__(self, net, n_frames, vrd_lr=1e-4, seed=1, device="cuda:0", h=600, w=1000, n_boxes=32, n_pairs=32,
+                 use_graph=True, data_device_resident=True):
+        from .model.faster_rcnn.faster_rcnn_SGG_emb import build_pair_tables, rasterize_masks
+        self.net, self.dev, self.n_frames = net, torch.device(device), n_frames
+        self.world = parallel.world_size()
+        head = net.vrd
+        im, info, annos = synthetic_sgg_batch(seed, n_frames, n_boxes, n_pairs, head.n_rel, head.n_obj, h, w)
+        head.source_gt_rels = annos
+        self.paths = sorted(annos, key=lambda s: int(s[1:]))
+        self.im = torch.from_numpy(im).to(self.dev)
+        self.info = torch.from_numpy(info).to(self.dev)
+        # pair tables -> static device inputs (the data layer's job; resident before the timed region)
+        boxes, relb, bounds, labels, ixs, ixo, counts, off = [], [], [], [], [], [], [], 0
+        for f, path in enumerate(self.paths):
+            gt, union, bnd, lab, s, o = build_pair_tables(annos[path], float(info[f][2]), float(info[f][0]),
+                                                          float(info[f][1]), head.n_rel)
+            b5 = np.zeros((gt.shape[0], 5), np.float32); b5[:, 0] = f; b5[:, 1:] = gt
+            r5 = np.zeros((union.shape[0], 5), np.float32); r5[:, 0] = f; r5[:, 1:] = union
+            boxes.append(b5); relb.append(r5); bounds.append(bnd); labels.append(lab)
+            ixs.append(s + off); ixo.append(o + off); counts.append(lab.shape[0]); off += gt.shape[0]
+        t = lambda a, dt=torch.float32: torch.from_numpy(np.concatenate(a)).to(self.dev, dt)
+        self.boxes, self.relb, self.labels = t(boxes), t(relb), t(labels)
+        self.ixs, self.ixo = t(ixs, torch.long), t(ixo, torch.long)
+        self.masks = rasterize_masks(np.concatenate(bounds), self.dev)
+        self.wrow = torch.cat([torch.full((c,), 1.0 / (c * len(counts))) for c in counts]).to(self.dev)
+        self.n_rows = int(self.boxes.shape[0] + self.relb.shape[0])
+        self.opt = FusedSGD([(n, p) for n, p in net.named_parameters() if n.startswith("vrd.")], vrd_lr)
+        self.loss = torch.zeros((), device=self.dev)
+        self.graph = None
+        self.use_graph = use_graph
+
+    def _body(self):
+        net = self.net
+        with torch.no_grad():
+            fmap = net.RCNN_base(self.im)
+        score, _ = net.vrd.forward_device(fmap, self.boxes, self.relb, self.masks, self.ixs, self.ixo)
+        per = torch.nn.functional.binary_cross_entropy_with_logits(score, self.labels, reduction="none").mean(1)
+        loss = (per * self.wrow).sum()
+        self.opt.zero_grad()
+        (loss / self.world).backward()
+        parallel.all_reduce_grads(self.opt.params())
+        self.opt.step()
+        self.loss.copy_(loss.detach())
+
+    def capture(self, warmup=2):
+        """Warm up eagerly on a side stream, then capture one whole step into a HIP graph."""
+        s = torch.cuda.Stream(self.dev)
+        s.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._body()
+        torch.cuda.current_stream(self.dev).wait_stream(s)
+        torch.cuda.synchronize(self.dev)
+        if not self.use_graph or self.world > 1:
+            return False           # RCCL collectives stay eager: one graph per rank buys nothing across ranks
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._body()
+            self.graph = g
+            return True
+        except Exception as e:      # report, fall back to eager launches
+            self.graph = None
+            self.graph_error = repr(e)
+            torch.cuda.synchronize(self.dev)
+            return False
+
+    def __call__(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._body()
+        return self.loss
+
+
+def build_sgg_net(layers=101, n_rel=62, n_cls=16, seed=0, device="cuda:0"):
+    """Random-init SGG_emb model of the reference architecture (no checkpoint is reachable)."""
+    import argparse
+    from .model.faster_rcnn.resnet_SGG_emb import resnet
+    torch.manual_seed(seed)
+    args = argparse.Namespace(num_relations=n_rel, num_classes=n_cls, emb_dim=300, use_obj_visual=True,
+                              spatial_type=2, vrd_task="pre_det")
+    net = resnet(tuple(range(n_cls)), args, layers, obj_vecs=syn.word_vectors(22, n_cls),
+                 prd_vecs=syn.word_vectors(21, n_rel))
+    net.create_architecture()
+    # frozen-BN statistics as a trained checkpoint would have them (gamma<1 on the block outputs keeps
+    # activations O(1) through 33 residual blocks)
+    g = torch.Generator().manual_seed(seed + 1)
+    for name, m in net.named_modules():
+        if m.__class__.__name__ == "FrozenBN":
+            c = m.weight.numel()
+            hi = 0.5 if name.endswith("bn3") else 1.0
+            m.weight.data.copy_(torch.rand(c, generator=g) * (hi - 0.2) + 0.2)
+            m.bias.data.copy_(torch.rand(c, generator=g) * 0.2 - 0.1)
+            m.running_mean.copy_(torch.rand(c, generator=g) * 0.2 - 0.1)
+            m.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+            m.invalidate()
+    return net.to(device).train()
+
+
+# FLOPs of the implicit-GEMM launches of one SGGEmbStep (algorithmic: 2*M*N*K per launch) -------------
+def conv_flops_backbone(n_frames, h=600, w=1000, blocks=(3, 4, 23)):
+    """2*MAC of conv1..layer3 for n_frames frames (166.1 GFLOP/frame at 600x1000).
+    Returns (flops, launches)."""
+    def out(n, k, s, p):
+        return (n + 2 * p - k) // s + 1
+    fl, n = 0, 0
+    H, W = out(h, 7, 2, 3), out(w, 7, 2, 3)
+    fl += 2 * H * W * 64 * 49 * 3; n += 1
+    H, W = -(-(H - 3) // 2) + 1, -(-(W - 3) // 2) + 1
+    cin = 64
+    for planes, nb, stride in ((64, blocks[0], 1), (128, blocks[1], 2), (256, blocks[2], 2)):
+        for i in range(nb):
+            s = stride if i == 0 else 1
+            Ho, Wo = out(H, 1, s, 0), out(W, 1, s, 0)
+            fl += 2 * Ho * Wo * planes * cin                       # conv1 1x1 (strided)
+            fl += 2 * Ho * Wo * planes * planes * 9                # conv2 3x3
+            fl += 2 * Ho * Wo * planes * 4 * planes                # conv3 1x1
+            n += 3
+            if i == 0:
+                fl += 2 * Ho * Wo * planes * 4 * cin               # downsample
+                n += 1
+            H, W, cin = Ho, Wo, planes * 4
+    return fl * n_frames, n
