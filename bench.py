@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", type=int, default=101)
+    ap.add_argument("--dump-launches", default="", help="write one line per GEMM launch of a profiled step")
     a = ap.parse_args()
 
     from i2vsgg_amd import ops, parallel, train
@@ -104,14 +105,20 @@ def main():
     torch.cuda.synchronize(dev)
     rec = ops.PROFILE
     ops.PROFILE = None
-    fwd = [(e0.elapsed_time(e1) * 1e-3, fl) for e0, e1, fl, tag in rec if tag in ("fwd", "dgrad")]
+    fwd = [(e0.elapsed_time(e1) * 1e-3, fl) for e0, e1, fl, tag, _d in rec if tag in ("fwd", "dgrad")]
     t_conv = sum(t for t, _ in fwd)
     f_conv = sum(f for _, f in fwd)
     by_tag = {}
-    for e0, e1, fl, tag in rec:
+    for e0, e1, fl, tag, _d in rec:
         d = by_tag.setdefault(tag, [0.0, 0.0, 0])
         d[0] += e0.elapsed_time(e1) * 1e-3; d[1] += fl; d[2] += 1
     achieved = f_conv / t_conv / 1e12
+    if a.dump_launches and rank == 0:
+        per = len(rec) // n_prof
+        with open(a.dump_launches, "w") as f:
+            for e0, e1, fl, tag, d in rec[-per:]:
+                t = e0.elapsed_time(e1) * 1e-3
+                f.write("%-6s %-40s %8.1f us %7.2f GF %6.1f TF\n" % (tag, d, t * 1e6, fl / 1e9, fl / t / 1e12))
 
     out = {
         "metric": "frames/sec (600x1000, 32 ROI/frame)", "value": world * FRAMES_PER_RANK * a.steps / elapsed,

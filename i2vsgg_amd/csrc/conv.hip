@@ -14,12 +14,16 @@
 // free.  K order inside a 8-deep step is permuted (lane half h owns k = 4h..4h+3) so a
 // fragment is ONE b128 read; A and B use the same permutation, so the sum is unchanged.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 16;          // k per LDS stage
+constexpr int BK = 16;          // k per LDS stage of the wgrad kernel
+constexpr int KTAB_MAX = 2560;  // filter-tap table entries (K/4): KH*KW*Cin <= 10240 for non-1x1 filters
+constexpr int BKS = 32;         // k per LDS stage of the forward/dgrad kernel (= floats per LDS row)
 constexpr int LDS_ROW = 20;     // floats per staged row (16 + 4 pad)
 constexpr int THREADS = 256;
 
@@ -32,6 +36,8 @@ struct ConvP {
     int ostride;                 // output pixel stride (dgrad of strided 1x1): y is (B,Ho*os..,Wo*os..,N)
     int Hy, Wy;                  // spatial size of the y buffer
     int lgCin;                   // log2(Cin) if power of two else -1
+    int force_tile;              // >=0: tile config override (tuning / tests), -1: cost model
+    unsigned x_bytes, w_bytes;   // sizes of x and w for the buffer descriptors (< 2 GiB each)
 };
 
 __device__ inline void split_k(const ConvP& p, int k, int& ky, int& kx, int& c) {
@@ -42,16 +48,26 @@ __device__ inline void split_k(const ConvP& p, int k, int& ky, int& kx, int& c) 
     else { ky = kpos / p.KW; kx = kpos - ky * p.KW; }
 }
 
-template <int BM, int BN, int WM, int WN>
+// Tile = (WAVES_M*TM*16) x (WAVES_N*TN*16) outputs, 4 waves, v_mfma_f32_16x16x4_f32.
+// A 32-deep K stage is staged per buffer; a lane (i = lane&15, g = lane>>4) owns k = 4g..4g+3 of
+// each 16-deep half, so one ds_read_b128 feeds four MFMAs (A and B use the same permutation).
+// LDS rows are 128 B, unpadded, with the 16-B column XOR-swizzled by (row>>1)&7: the four
+// 16-lane groups of a ds_read_b128 then touch 16 distinct slots of the 256-B bank row.
+template <int WAVES_M, int WAVES_N, int TM, int TN>
 __global__ void __launch_bounds__(THREADS)
 conv_igemm_f32(const ConvP p) {
-    constexpr int WAVES_N = BN / WN;
-    constexpr int MI = WM / 32, NI = WN / 32;
-    constexpr int A_LD = BM * 4 / THREADS, B_LD = BN * 4 / THREADS;
-    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per workgroup");
-    static_assert(A_LD >= 1 && B_LD >= 1, "tile too small");
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_ROW];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_ROW];
+    constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
+    constexpr int A_LD = (BM * 8 + THREADS - 1) / THREADS, B_LD = (BN * 8 + THREADS - 1) / THREADS;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    // one LDS block: [A stage 0 | A stage 1 | B stage 0 | B stage 1 | tap table]; after the K loop the
+    // same bytes stage the BM x BN output tile (row stride BN+4 floats) for a coalesced epilogue
+    constexpr int STAGE_FLOATS = 2 * (BM + BN) * BKS + KTAB_MAX;
+    constexpr int CROW = BN + 4;
+    constexpr int SMEM_FLOATS = STAGE_FLOATS > BM * CROW ? STAGE_FLOATS : BM * CROW;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    float (*As)[BM * BKS] = reinterpret_cast<float (*)[BM * BKS]>(smem);
+    float (*Bs)[BN * BKS] = reinterpret_cast<float (*)[BN * BKS]>(smem + 2 * BM * BKS);
+    unsigned* ktab = reinterpret_cast<unsigned*>(smem + 2 * (BM + BN) * BKS);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -61,128 +77,221 @@ conv_igemm_f32(const ConvP p) {
     const int kbeg = blockIdx.y * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
 
-    // per-thread gather metadata of its A rows (fixed over the K loop)
-    int a_iy0[A_LD], a_ix0[A_LD];
-    long long a_base[A_LD];
-    bool a_ok[A_LD];
+    // staging roles: slot = tid + q*256 -> row = slot>>3, 16-B column = slot&7 (= tid&7 for every q)
+    const int kc = tid & 7, kg = kc * 4;
+    const bool is1x1 = (p.KH == 1 && p.KW == 1 && p.pad == 0);
+    // filter-tap table (only for KHxKW > 1): entry e = k/4 -> (input offset of tap (ky,kx,c)) << 6 | kpos.
+    // Built once per workgroup, so the K loop has no integer division and no per-tap bounds math.
+    if (!is1x1) {
+        for (int e = tid; e < (p.K >> 2); e += THREADS) {
+            int ky, kx, c;
+            split_k(p, e << 2, ky, kx, c);
+            ktab[e] = (unsigned)(((ky * p.W + kx) * p.Cin + c) << 6) | (unsigned)(ky * p.KW + kx);
+        }
+    }
+    // Loads go through buffer resources: a masked lane gets an out-of-range offset and the hardware
+    // returns zeros -- no branches, no select-of-loads, 32-bit offsets instead of 64-bit pointers.
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    int a_off[A_LD];                  // float index of x[b][iy0][ix0][0] (may be negative: padded taps are masked)
+    unsigned long long a_mask[A_LD];  // bit kpos: tap (ky,kx) of this output pixel reads inside the image
 #pragma unroll
     for (int q = 0; q < A_LD; ++q) {
-        const int slot = tid + q * THREADS;
-        const int m = m0 + (slot >> 2);
-        a_ok[q] = m < p.M;
-        const int mm = a_ok[q] ? m : 0;
+        const int row = (tid >> 3) + q * (THREADS / 8);
+        const int m = m0 + row;
+        const bool ok = row < BM && m < p.M;
+        const int mm = ok ? m : 0;
         const int ox = mm % p.Wo, t = mm / p.Wo, oy = t % p.Ho, b = t / p.Ho;
-        a_iy0[q] = oy * p.stride - p.pad;
-        a_ix0[q] = ox * p.stride - p.pad;
-        a_base[q] = (long long)b * p.H * p.W * p.Cin;
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+        a_off[q] = ((b * p.H + iy0) * p.W + ix0) * p.Cin;
+        unsigned long long mask = 0;
+        if (ok) {
+            if (is1x1) mask = 1;
+            else
+                for (int ky = 0; ky < p.KH; ++ky)
+                    for (int kx = 0; kx < p.KW; ++kx)
+                        if (iy0 + ky >= 0 && iy0 + ky < p.H && ix0 + kx >= 0 && ix0 + kx < p.W)
+                            mask |= 1ull << (ky * p.KW + kx);
+        }
+        a_mask[q] = mask;
     }
-    const int kg = (tid & 3) * 4;          // this thread's k offset inside a BK stage
-    long long b_off[B_LD];
-    bool b_ok[B_LD];
+    int b_off[B_LD];
 #pragma unroll
     for (int q = 0; q < B_LD; ++q) {
-        const int n = n0 + ((tid + q * THREADS) >> 2);
-        b_ok[q] = n < p.N;
-        b_off[q] = (long long)(b_ok[q] ? n : 0) * p.K;
+        const int row = (tid >> 3) + q * (THREADS / 8);
+        const int n = n0 + row;
+        b_off[q] = (row < BN && n < p.N) ? n * p.K : -1;
     }
+    if (!is1x1) __syncthreads();      // ktab visible
 
+    // register prefetch: the loads of stage k+1 are in flight while stage k computes.  (A second
+    // register set, two stages in flight, measured slower: the extra VGPRs cost more occupancy than
+    // the deeper prefetch hides.)
+    constexpr unsigned OOB = 0xFFFFFFF0u;
     float4 ra[A_LD], rb[B_LD];
     auto gload = [&](int k0) {
         const int k = k0 + kg;
         const bool kin = k < kend;
-        int ky = 0, kx = 0, c = 0;
-        if (kin) split_k(p, k, ky, kx, c);
-#pragma unroll
-        for (int q = 0; q < A_LD; ++q) {
-            const int iy = a_iy0[q] + ky, ix = a_ix0[q] + kx;
-            const bool ok = kin && a_ok[q] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            ra[q] = ok ? *(const float4*)(p.x + a_base[q] + ((long long)iy * p.W + ix) * p.Cin + c)
-                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        int delta = k, kpos = 0;
+        if (!is1x1) {
+            const unsigned e = ktab[kin ? (k >> 2) : 0];
+            delta = (int)(e >> 6);
+            kpos = (int)(e & 63u);
         }
 #pragma unroll
-        for (int q = 0; q < B_LD; ++q)
-            rb[q] = (kin && b_ok[q]) ? *(const float4*)(p.w + b_off[q] + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < A_LD; ++q) {
+            const bool ok = kin && ((a_mask[q] >> kpos) & 1ull);
+            const unsigned off = ok ? (unsigned)(a_off[q] + delta) * 4u : OOB;
+            ra[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+        }
+#pragma unroll
+        for (int q = 0; q < B_LD; ++q) {
+            const unsigned off = (kin && b_off[q] >= 0) ? (unsigned)(b_off[q] + k) * 4u : OOB;
+            rb[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
+        }
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int S) {
 #pragma unroll
-        for (int q = 0; q < A_LD; ++q)
-            *(float4*)&As[buf][((tid + q * THREADS) >> 2) * LDS_ROW + kg] = ra[q];
+        for (int q = 0; q < A_LD; ++q) {
+            const int row = (tid >> 3) + q * (THREADS / 8);
+            if (row < BM) *(float4*)&As[S][row * BKS + ((kc ^ ((row >> 1) & 7)) << 2)] = ra[q];
+        }
 #pragma unroll
-        for (int q = 0; q < B_LD; ++q)
-            *(float4*)&Bs[buf][((tid + q * THREADS) >> 2) * LDS_ROW + kg] = rb[q];
+        for (int q = 0; q < B_LD; ++q) {
+            const int row = (tid >> 3) + q * (THREADS / 8);
+            if (row < BN) *(float4*)&Bs[S][row * BKS + ((kc ^ ((row >> 1) & 7)) << 2)] = rb[q];
+        }
     };
 
-    f32x16 acc[MI][NI];
+    f32x4 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int fr = lane & 31, fh = lane >> 5;
+    const int fr = lane & 15, fg = lane >> 4;
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float4 av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = (wm * TM + i) * 16 + fr;
+                av[i] = *(const float4*)&As[buf][row * BKS + (((s * 4 + fg) ^ ((row >> 1) & 7)) << 2)];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = (wn * TN + j) * 16 + fr;
+                bv[j] = *(const float4*)&Bs[buf][row * BKS + (((s * 4 + fg) ^ ((row >> 1) & 7)) << 2)];
+            }
+            // k component outermost: consecutive MFMAs hit DIFFERENT accumulators (the 16x16x4 f32
+            // MFMA issues every 32 cycles but a dependent one waits 40)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float a = t == 0 ? av[i].x : t == 1 ? av[i].y : t == 2 ? av[i].z : av[i].w;
+                        const float b = t == 0 ? bv[j].x : t == 1 ? bv[j].y : t == 2 ? bv[j].z : bv[j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i][j], 0, 0, 0);
+                    }
+        }
+    };
+    // residual tile: issued before the K loop so that its latency hides behind the MFMAs (small
+    // tiles only: C_LD float4 registers per thread)
+    constexpr int C_LD = (BM * (BN / 4) + THREADS - 1) / THREADS;
+    constexpr bool PREFETCH_RES = C_LD <= 8;
+    const bool vec_epi = p.splitk <= 1 && (p.N & 3) == 0;
+    float4 rres[PREFETCH_RES ? C_LD : 1];
+    if (PREFETCH_RES && vec_epi && (p.flags & I2V_EPI_RESIDUAL) && p.ostride == 1) {
+#pragma unroll
+        for (int it = 0; it < C_LD; ++it) {
+            const int e = tid + it * THREADS;
+            const int row = e / (BN / 4), col = (e % (BN / 4)) * 4;
+            const int m = m0 + row, n = n0 + col;
+            rres[it] = (e < BM * (BN / 4) && m < p.M && n < p.N) ? *(const float4*)(p.res + (long long)m * p.N + n)
+                                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     gload(kbeg);
     sstore(0);
     __syncthreads();
     int buf = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        const bool more = k0 + BK < kend;
-        if (more) gload(k0 + BK);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float4 av[MI], bv[NI];
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-                av[i] = *(const float4*)&As[buf][(wm * WM + i * 32 + fr) * LDS_ROW + s * 8 + fh * 4];
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-                bv[j] = *(const float4*)&Bs[buf][(wn * WN + j * 32 + fr) * LDS_ROW + s * 8 + fh * 4];
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
-                }
-        }
+    for (int k0 = kbeg; k0 < kend; k0 += BKS) {
+        const bool more = k0 + BKS < kend;
+        if (more) gload(k0 + BKS);
+        compute(buf);
         if (more) sstore(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
 
-    // epilogue: C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // epilogue.  C/D map of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + r.  The tile goes
+    // through LDS so that global stores (and the residual loads) are whole 16-B-per-lane rows
+    // instead of 64-B fragments of a line.  (The last loop iteration ended with a barrier: every
+    // wave is done reading the stage buffers.)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                smem[((wm * TM + i) * 16 + 4 * fg + r) * CROW + (wn * TN + j) * 16 + fr] = acc[i][j][r];
+    __syncthreads();
     const bool split = p.splitk > 1;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int n = n0 + wn * WN + j * 32 + fr;
-        if (n >= p.N) continue;
-        float sc = 1.f, sh = 0.f;
-        if (!split) {
-            if (p.flags & I2V_EPI_SCALE) sc = p.scale[n];
-            if (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) sh = p.shift[n];
+    auto out_index = [&](int m) -> long long {
+        if (p.ostride == 1) return (long long)m * p.N;
+        const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
+        return (((long long)b * p.Hy + oy * p.ostride) * p.Wy + ox * p.ostride) * p.N;
+    };
+    if (split) {                      // fp32 atomics: 64 lanes = 256 contiguous bytes per instruction
+        for (int e = tid; e < BM * BN; e += THREADS) {
+            const int row = e / BN, col = e % BN;
+            const int m = m0 + row, n = n0 + col;
+            if (m < p.M && n < p.N) atomicAdd(p.y + out_index(m) + n, smem[row * CROW + col]);
         }
+    } else if ((p.N & 3) == 0) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (m >= p.M) continue;
-                long long o;
-                if (p.ostride == 1) {
-                    o = (long long)m * p.N + n;
-                } else {
-                    const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
-                    o = (((long long)b * p.Hy + oy * p.ostride) * p.Wy + ox * p.ostride) * p.N + n;
-                }
-                float v = acc[i][j][r];
-                if (split) { atomicAdd(p.y + o, v); continue; }
-                v = v * sc + sh;
-                if (p.flags & I2V_EPI_RESIDUAL) v += p.res[o];
-                if (p.flags & I2V_EPI_RELU) v = fmaxf(v, 0.f);
-                p.y[o] = v;
+        for (int it = 0; it < C_LD; ++it) {
+            const int e = tid + it * THREADS;
+            if (e >= BM * (BN / 4)) break;
+            const int row = e / (BN / 4), col = (e % (BN / 4)) * 4;
+            const int m = m0 + row, n = n0 + col;
+            if (m >= p.M || n >= p.N) continue;           // N % 4 == 0: a float4 never straddles N
+            float4 v = *(const float4*)&smem[row * CROW + col];
+            if (p.flags & I2V_EPI_SCALE) {
+                const float4 sc = *(const float4*)(p.scale + n);
+                v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
             }
+            if (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) {
+                const float4 sh = *(const float4*)(p.shift + n);
+                v.x += sh.x; v.y += sh.y; v.z += sh.z; v.w += sh.w;
+            }
+            const long long o = out_index(m) + n;
+            if (p.flags & I2V_EPI_RESIDUAL) {
+                const float4 rr = (PREFETCH_RES && p.ostride == 1) ? rres[PREFETCH_RES ? it : 0]
+                                                                   : *(const float4*)(p.res + o);
+                v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+            }
+            if (p.flags & I2V_EPI_RELU) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            *(float4*)(p.y + o) = v;
+        }
+    } else {
+        for (int e = tid; e < BM * BN; e += THREADS) {
+            const int row = e / BN, col = e % BN;
+            const int m = m0 + row, n = n0 + col;
+            if (m >= p.M || n >= p.N) continue;
+            float v = smem[row * CROW + col];
+            if (p.flags & I2V_EPI_SCALE) v *= p.scale[n];
+            if (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) v += p.shift[n];
+            const long long o = out_index(m) + n;
+            if (p.flags & I2V_EPI_RESIDUAL) v += p.res[o];
+            if (p.flags & I2V_EPI_RELU) v = fmaxf(v, 0.f);
+            p.y[o] = v;
+        }
     }
 }
 
@@ -230,43 +339,81 @@ inline int ilog2_exact(int v) {
 }
 
 constexpr int NUM_CU = 256;
+int g_force_tile = -1;           // i2v_conv_set_tile(): tuning hook
 
-template <int BM, int BN, int WM, int WN>
+template <int WAVES_M, int WAVES_N, int TM, int TN>
 void launch_tile(const ConvP& p, hipStream_t st) {
+    constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
     const int tiles = i2v_cdiv(p.M, BM) * i2v_cdiv(p.N, BN);
-    conv_igemm_f32<BM, BN, WM, WN><<<dim3(tiles, p.splitk), THREADS, 0, st>>>(p);
+    conv_igemm_f32<WAVES_M, WAVES_N, TM, TN><<<dim3(tiles, p.splitk), THREADS, 0, st>>>(p);
 }
+
+struct TileCfg { int bm, bn; float eff; };
+// eff: relative MFMA efficiency of the tile shape (operand reuse per LDS byte), from measurements
+constexpr TileCfg kTiles[] = {{128, 128, 1.00f}, {128, 64, 0.97f}, {96, 64, 0.95f}, {80, 64, 0.95f}, {64, 64, 0.93f},
+                              {32, 64, 0.80f}};
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 int run_conv(ConvP p, hipStream_t st) {
     p.M = p.B * p.Ho * p.Wo;
     p.N = p.Cout;
     p.K = p.KH * p.KW * p.Cin;
     p.lgCin = ilog2_exact(p.Cin);
-    // tile choice: the largest tile that still gives every CU about two workgroups
-    auto ntiles = [&](int bm, int bn) { return (long long)i2v_cdiv(p.M, bm) * i2v_cdiv(p.N, bn); };
-    int cfg;
-    if (p.N > 64 && ntiles(128, 128) >= 2 * NUM_CU) cfg = 0;
-    else if (ntiles(128, 64) >= 2 * NUM_CU) cfg = 1;
-    else cfg = 2;
-    const long long tiles = cfg == 0 ? ntiles(128, 128) : cfg == 1 ? ntiles(128, 64) : ntiles(64, 64);
-    // split-K when the grid cannot fill the chip and K is deep (skinny vrd FCs, layer4)
-    int splitk = 1;
-    const int ksteps = i2v_cdiv(p.K, BK);
-    if (tiles < NUM_CU && ksteps >= 16 && p.ostride == 1) {
-        splitk = (int)((2 * NUM_CU + tiles - 1) / tiles);
-        splitk = splitk > ksteps / 8 ? ksteps / 8 : splitk;
-        if (splitk < 1) splitk = 1;
+    if (!(p.KH == 1 && p.KW == 1 && p.pad == 0)) {
+        if (p.K > KTAB_MAX * 4 || p.KH * p.KW > 64 || ((long long)(p.KH * p.W + p.KW) * p.Cin) >= (1ll << 26)) {
+            i2v_set_error("conv: filter %dx%dx%d too large for the tap table", p.KH, p.KW, p.Cin);
+            return I2V_ERR_UNSUPPORTED;
+        }
     }
+    const long long xb = (long long)p.B * p.H * p.W * p.Cin * 4, wb = (long long)p.N * p.K * 4;
+    if (xb >= (1ll << 31) || wb >= (1ll << 31)) {
+        i2v_set_error("conv: operand larger than 2 GiB (32-bit buffer offsets)");
+        return I2V_ERR_UNSUPPORTED;
+    }
+    p.x_bytes = (unsigned)xb;
+    p.w_bytes = (unsigned)wb;
+    const int force = p.force_tile;
+    const int ksteps = i2v_cdiv(p.K, BKS);
+    // tile + split-K choice: minimise (rounds over the 256 CUs) x (MACs per workgroup) / efficiency.
+    // The M of a 600x1000 frame pair at stride 16 is only 4788 rows, so wave quantisation decides
+    // the shape; skinny GEMMs (vrd FCs: M = 128 rows) fill the chip by splitting K.
+    auto plan = [&](int c, int& splitk) {
+        const long long t = (long long)i2v_cdiv(p.M, kTiles[c].bm) * i2v_cdiv(p.N, kTiles[c].bn);
+        splitk = 1;
+        if (t < NUM_CU && ksteps >= 8 && p.ostride == 1) {
+            splitk = (int)((2 * NUM_CU + t - 1) / t);
+            splitk = splitk > ksteps / 4 ? ksteps / 4 : splitk;
+            if (splitk < 1) splitk = 1;
+        }
+        const long long blocks = t * splitk;
+        const long long rounds = (blocks + NUM_CU - 1) / NUM_CU;
+        // beyond ~4 rounds several workgroups share a CU and the tail matters less
+        const double r = rounds <= 4 ? (double)rounds : (double)blocks / NUM_CU + 0.5;
+        double cost = r * kTiles[c].bm * kTiles[c].bn * (double)i2v_cdiv(ksteps, splitk) / kTiles[c].eff;
+        if (splitk > 1) cost *= 1.05;     // memset + atomics + separate epilogue pass
+        return cost;
+    };
+    int cfg = 0, splitk = 1;
+    double best = 1e300;
+    for (int c = 0; c < kNumTiles; ++c) {
+        int sk;
+        const double cost = plan(c, sk);
+        if (cost < best) { best = cost; cfg = c; splitk = sk; }
+    }
+    if (force >= 0 && force < kNumTiles) { cfg = force; plan(cfg, splitk); }
     p.splitk = splitk;
-    p.k_per_split = i2v_cdiv(ksteps, splitk) * BK;
+    p.k_per_split = i2v_cdiv(ksteps, splitk) * BKS;
     p.splitk = i2v_cdiv(p.K, p.k_per_split);
     const long long ytotal = (long long)p.M * p.N;
-    if (p.splitk > 1) {
-        hipMemsetAsync(p.y, 0, (size_t)ytotal * sizeof(float), st);
+    if (p.splitk > 1) hipMemsetAsync(p.y, 0, (size_t)ytotal * sizeof(float), st);
+    switch (cfg) {
+        case 0: launch_tile<2, 2, 4, 4>(p, st); break;
+        case 1: launch_tile<2, 2, 4, 2>(p, st); break;
+        case 2: launch_tile<2, 2, 3, 2>(p, st); break;
+        case 3: launch_tile<1, 4, 5, 1>(p, st); break;
+        case 4: launch_tile<2, 2, 2, 2>(p, st); break;
+        default: launch_tile<2, 2, 1, 2>(p, st); break;
     }
-    if (cfg == 0) launch_tile<128, 128, 64, 64>(p, st);
-    else if (cfg == 1) launch_tile<128, 64, 64, 32>(p, st);
-    else launch_tile<64, 64, 32, 32>(p, st);
     if (p.splitk > 1 && (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS | I2V_EPI_RESIDUAL | I2V_EPI_RELU))) {
         if (p.N % 4 == 0)
             conv_epilogue_kernel<<<(int)fmin((double)i2v_cdiv(ytotal / 4, 256), 4096.0), 256, 0, st>>>(
@@ -495,6 +642,11 @@ static int check_conv(const char* who, const void* a, const void* b, const void*
     return I2V_OK;
 }
 
+extern "C" int32_t i2v_conv_set_tile(int32_t cfg) {
+    g_force_tile = cfg;
+    return I2V_OK;
+}
+
 extern "C" int32_t i2v_conv_fwd(const float* x, const float* w, const float* scale, const float* shift,
                                 const float* res, float* y, int32_t B, int32_t H, int32_t W, int32_t Cin,
                                 int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad, int32_t flags,
@@ -510,6 +662,7 @@ extern "C" int32_t i2v_conv_fwd(const float* x, const float* w, const float* sca
     p.Ho = (H + 2 * pad - KH) / stride + 1;
     p.Wo = (W + 2 * pad - KW) / stride + 1;
     p.flags = flags; p.ostride = 1; p.Hy = p.Ho; p.Wy = p.Wo;
+    p.force_tile = g_force_tile;
     rc = run_conv(p, (hipStream_t)stream);
     if (rc) return rc;
     I2V_CHECK_LAUNCH("conv_fwd");
@@ -548,6 +701,7 @@ extern "C" int32_t i2v_conv_dgrad(const float* gy, const float* w, float* gx, in
     p.B = B; p.H = Ho; p.W = Wo; p.Cin = Cout; p.Cout = Cin; p.KH = KH; p.KW = KW; p.stride = 1;
     p.pad = KH - 1 - pad;
     p.flags = 0;
+    p.force_tile = g_force_tile;
     if (stride == 1) {
         p.Ho = H; p.Wo = W; p.ostride = 1; p.Hy = H; p.Wy = W;
         I2V_CHECK_ARG(KW - 1 - pad >= 0 && KH == KW, "conv_dgrad: unsupported padding");

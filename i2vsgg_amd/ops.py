@@ -228,10 +228,10 @@ PROFILE = None      # bench.py sets this to a list: (start_event, end_event, flo
 class _Timed:
     """HIP events around one launch on the launch stream (torch's current stream) when profiling."""
 
-    def __init__(self, flops, tag):
+    def __init__(self, flops, tag, desc=""):
         self.on = PROFILE is not None
         if self.on:
-            self.rec = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), flops, tag)
+            self.rec = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), flops, tag, desc)
 
     def __enter__(self):
         if self.on:
@@ -249,7 +249,8 @@ def _conv_fwd_raw(x, w, scale, shift, res, stride, pad, flags):
     Ho = (H + 2 * pad - KH) // stride + 1
     Wo = (W + 2 * pad - KW) // stride + 1
     y = torch.empty((B, Cout, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=_CL)
-    with _Timed(2.0 * B * Ho * Wo * Cout * KH * KW * Cin, "fwd"):
+    with _Timed(2.0 * B * Ho * Wo * Cout * KH * KW * Cin, "fwd",
+                "M%d N%d K%d (%dx%d s%d)" % (B * Ho * Wo, Cout, KH * KW * Cin, KH, KW, stride)):
         check(lib.i2v_conv_fwd(ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(res), ptr(y), B, H, W, Cin, Cout, KH, KW,
                                stride, pad, flags, stream()), "conv_fwd")
     return y
@@ -273,7 +274,8 @@ def _conv_dgrad_raw(g, w, in_shape, stride, pad):
         g, stride = gd, 1
     gx = torch.empty((B, Cin, H, W), device=dev, dtype=torch.float32, memory_format=_CL)
     ws = workspace(lib.i2v_conv_dgrad_workspace_bytes(Cin, Cout, KH, KW), dev, "dgrad")
-    with _Timed(2.0 * B * g.shape[2] * g.shape[3] * Cout * KH * KW * Cin, "dgrad"):
+    with _Timed(2.0 * B * g.shape[2] * g.shape[3] * Cout * KH * KW * Cin, "dgrad",
+                "M%d N%d K%d" % (B * H * W, Cin, KH * KW * Cout)):
         check(lib.i2v_conv_dgrad(ptr(g), ptr(w), ptr(gx), B, H, W, Cin, Cout, KH, KW, stride, pad, ptr(ws), ws.numel(),
                                  stream()), "conv_dgrad")
     return gx
@@ -283,7 +285,8 @@ def _conv_wgrad_raw(x, g, w_shape, stride, pad):
     B, Cin, H, W = x.shape
     Cout, _, KH, KW = w_shape
     gw = torch.empty(w_shape, device=x.device, dtype=torch.float32, memory_format=_CL)
-    with _Timed(2.0 * B * g.shape[2] * g.shape[3] * Cout * KH * KW * Cin, "wgrad"):
+    with _Timed(2.0 * B * g.shape[2] * g.shape[3] * Cout * KH * KW * Cin, "wgrad",
+                "N%d K%d M%d" % (Cout, KH * KW * Cin, B * g.shape[2] * g.shape[3])):
         check(lib.i2v_conv_wgrad(ptr(x), ptr(g), ptr(gw), B, H, W, Cin, Cout, KH, KW, stride, pad, 0.0, None, 0,
                                  stream()), "conv_wgrad")
     return gw

@@ -135,6 +135,8 @@ int32_t i2v_bbox_overlaps(const float* boxes, int32_t box_stride, int32_t box_of
 int32_t i2v_conv_fwd(const float* x, const float* w, const float* scale, const float* shift, const float* res,
                      float* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                      int32_t KH, int32_t KW, int32_t stride, int32_t pad, int32_t flags, void* stream);
+/* tuning hook: force the tile shape of subsequent conv launches (0..5), -1 = cost model */
+int32_t i2v_conv_set_tile(int32_t cfg);
 size_t  i2v_conv_dgrad_workspace_bytes(int32_t Cin, int32_t Cout, int32_t KH, int32_t KW);
 int32_t i2v_conv_dgrad(const float* gy, const float* w, float* gx, int32_t B, int32_t H, int32_t W,
                        int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,

@@ -368,3 +368,19 @@ def test_dstyle_pool(ops):
 def test_cpu_tensor_is_rejected_loudly(ops):
     with pytest.raises(Exception):
         ops.roi_align(torch.zeros(1, 4, 8, 8), torch.zeros(1, 5), 7, 7, 1 / 16.0)
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+def test_conv_every_tile_shape(ops, tile):
+    """Each (BM x BN) instantiation of conv_igemm_f32, forced through the tuning hook, incl. ragged M/N/K edges."""
+    from i2vsgg_amd import _lib
+    rng = np.random.default_rng(tile)
+    x = rng.standard_normal((2, 72, 13, 17), dtype=np.float32)          # M = 442 (ragged), K = 648 (not /32)
+    w = (rng.standard_normal((100, 72, 3, 3), dtype=np.float32) / 25).astype(np.float32)
+    ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), padding=1)
+    _lib.lib.i2v_conv_set_tile(tile)
+    try:
+        y = ops.conv2d(torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV), pad=1)
+    finally:
+        _lib.lib.i2v_conv_set_tile(-1)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
