@@ -1,0 +1,128 @@
+"""CPU tests of the host-side logic: config surface, roi_data_layer API, frame sharding, and the
+world_size-2 gloo rehearsal of the gradient exchange."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cfg_surface_matches_reference_yaml_and_rules():
+    from i2vsgg_amd.model.utils import config as c
+    c.cfg_from_file(c.default_cfg_file("res101"))
+    assert c.cfg.EXP_DIR == "res101" and c.cfg.TRAIN.BG_THRESH_LO == 0.0 and c.cfg.TRAIN.RPN_BATCHSIZE == 256
+    c.cfg_from_list(["ANCHOR_SCALES", "[8, 16, 32]", "ANCHOR_RATIOS", "[0.5,1,2]", "MAX_NUM_GT_BOXES", "30"])
+    assert c.cfg.MAX_NUM_GT_BOXES == 30
+    with pytest.raises(KeyError):
+        c._merge_a_into_b({"NOT_A_KEY": 1}, c.cfg)
+    with pytest.raises(ValueError):
+        c._merge_a_into_b({"TRAIN": {"BATCH_SIZE": "many"}}, c.cfg)
+    with pytest.raises(AssertionError):
+        c.cfg_from_list(["TRAIN.BATCH_SIZE", "1.5"])
+    assert c.cfg.TRAIN.RPN_PRE_NMS_TOP_N == 12000 and c.cfg.TEST.RPN_POST_NMS_TOP_N == 300
+
+
+def test_generate_anchors_matches_reference_golden(gold):
+    from i2vsgg_amd.model.rpn.generate_anchors import generate_anchors, shifted_anchors
+    g = gold("anchors")
+    base = generate_anchors(scales=np.array([8, 16, 32]), ratios=np.array([0.5, 1, 2]))
+    assert np.array_equal(base, g["base"])
+    assert np.array_equal(shifted_anchors(38, 63, 16, base), g["grid_38x63"])
+
+
+def test_roi_data_layer_api():
+    from i2vsgg_amd.model.utils import config as c
+    from i2vsgg_amd.model.utils.net_utils import sampler
+    from i2vsgg_amd.roi_data_layer.roidb import combined_roidb
+    from i2vsgg_amd.roi_data_layer.roibatchLoader import roibatchLoader
+    c.cfg.TRAIN.USE_FLIPPED = True
+    imdb, roidb, ratio_list, ratio_index = combined_roidb("synthetic_6")
+    assert len(roidb) == 12 and imdb.num_classes == 16
+    for key in ("boxes", "gt_classes", "gt_overlaps", "flipped", "img_id", "image", "width", "height", "max_classes",
+                "max_overlaps", "need_crop"):
+        assert key in roidb[0]
+    assert roidb[0]["boxes"].dtype == np.uint16 and roidb[6]["flipped"]
+    assert np.all(np.diff(ratio_list) >= 0)
+    ds = roibatchLoader(roidb, ratio_list, ratio_index, 2, imdb.num_classes, training=True)
+    np.random.seed(3)
+    data, im_info, gt, n = ds[0]
+    assert data.dim() == 3 and data.size(0) == 3 and im_info.shape == (3,)
+    assert min(data.shape[1:]) >= 600 and gt.shape == (c.cfg.MAX_NUM_GT_BOXES, 5) and n == 8
+    assert float(im_info[0]) == data.size(1) and float(im_info[1]) == data.size(2)
+    assert torch.all(gt[n:] == 0) and torch.all(gt[:n, 4] >= 1)
+    test = roibatchLoader(roidb, ratio_list, ratio_index, 1, imdb.num_classes, training=False)
+    d, info, g, nb, path = test[1]
+    assert nb == 0 and g.tolist() == [1, 1, 1, 1, 1] and path.startswith("synthetic://")
+    roidb[int(ratio_index[0])]["need_crop"] = 1
+    assert isinstance(ds[0], torch.Tensor) and ds[0].numel() == 3        # bare im_info, as the reference returns
+    idx = list(iter(sampler(10, 4)))
+    assert sorted(int(i) for i in idx) == list(range(10)) and [int(i) for i in idx[-2:]] == [8, 9]
+
+
+def test_shard_frames_is_a_partition():
+    from i2vsgg_amd.parallel import shard_frames
+    for n, w in ((16, 8), (32, 8), (5, 2), (3, 4)):
+        spans = [shard_frames(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under i2vsgg_amd/ or bench.py's GPU path may use it."""
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "i2vsgg_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                if "import oracle" in text or "from oracle" in text or "oracle/" in text:
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
+
+
+WORKER = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from i2vsgg_amd import parallel
+rk, world, dev = parallel.init_from_env("gloo")
+assert world == 2 and dev.type == "cpu"
+torch.manual_seed(0)
+lin = torch.nn.Sequential(torch.nn.Linear(300, 2000), torch.nn.ReLU(), torch.nn.Linear(2000, 7))   # one >1 MiB tensor, small ones
+x = torch.randn(8, 300)
+y = torch.randn(8, 7)
+lo, hi = parallel.shard_frames(8, rk, world)
+loss = torch.nn.functional.mse_loss(lin(x[lo:hi]), y[lo:hi])          # per-rank mean over its 4 frames
+(loss / world).backward()
+parallel.all_reduce_grads(list(lin.parameters()))
+ref = torch.nn.Sequential(torch.nn.Linear(300, 2000), torch.nn.ReLU(), torch.nn.Linear(2000, 7))
+ref.load_state_dict(lin.state_dict())
+torch.nn.functional.mse_loss(ref(x), y).backward()                     # single-process, whole batch
+for a, b in zip(lin.parameters(), ref.parameters()):
+    assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-7), (a.grad - b.grad).abs().max()
+m = parallel.max_over_ranks(float(rk + 1), dev)
+assert m == 2.0
+parallel.barrier()
+dist.destroy_process_group()
+print("rank", rk, "ok")
+"""
+
+
+def test_gradient_exchange_world_size_2_gloo(tmp_path):
+    """2 ranks, frames sharded, loss/world, one sum all-reduce == the single-process whole-batch gradient."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    port = 29500 + (os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert "rank %d ok" % r in o
