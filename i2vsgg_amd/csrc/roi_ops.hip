@@ -166,10 +166,10 @@ roi_align_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ r
 }
 
 // ---------------------------------------------------------------- ROIPool
-// roi_pooling_kernel.cu:24-93.  One wave per (roi, 64-channel chunk); lane = channel.
-// The PHxPW results of the chunk are staged in LDS so that an NCHW output (the
-// flatten order vrd.fc6 expects) is written as one contiguous 64*PH*PW run.
-__global__ void __launch_bounds__(64)
+// roi_pooling_kernel.cu:24-93.  One workgroup per (roi, 64-channel chunk); lane = channel, the four
+// waves split the pooled rows (ph % 4).  The PHxPW results of the chunk are staged in LDS so that an
+// NCHW output (the flatten order vrd.fc6 expects) is written as one contiguous 64*PH*PW run.
+__global__ void __launch_bounds__(256)
 roi_pool_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
                     int* __restrict__ argmax, int C, int H, int W, int PH, int PW, float scale, Strides fs,
                     Strides os, int out_nchw) {
@@ -179,7 +179,8 @@ roi_pool_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ ro
     int* sarg = (int*)(lds + 64 * P);
     const int chunks = (C + 63) / 64;
     const int r = blockIdx.x / chunks, c0 = (blockIdx.x % chunks) * 64;
-    const int c = c0 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = c0 + lane;
     const float* roi = rois + 5 * (long long)r;
     const int b = (int)roi[0];
     const int x1 = (int)roundf(roi[1] * scale), y1 = (int)roundf(roi[2] * scale);
@@ -188,7 +189,7 @@ roi_pool_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ ro
     const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
     const bool live = c < C;
     const float* fb = feat + (long long)b * fs.b + (live ? c : 0) * fs.c;
-    for (int ph = 0; ph < PH; ++ph) {
+    for (int ph = wave; ph < PH; ph += 4) {
         int hs = (int)floorf((float)ph * bh), he = (int)ceilf((float)(ph + 1) * bh);
         hs = min(max(hs + y1, 0), H); he = min(max(he + y1, 0), H);
         for (int pw = 0; pw < PW; ++pw) {
@@ -203,8 +204,8 @@ roi_pool_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ ro
                         float v = fb[h * fs.h + w * fs.w];
                         if (v > m) { m = v; mi = h * W + w; }
                     }
-            sval[threadIdx.x * P + ph * PW + pw] = m;
-            sarg[threadIdx.x * P + ph * PW + pw] = mi;
+            sval[lane * P + ph * PW + pw] = m;
+            sarg[lane * P + ph * PW + pw] = mi;
         }
     }
     __syncthreads();
@@ -212,13 +213,13 @@ roi_pool_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ ro
     if (out_nchw) {                      // (r, c0..c0+nch, :, :) is contiguous
         float* o = out + (long long)r * C * P + (long long)c0 * P;
         int* a = argmax + (long long)r * C * P + (long long)c0 * P;
-        for (int e = threadIdx.x; e < nch * P; e += 64) { o[e] = sval[e]; a[e] = sarg[e]; }
+        for (int e = threadIdx.x; e < nch * P; e += 256) { o[e] = sval[e]; a[e] = sarg[e]; }
     } else {                             // NHWC: (r, p, c) with c contiguous
-        for (int p = 0; p < P; ++p)
+        for (int p = wave; p < P; p += 4)
             if (live) {
                 long long o = (long long)r * P * C + (long long)p * C + c;
-                out[o] = sval[threadIdx.x * P + p];
-                argmax[o] = sarg[threadIdx.x * P + p];
+                out[o] = sval[lane * P + p];
+                argmax[o] = sarg[lane * P + p];
             }
     }
 }
@@ -296,7 +297,7 @@ extern "C" int32_t i2v_roi_pool_fwd(const float* feat, int32_t feat_layout, int3
     if (R == 0) return I2V_OK;
     Strides fs = feat_strides(feat_layout, C, H, W), os = out_strides(out_layout, C, PH, PW);
     size_t lds = (size_t)64 * PH * PW * 8;
-    roi_pool_fwd_kernel<<<R * ((C + 63) / 64), 64, lds, (hipStream_t)stream>>>(
+    roi_pool_fwd_kernel<<<R * ((C + 63) / 64), 256, lds, (hipStream_t)stream>>>(
         feat, rois, out, argmax, C, H, W, PH, PW, scale, fs, os, out_layout == I2V_LAYOUT_NCHW);
     I2V_CHECK_LAUNCH("roi_pool_fwd");
     return I2V_OK;

@@ -245,6 +245,91 @@ nms_scan_kernel(const unsigned long long* __restrict__ mask, int n, int nblk, in
     if (threadIdx.x == 0) num_out[img] = s_count;
 }
 
+// Pipelined variant for n <= 12288 (every RPN case): the mask rows of block rb+1 are fetched into
+// registers (4 rows per wave x 3 words per lane) while block rb is being resolved and folded in, so
+// global-load latency is off the serial chain; the chain per 64-row block is the 64-step resolve in
+// wave 0 plus two workgroup barriers.
+constexpr int SCAN_PIPE_WORDS = 3;      // words per lane: covers nblk - 1 <= 192 columns
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+nms_scan_pipelined_kernel(const unsigned long long* __restrict__ mask, int n, int nblk, int max_keep,
+                          int* __restrict__ keep_out, int* __restrict__ num_out) {
+    __shared__ unsigned long long removed[64 * SCAN_PIPE_WORDS + 1];
+    __shared__ unsigned long long s_kept;
+    __shared__ int s_count;
+    const int img = blockIdx.x;
+    const unsigned long long* M = mask + (long long)img * n * nblk;
+    int* keep = keep_out + (long long)img * n;
+    for (int i = threadIdx.x; i < nblk; i += SCAN_THREADS) removed[i] = 0;
+    if (threadIdx.x == 0) s_count = 0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int limit = max_keep > 0 ? max_keep : n;
+    unsigned long long pc[4][SCAN_PIPE_WORDS], pn[4][SCAN_PIPE_WORDS], dc = 0, dn = 0;
+    auto fetch = [&](int rb, unsigned long long (&P)[4][SCAN_PIPE_WORDS], unsigned long long& diag) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = rb * 64 + wave * 4 + r;
+#pragma unroll
+            for (int c = 0; c < SCAN_PIPE_WORDS; ++c) {
+                const int j = rb + 1 + lane + 64 * c;
+                P[r][c] = (row < n && j < nblk) ? M[(long long)row * nblk + j] : 0ull;
+            }
+        }
+        if (wave == 0) {
+            const int row = rb * 64 + lane;
+            diag = row < n ? M[(long long)row * nblk + rb] : 0ull;
+        }
+    };
+    fetch(0, pc, dc);
+    __syncthreads();
+    for (int rb = 0; rb < nblk; ++rb) {
+        if (rb + 1 < nblk) fetch(rb + 1, pn, dn);            // lands during this iteration
+        if (wave == 0) {
+            const int row = rb * 64 + lane;
+            unsigned long long cur = removed[rb];
+            const int valid = min(64, n - rb * 64);
+            if (valid < 64) cur |= ~0ull << valid;
+            unsigned long long kept = 0;
+            const int count0 = s_count;
+            int count = count0;
+            // serial greedy resolve of the 64 rows of this block, entirely in scalar registers: jump
+            // to the next unsuppressed row with ffs, fetch its diagonal word with v_readlane
+            const unsigned dlo = (unsigned)dc, dhi = (unsigned)(dc >> 32);
+            unsigned long long todo = ~cur;
+            while (todo && count < limit) {
+                const int i = __builtin_ctzll(todo);
+                const unsigned long long d = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, i) << 32) |
+                                             (unsigned)__builtin_amdgcn_readlane((int)dlo, i);
+                kept |= 1ull << i;
+                ++count;
+                cur |= d;
+                todo = ~cur & ~((2ull << i) - 1ull);       // rows after i that are still alive
+            }
+            if ((kept >> lane) & 1ull) keep[count0 + __popcll(kept & ((1ull << lane) - 1ull))] = row;
+            if (lane == 0) { s_kept = kept; s_count = count; }
+        }
+        __syncthreads();
+        const unsigned long long kept = s_kept;
+        if (s_count >= limit) break;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (!((kept >> (wave * 4 + r)) & 1ull)) continue;
+#pragma unroll
+            for (int c = 0; c < SCAN_PIPE_WORDS; ++c) {
+                const int j = rb + 1 + lane + 64 * c;
+                if (j < nblk && pc[r][c]) atomicOr(&removed[j], pc[r][c]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < SCAN_PIPE_WORDS; ++c) pc[r][c] = pn[r][c];
+        dc = dn;
+    }
+    if (threadIdx.x == 0) num_out[img] = s_count;
+}
+
 // ------------------------------------------------------------------ emit rois
 __global__ void write_rois(const float* __restrict__ dets, const int* __restrict__ src_idx,
                            const int* __restrict__ keep, const int* __restrict__ num, int n_top, int post,
@@ -336,7 +421,10 @@ int launch_nms(const float* dets, int n_img, int n, float thresh, int max_keep, 
                unsigned long long* mask, hipStream_t st) {
     const int nblk = (n + 63) / 64;
     nms_mask_kernel<<<dim3(nblk, nblk, n_img), 64, 0, st>>>(dets, n, nblk, thresh, mask);
-    nms_scan_kernel<<<n_img, SCAN_THREADS, 0, st>>>(mask, n, nblk, max_keep, keep, num);
+    if (nblk - 1 <= 64 * SCAN_PIPE_WORDS)
+        nms_scan_pipelined_kernel<<<n_img, SCAN_THREADS, 0, st>>>(mask, n, nblk, max_keep, keep, num);
+    else
+        nms_scan_kernel<<<n_img, SCAN_THREADS, 0, st>>>(mask, n, nblk, max_keep, keep, num);
     return 0;
 }
 
