@@ -15,6 +15,7 @@
 // fragment is ONE b128 read; A and B use the same permutation, so the sum is unchanged.
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
@@ -72,7 +73,15 @@ conv_igemm_f32(const ConvP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int tile = blockIdx.x;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), so
+    // give each XCD a contiguous run of tiles -- the n-tiles of one m-tile then share an L2 and the
+    // activation rows cross the fabric once instead of once per XCD.  (Bijective for any grid size;
+    // placement only affects speed.)
+    int tile;
+    {
+        const int nt = gridDim.x, q = nt >> 3, r = nt & 7, x = blockIdx.x & 7, i = blockIdx.x >> 3;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     const int kbeg = blockIdx.y * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
@@ -340,6 +349,7 @@ inline int ilog2_exact(int v) {
 
 constexpr int NUM_CU = 256;
 int g_force_tile = -1;           // i2v_conv_set_tile(): tuning hook
+int g_split_below = [] { const char* e = getenv("I2V_SPLIT_BELOW"); return e ? atoi(e) : NUM_CU; }();
 
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 void launch_tile(const ConvP& p, hipStream_t st) {
@@ -380,7 +390,7 @@ int run_conv(ConvP p, hipStream_t st) {
     auto plan = [&](int c, int& splitk) {
         const long long t = (long long)i2v_cdiv(p.M, kTiles[c].bm) * i2v_cdiv(p.N, kTiles[c].bn);
         splitk = 1;
-        if (t < NUM_CU && ksteps >= 8 && p.ostride == 1) {
+        if (t < g_split_below && ksteps >= 8 && p.ostride == 1) {
             splitk = (int)((2 * NUM_CU + t - 1) / t);
             splitk = splitk > ksteps / 4 ? ksteps / 4 : splitk;
             if (splitk < 1) splitk = 1;
