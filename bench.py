@@ -120,6 +120,17 @@ def main():
                 t = e0.elapsed_time(e1) * 1e-3
                 f.write("%-6s %-40s %8.1f us %7.2f GF %6.1f TF\n" % (tag, d, t * 1e6, fl / 1e9, fl / t / 1e12))
 
+    # HBM traffic of the same kernel from the PMC passes committed under profiles/ (rocprofv3 cannot
+    # be run from inside the timed process); null when no summary for this round exists
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    if os.path.exists(pmc):
+        try:
+            with open(pmc) as f:
+                traffic = json.load(f)["conv_igemm_f32"]["hbm_bytes_per_launch_corrected"]
+            traffic_src = "profiles/r01_pmc_summary.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, bytes per launch)"
+        except Exception:
+            traffic = None
     out = {
         "metric": "frames/sec (600x1000, 32 ROI/frame)", "value": world * FRAMES_PER_RANK * a.steps / elapsed,
         "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -132,7 +143,9 @@ def main():
                    "loss": loss},
         "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (fwd + dgrad launches)", "achieved": achieved,
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
-                     "traffic": None, "launches_per_step": len(fwd) // n_prof,
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": 4.8e9 / 117,
+                     "launches_per_step": len(fwd) // n_prof,
                      "avg_launch_us": 1e6 * t_conv / max(len(fwd), 1),
                      "gflop_per_step": f_conv / n_prof / 1e9,
                      "by_kind": {k: {"ms_per_step": 1e3 * v[0] / n_prof, "tflops": v[1] / max(v[0], 1e-12) / 1e12,
