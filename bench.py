@@ -139,7 +139,7 @@ def main():
         "config": {"workload": "BASELINE.json configs[1]: cfgs/res101.yml, SGG_emb fwd+bwd+SGD, %d frames/GPU "
                                "600x1000, 32 boxes + 32 pairs/frame, ResNet-%d C4" % (FRAMES_PER_RANK, a.layers),
                    "frames_per_gpu": FRAMES_PER_RANK, "global_frames": world * FRAMES_PER_RANK,
-                   "hip_graph": bool(graphed), "parallelism": "dp%d (frames sharded, RCCL all-reduce of vrd grads)" % world,
+                   "hip_graph": bool(graphed), "graph_error": getattr(step, "graph_error", None), "parallelism": "dp%d (frames sharded, RCCL all-reduce of vrd grads)" % world,
                    "loss": loss},
         "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (fwd + dgrad launches)", "achieved": achieved,
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,

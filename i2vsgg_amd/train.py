@@ -96,7 +96,7 @@ class SGGEmbStep:
         self.graph = None
         self.use_graph = use_graph
 
-    def _body(self):
+    def _fwd_bwd(self):
         net = self.net
         with torch.no_grad():
             fmap = net.RCNN_base(self.im)
@@ -105,12 +105,21 @@ class SGGEmbStep:
         loss = (per * self.wrow).sum()
         self.opt.zero_grad()
         (loss / self.world).backward()
-        parallel.all_reduce_grads(self.opt.params())
-        self.opt.step()
         self.loss.copy_(loss.detach())
 
+    def _body(self):
+        self._fwd_bwd()
+        parallel.all_reduce_grads(self.opt.params())
+        self.opt.step()
+
     def capture(self, warmup=2):
-        """Warm up eagerly on a side stream, then capture one whole step into a HIP graph."""
+        """Warm up eagerly on a side stream, then capture the step into HIP graphs.
+
+        world == 1: one graph for the whole step.  world > 1 (or I2V_SPLIT_GRAPH=1): graph A =
+        forward + backward, the RCCL all-reduce of the (graph-static) gradient tensors runs eagerly
+        between, graph B = the SGD update -- the collective stays outside capture, the ~330 compute
+        launches do not go through Python."""
+        import os
         s = torch.cuda.Stream(self.dev)
         s.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(s):
@@ -118,13 +127,23 @@ class SGGEmbStep:
                 self._body()
         torch.cuda.current_stream(self.dev).wait_stream(s)
         torch.cuda.synchronize(self.dev)
-        if not self.use_graph or self.world > 1:
-            return False           # RCCL collectives stay eager: one graph per rank buys nothing across ranks
+        if not self.use_graph:
+            return False
+        split = self.world > 1 or os.environ.get("I2V_SPLIT_GRAPH") == "1"
         try:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._body()
-            self.graph = g
+            if not split:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._body()
+                self.graph = (g,)
+            else:
+                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga):
+                    self._fwd_bwd()
+                self._grads = [p.grad for p in self.opt.params()]      # static tensors owned by graph A's pool
+                with torch.cuda.graph(gb, pool=ga.pool()):
+                    self.opt.step()
+                self.graph = (ga, gb)
             return True
         except Exception as e:      # report, fall back to eager launches
             self.graph = None
@@ -133,10 +152,14 @@ class SGGEmbStep:
             return False
 
     def __call__(self):
-        if self.graph is not None:
-            self.graph.replay()
-        else:
+        if self.graph is None:
             self._body()
+        elif len(self.graph) == 1:
+            self.graph[0].replay()
+        else:
+            self.graph[0].replay()
+            parallel.all_reduce_grads(self.opt.params())
+            self.graph[1].replay()
         return self.loss
 
 
