@@ -163,6 +163,73 @@ class SGGEmbStep:
         return self.loss
 
 
+class InstanceStyleDStep:
+    """One D+G adversarial step (trainval_net_instance_styleD_bilinear.py:262-341): source forward with
+    detection + RPN losses and 0.5*mean(d^2) for both discriminators, target forward with
+    0.5*mean((1-d)^2), style terms weighted by style_lambda, ONE backward through the gradient-reversal
+    layers, one SGD step over every trainable parameter.  Eager (the target layers sample on the host
+    with the reference's np.random stream, which needs two small D2H copies per step)."""
+
+    def __init__(self, net, n_frames, lr=5e-4, eta=0.1, eta_style=0.001, style_lambda=1.0, seed=3, device="cuda:0",
+                 h=600, w=1000, n_gt=8):
+        self.net, self.dev = net, torch.device(device)
+        self.world = parallel.world_size()
+        self.eta, self.eta_style, self.style_lambda = eta, eta_style, style_lambda
+        ims, info = syn.frames(seed, n_frames, h, w)
+        imt, _ = syn.frames(seed + 100, n_frames, h, w)
+        gt, nb = syn.gt_boxes(seed, n_frames, n_gt, net.n_classes, cfg.MAX_NUM_GT_BOXES, h, w)
+        to = lambda a: torch.from_numpy(a).to(self.dev)
+        self.im_s, self.im_t, self.info, self.gt, self.nb = to(ims), to(imt), to(info), to(gt), to(nb)
+        self.gt_t = torch.zeros((n_frames, 1, 5), device=self.dev)
+        self.nb_t = torch.zeros((n_frames,), device=self.dev)
+        self.opt = FusedSGD(list(net.named_parameters()), lr)
+        self.losses = {}
+
+    def __call__(self):
+        net = self.net
+        out = net(self.im_s, self.info, self.gt, self.nb, target=False, eta=self.eta, eta_style=self.eta_style)
+        _, _, _, l_rpn_cls, l_rpn_box, l_cls, l_box, _, d_inst, d_style = out
+        loss = l_rpn_cls.mean() + l_rpn_box.mean() + l_cls.mean() + l_box.mean()
+        dloss_s = 0.5 * torch.mean(d_inst ** 2)
+        dloss_s_style = 0.5 * torch.mean(d_style ** 2)
+        d_inst_t, d_style_t = net(self.im_t, self.info, self.gt_t, self.nb_t, target=True, eta=self.eta,
+                                  eta_style=self.eta_style)
+        dloss_t = 0.5 * torch.mean((1 - d_inst_t) ** 2)
+        dloss_t_style = 0.5 * torch.mean((1 - d_style_t) ** 2)
+        total = loss + dloss_s + dloss_t + self.style_lambda * (dloss_s_style + dloss_t_style)
+        self.opt.zero_grad()
+        (total / self.world).backward()
+        parallel.all_reduce_grads(self.opt.params())
+        self.opt.step()
+        self.losses = dict(total=total.detach(), det=loss.detach(), dloss_s=dloss_s.detach(), dloss_t=dloss_t.detach(),
+                           dloss_s_style=dloss_s_style.detach(), dloss_t_style=dloss_t_style.detach())
+        return self.losses["total"]
+
+
+def build_instance_styled_net(layers=101, n_cls=16, seed=0, device="cuda:0"):
+    from .model.faster_rcnn.resnet_instance_styleD_bilinear import resnet
+    torch.manual_seed(seed)
+    net = resnet(tuple(range(n_cls)), layers)
+    net.create_architecture()
+    _randomise_bn(net, seed + 1)
+    return net.to(device).train()
+
+
+def _randomise_bn(net, seed):
+    """Frozen-BN statistics as a trained checkpoint would have them (gamma < 1 on the block outputs keeps
+    activations O(1) through 33 residual blocks)."""
+    g = torch.Generator().manual_seed(seed)
+    for name, m in net.named_modules():
+        if m.__class__.__name__ == "FrozenBN":
+            c = m.weight.numel()
+            hi = 0.5 if name.endswith("bn3") else 1.0
+            m.weight.data.copy_(torch.rand(c, generator=g) * (hi - 0.2) + 0.2)
+            m.bias.data.copy_(torch.rand(c, generator=g) * 0.2 - 0.1)
+            m.running_mean.copy_(torch.rand(c, generator=g) * 0.2 - 0.1)
+            m.running_var.copy_(torch.rand(c, generator=g) + 0.5)
+            m.invalidate()
+
+
 def build_sgg_net(layers=101, n_rel=62, n_cls=16, seed=0, device="cuda:0"):
     """Random-init SGG_emb model of the reference architecture (no checkpoint is reachable)."""
     import argparse
@@ -173,18 +240,7 @@ def build_sgg_net(layers=101, n_rel=62, n_cls=16, seed=0, device="cuda:0"):
     net = resnet(tuple(range(n_cls)), args, layers, obj_vecs=syn.word_vectors(22, n_cls),
                  prd_vecs=syn.word_vectors(21, n_rel))
     net.create_architecture()
-    # frozen-BN statistics as a trained checkpoint would have them (gamma<1 on the block outputs keeps
-    # activations O(1) through 33 residual blocks)
-    g = torch.Generator().manual_seed(seed + 1)
-    for name, m in net.named_modules():
-        if m.__class__.__name__ == "FrozenBN":
-            c = m.weight.numel()
-            hi = 0.5 if name.endswith("bn3") else 1.0
-            m.weight.data.copy_(torch.rand(c, generator=g) * (hi - 0.2) + 0.2)
-            m.bias.data.copy_(torch.rand(c, generator=g) * 0.2 - 0.1)
-            m.running_mean.copy_(torch.rand(c, generator=g) * 0.2 - 0.1)
-            m.running_var.copy_(torch.rand(c, generator=g) + 0.5)
-            m.invalidate()
+    _randomise_bn(net, seed + 1)
     return net.to(device).train()
 
 
