@@ -39,6 +39,7 @@ struct ConvP {
     int lgCin;                   // log2(Cin) if power of two else -1
     int force_tile;              // >=0: tile config override (tuning / tests), -1: cost model
     unsigned x_bytes, w_bytes;   // sizes of x and w for the buffer descriptors (< 2 GiB each)
+    unsigned long long* clk;     // diagnostic only (i2v_conv_debug_clock): per-workgroup {shader cycles, 100 MHz ticks}
 };
 
 __device__ inline void split_k(const ConvP& p, int k, int& ky, int& kx, int& c) {
@@ -54,10 +55,17 @@ __device__ inline void split_k(const ConvP& p, int k, int& ky, int& kx, int& c) 
 // each 16-deep half, so one ds_read_b128 feeds four MFMAs (A and B use the same permutation).
 // LDS rows are 128 B, unpadded, with the 16-B column XOR-swizzled by (row>>1)&7: the four
 // 16-lane groups of a ds_read_b128 then touch 16 distinct slots of the 256-B bank row.
-template <int WAVES_M, int WAVES_N, int TM, int TN>
-__global__ void __launch_bounds__(THREADS)
+//
+// SPEC = true: 8 waves per workgroup, specialised.  Waves 4-7 ("loaders") do all the address math,
+// global loads and LDS stores; waves 0-3 ("MFMA waves") only read fragments and issue MFMAs.  At ~1
+// workgroup per CU (the 4788-row layer3 GEMMs) a single wave per SIMD would otherwise serialise
+// {address math + loads, LDS reads, MFMAs, LDS stores, barrier}; here the loader wave of a SIMD runs
+// beside its MFMA wave (VALU/VMEM and the matrix pipe issue independently).
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool SPEC>
+__global__ void __launch_bounds__(SPEC ? 2 * THREADS : THREADS)
 conv_igemm_f32(const ConvP p) {
     constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
+    constexpr int NT = SPEC ? 2 * THREADS : THREADS;      // threads per workgroup
     constexpr int A_LD = (BM * 8 + THREADS - 1) / THREADS, B_LD = (BN * 8 + THREADS - 1) / THREADS;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     // one LDS block: [A stage 0 | A stage 1 | B stage 0 | B stage 1 | tap table]; after the K loop the
@@ -70,7 +78,11 @@ conv_igemm_f32(const ConvP p) {
     float (*Bs)[BN * BKS] = reinterpret_cast<float (*)[BN * BKS]>(smem + 2 * BM * BKS);
     unsigned* ktab = reinterpret_cast<unsigned*>(smem + 2 * (BM + BN) * BKS);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gtid = threadIdx.x;                 // 0..NT-1
+    unsigned long long t0c = 0, t0r = 0;
+    if (p.clk) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
+    const int tid = gtid & (THREADS - 1);         // staging role (loader waves when SPEC) / epilogue lane
+    const int lane = gtid & 63, wave = (gtid >> 6) & 3;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int tiles_n = (p.N + BN - 1) / BN;
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share one), so
@@ -92,7 +104,7 @@ conv_igemm_f32(const ConvP p) {
     // filter-tap table (only for KHxKW > 1): entry e = k/4 -> (input offset of tap (ky,kx,c)) << 6 | kpos.
     // Built once per workgroup, so the K loop has no integer division and no per-tap bounds math.
     if (!is1x1) {
-        for (int e = tid; e < (p.K >> 2); e += THREADS) {
+        for (int e = gtid; e < (p.K >> 2); e += NT) {
             int ky, kx, c;
             split_k(p, e << 2, ky, kx, c);
             ktab[e] = (unsigned)(((ky * p.W + kx) * p.Cin + c) << 6) | (unsigned)(ky * p.KW + kx);
@@ -209,44 +221,74 @@ conv_igemm_f32(const ConvP p) {
     };
     // residual tile: issued before the K loop so that its latency hides behind the MFMAs (small
     // tiles only: C_LD float4 registers per thread)
-    constexpr int C_LD = (BM * (BN / 4) + THREADS - 1) / THREADS;
+    constexpr int C_LD = (BM * (BN / 4) + NT - 1) / NT;
     constexpr bool PREFETCH_RES = C_LD <= 8;
     const bool vec_epi = p.splitk <= 1 && (p.N & 3) == 0;
     float4 rres[PREFETCH_RES ? C_LD : 1];
     if (PREFETCH_RES && vec_epi && (p.flags & I2V_EPI_RESIDUAL) && p.ostride == 1) {
 #pragma unroll
         for (int it = 0; it < C_LD; ++it) {
-            const int e = tid + it * THREADS;
+            const int e = gtid + it * NT;
             const int row = e / (BN / 4), col = (e % (BN / 4)) * 4;
             const int m = m0 + row, n = n0 + col;
             rres[it] = (e < BM * (BN / 4) && m < p.M && n < p.N) ? *(const float4*)(p.res + (long long)m * p.N + n)
                                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    gload(kbeg);
-    sstore(0);
-    __syncthreads();
-    int buf = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += BKS) {
-        const bool more = k0 + BKS < kend;
-        if (more) gload(k0 + BKS);
-        compute(buf);
-        if (more) sstore(buf ^ 1);
+    if constexpr (SPEC) {
+        if (gtid >= THREADS) {                // ---- loader waves
+            gload(kbeg);
+            sstore(0);
+            if (kbeg + BKS < kend) gload(kbeg + BKS);
+            __syncthreads();                  // stage 0 visible
+            int buf = 0;
+            for (int k0 = kbeg; k0 < kend; k0 += BKS) {
+                if (k0 + BKS < kend) sstore(buf ^ 1);            // registers hold stage k0+32
+                if (k0 + 2 * BKS < kend) gload(k0 + 2 * BKS);    // lands during the next stage
+                __syncthreads();
+                buf ^= 1;
+            }
+        } else {                              // ---- MFMA waves
+            __syncthreads();
+            int buf = 0;
+            for (int k0 = kbeg; k0 < kend; k0 += BKS) {
+                compute(buf);
+                __syncthreads();
+                buf ^= 1;
+            }
+        }
+    } else {
+        gload(kbeg);
+        sstore(0);
         __syncthreads();
-        buf ^= 1;
+        int buf = 0;
+        for (int k0 = kbeg; k0 < kend; k0 += BKS) {
+            const bool more = k0 + BKS < kend;
+            if (more) gload(k0 + BKS);
+            compute(buf);
+            if (more) sstore(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
     }
 
+    if (p.clk && gtid == 0) {     // diagnostic build path: stamps go to their own buffer, never to an output
+        p.clk[2 * (blockIdx.y * gridDim.x + blockIdx.x)] = __builtin_amdgcn_s_memtime() - t0c;
+        p.clk[2 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
+    }
     // epilogue.  C/D map of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + r.  The tile goes
     // through LDS so that global stores (and the residual loads) are whole 16-B-per-lane rows
     // instead of 64-B fragments of a line.  (The last loop iteration ended with a barrier: every
     // wave is done reading the stage buffers.)
+    if (!SPEC || gtid < THREADS) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                smem[((wm * TM + i) * 16 + 4 * fg + r) * CROW + (wn * TN + j) * 16 + fr] = acc[i][j][r];
+                for (int r = 0; r < 4; ++r)
+                    smem[((wm * TM + i) * 16 + 4 * fg + r) * CROW + (wn * TN + j) * 16 + fr] = acc[i][j][r];
+    }
     __syncthreads();
     const bool split = p.splitk > 1;
     auto out_index = [&](int m) -> long long {
@@ -255,7 +297,7 @@ conv_igemm_f32(const ConvP p) {
         return (((long long)b * p.Hy + oy * p.ostride) * p.Wy + ox * p.ostride) * p.N;
     };
     if (split) {                      // fp32 atomics: 64 lanes = 256 contiguous bytes per instruction
-        for (int e = tid; e < BM * BN; e += THREADS) {
+        for (int e = gtid; e < BM * BN; e += NT) {
             const int row = e / BN, col = e % BN;
             const int m = m0 + row, n = n0 + col;
             if (m < p.M && n < p.N) atomicAdd(p.y + out_index(m) + n, smem[row * CROW + col]);
@@ -263,7 +305,7 @@ conv_igemm_f32(const ConvP p) {
     } else if ((p.N & 3) == 0) {
 #pragma unroll
         for (int it = 0; it < C_LD; ++it) {
-            const int e = tid + it * THREADS;
+            const int e = gtid + it * NT;
             if (e >= BM * (BN / 4)) break;
             const int row = e / (BN / 4), col = (e % (BN / 4)) * 4;
             const int m = m0 + row, n = n0 + col;
@@ -289,7 +331,7 @@ conv_igemm_f32(const ConvP p) {
             *(float4*)(p.y + o) = v;
         }
     } else {
-        for (int e = tid; e < BM * BN; e += THREADS) {
+        for (int e = gtid; e < BM * BN; e += NT) {
             const int row = e / BN, col = e % BN;
             const int m = m0 + row, n = n0 + col;
             if (m >= p.M || n >= p.N) continue;
@@ -348,14 +390,17 @@ inline int ilog2_exact(int v) {
 }
 
 constexpr int NUM_CU = 256;
-int g_force_tile = -1;           // i2v_conv_set_tile(): tuning hook
+int g_force_tile = -1;           // i2v_conv_set_tile(): tuning hook (low byte: tile, bits 8-9: spec mode + 1)
+unsigned long long* g_clk = nullptr;   // i2v_conv_debug_clock()
+int g_spec_mode = -1;            // -1 auto, 0 plain 4-wave kernel, 1 loader/MFMA specialised 8-wave kernel
 int g_split_below = [] { const char* e = getenv("I2V_SPLIT_BELOW"); return e ? atoi(e) : NUM_CU; }();
 
 template <int WAVES_M, int WAVES_N, int TM, int TN>
-void launch_tile(const ConvP& p, hipStream_t st) {
+void launch_tile(const ConvP& p, bool spec, hipStream_t st) {
     constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
     const int tiles = i2v_cdiv(p.M, BM) * i2v_cdiv(p.N, BN);
-    conv_igemm_f32<WAVES_M, WAVES_N, TM, TN><<<dim3(tiles, p.splitk), THREADS, 0, st>>>(p);
+    if (spec) conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, true><<<dim3(tiles, p.splitk), 2 * THREADS, 0, st>>>(p);
+    else conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false><<<dim3(tiles, p.splitk), THREADS, 0, st>>>(p);
 }
 
 struct TileCfg { int bm, bn; float eff; };
@@ -382,6 +427,7 @@ int run_conv(ConvP p, hipStream_t st) {
     }
     p.x_bytes = (unsigned)xb;
     p.w_bytes = (unsigned)wb;
+    p.clk = g_clk;
     const int force = p.force_tile;
     const int ksteps = i2v_cdiv(p.K, BKS);
     // tile + split-K choice: minimise (rounds over the 256 CUs) x (MACs per workgroup) / efficiency.
@@ -416,13 +462,18 @@ int run_conv(ConvP p, hipStream_t st) {
     p.splitk = i2v_cdiv(p.K, p.k_per_split);
     const long long ytotal = (long long)p.M * p.N;
     if (p.splitk > 1) hipMemsetAsync(p.y, 0, (size_t)ytotal * sizeof(float), st);
+    // wave specialisation pays where few workgroups share a CU (nothing else hides the staging)
+    const long long nblocks = (long long)i2v_cdiv(p.M, kTiles[cfg].bm) * i2v_cdiv(p.N, kTiles[cfg].bn) * p.splitk;
+    // measured neutral on the backbone shapes (l2 c2 +6 %, l3 ds -12 %): off unless forced
+    const bool spec = g_spec_mode > 0;
+    (void)nblocks;
     switch (cfg) {
-        case 0: launch_tile<2, 2, 4, 4>(p, st); break;
-        case 1: launch_tile<2, 2, 4, 2>(p, st); break;
-        case 2: launch_tile<2, 2, 3, 2>(p, st); break;
-        case 3: launch_tile<1, 4, 5, 1>(p, st); break;
-        case 4: launch_tile<2, 2, 2, 2>(p, st); break;
-        default: launch_tile<2, 2, 1, 2>(p, st); break;
+        case 0: launch_tile<2, 2, 4, 4>(p, spec, st); break;
+        case 1: launch_tile<2, 2, 4, 2>(p, spec, st); break;
+        case 2: launch_tile<2, 2, 3, 2>(p, spec, st); break;
+        case 3: launch_tile<1, 4, 5, 1>(p, spec, st); break;
+        case 4: launch_tile<2, 2, 2, 2>(p, spec, st); break;
+        default: launch_tile<2, 2, 1, 2>(p, spec, st); break;
     }
     if (p.splitk > 1 && (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS | I2V_EPI_RESIDUAL | I2V_EPI_RELU))) {
         if (p.N % 4 == 0)
@@ -652,8 +703,15 @@ static int check_conv(const char* who, const void* a, const void* b, const void*
     return I2V_OK;
 }
 
+extern "C" int32_t i2v_conv_debug_clock(void* buf) {
+    g_clk = (unsigned long long*)buf;      // device buffer of 2 u64 per workgroup, or NULL to switch off
+    return I2V_OK;
+}
+
 extern "C" int32_t i2v_conv_set_tile(int32_t cfg) {
-    g_force_tile = cfg;
+    if (cfg < 0) { g_force_tile = -1; g_spec_mode = -1; return I2V_OK; }
+    g_force_tile = (cfg & 0xFF) == 0xFF ? -1 : (cfg & 0xFF);
+    g_spec_mode = ((cfg >> 8) & 3) - 1;
     return I2V_OK;
 }
 

@@ -135,8 +135,12 @@ int32_t i2v_bbox_overlaps(const float* boxes, int32_t box_stride, int32_t box_of
 int32_t i2v_conv_fwd(const float* x, const float* w, const float* scale, const float* shift, const float* res,
                      float* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                      int32_t KH, int32_t KW, int32_t stride, int32_t pad, int32_t flags, void* stream);
-/* tuning hook: force the tile shape of subsequent conv launches (0..5), -1 = cost model */
+/* tuning hook: cfg < 0 = cost model; else low byte = tile shape 0..5 (0xFF = cost model),
+ * bits 8-9 = 0 auto / 1 plain 4-wave kernel / 2 loader+MFMA specialised 8-wave kernel */
 int32_t i2v_conv_set_tile(int32_t cfg);
+/* diagnostic: when buf != NULL every conv workgroup writes {shader cycles, 100 MHz ticks} of its main loop to
+ * buf[2*wg .. 2*wg+1] (device memory, >= 16 B per workgroup); the in-kernel clock is cycles/ticks * 100 MHz */
+int32_t i2v_conv_debug_clock(void* buf);
 size_t  i2v_conv_dgrad_workspace_bytes(int32_t Cin, int32_t Cout, int32_t KH, int32_t KW);
 int32_t i2v_conv_dgrad(const float* gy, const float* w, float* gx, int32_t B, int32_t H, int32_t W,
                        int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,

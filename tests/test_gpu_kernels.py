@@ -370,17 +370,27 @@ def test_cpu_tensor_is_rejected_loudly(ops):
         ops.roi_align(torch.zeros(1, 4, 8, 8), torch.zeros(1, 5), 7, 7, 1 / 16.0)
 
 
+@pytest.mark.parametrize("spec", [1, 2])
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
-def test_conv_every_tile_shape(ops, tile):
-    """Each (BM x BN) instantiation of conv_igemm_f32, forced through the tuning hook, incl. ragged M/N/K edges."""
+def test_conv_every_tile_shape(ops, tile, spec):
+    """Each (BM x BN) instantiation of conv_igemm_f32 -- plain 4-wave (spec=1) and loader/MFMA specialised
+    8-wave (spec=2) -- forced through the tuning hook, incl. ragged M/N/K edges, residual and split-K."""
     from i2vsgg_amd import _lib
     rng = np.random.default_rng(tile)
     x = rng.standard_normal((2, 72, 13, 17), dtype=np.float32)          # M = 442 (ragged), K = 648 (not /32)
     w = (rng.standard_normal((100, 72, 3, 3), dtype=np.float32) / 25).astype(np.float32)
     ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), padding=1)
-    _lib.lib.i2v_conv_set_tile(tile)
+    res = torch.from_numpy(rng.standard_normal(tuple(ref.shape), dtype=np.float32))
+    x8 = rng.standard_normal((1, 512, 5, 6), dtype=np.float32)                       # M = 30, deep K -> split-K
+    w8 = (rng.standard_normal((64, 512, 3, 3), dtype=np.float32) / 60).astype(np.float32)
+    ref8 = F.conv2d(torch.from_numpy(x8), torch.from_numpy(w8), padding=1)
+    _lib.lib.i2v_conv_set_tile(tile | (spec << 8))
     try:
         y = ops.conv2d(torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV), pad=1)
+        y2 = ops.conv2d(torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV), None, None, res.to(DEV), 1, 1, relu=True)
+        y8 = ops.conv2d(torch.from_numpy(x8).to(DEV), torch.from_numpy(w8).to(DEV), pad=1)
     finally:
         _lib.lib.i2v_conv_set_tile(-1)
     np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(y2.cpu().numpy(), F.relu(ref + res).numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(y8.cpu().numpy(), ref8.numpy(), rtol=2e-5, atol=2e-5)

@@ -37,8 +37,9 @@ for name, cin, h, w, cout, k, s, p in SHAPES:
     ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
     fl = 2.0 * B * ho * wo * cout * k * k * cin
     res = []
+    SP = int(os.environ.get("SPEC", "0"))
     for cfg in list(range(6)) + [-1]:
-        _lib.lib.i2v_conv_set_tile(cfg)
+        _lib.lib.i2v_conv_set_tile((cfg if cfg >= 0 else 0xFF) | (SP << 8))
         for _ in range(2):
             ops.conv2d(x, wt, sc, sh, None, s, p, relu=True)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
