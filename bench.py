@@ -141,7 +141,7 @@ def main():
                    "frames_per_gpu": FRAMES_PER_RANK, "global_frames": world * FRAMES_PER_RANK,
                    "hip_graph": bool(graphed), "graph_error": getattr(step, "graph_error", None), "parallelism": "dp%d (frames sharded, RCCL all-reduce of vrd grads)" % world,
                    "loss": loss},
-        "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (fwd + dgrad launches)", "achieved": achieved,
+        "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (every i2v_conv_fwd/_dgrad call: kernel + its split-K helper kernels)", "achieved": achieved,
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": 4.8e9 / 117,

@@ -510,6 +510,7 @@ __global__ void weight_dgrad_layout(const float* __restrict__ w, float* __restri
 // the MFMA fragments want; split over m across blockIdx.y with fp32 atomics.
 struct WgP {
     const float* x; const float* gy; float* gw; int direct;
+    float* sgd_m; float lr, mom, wd;       // sgd_m != NULL: gw is the PARAMETER, updated in place (fused SGD)
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, M, N, K, m_per_split, lgCin;
 };
 
@@ -610,8 +611,17 @@ conv_wgrad_f32(const WgP p) {
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (n < p.N) {
-                    if (p.direct) p.gw[(long long)n * p.K + k] = acc[i][j][r];
-                    else atomicAdd(p.gw + (long long)n * p.K + k, acc[i][j][r]);
+                    const long long o = (long long)n * p.K + k;
+                    if (p.sgd_m) {          // g' = g + wd*p ; m = mom*m + g' ; p -= lr*m   (same order as sgd_momentum_kernel)
+                        const float pv = p.gw[o];
+                        const float mv = p.mom * p.sgd_m[o] + (acc[i][j][r] + p.wd * pv);
+                        p.sgd_m[o] = mv;
+                        p.gw[o] = pv - p.lr * mv;
+                    } else if (p.direct) {
+                        p.gw[o] = acc[i][j][r];
+                    } else {
+                        atomicAdd(p.gw + o, acc[i][j][r]);
+                    }
                 }
             }
     }
@@ -812,12 +822,42 @@ extern "C" int32_t i2v_conv_wgrad(const float* x, const float* gy, float* gw, in
     return I2V_OK;
 }
 
+// wgrad with the SGD(momentum) update of that filter fused into the accumulator epilogue: the gradient
+// never goes to HBM (for vrd.fc6 that is 822 MB written + 822 MB read back per step).  Only when the whole
+// reduction over the pixels fits one workgroup pass (no split over m), i.e. the skinny relation-head GEMMs.
+extern "C" int32_t i2v_conv_wgrad_sgd(const float* x, const float* gy, float* w, float* m, int32_t B, int32_t H,
+                                      int32_t W, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride,
+                                      int32_t pad, float lr, float momentum, float weight_decay, void* stream) {
+    int rc = check_conv("conv_wgrad_sgd", x, gy, w, B, H, W, Cin, Cout, KH, KW, stride, pad);
+    if (rc) return rc;
+    I2V_CHECK_ARG(m, "conv_wgrad_sgd: null momentum buffer");
+    WgP p = {};
+    p.x = x; p.gy = gy; p.gw = w; p.sgd_m = m; p.lr = lr; p.mom = momentum; p.wd = weight_decay;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+    p.Ho = (H + 2 * pad - KH) / stride + 1;
+    p.Wo = (W + 2 * pad - KW) / stride + 1;
+    p.M = B * p.Ho * p.Wo; p.N = Cout; p.K = KH * KW * Cin;
+    p.lgCin = ilog2_exact(Cin);
+    const long long tiles = (long long)i2v_cdiv(p.N, 64) * i2v_cdiv(p.K, 64);
+    if (tiles < 2 * NUM_CU || p.M > 4096) {
+        i2v_set_error("conv_wgrad_sgd: shape needs a split over pixels; use i2v_conv_wgrad + i2v_sgd_momentum");
+        return I2V_ERR_UNSUPPORTED;
+    }
+    p.m_per_split = i2v_cdiv(p.M, 16) * 16;
+    p.direct = 1;
+    conv_wgrad_f32<64, 64><<<dim3((unsigned)tiles, 1), THREADS, 0, (hipStream_t)stream>>>(p);
+    I2V_CHECK_LAUNCH("conv_wgrad_sgd");
+    return I2V_OK;
+}
+
 extern "C" int32_t i2v_epilogue_bwd(const float* gy, const float* y, const float* scale, float* g, float* gbias,
                                     int64_t M, int32_t N, int32_t relu, void* stream) {
     I2V_CHECK_ARG(gy && M >= 0 && N > 0, "epilogue_bwd: bad argument");
     I2V_CHECK_ARG(!relu || y, "epilogue_bwd: relu needs y");
     if (M == 0) return I2V_OK;
-    const int rows = 64;
+    // enough workgroups to cover the chip even for the 64..128-row tensors of the relation head
+    int rows = 64;
+    while (rows > 4 && (long long)i2v_cdiv(M, rows) * i2v_cdiv(N, 256) < 2 * NUM_CU) rows >>= 1;
     epilogue_bwd_kernel<<<dim3(i2v_cdiv(M, rows), i2v_cdiv(N, 256)), 256, 0, (hipStream_t)stream>>>(
         gy, y, scale, g, gbias, M, N, relu, rows);
     I2V_CHECK_LAUNCH("epilogue_bwd");

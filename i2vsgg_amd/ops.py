@@ -292,6 +292,22 @@ def _conv_wgrad_raw(x, g, w_shape, stride, pad):
     return gw
 
 
+# parameter storage pointer -> (momentum buffer, lr, momentum, weight_decay): filters whose SGD update is
+# fused into their wgrad epilogue (train.FusedSGD.fuse_wgrad); their .grad is then never materialised
+FUSED_SGD = {}
+
+
+def _conv_wgrad_sgd_raw(x, g, w, cfg, stride, pad):
+    m, lr, mom, wd = cfg
+    B, Cin, H, W = x.shape
+    Cout, _, KH, KW = w.shape
+    with _Timed(2.0 * B * g.shape[2] * g.shape[3] * Cout * KH * KW * Cin, "wgrad",
+                "N%d K%d M%d +sgd" % (Cout, KH * KW * Cin, B * g.shape[2] * g.shape[3])):
+        rc = lib.i2v_conv_wgrad_sgd(ptr(x), ptr(g), ptr(w), ptr(m), B, H, W, Cin, Cout, KH, KW, stride, pad, float(lr),
+                                    float(mom), float(wd), stream())
+    return rc
+
+
 class _ConvFn(torch.autograd.Function):
     """y = relu?( conv(x,w)*scale + shift + res ).  scale/shift of a frozen BN get no gradient;
     a bias (shift without scale) does."""
@@ -344,7 +360,12 @@ class _ConvFn(torch.autograd.Function):
             g = epi(g_pre, None, scale, True, None, False) if has_scale else g_pre
             gres = g_pre if need_res else None
         gx = _conv_dgrad_raw(g, w, x.shape, stride, pad) if ctx.needs_input_grad[0] else None
-        gw = _conv_wgrad_raw(x, g, w.shape, stride, pad) if ctx.needs_input_grad[1] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            fused = FUSED_SGD.get(w.data_ptr())
+            # the filter is read by dgrad above before it is updated here
+            if fused is None or _conv_wgrad_sgd_raw(x, g, w, fused, stride, pad) != 0:
+                gw = _conv_wgrad_raw(x, g, w.shape, stride, pad)
         return gx, gw, None, gbias, gres, None, None, None
 
 

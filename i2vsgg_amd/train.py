@@ -25,6 +25,7 @@ class FusedSGD:
         self.momentum = T.MOMENTUM if momentum is None else momentum
         wd = T.WEIGHT_DECAY if weight_decay is None else weight_decay
         self.items = []
+        self._fused_keys = []
         for name, p in named_params:
             if not p.requires_grad:
                 continue
@@ -33,6 +34,31 @@ class FusedSGD:
                 name=name, p=p, m=torch.zeros_like(p),
                 lr=lr * ((T.DOUBLE_BIAS + 1) if is_bias else 1),
                 wd=(wd if T.BIAS_DECAY else 0.0) if is_bias else wd))
+
+    def fuse_wgrad(self, min_numel=1 << 24):
+        """Fuse the update of large filters into their wgrad epilogue (single-GPU only: with data
+        parallelism the gradient must be all-reduced before the update).  Returns the fused names."""
+        names = []
+        if parallel.world_size() > 1:
+            return names
+        for it in self.items:
+            p = it["p"]
+            if p.dim() >= 2 and p.numel() >= min_numel:
+                ops.FUSED_SGD[p.data_ptr()] = (it["m"], it["lr"], self.momentum, it["wd"])
+                self._fused_keys.append(p.data_ptr())
+                names.append(it["name"])
+        return names
+
+    def unfuse(self):
+        for k in self._fused_keys:
+            ops.FUSED_SGD.pop(k, None)
+        self._fused_keys = []
+
+    def __del__(self):
+        try:
+            self.unfuse()
+        except Exception:
+            pass
 
     def params(self):
         return [it["p"] for it in self.items]
@@ -66,7 +92,7 @@ def synthetic_sgg_batch(seed, n_frames, n_boxes=32, n_pairs=32, n_rel=62, n_cls=
 
 class SGGEmbStep:
     def __init__(self, net, n_frames, vrd_lr=1e-4, seed=1, device="cuda:0", h=600, w=1000, n_boxes=32, n_pairs=32,
-                 use_graph=True, data_device_resident=True):
+                 use_graph=True, fuse_sgd=True):
         from .model.faster_rcnn.faster_rcnn_SGG_emb import build_pair_tables, rasterize_masks
         self.net, self.dev, self.n_frames = net, torch.device(device), n_frames
         self.world = parallel.world_size()
@@ -92,6 +118,7 @@ class SGGEmbStep:
         self.wrow = torch.cat([torch.full((c,), 1.0 / (c * len(counts))) for c in counts]).to(self.dev)
         self.n_rows = int(self.boxes.shape[0] + self.relb.shape[0])
         self.opt = FusedSGD([(n, p) for n, p in net.named_parameters() if n.startswith("vrd.")], vrd_lr)
+        self.fused = self.opt.fuse_wgrad() if fuse_sgd else []
         self.loss = torch.zeros((), device=self.dev)
         self.graph = None
         self.use_graph = use_graph

@@ -151,6 +151,13 @@ int32_t i2v_conv_wgrad(const float* x, const float* gy, float* gw, int32_t B, in
                        int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                        float beta, void* workspace, size_t workspace_bytes, void* stream);
 
+/* wgrad with the SGD(momentum) step of that filter fused into the epilogue: w and m are updated in place and
+ * the gradient is never written (g' = g + wd*w; m = mom*m + g'; w -= lr*m).  Only for shapes whose pixel
+ * reduction needs no split (M <= 4096 and >= 512 filter tiles), else I2V_ERR_UNSUPPORTED. */
+int32_t i2v_conv_wgrad_sgd(const float* x, const float* gy, float* w, float* m, int32_t B, int32_t H, int32_t W,
+                           int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
+                           float lr, float momentum, float weight_decay, void* stream);
+
 /* epilogue backward: g = gy * (y>0) [relu], optional channel scale; optional per-channel
  * sum of g into gshift (bias gradient).  In-place (g==gy) allowed. */
 int32_t i2v_epilogue_bwd(const float* gy, const float* y, const float* scale, float* g, float* gbias,

@@ -247,3 +247,30 @@ def test_instance_styled_source_and_target_step_runs_and_is_finite(cfg):
     finally:
         cfg.TRAIN.BATCH_SIZE = 128
         cfg.TRAIN.RPN_POST_NMS_TOP_N_TARGET = 128
+
+
+def test_fused_wgrad_sgd_equals_separate_update(cfg):
+    """vrd.fc6-style skinny GEMM: SGD fused into the wgrad epilogue == wgrad followed by the SGD kernel (bitwise)."""
+    from i2vsgg_amd import ops
+    rng = np.random.default_rng(17)
+    x = torch.from_numpy(rng.standard_normal((64, 9216), dtype=np.float32)).to(DEV)
+    w0 = (rng.standard_normal((4096, 9216), dtype=np.float32) / 96).astype(np.float32)
+    gy = torch.from_numpy(rng.standard_normal((64, 4096), dtype=np.float32)).to(DEV)
+    res = []
+    for fused in (False, True):
+        w = torch.from_numpy(w0.copy()).to(DEV).requires_grad_()
+        m = torch.from_numpy(rng.standard_normal(w0.shape, dtype=np.float32) * 0 + 0.01).to(DEV)
+        if fused:
+            ops.FUSED_SGD[w.data_ptr()] = (m, 1e-2, 0.9, 5e-4)
+        try:
+            y = ops.linear(x, w)
+            y.backward(gy)
+        finally:
+            ops.FUSED_SGD.clear()
+        if fused:
+            assert w.grad is None
+        else:
+            ops.sgd_momentum_(w.data, w.grad, m, 1e-2, 0.9, 5e-4)
+        res.append((w.detach().cpu().numpy().copy(), m.cpu().numpy().copy()))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert not np.array_equal(res[0][0], w0)
