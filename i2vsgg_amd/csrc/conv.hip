@@ -237,16 +237,63 @@ conv_igemm_f32(const ConvP p) {
     }
     if constexpr (SPEC) {
         if (gtid >= THREADS) {                // ---- loader waves
-            gload(kbeg);
-            sstore(0);
-            if (kbeg + BKS < kend) gload(kbeg + BKS);
+            // two register sets: the loads of stages s+2 and s+3 are in flight while stage s computes
+            // (loaders hold no accumulators, so the second set is free here)
+            float4 ra2[2][A_LD], rb2[2][B_LD];
+            auto gl = [&](auto SET, int k0) {
+                constexpr int S = decltype(SET)::value;
+                const int k = k0 + kg;
+                const bool kin = k < kend;
+                int delta = k, kpos = 0;
+                if (!is1x1) {
+                    const unsigned e = ktab[kin ? (k >> 2) : 0];
+                    delta = (int)(e >> 6);
+                    kpos = (int)(e & 63u);
+                }
+#pragma unroll
+                for (int q = 0; q < A_LD; ++q) {
+                    const bool ok = kin && ((a_mask[q] >> kpos) & 1ull);
+                    const unsigned off = ok ? (unsigned)(a_off[q] + delta) * 4u : OOB;
+                    ra2[S][q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+                }
+#pragma unroll
+                for (int q = 0; q < B_LD; ++q) {
+                    const unsigned off = (kin && b_off[q] >= 0) ? (unsigned)(b_off[q] + k) * 4u : OOB;
+                    rb2[S][q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
+                }
+            };
+            auto st = [&](auto SET) {          // register set S always feeds LDS buffer S
+                constexpr int S = decltype(SET)::value;
+#pragma unroll
+                for (int q = 0; q < A_LD; ++q) {
+                    const int row = (tid >> 3) + q * (THREADS / 8);
+                    if (row < BM) *(float4*)&As[S][row * BKS + ((kc ^ ((row >> 1) & 7)) << 2)] = ra2[S][q];
+                }
+#pragma unroll
+                for (int q = 0; q < B_LD; ++q) {
+                    const int row = (tid >> 3) + q * (THREADS / 8);
+                    if (row < BN) *(float4*)&Bs[S][row * BKS + ((kc ^ ((row >> 1) & 7)) << 2)] = rb2[S][q];
+                }
+            };
+            using S0 = std::integral_constant<int, 0>;
+            using S1 = std::integral_constant<int, 1>;
+            gl(S0{}, kbeg);
+            st(S0{});
+            if (kbeg + BKS < kend) gl(S1{}, kbeg + BKS);
+            if (kbeg + 2 * BKS < kend) gl(S0{}, kbeg + 2 * BKS);
             __syncthreads();                  // stage 0 visible
-            int buf = 0;
-            for (int k0 = kbeg; k0 < kend; k0 += BKS) {
-                if (k0 + BKS < kend) sstore(buf ^ 1);            // registers hold stage k0+32
-                if (k0 + 2 * BKS < kend) gload(k0 + 2 * BKS);    // lands during the next stage
+            for (int k0 = kbeg; k0 < kend;) {
+                // even stage s computes from buffer 0: publish stage s+1 (set 1), refill set 1 with s+3
+                if (k0 + BKS < kend) st(S1{});
+                if (k0 + 3 * BKS < kend) gl(S1{}, k0 + 3 * BKS);
                 __syncthreads();
-                buf ^= 1;
+                k0 += BKS;
+                if (k0 >= kend) break;
+                // odd stage computes from buffer 1: publish stage s+1 (set 0), refill set 0 with s+3
+                if (k0 + BKS < kend) st(S0{});
+                if (k0 + 3 * BKS < kend) gl(S0{}, k0 + 3 * BKS);
+                __syncthreads();
+                k0 += BKS;
             }
         } else {                              // ---- MFMA waves
             __syncthreads();
@@ -392,7 +439,8 @@ inline int ilog2_exact(int v) {
 constexpr int NUM_CU = 256;
 int g_force_tile = -1;           // i2v_conv_set_tile(): tuning hook (low byte: tile, bits 8-9: spec mode + 1)
 unsigned long long* g_clk = nullptr;   // i2v_conv_debug_clock()
-int g_spec_mode = -1;            // -1 auto, 0 plain 4-wave kernel, 1 loader/MFMA specialised 8-wave kernel
+// -1 / 0: plain 4-wave kernel, 1: loader/MFMA specialised 8-wave kernel, 2: specialised when <= 3 workgroups per CU
+int g_spec_mode = [] { const char* e = getenv("I2V_CONV_SPEC"); return e ? atoi(e) : -1; }();
 int g_split_below = [] { const char* e = getenv("I2V_SPLIT_BELOW"); return e ? atoi(e) : NUM_CU; }();
 
 template <int WAVES_M, int WAVES_N, int TM, int TN>
@@ -465,8 +513,7 @@ int run_conv(ConvP p, hipStream_t st) {
     // wave specialisation pays where few workgroups share a CU (nothing else hides the staging)
     const long long nblocks = (long long)i2v_cdiv(p.M, kTiles[cfg].bm) * i2v_cdiv(p.N, kTiles[cfg].bn) * p.splitk;
     // measured neutral on the backbone shapes (l2 c2 +6 %, l3 ds -12 %): off unless forced
-    const bool spec = g_spec_mode > 0;
-    (void)nblocks;
+    const bool spec = g_spec_mode < 0 ? false : (g_spec_mode == 2 ? nblocks <= 3 * NUM_CU : g_spec_mode != 0);
     switch (cfg) {
         case 0: launch_tile<2, 2, 4, 4>(p, spec, st); break;
         case 1: launch_tile<2, 2, 4, 2>(p, spec, st); break;

@@ -251,11 +251,11 @@ inline Strides out_strides(int layout, int C, int PH, int PW) {
 extern "C" int32_t i2v_roi_align_fwd(const float* feat, int32_t feat_layout, int32_t B, int32_t C, int32_t H,
                                      int32_t W, const float* rois, int32_t R, int32_t PH, int32_t PW,
                                      float scale, int32_t avg, float* out, int32_t out_layout, void* stream) {
+    if (R == 0) return I2V_OK;          // empty roi set: nothing to do (tensors may have null storage)
     I2V_CHECK_ARG(feat && rois && out, "roi_align_fwd: null pointer");
     I2V_CHECK_ARG(B > 0 && C > 0 && H >= 2 && W >= 2 && R >= 0 && PH > 0 && PW > 0, "roi_align_fwd: bad shape");
     I2V_CHECK_ARG(avg == 0 || avg == 1, "roi_align_fwd: avg must be 0/1");
     I2V_CHECK_ARG(avg || (PH > 1 && PW > 1), "roi_align_fwd: aligned grid needs >=2 points per side");
-    if (R == 0) return I2V_OK;
     hipStream_t st = (hipStream_t)stream;
     Strides os = out_strides(out_layout, C, PH, PW);
     if (feat_layout == I2V_LAYOUT_NHWC && (C % 4) == 0) {
@@ -276,10 +276,10 @@ extern "C" int32_t i2v_roi_align_bwd(const float* gout, int32_t out_layout, cons
                                      int32_t PH, int32_t PW, float scale, int32_t avg, float* gfeat,
                                      int32_t feat_layout, int32_t B, int32_t C, int32_t H, int32_t W,
                                      void* stream) {
+    if (R == 0) return I2V_OK;          // empty roi set: nothing to do (tensors may have null storage)
     I2V_CHECK_ARG(gout && rois && gfeat, "roi_align_bwd: null pointer");
     I2V_CHECK_ARG(B > 0 && C > 0 && H >= 2 && W >= 2 && R >= 0 && PH > 0 && PW > 0, "roi_align_bwd: bad shape");
     I2V_CHECK_ARG(avg == 0 || avg == 1, "roi_align_bwd: avg must be 0/1");
-    if (R == 0) return I2V_OK;
     hipStream_t st = (hipStream_t)stream;
     Strides os = out_strides(out_layout, C, PH, PW), fs = feat_strides(feat_layout, C, H, W);
     if (avg) roi_align_bwd_kernel<1><<<R * (PH + 1), 256, 0, st>>>(gout, rois, gfeat, C, H, W, PH, PW, scale, fs, os);
@@ -291,10 +291,10 @@ extern "C" int32_t i2v_roi_align_bwd(const float* gout, int32_t out_layout, cons
 extern "C" int32_t i2v_roi_pool_fwd(const float* feat, int32_t feat_layout, int32_t B, int32_t C, int32_t H,
                                     int32_t W, const float* rois, int32_t R, int32_t PH, int32_t PW, float scale,
                                     float* out, int32_t* argmax, int32_t out_layout, void* stream) {
+    if (R == 0) return I2V_OK;          // empty roi set: nothing to do (tensors may have null storage)
     I2V_CHECK_ARG(feat && rois && out && argmax, "roi_pool_fwd: null pointer");
     I2V_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && R >= 0 && PH > 0 && PW > 0, "roi_pool_fwd: bad shape");
     I2V_CHECK_ARG(PH * PW <= 256, "roi_pool_fwd: pooled grid too large for the LDS stage");
-    if (R == 0) return I2V_OK;
     Strides fs = feat_strides(feat_layout, C, H, W), os = out_strides(out_layout, C, PH, PW);
     size_t lds = (size_t)64 * PH * PW * 8;
     roi_pool_fwd_kernel<<<R * ((C + 63) / 64), 256, lds, (hipStream_t)stream>>>(
@@ -307,9 +307,9 @@ extern "C" int32_t i2v_roi_pool_bwd(const float* gout, const int32_t* argmax, in
                                     const float* rois, int32_t R, int32_t PH, int32_t PW, float* gfeat,
                                     int32_t feat_layout, int32_t B, int32_t C, int32_t H, int32_t W,
                                     void* stream) {
+    if (R == 0) return I2V_OK;          // empty roi set: nothing to do (tensors may have null storage)
     I2V_CHECK_ARG(gout && argmax && rois && gfeat, "roi_pool_bwd: null pointer");
     I2V_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && R >= 0 && PH > 0 && PW > 0, "roi_pool_bwd: bad shape");
-    if (R == 0) return I2V_OK;
     Strides fs = feat_strides(feat_layout, C, H, W);
     long long total = (long long)R * C * PH * PW;
     int grid = (int)fmin((double)i2v_cdiv(total, 256), 65535.0 * 4);

@@ -394,3 +394,52 @@ def test_conv_every_tile_shape(ops, tile, spec):
     np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(y2.cpu().numpy(), F.relu(ref + res).numpy(), rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(y8.cpu().numpy(), ref8.numpy(), rtol=2e-5, atol=2e-5)
+
+
+# --------------------------------------------------------------------------- edge cases
+def test_empty_and_degenerate_inputs(ops):
+    feat = torch.randn(1, 64, 10, 12, device=DEV).contiguous(memory_format=torch.channels_last)
+    empty = torch.zeros((0, 5), device=DEV)
+    assert ops.roi_align(feat, empty, 7, 7, 1 / 16.0).shape == (0, 64, 7, 7)          # R = 0
+    assert ops.roi_pool(feat, empty, 7, 7, 1 / 16.0).shape == (0, 64, 7, 7)
+    with pytest.raises(ValueError):
+        ops.roi_align(feat, torch.zeros((3, 4), device=DEV), 7, 7, 1 / 16.0)            # roi_align.c:28-31: (K,5) only
+    # a single box: NMS keeps it; two identical boxes: the second is suppressed
+    one = torch.tensor([[10., 10., 50., 50., 0.9]], device=DEV)
+    keep, num = ops.nms_sorted(one, 0.7)
+    assert int(num) == 1 and int(keep[0, 0]) == 0
+    two = torch.tensor([[10., 10., 50., 50., 0.9], [10., 10., 50., 50., 0.8]], device=DEV)
+    keep, num = ops.nms_sorted(two, 0.7)
+    assert int(num) == 1
+    # IoU exactly at the threshold is KEPT (nms_cpu.py:31 `ovr <= thresh`): boxes 0..9 and 0..19 wide -> IoU 0.5
+    th = torch.tensor([[0., 0., 9., 9., 0.9], [0., 0., 19., 9., 0.8]], device=DEV)
+    keep, num = ops.nms_sorted(th, 0.5)
+    assert int(num) == 2
+
+
+def test_nms_large_n_uses_generic_scan(ops, oracle):
+    """n = 20000 (> 12288): the non-pipelined scan path; still bit-exact against the oracle."""
+    cops, _ = oracle
+    dets = syn.tie_free_dets(99, 20000, clustered=True)
+    keep, num = ops.nms_sorted(torch.from_numpy(dets).to(DEV), 0.7)
+    ref = cops.nms_sorted(dets, 0.7)
+    assert int(num) == ref.size and np.array_equal(keep[0, :ref.size].cpu().numpy(), ref)
+
+
+def test_proposal_layer_fewer_survivors_than_post_nms_is_zero_padded(ops, oracle):
+    """All anchors decode to nearly the same box -> a handful survive NMS; the rest of the (B,post,5) block is
+    zero with the image index in column 0 (proposal_layer.py:158-161)."""
+    _, rpn = oracle
+    cls = torch.randn(2, 18, 8, 9, device=DEV)
+    box = torch.zeros(2, 36, 8, 9, device=DEV)
+    box[:, 2::4] = -20.0          # exp(-20) ~ 0: every proposal collapses to its anchor centre (tiny boxes)
+    box[:, 3::4] = -20.0
+    info = torch.tensor([[128., 144., 1.0]] * 2, device=DEV)
+    base = torch.from_numpy(rpn.base_anchors().astype(np.float32)).to(DEV)
+    rois, kept, num = ops.rpn_proposal(cls, box, info, base, 16, 6000, 300, 0.7, is_prob=False, want_index=True)
+    assert rois.shape == (2, 300, 5)
+    for b in range(2):
+        k = int(num[b])
+        assert 0 < k <= 300
+        assert torch.all(rois[b, :, 0] == b)
+        assert torch.all(rois[b, k:, 1:] == 0) and torch.all(kept[b, k:] == -1)
