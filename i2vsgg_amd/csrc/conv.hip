@@ -727,11 +727,41 @@ __global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restri
     }
 }
 
-// g = gy * (y > 0) * scale[n]; gbias[n] += sum_m gy*(y>0)   (column sums via LDS + atomics)
+// g_pre = gy * (y > 0); g = g_pre * scale[n]; gbias[n] += sum_m g_pre.  One streaming pass: thread = 4 columns
+// (float4), a workgroup covers rows_per_blk rows x 1024 columns; either output may be NULL.
 __global__ void __launch_bounds__(256)
 epilogue_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ scale,
-                    float* __restrict__ g, float* __restrict__ gbias, long long M, int N, int relu, int rows_per_blk) {
-    // block covers rows [r0, r0+rows_per_blk) x 256 columns starting at blockIdx.y*256; thread = column
+                    float* __restrict__ g, float* __restrict__ gpre, float* __restrict__ gbias, long long M, int N,
+                    int relu, int rows_per_blk) {
+    const int n = (blockIdx.y * 256 + threadIdx.x) * 4;
+    if (n >= N) return;
+    const long long r0 = (long long)blockIdx.x * rows_per_blk;
+    const long long r1 = r0 + rows_per_blk < M ? r0 + rows_per_blk : M;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (scale) sc = *(const float4*)(scale + n);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (long long r = r0; r < r1; ++r) {
+        float4 v = *(const float4*)(gy + r * N + n);
+        if (relu) {
+            const float4 yy = *(const float4*)(y + r * N + n);
+            v.x = yy.x > 0.f ? v.x : 0.f; v.y = yy.y > 0.f ? v.y : 0.f;
+            v.z = yy.z > 0.f ? v.z : 0.f; v.w = yy.w > 0.f ? v.w : 0.f;
+        }
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        if (gpre) *(float4*)(gpre + r * N + n) = v;
+        if (g) *(float4*)(g + r * N + n) = make_float4(v.x * sc.x, v.y * sc.y, v.z * sc.z, v.w * sc.w);
+    }
+    if (gbias) {
+        atomicAdd(gbias + n, s.x); atomicAdd(gbias + n + 1, s.y);
+        atomicAdd(gbias + n + 2, s.z); atomicAdd(gbias + n + 3, s.w);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+epilogue_bwd_scalar_kernel(const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ scale,
+                           float* __restrict__ g, float* __restrict__ gpre, float* __restrict__ gbias, long long M,
+                           int N, int relu, int rows_per_blk) {
     const int n = blockIdx.y * 256 + threadIdx.x;
     if (n >= N) return;
     const long long r0 = (long long)blockIdx.x * rows_per_blk;
@@ -742,6 +772,7 @@ epilogue_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, c
         float v = gy[r * N + n];
         if (relu && !(y[r * N + n] > 0.f)) v = 0.f;
         s += v;
+        if (gpre) gpre[r * N + n] = v;
         if (g) g[r * N + n] = v * sc;
     }
     if (gbias) atomicAdd(gbias + n, s);
@@ -897,16 +928,19 @@ extern "C" int32_t i2v_conv_wgrad_sgd(const float* x, const float* gy, float* w,
     return I2V_OK;
 }
 
-extern "C" int32_t i2v_epilogue_bwd(const float* gy, const float* y, const float* scale, float* g, float* gbias,
-                                    int64_t M, int32_t N, int32_t relu, void* stream) {
+extern "C" int32_t i2v_epilogue_bwd(const float* gy, const float* y, const float* scale, float* g, float* gpre,
+                                    float* gbias, int64_t M, int32_t N, int32_t relu, void* stream) {
     I2V_CHECK_ARG(gy && M >= 0 && N > 0, "epilogue_bwd: bad argument");
     I2V_CHECK_ARG(!relu || y, "epilogue_bwd: relu needs y");
     if (M == 0) return I2V_OK;
+    const bool vec = (N & 3) == 0;
+    const int cols = vec ? 1024 : 256;
     // enough workgroups to cover the chip even for the 64..128-row tensors of the relation head
     int rows = 64;
-    while (rows > 4 && (long long)i2v_cdiv(M, rows) * i2v_cdiv(N, 256) < 2 * NUM_CU) rows >>= 1;
-    epilogue_bwd_kernel<<<dim3(i2v_cdiv(M, rows), i2v_cdiv(N, 256)), 256, 0, (hipStream_t)stream>>>(
-        gy, y, scale, g, gbias, M, N, relu, rows);
+    while (rows > 4 && (long long)i2v_cdiv(M, rows) * i2v_cdiv(N, cols) < 2 * NUM_CU) rows >>= 1;
+    dim3 grid(i2v_cdiv(M, rows), i2v_cdiv(N, cols));
+    if (vec) epilogue_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(gy, y, scale, g, gpre, gbias, M, N, relu, rows);
+    else epilogue_bwd_scalar_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(gy, y, scale, g, gpre, gbias, M, N, relu, rows);
     I2V_CHECK_LAUNCH("epilogue_bwd");
     return I2V_OK;
 }

@@ -343,22 +343,22 @@ class _ConvFn(torch.autograd.Function):
         need_res = has_res and ctx.needs_input_grad[4]
         gbias = torch.zeros((N,), device=gy.device, dtype=torch.float32) if need_bias else None
 
-        def epi(src, yy, sc, want_out, bias, rl):
-            out = torch.empty_like(src) if want_out else None
-            check(lib.i2v_epilogue_bwd(ptr(src), ptr(yy), ptr(sc), ptr(out), ptr(bias), M, N, int(rl), stream()),
-                  "epilogue_bwd")
-            return out
-
-        if relu and has_scale and not need_res:
-            g = epi(gy, y, scale, True, None, True)          # mask and BN scale in one pass
+        # one pass over gy: g_pre = gy*(y>0) feeds the residual branch and the bias sum, g = g_pre*scale feeds
+        # dgrad / wgrad
+        if relu or has_scale or need_bias:
+            want_pre = need_res and (relu or has_scale)
+            want_g = has_scale or relu
+            g = torch.empty_like(gy) if want_g else None
+            gpre = torch.empty_like(gy) if (want_pre and has_scale) else None
+            check(lib.i2v_epilogue_bwd(ptr(gy), ptr(y), ptr(scale) if has_scale else None, ptr(g), ptr(gpre), ptr(gbias),
+                                       M, N, int(relu), stream()), "epilogue_bwd")
+            if g is None:
+                g = gy
+            if need_res:
+                gres = gpre if gpre is not None else g       # without a BN scale g IS g_pre
         else:
-            g_pre = gy
-            if relu:
-                g_pre = epi(gy, y, None, True, gbias, True)  # g_pre = gy * (y > 0) [+ bias column sums]
-            elif need_bias:
-                epi(gy, None, None, False, gbias, False)
-            g = epi(g_pre, None, scale, True, None, False) if has_scale else g_pre
-            gres = g_pre if need_res else None
+            g = gy
+            gres = gy if need_res else None
         gx = _conv_dgrad_raw(g, w, x.shape, stride, pad) if ctx.needs_input_grad[0] else None
         gw = None
         if ctx.needs_input_grad[1]:

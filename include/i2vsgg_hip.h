@@ -158,9 +158,9 @@ int32_t i2v_conv_wgrad_sgd(const float* x, const float* gy, float* w, float* m, 
                            int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                            float lr, float momentum, float weight_decay, void* stream);
 
-/* epilogue backward: g = gy * (y>0) [relu], optional channel scale; optional per-channel
- * sum of g into gshift (bias gradient).  In-place (g==gy) allowed. */
-int32_t i2v_epilogue_bwd(const float* gy, const float* y, const float* scale, float* g, float* gbias,
+/* epilogue backward, one streaming pass: g_pre = gy * (y>0) [relu]; g = g_pre * scale[n] (scale may be NULL);
+ * gbias[n] += column sums of g_pre.  g, gpre and gbias may each be NULL; in-place (g == gy or gpre == gy) allowed. */
+int32_t i2v_epilogue_bwd(const float* gy, const float* y, const float* scale, float* g, float* gpre, float* gbias,
                          int64_t M, int32_t N, int32_t relu, void* stream);
 
 /* 3x3 / stride 2 / pad 0 / ceil_mode max pool of the stem (resnet_instance...:228), NHWC */
