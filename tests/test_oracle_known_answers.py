@@ -1,0 +1,60 @@
+"""Hand-worked known answers for the two oracle pieces that have no runnable reference here (ROIAlign,
+ROIPool: "parity unpinned").  Every expected number below is derived by hand from
+roi_align.c:91-134 / roi_pooling_kernel.cu:45-92 in the comments, not produced by the code under test."""
+import numpy as np
+
+from oracle import cops
+
+
+def test_roi_align_hand_worked():
+    # feature f[h][w] = 10*h + w on a 6x8 map (one channel), scale 1.
+    H, W = 6, 8
+    feat = (10.0 * np.arange(H)[:, None] + np.arange(W)[None, :]).astype(np.float32)[None, None]
+    # ROI x1=1,y1=1,x2=4,y2=3 -> roi_w = 4-1+1 = 4, roi_h = 3-1+1 = 3; aligned 3x3 -> bin = roi/(3-1): bw=2, bh=1.5
+    # sample points h = ph*1.5 + 1 in {1, 2.5, 4}; w = pw*2 + 1 in {1, 3, 5}
+    # f is bilinear-exact for a linear ramp: value = 10*h + w
+    rois = np.array([[0, 1, 1, 4, 3]], np.float32)
+    out = cops.roi_align_fwd(feat, rois, 3, 3, 1.0)
+    exp = np.array([[10 * h + w for w in (1, 3, 5)] for h in (1, 2.5, 4)], np.float32)
+    assert np.array_equal(out[0, 0], exp)
+    # RoIAlignAvg(2,2): aligned 3x3 then 2x2 stride-1 mean
+    avg = cops.roi_align_avg_fwd(feat, rois, 2, 2, 1.0)
+    exp_avg = np.array([[(exp[i, j] + exp[i, j + 1] + exp[i + 1, j] + exp[i + 1, j + 1]) / 4 for j in range(2)]
+                        for i in range(2)], np.float32)
+    assert np.array_equal(avg[0, 0], exp_avg)
+    # full-image ROI: x2 = W-1 -> roi_w = W, bin = W/(AW-1): the last sample column is w = W (>= W) -> 0
+    full = cops.roi_align_fwd(feat, np.array([[0, 0, 0, W - 1, H - 1]], np.float32), 3, 3, 1.0)
+    assert np.all(full[0, 0, 2, :] == 0) and np.all(full[0, 0, :, 2] == 0)
+    assert full[0, 0, 0, 0] == 0.0 and full[0, 0, 1, 1] == 10 * 3.0 + 4.0        # h = 1*6/2 = 3, w = 1*8/2 = 4
+    # extrapolation at the last row: h = 5.5 -> hstart = min(5, H-2) = 4, h_ratio = 1.5:
+    # f(4)*(1-1.5) + f(5)*1.5 = 40*(-0.5) + 50*1.5 = 55 (+ w)
+    edge = cops.roi_align_fwd(feat, np.array([[0, 2, 5.5, 2, 5.5]], np.float32), 2, 2, 1.0)
+    assert edge[0, 0, 0, 0] == 55.0 + 2.0
+    # backward of a single sample with weights (hr, wr) = (0.5, 0): gradient 1 at sample (h=2.5, w=3)
+    g = np.zeros((1, 1, 3, 3), np.float32)
+    g[0, 0, 1, 1] = 1.0
+    gin = cops.roi_align_bwd(g, rois, (1, 1, H, W), 1.0)
+    assert gin[0, 0, 2, 3] == 0.5 and gin[0, 0, 3, 3] == 0.5 and gin.sum() == 1.0
+
+
+def test_roi_pool_hand_worked():
+    # 1 channel 4x6 map, values row-major 0..23; scale 1
+    feat = np.arange(24, dtype=np.float32).reshape(1, 1, 4, 6)
+    # ROI x1=1,y1=0,x2=4,y2=3 -> 4 wide, 4 high; pooled 2x2 -> bins 2x2 pixels
+    rois = np.array([[0, 1, 0, 4, 3]], np.float32)
+    out, arg = cops.roi_pool_fwd(feat, rois, 2, 2, 1.0)
+    # bin (0,0): rows 0-1, cols 1-2 -> max = f[1][2] = 8 ; bin (0,1): cols 3-4 -> f[1][4] = 10
+    # bin (1,0): rows 2-3 -> f[3][2] = 20 ; bin (1,1): f[3][4] = 22
+    assert np.array_equal(out[0, 0], np.array([[8, 10], [20, 22]], np.float32))
+    assert np.array_equal(arg[0, 0], np.array([[8, 10], [20, 22]], np.int32))      # h*W + w of the winner
+    # rounding is half away from zero: x1 = 2.5 -> 3 (roi_pooling_kernel.cu:46)
+    out2, _ = cops.roi_pool_fwd(feat, np.array([[0, 2.5, 0, 5, 0]], np.float32), 1, 1, 1.0)
+    assert out2[0, 0, 0, 0] == 5.0                                                 # row 0, cols 3..5 -> max 5
+    # ROI entirely right of the map: empty bins -> 0 and argmax -1 (:66-70)
+    out3, arg3 = cops.roi_pool_fwd(feat, np.array([[0, 40, 40, 50, 50]], np.float32), 2, 2, 1.0)
+    assert np.all(out3 == 0) and np.all(arg3 == -1)
+    # backward routes each bin's gradient to its argmax
+    gin = cops.roi_pool_bwd(np.ones((1, 1, 2, 2), np.float32), rois, arg, feat.shape)
+    exp = np.zeros((4, 6), np.float32)
+    exp[1, 2] = exp[1, 4] = exp[3, 2] = exp[3, 4] = 1
+    assert np.array_equal(gin[0, 0], exp)
