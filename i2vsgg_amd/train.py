@@ -93,16 +93,25 @@ def synthetic_sgg_batch(seed, n_frames, n_boxes=32, n_pairs=32, n_rel=62, n_cls=
 class SGGEmbStep:
     def __init__(self, net, n_frames, vrd_lr=1e-4, seed=1, device="cuda:0", h=600, w=1000, n_boxes=32, n_pairs=32,
                  use_graph=True, fuse_sgd=True):
-        from .model.faster_rcnn.faster_rcnn_SGG_emb import build_pair_tables, rasterize_masks
         self.net, self.dev, self.n_frames = net, torch.device(device), n_frames
         self.world = parallel.world_size()
-        head = net.vrd
-        im, info, annos = synthetic_sgg_batch(seed, n_frames, n_boxes, n_pairs, head.n_rel, head.n_obj, h, w)
+        self.geom = (h, w, n_boxes, n_pairs)
+        self.reseed(seed)
+        self.opt = FusedSGD([(n, p) for n, p in net.named_parameters() if n.startswith("vrd.")], vrd_lr)
+        self.fused = self.opt.fuse_wgrad() if fuse_sgd else []
+        self.loss = torch.zeros((), device=self.dev)
+        self.graph = None
+        self.use_graph = use_graph
+
+    def reseed(self, seed):
+        """(Re)generate the synthetic minibatch: frames, pair tables, masks, labels -> static device inputs (the
+        data layer's job; resident before the timed region).  Shapes do not depend on the seed."""
+        from .model.faster_rcnn.faster_rcnn_SGG_emb import build_pair_tables, rasterize_masks
+        h, w, n_boxes, n_pairs = self.geom
+        head = self.net.vrd
+        im, info, annos = synthetic_sgg_batch(seed, self.n_frames, n_boxes, n_pairs, head.n_rel, head.n_obj, h, w)
         head.source_gt_rels = annos
         self.paths = sorted(annos, key=lambda s: int(s[1:]))
-        self.im = torch.from_numpy(im).to(self.dev)
-        self.info = torch.from_numpy(info).to(self.dev)
-        # pair tables -> static device inputs (the data layer's job; resident before the timed region)
         boxes, relb, bounds, labels, ixs, ixo, counts, off = [], [], [], [], [], [], [], 0
         for f, path in enumerate(self.paths):
             gt, union, bnd, lab, s, o = build_pair_tables(annos[path], float(info[f][2]), float(info[f][0]),
@@ -112,16 +121,17 @@ class SGGEmbStep:
             boxes.append(b5); relb.append(r5); bounds.append(bnd); labels.append(lab)
             ixs.append(s + off); ixo.append(o + off); counts.append(lab.shape[0]); off += gt.shape[0]
         t = lambda a, dt=torch.float32: torch.from_numpy(np.concatenate(a)).to(self.dev, dt)
-        self.boxes, self.relb, self.labels = t(boxes), t(relb), t(labels)
-        self.ixs, self.ixo = t(ixs, torch.long), t(ixo, torch.long)
-        self.masks = rasterize_masks(np.concatenate(bounds), self.dev)
-        self.wrow = torch.cat([torch.full((c,), 1.0 / (c * len(counts))) for c in counts]).to(self.dev)
+        new = dict(im=torch.from_numpy(im).to(self.dev), info=torch.from_numpy(info).to(self.dev), boxes=t(boxes),
+                   relb=t(relb), labels=t(labels), ixs=t(ixs, torch.long), ixo=t(ixo, torch.long),
+                   masks=rasterize_masks(np.concatenate(bounds), self.dev),
+                   wrow=torch.cat([torch.full((c,), 1.0 / (c * len(counts))) for c in counts]).to(self.dev))
+        for k, v in new.items():
+            cur = getattr(self, k, None)
+            if cur is not None and cur.shape == v.shape:
+                cur.copy_(v)                 # keep addresses: a captured graph stays valid
+            else:
+                setattr(self, k, v)
         self.n_rows = int(self.boxes.shape[0] + self.relb.shape[0])
-        self.opt = FusedSGD([(n, p) for n, p in net.named_parameters() if n.startswith("vrd.")], vrd_lr)
-        self.fused = self.opt.fuse_wgrad() if fuse_sgd else []
-        self.loss = torch.zeros((), device=self.dev)
-        self.graph = None
-        self.use_graph = use_graph
 
     def _fwd_bwd(self):
         net = self.net
