@@ -558,6 +558,7 @@ __global__ void weight_dgrad_layout(const float* __restrict__ w, float* __restri
 struct WgP {
     const float* x; const float* gy; float* gw; int direct;
     float* sgd_m; float lr, mom, wd;       // sgd_m != NULL: gw is the PARAMETER, updated in place (fused SGD)
+    unsigned x_bytes, gy_bytes;            // buffer descriptor sizes (v2 kernel)
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, M, N, K, m_per_split, lgCin;
 };
 
@@ -674,6 +675,182 @@ conv_wgrad_f32(const WgP p) {
     }
 }
 
+// ---------------------------------------------------------------- wgrad v2
+// Same GEMM as conv_wgrad_f32 on the conv_igemm_f32 machinery: 16x16x4 MFMAs, 32 reduction rows per
+// stage, swizzled 128-B LDS rows, register prefetch + double-buffered LDS.  Both operands arrive
+// reduction-major, so every thread owns 4x4 blocks (4 consecutive pixels x 4 columns): four 16-B loads,
+// an in-register transpose, four ds_write_b128 -- no scalar LDS traffic, no bank-conflicted transposes.
+template <int TM, int TN>       // tile = (2*TM*16) filters x (2*TN*16) taps, 4 waves as 2x2
+__global__ void __launch_bounds__(THREADS)
+conv_wgrad2_f32(const WgP p) {
+    constexpr int BMW = 2 * TM * 16, BNW = 2 * TN * 16;
+    constexpr int A_BLK = BMW * 2, B_BLK = BNW * 2;             // (cols/4) * 8 row-groups
+    constexpr int NBLK = (A_BLK + B_BLK + THREADS - 1) / THREADS;
+    constexpr int STAGE_FLOATS = 2 * (BMW + BNW) * BKS;
+    constexpr int CROW = BNW + 4;
+    constexpr int SMEM_FLOATS = STAGE_FLOATS > BMW * CROW ? STAGE_FLOATS : BMW * CROW;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    float (*As)[BMW * BKS] = reinterpret_cast<float (*)[BMW * BKS]>(smem);
+    float (*Bs)[BNW * BKS] = reinterpret_cast<float (*)[BNW * BKS]>(smem + 2 * BMW * BKS);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_k = (p.K + BNW - 1) / BNW;
+    const int n0 = (blockIdx.x / tiles_k) * BMW, k0 = (blockIdx.x % tiles_k) * BNW;
+    const int mbeg = blockIdx.y * p.m_per_split, mend = min(p.M, mbeg + p.m_per_split);
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)p.gy, 0, p.gy_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+
+    // per-thread block roles (fixed over the m loop)
+    bool is_a[NBLK], live[NBLK];
+    int cg[NBLK], m4[NBLK], coff[NBLK], ky[NBLK], kx[NBLK];
+#pragma unroll
+    for (int q = 0; q < NBLK; ++q) {
+        const int id = tid + q * THREADS;
+        is_a[q] = id < A_BLK;
+        const int j = is_a[q] ? id : id - A_BLK;
+        const int groups = (is_a[q] ? BMW : BNW) / 4;
+        live[q] = id < A_BLK + B_BLK;
+        cg[q] = j % groups;
+        m4[q] = j / groups;
+        ky[q] = kx[q] = 0;
+        if (is_a[q]) {
+            const int n = n0 + 4 * cg[q];
+            coff[q] = n;
+            live[q] = live[q] && n < p.N;
+        } else {
+            const int k = k0 + 4 * cg[q];
+            live[q] = live[q] && k < p.K;
+            int kpos, c;
+            const int kk = live[q] ? k : 0;
+            if (p.lgCin >= 0) { kpos = kk >> p.lgCin; c = kk & (p.Cin - 1); } else { kpos = kk / p.Cin; c = kk - kpos * p.Cin; }
+            ky[q] = kpos / p.KW;
+            kx[q] = kpos - ky[q] * p.KW;
+            coff[q] = c;
+        }
+    }
+    float4 r[NBLK][4];
+    auto gload = [&](int ms) {
+#pragma unroll
+        for (int q = 0; q < NBLK; ++q) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int m = ms + 4 * m4[q] + t;
+                unsigned off = OOB;
+                if (live[q] && m < mend) {
+                    if (is_a[q]) {
+                        off = (unsigned)(m * p.N + coff[q]) * 4u;
+                    } else {
+                        const int ox = m % p.Wo, tt = m / p.Wo, oy = tt % p.Ho, b = tt / p.Ho;
+                        const int iy = oy * p.stride - p.pad + ky[q], ix = ox * p.stride - p.pad + kx[q];
+                        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                            off = (unsigned)(((b * p.H + iy) * p.W + ix) * p.Cin + coff[q]) * 4u;
+                    }
+                }
+                r[q][t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(is_a[q] ? gr : xr, off, 0, 0));
+            }
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NBLK; ++q) {
+            if (tid + q * THREADS >= A_BLK + B_BLK) continue;
+            float* base = is_a[q] ? As[buf] : Bs[buf];
+            const float4 c0 = make_float4(r[q][0].x, r[q][1].x, r[q][2].x, r[q][3].x);
+            const float4 c1 = make_float4(r[q][0].y, r[q][1].y, r[q][2].y, r[q][3].y);
+            const float4 c2 = make_float4(r[q][0].z, r[q][1].z, r[q][2].z, r[q][3].z);
+            const float4 c3 = make_float4(r[q][0].w, r[q][1].w, r[q][2].w, r[q][3].w);
+            const int row = 4 * cg[q];
+            *(float4*)&base[(row + 0) * BKS + ((m4[q] ^ (((row + 0) >> 1) & 7)) << 2)] = c0;
+            *(float4*)&base[(row + 1) * BKS + ((m4[q] ^ (((row + 1) >> 1) & 7)) << 2)] = c1;
+            *(float4*)&base[(row + 2) * BKS + ((m4[q] ^ (((row + 2) >> 1) & 7)) << 2)] = c2;
+            *(float4*)&base[(row + 3) * BKS + ((m4[q] ^ (((row + 3) >> 1) & 7)) << 2)] = c3;
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fg = lane >> 4;
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float4 av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = (wm * TM + i) * 16 + fr;
+                av[i] = *(const float4*)&As[buf][row * BKS + (((s2 * 4 + fg) ^ ((row >> 1) & 7)) << 2)];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = (wn * TN + j) * 16 + fr;
+                bv[j] = *(const float4*)&Bs[buf][row * BKS + (((s2 * 4 + fg) ^ ((row >> 1) & 7)) << 2)];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float a = t == 0 ? av[i].x : t == 1 ? av[i].y : t == 2 ? av[i].z : av[i].w;
+                        const float b = t == 0 ? bv[j].x : t == 1 ? bv[j].y : t == 2 ? bv[j].z : bv[j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i][j], 0, 0, 0);
+                    }
+        }
+    };
+
+    gload(mbeg);
+    sstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int ms = mbeg; ms < mend; ms += BKS) {
+        const bool more = ms + BKS < mend;
+        if (more) gload(ms + BKS);
+        compute(buf);
+        if (more) sstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // epilogue through LDS: rows = filters n, columns = taps k (contiguous in gw)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+                smem[((wm * TM + i) * 16 + 4 * fg + rr) * CROW + (wn * TN + j) * 16 + fr] = acc[i][j][rr];
+    __syncthreads();
+    if (p.sgd_m || p.direct) {
+        for (int e = tid; e < BMW * (BNW / 4); e += THREADS) {
+            const int row = e / (BNW / 4), col = (e % (BNW / 4)) * 4;
+            const int n = n0 + row, k = k0 + col;
+            if (n >= p.N || k >= p.K) continue;                     // K % 4 == 0
+            const long long o = (long long)n * p.K + k;
+            float4 g = *(const float4*)&smem[row * CROW + col];
+            if (p.sgd_m) {      // g' = g + wd*p ; m = mom*m + g' ; p -= lr*m   (same order as sgd_momentum_kernel)
+                float4 pv = *(const float4*)(p.gw + o), mv = *(const float4*)(p.sgd_m + o);
+                mv.x = p.mom * mv.x + (g.x + p.wd * pv.x); mv.y = p.mom * mv.y + (g.y + p.wd * pv.y);
+                mv.z = p.mom * mv.z + (g.z + p.wd * pv.z); mv.w = p.mom * mv.w + (g.w + p.wd * pv.w);
+                pv.x -= p.lr * mv.x; pv.y -= p.lr * mv.y; pv.z -= p.lr * mv.z; pv.w -= p.lr * mv.w;
+                *(float4*)(p.sgd_m + o) = mv;
+                *(float4*)(p.gw + o) = pv;
+            } else {
+                *(float4*)(p.gw + o) = g;
+            }
+        }
+    } else {
+        for (int e = tid; e < BMW * BNW; e += THREADS) {
+            const int row = e / BNW, col = e % BNW;
+            const int n = n0 + row, k = k0 + col;
+            if (n < p.N && k < p.K) atomicAdd(p.gw + (long long)n * p.K + k, smem[row * CROW + col]);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- small elementwise pieces
 __global__ void maxpool3x3s2_kernel(const float* __restrict__ x, float* __restrict__ y, int* __restrict__ arg, int B,
                                     int H, int W, int C, int Ho, int Wo) {
@@ -779,6 +956,41 @@ epilogue_bwd_scalar_kernel(const float* __restrict__ gy, const float* __restrict
 }
 
 }  // namespace
+
+static int g_wgrad_v2 = [] { const char* e = getenv("I2V_WGRAD_V2"); return e ? atoi(e) : 1; }();
+
+// picks the kernel + pixel split for one wgrad problem; returns false when v2 cannot be used
+static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st) {
+    const long long xb = (long long)p.B * p.H * p.W * p.Cin * 4, gb = (long long)p.M * p.N * 4;
+    const bool v2 = (p.N % 4 == 0) && xb < (1ll << 31) && gb < (1ll << 31) && g_wgrad_v2;
+    // bigger tiles raise the FLOP per staged byte (the reduction dim is streamed): 128x128 = 32 FLOP/B vs 16
+    int tm = 64, tk = 64;
+    if (v2 && g_wgrad_v2 >= 2) {
+        if (p.N >= 128) tm = 128;
+        if (p.K >= 128 && tm == 128) tk = 128;
+    }
+    const long long tiles = (long long)i2v_cdiv(p.N, tm) * i2v_cdiv(p.K, tk);
+    const int rs = v2 ? BKS : 16;
+    int splits = 1;
+    const int msteps = i2v_cdiv(p.M, rs);
+    if (!fused) {
+        splits = (int)((4 * NUM_CU + tiles - 1) / tiles);
+        if (splits > msteps / 4) splits = msteps / 4;
+        if (splits < 1) splits = 1;
+    }
+    p.m_per_split = i2v_cdiv(msteps, splits) * rs;
+    splits = i2v_cdiv(p.M, p.m_per_split);
+    p.direct = (splits == 1 && beta == 0.f) || fused;
+    if (beta == 0.f && !p.direct) hipMemsetAsync(p.gw, 0, (size_t)p.N * p.K * sizeof(float), st);
+    p.x_bytes = (unsigned)xb;
+    p.gy_bytes = (unsigned)gb;
+    const dim3 grid((unsigned)tiles, splits);
+    if (!v2) conv_wgrad_f32<64, 64><<<grid, THREADS, 0, st>>>(p);
+    else if (tm == 128 && tk == 128) conv_wgrad2_f32<4, 4><<<grid, THREADS, 0, st>>>(p);
+    else if (tm == 128) conv_wgrad2_f32<4, 2><<<grid, THREADS, 0, st>>>(p);
+    else conv_wgrad2_f32<2, 2><<<grid, THREADS, 0, st>>>(p);
+    return true;
+}
 
 static int check_conv(const char* who, const void* a, const void* b, const void* c, int B, int H, int W, int Cin,
                       int Cout, int KH, int KW, int stride, int pad) {
@@ -886,16 +1098,7 @@ extern "C" int32_t i2v_conv_wgrad(const float* x, const float* gy, float* gw, in
     p.M = B * p.Ho * p.Wo; p.N = Cout; p.K = KH * KW * Cin;
     p.lgCin = ilog2_exact(Cin);
     I2V_CHECK_ARG(beta == 0.f || beta == 1.f, "conv_wgrad: beta must be 0 or 1");
-    const long long tiles = (long long)i2v_cdiv(p.N, 64) * i2v_cdiv(p.K, 64);
-    int splits = (int)((4 * NUM_CU + tiles - 1) / tiles);
-    const int msteps = i2v_cdiv(p.M, 16);
-    if (splits > msteps / 4) splits = msteps / 4;
-    if (splits < 1) splits = 1;
-    p.m_per_split = i2v_cdiv(msteps, splits) * 16;
-    splits = i2v_cdiv(p.M, p.m_per_split);
-    p.direct = (splits == 1 && beta == 0.f);
-    if (beta == 0.f && !p.direct) hipMemsetAsync(gw, 0, (size_t)p.N * p.K * sizeof(float), st);
-    conv_wgrad_f32<64, 64><<<dim3((unsigned)tiles, splits), THREADS, 0, st>>>(p);
+    launch_wgrad(p, beta, false, st);
     I2V_CHECK_LAUNCH("conv_wgrad");
     return I2V_OK;
 }
@@ -921,9 +1124,7 @@ extern "C" int32_t i2v_conv_wgrad_sgd(const float* x, const float* gy, float* w,
         i2v_set_error("conv_wgrad_sgd: shape needs a split over pixels; use i2v_conv_wgrad + i2v_sgd_momentum");
         return I2V_ERR_UNSUPPORTED;
     }
-    p.m_per_split = i2v_cdiv(p.M, 16) * 16;
-    p.direct = 1;
-    conv_wgrad_f32<64, 64><<<dim3((unsigned)tiles, 1), THREADS, 0, (hipStream_t)stream>>>(p);
+    launch_wgrad(p, 0.f, true, (hipStream_t)stream);
     I2V_CHECK_LAUNCH("conv_wgrad_sgd");
     return I2V_OK;
 }
