@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libi2vsgg_hip.so")
 
 LAYOUT_NHWC, LAYOUT_NCHW = 0, 1
-EPI_RELU, EPI_RESIDUAL, EPI_SCALE, EPI_BIAS = 1, 2, 4, 8
+EPI_RELU, EPI_RESIDUAL, EPI_SCALE, EPI_BIAS, EPI_ZEROED = 1, 2, 4, 8, 16
 
 _p, _i, _f, _z, _l = C.c_void_p, C.c_int32, C.c_float, C.c_size_t, C.c_int64
 
@@ -35,6 +35,7 @@ SIGNATURES = {
     "i2v_sort_desc": (_i, [_p, _i, _i, _p, _p, _z, _p]),
     "i2v_bbox_overlaps": (_i, [_p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p]),
     "i2v_conv_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "i2v_conv_fwd_splits": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "i2v_conv_set_tile": (_i, [_i]),
     "i2v_conv_debug_clock": (_i, [_p]),
     "i2v_conv_dgrad_workspace_bytes": (_z, [_i, _i, _i, _i]),

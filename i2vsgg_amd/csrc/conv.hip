@@ -39,6 +39,7 @@ struct ConvP {
     int lgCin;                   // log2(Cin) if power of two else -1
     int force_tile;              // >=0: tile config override (tuning / tests), -1: cost model
     unsigned x_bytes, w_bytes;   // sizes of x and w for the buffer descriptors (< 2 GiB each)
+    int dry;                     // plan only: run_conv returns the chosen split-K factor instead of launching
     unsigned long long* clk;     // diagnostic only (i2v_conv_debug_clock): per-workgroup {shader cycles, 100 MHz ticks}
 };
 
@@ -508,8 +509,9 @@ int run_conv(ConvP p, hipStream_t st) {
     p.splitk = splitk;
     p.k_per_split = i2v_cdiv(ksteps, splitk) * BKS;
     p.splitk = i2v_cdiv(p.K, p.k_per_split);
+    if (p.dry) return p.splitk;
     const long long ytotal = (long long)p.M * p.N;
-    if (p.splitk > 1) hipMemsetAsync(p.y, 0, (size_t)ytotal * sizeof(float), st);
+    if (p.splitk > 1 && !(p.flags & I2V_EPI_ZEROED)) hipMemsetAsync(p.y, 0, (size_t)ytotal * sizeof(float), st);
     // wave specialisation pays where few workgroups share a CU (nothing else hides the staging)
     const long long nblocks = (long long)i2v_cdiv(p.M, kTiles[cfg].bm) * i2v_cdiv(p.N, kTiles[cfg].bn) * p.splitk;
     // measured neutral on the backbone shapes (l2 c2 +6 %, l3 ds -12 %): off unless forced
@@ -1013,6 +1015,22 @@ extern "C" int32_t i2v_conv_set_tile(int32_t cfg) {
     g_force_tile = (cfg & 0xFF) == 0xFF ? -1 : (cfg & 0xFF);
     g_spec_mode = ((cfg >> 8) & 3) - 1;
     return I2V_OK;
+}
+
+// 1 if i2v_conv_fwd will accumulate split-K partials with atomics for this shape (its output must then start at
+// zero: the call clears it itself unless the caller passes I2V_EPI_ZEROED), 0 otherwise, < 0 on error.
+extern "C" int32_t i2v_conv_fwd_splits(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH,
+                                       int32_t KW, int32_t stride, int32_t pad) {
+    int dummy = 0;
+    int rc = check_conv("conv_fwd_splits", &dummy, &dummy, &dummy, B, H, W, Cin, Cout, KH, KW, stride, pad);
+    if (rc) return rc;
+    ConvP p = {};
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+    p.Ho = (H + 2 * pad - KH) / stride + 1;
+    p.Wo = (W + 2 * pad - KW) / stride + 1;
+    p.ostride = 1; p.force_tile = g_force_tile; p.dry = 1;
+    rc = run_conv(p, nullptr);
+    return rc < 0 ? rc : (rc > 1 ? 1 : 0);
 }
 
 extern "C" int32_t i2v_conv_fwd(const float* x, const float* w, const float* scale, const float* shift,

@@ -12,7 +12,8 @@ Conventions
 import torch
 
 from . import _lib
-from ._lib import EPI_BIAS, EPI_RELU, EPI_RESIDUAL, EPI_SCALE, LAYOUT_NCHW, LAYOUT_NHWC, check, lib, ptr, stream
+from ._lib import (EPI_BIAS, EPI_RELU, EPI_RESIDUAL, EPI_SCALE, EPI_ZEROED, LAYOUT_NCHW, LAYOUT_NHWC, check, lib, ptr,
+                   stream)
 
 _CL = torch.channels_last
 
@@ -243,12 +244,48 @@ class _Timed:
             PROFILE.append(self.rec)
 
 
+class ZeroArena:
+    """Pre-zeroed output arena for the split-K convolutions of one step: ONE clear per step instead of one
+    hipMemsetAsync per launch (~70 per SGG_emb step).  ``reset()`` at the top of a step clears the prefix used
+    last step and rewinds; ``take()`` hands out channels_last tensors.  When it runs out it reports the size
+    it would have needed (``wanted``) and the conv falls back to clearing its own output."""
+
+    def __init__(self, nbytes, device):
+        self.buf = torch.zeros(max(int(nbytes), 1024) // 4, dtype=torch.float32, device=device)
+        self.off = self.used = self.wanted = 0
+
+    def reset(self):
+        if self.used:
+            self.buf[:self.used].zero_()
+        self.off = self.wanted = 0
+
+    def take(self, B, C, H, W):
+        n = B * C * H * W
+        n_al = (n + 63) // 64 * 64
+        self.wanted += n_al
+        if self.off + n_al > self.buf.numel():
+            return None
+        t = self.buf[self.off:self.off + n].view(B, H, W, C).permute(0, 3, 1, 2)
+        self.off += n_al
+        self.used = max(self.used, self.off)
+        return t
+
+
+ARENA = None        # set by a training step object (train.SGGEmbStep) around its forward/backward
+
+
 def _conv_fwd_raw(x, w, scale, shift, res, stride, pad, flags):
     B, Cin, H, W = x.shape
     Cout, _, KH, KW = w.shape
     Ho = (H + 2 * pad - KH) // stride + 1
     Wo = (W + 2 * pad - KW) // stride + 1
-    y = torch.empty((B, Cout, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=_CL)
+    y = None
+    if ARENA is not None and lib.i2v_conv_fwd_splits(B, H, W, Cin, Cout, KH, KW, stride, pad) == 1:
+        y = ARENA.take(B, Cout, Ho, Wo)
+        if y is not None:
+            flags |= EPI_ZEROED
+    if y is None:
+        y = torch.empty((B, Cout, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=_CL)
     with _Timed(2.0 * B * Ho * Wo * Cout * KH * KW * Cin, "fwd",
                 "M%d N%d K%d (%dx%d s%d)" % (B * Ho * Wo, Cout, KH * KW * Cin, KH, KW, stride)):
         check(lib.i2v_conv_fwd(ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(res), ptr(y), B, H, W, Cin, Cout, KH, KW,

@@ -92,7 +92,7 @@ def synthetic_sgg_batch(seed, n_frames, n_boxes=32, n_pairs=32, n_rel=62, n_cls=
 
 class SGGEmbStep:
     def __init__(self, net, n_frames, vrd_lr=1e-4, seed=1, device="cuda:0", h=600, w=1000, n_boxes=32, n_pairs=32,
-                 use_graph=True, fuse_sgd=True):
+                 use_graph=True, fuse_sgd=True, zero_arena=True):
         self.net, self.dev, self.n_frames = net, torch.device(device), n_frames
         self.world = parallel.world_size()
         self.geom = (h, w, n_boxes, n_pairs)
@@ -102,6 +102,7 @@ class SGGEmbStep:
         self.loss = torch.zeros((), device=self.dev)
         self.graph = None
         self.use_graph = use_graph
+        self.arena = ops.ZeroArena(1024, self.dev) if zero_arena else None    # sized after the first step
 
     def reseed(self, seed):
         """(Re)generate the synthetic minibatch: frames, pair tables, masks, labels -> static device inputs (the
@@ -135,6 +136,16 @@ class SGGEmbStep:
 
     def _fwd_bwd(self):
         net = self.net
+        if self.arena is not None:
+            self.arena.reset()          # one clear for every split-K output of this step
+        ops.ARENA = self.arena
+        try:
+            self._fwd_bwd_inner()
+        finally:
+            ops.ARENA = None
+
+    def _fwd_bwd_inner(self):
+        net = self.net
         with torch.no_grad():
             fmap = net.RCNN_base(self.im)
         score, _ = net.vrd.forward_device(fmap, self.boxes, self.relb, self.masks, self.ixs, self.ixo)
@@ -160,8 +171,10 @@ class SGGEmbStep:
         s = torch.cuda.Stream(self.dev)
         s.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(s):
-            for _ in range(warmup):
+            for i in range(warmup):
                 self._body()
+                if i == 0 and self.arena is not None and self.arena.wanted * 4 > self.arena.buf.numel() * 4:
+                    self.arena = ops.ZeroArena(int(self.arena.wanted * 4 * 1.05) + 4096, self.dev)
         torch.cuda.current_stream(self.dev).wait_stream(s)
         torch.cuda.synchronize(self.dev)
         if not self.use_graph:

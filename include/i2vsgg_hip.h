@@ -42,6 +42,7 @@ extern "C" {
 #define I2V_EPI_RESIDUAL  2
 #define I2V_EPI_SCALE     4      /* y = acc*scale[n] + shift[n]  (frozen BN)       */
 #define I2V_EPI_BIAS      8      /* y = acc + shift[n]                             */
+#define I2V_EPI_ZEROED   16      /* caller guarantees y is all zeros (skips the split-K clear) */
 
 int32_t     i2v_version(void);
 const char* i2v_last_error(void);
@@ -135,6 +136,10 @@ int32_t i2v_bbox_overlaps(const float* boxes, int32_t box_stride, int32_t box_of
 int32_t i2v_conv_fwd(const float* x, const float* w, const float* scale, const float* shift, const float* res,
                      float* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                      int32_t KH, int32_t KW, int32_t stride, int32_t pad, int32_t flags, void* stream);
+/* 1 if i2v_conv_fwd will use split-K atomics for this shape (y must start at zero: the call clears it unless
+ * I2V_EPI_ZEROED is passed -- lets a caller batch many clears into one), 0 if not, < 0 on error */
+int32_t i2v_conv_fwd_splits(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW,
+                            int32_t stride, int32_t pad);
 /* tuning hook: cfg < 0 = cost model; else low byte = tile shape 0..5 (0xFF = cost model),
  * bits 8-9 = 0 auto / 1 plain 4-wave kernel / 2 loader+MFMA specialised 8-wave kernel */
 int32_t i2v_conv_set_tile(int32_t cfg);
