@@ -11,13 +11,18 @@ SOURCES = ["api.cpp", "roi_ops.hip", "rpn.hip", "conv.hip", "heads.hip"]
 # reference's CPU path (no FMA contraction), or NMS threshold decisions can flip.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
          "-Wno-unused-value", "-Wno-unused-result"]
+# MFMA accumulators in VGPRs, not AGPRs: measured on MI355X (tools/micro/mfma_rate.hip, tools/conv_ablate.py) a
+# back-to-back v_mfma_f32_16x16x4_f32 stream issues every 32 cycles with VGPR accumulators but only every ~45
+# cycles in the AGPR form hipcc picks by default for these kernels.
+EXTRA = {"conv.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _stale():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "i2vsgg_hip.h")]
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "i2vsgg_hip.h"),
+                                                                os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
@@ -35,7 +40,7 @@ def build(force=False, verbose=False):
             continue
         obj = os.path.join(objdir, src.rsplit(".", 1)[0] + ".o")
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", path, "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", path, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -39,6 +39,7 @@ struct ConvP {
     int lgCin;                   // log2(Cin) if power of two else -1
     int force_tile;              // >=0: tile config override (tuning / tests), -1: cost model
     unsigned x_bytes, w_bytes;   // sizes of x and w for the buffer descriptors (< 2 GiB each)
+    int ablate;                  // diagnostic (i2v_conv_set_tile bits 10-11): 1 = skip staging in the K loop, 2 = skip MFMAs
     int dry;                     // plan only: run_conv returns the chosen split-K factor instead of launching
     unsigned long long* clk;     // diagnostic only (i2v_conv_debug_clock): per-workgroup {shader cycles, 100 MHz ticks}
 };
@@ -62,7 +63,7 @@ __device__ inline void split_k(const ConvP& p, int k, int& ky, int& kx, int& c) 
 // workgroup per CU (the 4788-row layer3 GEMMs) a single wave per SIMD would otherwise serialise
 // {address math + loads, LDS reads, MFMAs, LDS stores, barrier}; here the loader wave of a SIMD runs
 // beside its MFMA wave (VALU/VMEM and the matrix pipe issue independently).
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool SPEC>
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool SPEC, int ABL = 0>
 __global__ void __launch_bounds__(SPEC ? 2 * THREADS : THREADS)
 conv_igemm_f32(const ConvP p) {
     constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
@@ -102,21 +103,30 @@ conv_igemm_f32(const ConvP p) {
     // staging roles: slot = tid + q*256 -> row = slot>>3, 16-B column = slot&7 (= tid&7 for every q)
     const int kc = tid & 7, kg = kc * 4;
     const bool is1x1 = (p.KH == 1 && p.KW == 1 && p.pad == 0);
-    // filter-tap table (only for KHxKW > 1): entry e = k/4 -> (input offset of tap (ky,kx,c)) << 6 | kpos.
+    const bool wide = p.KH * p.KW > 32;       // more than 32 taps (7x7 stem, 8x8): second mask word
+    // filter-tap table (only for KHxKW > 1): entry e = k/4 -> (byte offset of tap (ky,kx,c)) << 6 | tap id.
     // Built once per workgroup, so the K loop has no integer division and no per-tap bounds math.
     if (!is1x1) {
-        for (int e = gtid; e < (p.K >> 2); e += NT) {
-            int ky, kx, c;
-            split_k(p, e << 2, ky, kx, c);
-            ktab[e] = (unsigned)(((ky * p.W + kx) * p.Cin + c) << 6) | (unsigned)(ky * p.KW + kx);
+        const int n_e = min(KTAB_MAX, ((p.K + BKS - 1) / BKS) * (BKS / 4));
+        for (int e = gtid; e < n_e; e += NT) {
+            unsigned v = 0;
+            if ((e << 2) < p.K) {
+                int ky, kx, c;
+                split_k(p, e << 2, ky, kx, c);
+                v = (unsigned)((((ky * p.W + kx) * p.Cin + c) * 4) << 6) | (unsigned)(ky * p.KW + kx);
+            }
+            ktab[e] = v;
         }
     }
     // Loads go through buffer resources: a masked lane gets an out-of-range offset and the hardware
-    // returns zeros -- no branches, no select-of-loads, 32-bit offsets instead of 64-bit pointers.
+    // returns zeros -- no branches, no select-of-loads, 32-bit byte offsets instead of 64-bit pointers.
+    // INV (2 GiB) + any in-tile delta stays beyond every buffer (< 2 GiB), so rows outside the tile need
+    // no per-stage test at all.
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
-    int a_off[A_LD];                  // float index of x[b][iy0][ix0][0] (may be negative: padded taps are masked)
-    unsigned long long a_mask[A_LD];  // bit kpos: tap (ky,kx) of this output pixel reads inside the image
+    constexpr unsigned INV = 0x80000000u, OOB = 0xFFFFFFF0u;
+    unsigned a_off4[A_LD];            // byte offset of x[b][iy0][ix0][0] (mod 2^32: padded taps are masked)
+    unsigned a_mlo[A_LD], a_mhi[A_LD];  // bit t: tap t of this output pixel reads inside the image
 #pragma unroll
     for (int q = 0; q < A_LD; ++q) {
         const int row = (tid >> 3) + q * (THREADS / 8);
@@ -125,53 +135,63 @@ conv_igemm_f32(const ConvP p) {
         const int mm = ok ? m : 0;
         const int ox = mm % p.Wo, t = mm / p.Wo, oy = t % p.Ho, b = t / p.Ho;
         const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-        a_off[q] = ((b * p.H + iy0) * p.W + ix0) * p.Cin;
+        a_off4[q] = ok ? (unsigned)(((b * p.H + iy0) * p.W + ix0) * p.Cin) * 4u : INV;
         unsigned long long mask = 0;
-        if (ok) {
-            if (is1x1) mask = 1;
-            else
-                for (int ky = 0; ky < p.KH; ++ky)
-                    for (int kx = 0; kx < p.KW; ++kx)
-                        if (iy0 + ky >= 0 && iy0 + ky < p.H && ix0 + kx >= 0 && ix0 + kx < p.W)
-                            mask |= 1ull << (ky * p.KW + kx);
+        if (ok && !is1x1) {
+            // taps (ky,kx) inside the image form a rectangle: kx in [kx_lo,kx_hi) for ky in [ky_lo,ky_hi)
+            const int kx_lo = max(0, -ix0), kx_hi = min(p.KW, p.W - ix0);
+            const int ky_lo = max(0, -iy0), ky_hi = min(p.KH, p.H - iy0);
+            if (kx_hi > kx_lo) {
+                const unsigned long long rowbits = ((1ull << kx_hi) - 1ull) & ~((1ull << kx_lo) - 1ull);
+                for (int ky = ky_lo; ky < ky_hi; ++ky) mask |= rowbits << (ky * p.KW);
+            }
         }
-        a_mask[q] = mask;
+        a_mlo[q] = (unsigned)mask;
+        a_mhi[q] = (unsigned)(mask >> 32);
     }
-    int b_off[B_LD];
+    unsigned b_off4[B_LD];
 #pragma unroll
     for (int q = 0; q < B_LD; ++q) {
         const int row = (tid >> 3) + q * (THREADS / 8);
         const int n = n0 + row;
-        b_off[q] = (row < BN && n < p.N) ? n * p.K : -1;
+        b_off4[q] = (row < BN && n < p.N) ? (unsigned)(n * p.K) * 4u : INV;
     }
     if (!is1x1) __syncthreads();      // ktab visible
 
-    // register prefetch: the loads of stage k+1 are in flight while stage k computes.  (A second
-    // register set, two stages in flight, measured slower: the extra VGPRs cost more occupancy than
-    // the deeper prefetch hides.)
-    constexpr unsigned OOB = 0xFFFFFFF0u;
-    float4 ra[A_LD], rb[B_LD];
-    auto gload = [&](int k0) {
+    // one stage of global loads into a register set (~25 VALU + the buffer loads per thread)
+    auto stage_load = [&](float4 (&A)[A_LD], float4 (&Bq)[B_LD], int k0) {
         const int k = k0 + kg;
         const bool kin = k < kend;
-        int delta = k, kpos = 0;
-        if (!is1x1) {
-            const unsigned e = ktab[kin ? (k >> 2) : 0];
-            delta = (int)(e >> 6);
-            kpos = (int)(e & 63u);
-        }
+        const unsigned k4 = (unsigned)k * 4u;
+        if (is1x1) {
 #pragma unroll
-        for (int q = 0; q < A_LD; ++q) {
-            const bool ok = kin && ((a_mask[q] >> kpos) & 1ull);
-            const unsigned off = ok ? (unsigned)(a_off[q] + delta) * 4u : OOB;
-            ra[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+            for (int q = 0; q < A_LD; ++q) {
+                const unsigned off = kin ? a_off4[q] + k4 : OOB;
+                A[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+            }
+        } else {
+            const unsigned e = ktab[k >> 2];
+            const unsigned d4 = e >> 6, kp = e & 31u;
+            const bool hi = wide && (e & 32u);
+#pragma unroll
+            for (int q = 0; q < A_LD; ++q) {
+                const unsigned mword = hi ? a_mhi[q] : a_mlo[q];
+                const bool ok = kin && ((mword >> kp) & 1u);
+                const unsigned off = ok ? a_off4[q] + d4 : OOB;
+                A[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+            }
         }
 #pragma unroll
         for (int q = 0; q < B_LD; ++q) {
-            const unsigned off = (kin && b_off[q] >= 0) ? (unsigned)(b_off[q] + k) * 4u : OOB;
-            rb[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
+            const unsigned off = kin ? b_off4[q] + k4 : OOB;
+            Bq[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
         }
     };
+    // register prefetch: the loads of stage k+1 are in flight while stage k computes.  (A second
+    // register set, two stages in flight, measured slower in the 4-wave kernel: the extra VGPRs cost more
+    // occupancy than the deeper prefetch hides.)
+    float4 ra[A_LD], rb[B_LD];
+    auto gload = [&](int k0) { stage_load(ra, rb, k0); };
     auto sstore = [&](int S) {
 #pragma unroll
         for (int q = 0; q < A_LD; ++q) {
@@ -196,15 +216,22 @@ conv_igemm_f32(const ConvP p) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             float4 av[TM], bv[TN];
+            if constexpr (ABL & 8) {          // diagnostic: no LDS fragment reads (operands are lane constants)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = (wm * TM + i) * 16 + fr;
-                av[i] = *(const float4*)&As[buf][row * BKS + (((s * 4 + fg) ^ ((row >> 1) & 7)) << 2)];
-            }
+                for (int i = 0; i < TM; ++i) av[i] = make_float4(1.f + lane, 2.f + buf, 3.f, 4.f);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = (wn * TN + j) * 16 + fr;
-                bv[j] = *(const float4*)&Bs[buf][row * BKS + (((s * 4 + fg) ^ ((row >> 1) & 7)) << 2)];
+                for (int j = 0; j < TN; ++j) bv[j] = make_float4(1.f, 2.f + lane, 3.f + buf, 4.f);
+            } else {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = (wm * TM + i) * 16 + fr;
+                    av[i] = *(const float4*)&As[buf][row * BKS + (((s * 4 + fg) ^ ((row >> 1) & 7)) << 2)];
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int row = (wn * TN + j) * 16 + fr;
+                    bv[j] = *(const float4*)&Bs[buf][row * BKS + (((s * 4 + fg) ^ ((row >> 1) & 7)) << 2)];
+                }
             }
             // k component outermost: consecutive MFMAs hit DIFFERENT accumulators (the 16x16x4 f32
             // MFMA issues every 32 cycles but a dependent one waits 40)
@@ -236,93 +263,95 @@ conv_igemm_f32(const ConvP p) {
                                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
+    unsigned long long t1c = 0;
+    if (p.clk) t1c = __builtin_amdgcn_s_memtime();
     if constexpr (SPEC) {
         if (gtid >= THREADS) {                // ---- loader waves
-            // two register sets: the loads of stages s+2 and s+3 are in flight while stage s computes
-            // (loaders hold no accumulators, so the second set is free here)
-            float4 ra2[2][A_LD], rb2[2][B_LD];
+            // four register sets: the loads of stages s+2 .. s+5 are in flight while stage s computes.  A CU
+            // ingests only ~12 B/clk with one 18 KB stage in flight (L1 miss capacity x L2 latency; measured with
+            // tools/conv_ablate.py) -- the matrix pipe needs ~14 B/clk at this tile shape -- so the loaders keep
+            // ~70 KB in flight; they hold no accumulators, the extra sets are free here.
+            constexpr int NSET = 4;
+            float4 ra2[NSET][A_LD], rb2[NSET][B_LD];
             auto gl = [&](auto SET, int k0) {
                 constexpr int S = decltype(SET)::value;
-                const int k = k0 + kg;
-                const bool kin = k < kend;
-                int delta = k, kpos = 0;
-                if (!is1x1) {
-                    const unsigned e = ktab[kin ? (k >> 2) : 0];
-                    delta = (int)(e >> 6);
-                    kpos = (int)(e & 63u);
-                }
-#pragma unroll
-                for (int q = 0; q < A_LD; ++q) {
-                    const bool ok = kin && ((a_mask[q] >> kpos) & 1ull);
-                    const unsigned off = ok ? (unsigned)(a_off[q] + delta) * 4u : OOB;
-                    ra2[S][q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
-                }
-#pragma unroll
-                for (int q = 0; q < B_LD; ++q) {
-                    const unsigned off = (kin && b_off[q] >= 0) ? (unsigned)(b_off[q] + k) * 4u : OOB;
-                    rb2[S][q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
-                }
+                stage_load(ra2[S], rb2[S], k0);
             };
-            auto st = [&](auto SET) {          // register set S always feeds LDS buffer S
-                constexpr int S = decltype(SET)::value;
+            auto st = [&](auto SET, auto BUF) {
+                constexpr int S = decltype(SET)::value, Bf = decltype(BUF)::value;
 #pragma unroll
                 for (int q = 0; q < A_LD; ++q) {
                     const int row = (tid >> 3) + q * (THREADS / 8);
-                    if (row < BM) *(float4*)&As[S][row * BKS + ((kc ^ ((row >> 1) & 7)) << 2)] = ra2[S][q];
+                    if (row < BM) *(float4*)&As[Bf][row * BKS + ((kc ^ ((row >> 1) & 7)) << 2)] = ra2[S][q];
                 }
 #pragma unroll
                 for (int q = 0; q < B_LD; ++q) {
                     const int row = (tid >> 3) + q * (THREADS / 8);
-                    if (row < BN) *(float4*)&Bs[S][row * BKS + ((kc ^ ((row >> 1) & 7)) << 2)] = rb2[S][q];
+                    if (row < BN) *(float4*)&Bs[Bf][row * BKS + ((kc ^ ((row >> 1) & 7)) << 2)] = rb2[S][q];
                 }
             };
-            using S0 = std::integral_constant<int, 0>;
-            using S1 = std::integral_constant<int, 1>;
-            gl(S0{}, kbeg);
-            st(S0{});
-            if (kbeg + BKS < kend) gl(S1{}, kbeg + BKS);
-            if (kbeg + 2 * BKS < kend) gl(S0{}, kbeg + 2 * BKS);
+            using I0 = std::integral_constant<int, 0>;
+            using I1 = std::integral_constant<int, 1>;
+            using I2 = std::integral_constant<int, 2>;
+            using I3 = std::integral_constant<int, 3>;
+            gl(I0{}, kbeg);
+            st(I0{}, I0{});
+            if (kbeg + 1 * BKS < kend) gl(I1{}, kbeg + 1 * BKS);
+            if (kbeg + 2 * BKS < kend) gl(I2{}, kbeg + 2 * BKS);
+            if (kbeg + 3 * BKS < kend) gl(I3{}, kbeg + 3 * BKS);
+            if (kbeg + 4 * BKS < kend) gl(I0{}, kbeg + 4 * BKS);
             __syncthreads();                  // stage 0 visible
-            for (int k0 = kbeg; k0 < kend;) {
-                // even stage s computes from buffer 0: publish stage s+1 (set 1), refill set 1 with s+3
-                if (k0 + BKS < kend) st(S1{});
-                if (k0 + 3 * BKS < kend) gl(S1{}, k0 + 3 * BKS);
-                __syncthreads();
-                k0 += BKS;
-                if (k0 >= kend) break;
-                // odd stage computes from buffer 1: publish stage s+1 (set 0), refill set 0 with s+3
-                if (k0 + BKS < kend) st(S0{});
-                if (k0 + 3 * BKS < kend) gl(S0{}, k0 + 3 * BKS);
-                __syncthreads();
-                k0 += BKS;
+            // stage s computes from LDS buffer s&1; this iteration publishes stage s+1 (register set (s+1)&3)
+            // into buffer (s+1)&1 and refills that set with stage s+5
+#define I2V_LOADER_STEP(SET, BUF)                                   \
+            if (k0 + BKS < kend) st(SET{}, BUF{});                  \
+            if (k0 + 5 * BKS < kend) gl(SET{}, k0 + 5 * BKS);       \
+            __syncthreads();                                        \
+            k0 += BKS;                                              \
+            if (k0 >= kend) break;
+            for (int k0 = kbeg;;) {
+                I2V_LOADER_STEP(I1, I1)
+                I2V_LOADER_STEP(I2, I0)
+                I2V_LOADER_STEP(I3, I1)
+                I2V_LOADER_STEP(I0, I0)
             }
+#undef I2V_LOADER_STEP
         } else {                              // ---- MFMA waves
             __syncthreads();
             int buf = 0;
+            unsigned long long c_mm = 0;
             for (int k0 = kbeg; k0 < kend; k0 += BKS) {
+                const unsigned long long a0 = p.clk ? __builtin_amdgcn_s_memtime() : 0ull;
                 compute(buf);
+                if (p.clk) c_mm += __builtin_amdgcn_s_memtime() - a0;
                 __syncthreads();
                 buf ^= 1;
             }
+            if (p.clk && gtid == 0) p.clk[8 * (blockIdx.y * gridDim.x + blockIdx.x) + 7] = c_mm;
         }
     } else {
         gload(kbeg);
         sstore(0);
         __syncthreads();
         int buf = 0;
+        const bool no_stage = p.ablate & 1, no_mfma = p.ablate & 2;
         for (int k0 = kbeg; k0 < kend; k0 += BKS) {
-            const bool more = k0 + BKS < kend;
+            const bool more = k0 + BKS < kend && !no_stage;
             if (more) gload(k0 + BKS);
-            compute(buf);
+            if (!no_mfma) compute(buf);
             if (more) sstore(buf ^ 1);
-            __syncthreads();
+            if constexpr (!(ABL & 4)) __syncthreads();
             buf ^= 1;
         }
     }
 
     if (p.clk && gtid == 0) {     // diagnostic build path: stamps go to their own buffer, never to an output
-        p.clk[2 * (blockIdx.y * gridDim.x + blockIdx.x)] = __builtin_amdgcn_s_memtime() - t0c;
-        p.clk[2 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = __builtin_amdgcn_s_memrealtime() - t0r;
+        const unsigned long long t2c = __builtin_amdgcn_s_memtime();
+        unsigned long long* o = p.clk + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
+        o[0] = t2c - t1c;                                  // K loop (incl. its prologue stage)
+        o[1] = __builtin_amdgcn_s_memrealtime() - t0r;     // 100 MHz ticks, whole kernel so far
+        o[2] = t1c - t0c;                                  // setup: tap table, row masks, residual prefetch
+        o[3] = t2c - t0c;
     }
     // epilogue.  C/D map of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + r.  The tile goes
     // through LDS so that global stores (and the residual loads) are whole 16-B-per-lane rows
@@ -439,6 +468,7 @@ inline int ilog2_exact(int v) {
 
 constexpr int NUM_CU = 256;
 int g_force_tile = -1;           // i2v_conv_set_tile(): tuning hook (low byte: tile, bits 8-9: spec mode + 1)
+int g_ablate = 0;
 unsigned long long* g_clk = nullptr;   // i2v_conv_debug_clock()
 // -1 / 0: plain 4-wave kernel, 1: loader/MFMA specialised 8-wave kernel, 2: specialised when <= 3 workgroups per CU
 int g_spec_mode = [] { const char* e = getenv("I2V_CONV_SPEC"); return e ? atoi(e) : -1; }();
@@ -448,6 +478,10 @@ template <int WAVES_M, int WAVES_N, int TM, int TN>
 void launch_tile(const ConvP& p, bool spec, hipStream_t st) {
     constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
     const int tiles = i2v_cdiv(p.M, BM) * i2v_cdiv(p.N, BN);
+    if constexpr (WAVES_M == 1) {      // diagnostic instantiations (tools/conv_ablate.py), 80x64 tile only
+        if ((p.ablate & 12) == 4) { conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false, 4><<<dim3(tiles, p.splitk), THREADS, 0, st>>>(p); return; }
+        if ((p.ablate & 12) == 12) { conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false, 12><<<dim3(tiles, p.splitk), THREADS, 0, st>>>(p); return; }
+    }
     if (spec) conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, true><<<dim3(tiles, p.splitk), 2 * THREADS, 0, st>>>(p);
     else conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false><<<dim3(tiles, p.splitk), THREADS, 0, st>>>(p);
 }
@@ -464,7 +498,7 @@ int run_conv(ConvP p, hipStream_t st) {
     p.K = p.KH * p.KW * p.Cin;
     p.lgCin = ilog2_exact(p.Cin);
     if (!(p.KH == 1 && p.KW == 1 && p.pad == 0)) {
-        if (p.K > KTAB_MAX * 4 || p.KH * p.KW > 64 || ((long long)(p.KH * p.W + p.KW) * p.Cin) >= (1ll << 26)) {
+        if (p.K > KTAB_MAX * 4 || p.KH * p.KW > 64 || ((long long)(p.KH * p.W + p.KW) * p.Cin) >= (1ll << 24)) {
             i2v_set_error("conv: filter %dx%dx%d too large for the tap table", p.KH, p.KW, p.Cin);
             return I2V_ERR_UNSUPPORTED;
         }
@@ -477,6 +511,7 @@ int run_conv(ConvP p, hipStream_t st) {
     p.x_bytes = (unsigned)xb;
     p.w_bytes = (unsigned)wb;
     p.clk = g_clk;
+    p.ablate = g_ablate;
     const int force = p.force_tile;
     const int ksteps = i2v_cdiv(p.K, BKS);
     // tile + split-K choice: minimise (rounds over the 256 CUs) x (MACs per workgroup) / efficiency.
@@ -1011,9 +1046,10 @@ extern "C" int32_t i2v_conv_debug_clock(void* buf) {
 }
 
 extern "C" int32_t i2v_conv_set_tile(int32_t cfg) {
-    if (cfg < 0) { g_force_tile = -1; g_spec_mode = -1; return I2V_OK; }
+    if (cfg < 0) { g_force_tile = -1; g_spec_mode = -1; g_ablate = 0; return I2V_OK; }
     g_force_tile = (cfg & 0xFF) == 0xFF ? -1 : (cfg & 0xFF);
     g_spec_mode = ((cfg >> 8) & 3) - 1;
+    g_ablate = (cfg >> 10) & 15;
     return I2V_OK;
 }
 

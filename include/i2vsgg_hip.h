@@ -143,8 +143,9 @@ int32_t i2v_conv_fwd_splits(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_
 /* tuning hook: cfg < 0 = cost model; else low byte = tile shape 0..5 (0xFF = cost model),
  * bits 8-9 = 0 auto / 1 plain 4-wave kernel / 2 loader+MFMA specialised 8-wave kernel */
 int32_t i2v_conv_set_tile(int32_t cfg);
-/* diagnostic: when buf != NULL every conv workgroup writes {shader cycles, 100 MHz ticks} of its main loop to
- * buf[2*wg .. 2*wg+1] (device memory, >= 16 B per workgroup); the in-kernel clock is cycles/ticks * 100 MHz */
+/* diagnostic: when buf != NULL every conv workgroup writes 8 u64 to buf[8*wg ..]: {K-loop shader cycles, 100 MHz
+ * ticks since kernel start, setup cycles, total cycles, then (specialised kernel only) loader LDS-store / load-issue /
+ * barrier cycles and MFMA-wave compute cycles}; the in-kernel clock is total cycles / ticks * 100 MHz */
 int32_t i2v_conv_debug_clock(void* buf);
 size_t  i2v_conv_dgrad_workspace_bytes(int32_t Cin, int32_t Cout, int32_t KH, int32_t KW);
 int32_t i2v_conv_dgrad(const float* gy, const float* w, float* gx, int32_t B, int32_t H, int32_t W,

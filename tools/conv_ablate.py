@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Where does a K-loop stage go?  In-kernel cycle stamps (s_memtime) of the main loop of conv_igemm_f32 at ~1
+workgroup per CU (layer3 3x3, 80x64 tile, no split-K), with staging or MFMAs ablated.  Diagnostic only."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["I2V_SPLIT_BELOW"] = os.environ.get("I2V_SPLIT_BELOW", "0")
+import torch
+from i2vsgg_amd import ops, _lib
+B = 2
+cases = [("l3 c2 3x3 256 (72 stages)", 256, 38, 63, 256, 3, 1, 1, 72), ("l3 c1 1024->256 (32 stages)", 1024, 38, 63, 256, 1, 1, 0, 32)]
+for name, cin, h, w, cout, k, s, p, stages in cases:
+    x = torch.randn(B, cin, h, w, device="cuda").contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(cout, cin, k, k, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last)
+    for tile in (3,):
+        for label, cfg in (("plain", tile | (1 << 8)), ("plain, no staging", tile | (1 << 8) | (1 << 10)),
+                           ("plain, no MFMA", tile | (1 << 8) | (2 << 10)), ("specialised", tile | (2 << 8)),
+                           ("no staging, no barrier", tile | (1 << 8) | (5 << 10)),
+                           ("no staging/barrier/ds_read", tile | (1 << 8) | (13 << 10))):
+            buf = torch.zeros(8 * 8192, dtype=torch.int64, device="cuda")
+            _lib.lib.i2v_conv_set_tile(cfg)
+            for _ in range(50):
+                ops.conv2d(x, wt, None, None, None, s, p)
+            _lib.lib.i2v_conv_debug_clock(buf.data_ptr())
+            ops.conv2d(x, wt, None, None, None, s, p)
+            _lib.lib.i2v_conv_debug_clock(None)
+            torch.cuda.synchronize()
+            v = buf.view(-1, 8).cpu()
+            v = v[v[:, 1] > 0]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                ops.conv2d(x, wt, None, None, None, s, p)
+            e1.record(); torch.cuda.synchronize()
+            print("%-28s tile %d %-28s WGs %4d  loop cycles/stage %6.0f (MFMA issue bound %d)  setup %6.0f cyc  kernel %6.1f us" % (
+                name, tile, label, v.shape[0], v[:, 0].double().median().item() / stages, 1280 if tile == 3 else 1024,
+                v[:, 2].double().median().item(), e0.elapsed_time(e1) / 20 * 1e3))
+            if label == "specialised":
+                m = lambda i: v[:, i].double().median().item() / stages
+                print("    specialised per stage: loader LDS-store %5.0f  load-issue %5.0f  barrier-wait %5.0f | MFMA wave compute %5.0f" % (m(4), m(5), m(6), m(7)))
+    _lib.lib.i2v_conv_set_tile(-1)
