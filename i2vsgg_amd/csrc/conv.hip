@@ -14,6 +14,7 @@
 // free.  K order inside a 8-deep step is permuted (lane half h owns k = 4h..4h+3) so a
 // fragment is ONE b128 read; A and B use the same permutation, so the sum is unchanged.
 #include "common.h"
+#include <mutex>
 #include <type_traits>
 #include <stdlib.h>
 
@@ -21,12 +22,14 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 16;          // k per LDS stage of the wgrad kernel
 constexpr int KTAB_MAX = 2560;  // filter-tap table entries (K/4): KH*KW*Cin <= 10240 for non-1x1 filters
 constexpr int BKS = 32;         // k per LDS stage of the forward/dgrad kernel (= floats per LDS row)
 constexpr int LDS_ROW = 20;     // floats per staged row (16 + 4 pad)
 constexpr int THREADS = 256;
+constexpr int kSplitInKernelMax = 8;   // most splits the in-kernel split-K finish sums (else: atomics)
 
 struct ConvP {
     const float* x; const float* w; const float* scale; const float* shift; const float* res; float* y;
@@ -42,6 +45,8 @@ struct ConvP {
     int ablate;                  // diagnostic (i2v_conv_set_tile bits 10-11): 1 = skip staging in the K loop, 2 = skip MFMAs
     int dry;                     // plan only: run_conv returns the chosen split-K factor instead of launching
     unsigned long long* clk;     // diagnostic only (i2v_conv_debug_clock): per-workgroup {shader cycles, 100 MHz ticks}
+    float* ws;                   // split-K partial tiles [split][tile][BM*BN] (nullptr: fp32 atomics into y)
+    int* cnt;                    // split-K arrival counters, one per tile, zero between launches
 };
 
 __device__ inline void split_k(const ConvP& p, int k, int& ky, int& kx, int& c) {
@@ -103,7 +108,7 @@ conv_igemm_f32(const ConvP p) {
     // staging roles: slot = tid + q*256 -> row = slot>>3, 16-B column = slot&7 (= tid&7 for every q)
     const int kc = tid & 7, kg = kc * 4;
     const bool is1x1 = (p.KH == 1 && p.KW == 1 && p.pad == 0);
-    const bool wide = p.KH * p.KW > 32;       // more than 32 taps (7x7 stem, 8x8): second mask word
+    const unsigned m1x1 = is1x1 ? 0xFFFFFFFFu : 0u;
     // filter-tap table (only for KHxKW > 1): entry e = k/4 -> (byte offset of tap (ky,kx,c)) << 6 | tap id.
     // Built once per workgroup, so the K loop has no integer division and no per-tap bounds math.
     if (!is1x1) {
@@ -137,6 +142,7 @@ conv_igemm_f32(const ConvP p) {
         const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
         a_off4[q] = ok ? (unsigned)(((b * p.H + iy0) * p.W + ix0) * p.Cin) * 4u : INV;
         unsigned long long mask = 0;
+        if (ok && is1x1) mask = 1;
         if (ok && !is1x1) {
             // taps (ky,kx) inside the image form a rectangle: kx in [kx_lo,kx_hi) for ky in [ky_lo,ky_hi)
             const int kx_lo = max(0, -ix0), kx_hi = min(p.KW, p.W - ix0);
@@ -158,34 +164,30 @@ conv_igemm_f32(const ConvP p) {
     }
     if (!is1x1) __syncthreads();      // ktab visible
 
-    // one stage of global loads into a register set (~25 VALU + the buffer loads per thread)
+    // one stage of global loads into a register set.  Masking is pure integer arithmetic (OR-ing INV
+    // into the offset): with `cond ? offset : OOB` the compiler threads the condition into divergent
+    // branches that each hold a copy of the load writing the same registers, and guards the second copy
+    // with s_waitcnt vmcnt(0) -- which drains every stage still in flight.
     auto stage_load = [&](float4 (&A)[A_LD], float4 (&Bq)[B_LD], int k0) {
         const int k = k0 + kg;
-        const bool kin = k < kend;
+        const unsigned kinv = ~(unsigned)((k - kend) >> 31) & INV;      // INV when k >= kend
         const unsigned k4 = (unsigned)k * 4u;
-        if (is1x1) {
+        // 1x1 filters have no tap table: their "entry" is (k*4) << 6 | tap 0.  One load sequence serves
+        // both cases (selected by mask arithmetic, not a branch: two copies of the loads under a branch
+        // write the same registers and cost a vmcnt(0) each)
+        const unsigned e = ktab[(unsigned)min(k >> 2, KTAB_MAX - 1) & ~m1x1];
+        const unsigned ee = (e & ~m1x1) | ((k4 << 6) & m1x1);
+        const unsigned d4 = ee >> 6, kp = ee & 63u;
 #pragma unroll
-            for (int q = 0; q < A_LD; ++q) {
-                const unsigned off = kin ? a_off4[q] + k4 : OOB;
-                A[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
-            }
-        } else {
-            const unsigned e = ktab[k >> 2];
-            const unsigned d4 = e >> 6, kp = e & 31u;
-            const bool hi = wide && (e & 32u);
-#pragma unroll
-            for (int q = 0; q < A_LD; ++q) {
-                const unsigned mword = hi ? a_mhi[q] : a_mlo[q];
-                const bool ok = kin && ((mword >> kp) & 1u);
-                const unsigned off = ok ? a_off4[q] + d4 : OOB;
-                A[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
-            }
+        for (int q = 0; q < A_LD; ++q) {
+            const unsigned long long m64 = ((unsigned long long)a_mhi[q] << 32) | a_mlo[q];
+            const unsigned tinv = (((unsigned)(m64 >> kp) & 1u) - 1u) & INV;  // INV when the tap is padding
+            A[q] = __builtin_bit_cast(float4,
+                                      __builtin_amdgcn_raw_buffer_load_b128(xr, (a_off4[q] + d4) | tinv | kinv, 0, 0));
         }
 #pragma unroll
-        for (int q = 0; q < B_LD; ++q) {
-            const unsigned off = kin ? b_off4[q] + k4 : OOB;
-            Bq[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, 0, 0));
-        }
+        for (int q = 0; q < B_LD; ++q)
+            Bq[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, (b_off4[q] + k4) | kinv, 0, 0));
     };
     // register prefetch: the loads of stage k+1 are in flight while stage k computes.  (A second
     // register set, two stages in flight, measured slower in the 4-wave kernel: the extra VGPRs cost more
@@ -267,6 +269,7 @@ conv_igemm_f32(const ConvP p) {
     if (p.clk) t1c = __builtin_amdgcn_s_memtime();
     if constexpr (SPEC) {
         if (gtid >= THREADS) {                // ---- loader waves
+            __builtin_amdgcn_s_setprio(3);
             // four register sets: the loads of stages s+2 .. s+5 are in flight while stage s computes.  A CU
             // ingests only ~12 B/clk with one 18 KB stage in flight (L1 miss capacity x L2 latency; measured with
             // tools/conv_ablate.py) -- the matrix pipe needs ~14 B/clk at this tile shape -- so the loaders keep
@@ -296,26 +299,50 @@ conv_igemm_f32(const ConvP p) {
             using I3 = std::integral_constant<int, 3>;
             gl(I0{}, kbeg);
             st(I0{}, I0{});
-            if (kbeg + 1 * BKS < kend) gl(I1{}, kbeg + 1 * BKS);
-            if (kbeg + 2 * BKS < kend) gl(I2{}, kbeg + 2 * BKS);
-            if (kbeg + 3 * BKS < kend) gl(I3{}, kbeg + 3 * BKS);
-            if (kbeg + 4 * BKS < kend) gl(I0{}, kbeg + 4 * BKS);
+            // loads past kend are issued unconditionally (masked to out-of-range offsets, they move no
+            // data): a load under a condition makes the in-flight count unknowable and the compiler
+            // falls back to s_waitcnt vmcnt(0) before every LDS store
+            gl(I1{}, kbeg + 1 * BKS);
+            gl(I2{}, kbeg + 2 * BKS);
+            gl(I3{}, kbeg + 3 * BKS);
+            gl(I0{}, kbeg + 4 * BKS);
             __syncthreads();                  // stage 0 visible
             // stage s computes from LDS buffer s&1; this iteration publishes stage s+1 (register set (s+1)&3)
             // into buffer (s+1)&1 and refills that set with stage s+5
+            // (no `break` inside the unrolled group: the compiler routes a mid-loop exit through the loop
+            // header, and the wait-count pass then sees this step's own refill as the load it must wait
+            // for -- vmcnt(0), a full drain, once per group)
 #define I2V_LOADER_STEP(SET, BUF)                                   \
+            if (p.clk) c_t0 = __builtin_amdgcn_s_memtime();         \
             if (k0 + BKS < kend) st(SET{}, BUF{});                  \
-            if (k0 + 5 * BKS < kend) gl(SET{}, k0 + 5 * BKS);       \
+            if (p.clk) { c_t1 = __builtin_amdgcn_s_memtime(); c_st += c_t1 - c_t0; } \
+            gl(SET{}, k0 + 5 * BKS);                                \
+            if (p.clk) { c_t0 = __builtin_amdgcn_s_memtime(); c_gl += c_t0 - c_t1; } \
             __syncthreads();                                        \
-            k0 += BKS;                                              \
-            if (k0 >= kend) break;
-            for (int k0 = kbeg;;) {
+            if (p.clk) c_bar += __builtin_amdgcn_s_memtime() - c_t0; \
+            k0 += BKS;
+            unsigned long long c_t0 = 0, c_t1 = 0, c_st = 0, c_gl = 0, c_bar = 0;
+            const int nst = (kend - kbeg + BKS - 1) / BKS;
+            int k0 = kbeg, sdone = 0;
+            for (; sdone + 4 <= nst; sdone += 4) {
                 I2V_LOADER_STEP(I1, I1)
                 I2V_LOADER_STEP(I2, I0)
                 I2V_LOADER_STEP(I3, I1)
                 I2V_LOADER_STEP(I0, I0)
             }
+            const int rem = nst - sdone;
+            if (rem >= 1) {
+                I2V_LOADER_STEP(I1, I1)
+                if (rem >= 2) {
+                    I2V_LOADER_STEP(I2, I0)
+                    if (rem >= 3) { I2V_LOADER_STEP(I3, I1) }
+                }
+            }
 #undef I2V_LOADER_STEP
+            if (p.clk && gtid == THREADS) {
+                unsigned long long* o = p.clk + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
+                o[4] = c_st; o[5] = c_gl; o[6] = c_bar;
+            }
         } else {                              // ---- MFMA waves
             __syncthreads();
             int buf = 0;
@@ -373,7 +400,91 @@ conv_igemm_f32(const ConvP p) {
         const int ox = m % p.Wo, t = m / p.Wo, oy = t % p.Ho, b = t / p.Ho;
         return (((long long)b * p.Hy + oy * p.ostride) * p.Wy + ox * p.ostride) * p.N;
     };
-    if (split) {                      // fp32 atomics: 64 lanes = 256 contiguous bytes per instruction
+    if (split && p.ws) {
+        // Split-K finish inside the kernel: every split stores its partial tile (plain 16-B stores, tile-
+        // contiguous), the last one to arrive at the tile's counter adds the partials in split order and
+        // runs the fused epilogue.  No clear of y, no atomics on y (fp32 atomics move ~1.3 TB/s chip-wide),
+        // no separate epilogue pass, and the sum no longer depends on arrival order.
+        //
+        // The 8 XCDs have private, mutually non-coherent L2s: a release/acquire fence pair at agent scope
+        // writes back and invalidates a whole L2 per fence (measured: the layer3 3x3 went 65 -> 153 us with
+        // __threadfence()).  Instead the partials are stored and re-read with the sc0 sc1 cache bits --
+        // write-through to, and reads from, the memory side of the L2s -- so only these 20-64 KB tiles pay
+        // for coherence; s_waitcnt vmcnt(0) orders the stores before the (device-scope) arrival count.
+        constexpr int SC01 = 17;          // buffer aux: bit 0 = sc0, bit 4 = sc1
+        const size_t split_stride = (size_t)gridDim.x * (BM * BN);      // floats between splits of a tile
+        const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.ws + (size_t)tile * (BM * BN)), 0, 0x7FFFFFF0, 0x00020000);
+        const unsigned mine = (unsigned)(blockIdx.y * split_stride * sizeof(float));
+        for (int e = gtid; e < BM * (BN / 4); e += NT) {
+            const int row = e / (BN / 4), col = (e % (BN / 4)) * 4;
+            const float4 v = *(const float4*)&smem[row * CROW + col];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), wsr,
+                                                   mine + (unsigned)(row * BN + col) * 4u, 0, SC01);
+        }
+        __builtin_amdgcn_s_waitcnt(0);    // vmcnt(0): my stores have been acknowledged by memory
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem);       // the staged tile is no longer needed
+        if (gtid == 0) {
+            const int arrived = __hip_atomic_fetch_add(p.cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = arrived == (int)gridDim.y - 1;
+            if (last) __hip_atomic_store(p.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+            *flag = last;
+        }
+        __syncthreads();
+        if (!*flag) return;
+        const int nsplit = gridDim.y;
+        for (int e = gtid; e < BM * (BN / 4); e += NT) {
+            const int row = e / (BN / 4), col = (e % (BN / 4)) * 4;
+            const int m = m0 + row, n = n0 + col;
+            if (m >= p.M || n >= p.N) continue;
+            const unsigned off = (unsigned)(row * BN + col) * 4u;
+            // all partials of this element in flight at once (these reads come from beyond the L2), then
+            // summed in split order
+            float4 u[kSplitInKernelMax];
+#pragma unroll
+            for (int sp = 0; sp < kSplitInKernelMax; ++sp)
+                u[sp] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                    wsr, sp < nsplit ? off + (unsigned)(sp * split_stride * sizeof(float)) : 0xFFFFFFF0u, 0, SC01));
+            float4 v = u[0];
+#pragma unroll
+            for (int sp = 1; sp < kSplitInKernelMax; ++sp) {       // slots >= nsplit read out of range: zeros
+                v.x += u[sp].x; v.y += u[sp].y; v.z += u[sp].z; v.w += u[sp].w;
+            }
+            const long long o = (long long)m * p.N + n;          // split-K only runs with ostride == 1
+            float vv[4] = {v.x, v.y, v.z, v.w};
+            if ((p.N & 3) == 0) {
+                if (p.flags & I2V_EPI_SCALE) {
+                    const float4 sc = *(const float4*)(p.scale + n);
+                    vv[0] *= sc.x; vv[1] *= sc.y; vv[2] *= sc.z; vv[3] *= sc.w;
+                }
+                if (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) {
+                    const float4 sh = *(const float4*)(p.shift + n);
+                    vv[0] += sh.x; vv[1] += sh.y; vv[2] += sh.z; vv[3] += sh.w;
+                }
+                if (p.flags & I2V_EPI_RESIDUAL) {
+                    const float4 rr = *(const float4*)(p.res + o);
+                    vv[0] += rr.x; vv[1] += rr.y; vv[2] += rr.z; vv[3] += rr.w;
+                }
+                if (p.flags & I2V_EPI_RELU) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) vv[c] = fmaxf(vv[c], 0.f);
+                }
+                *(float4*)(p.y + o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if (n + c >= p.N) break;
+                    float t = vv[c];
+                    if (p.flags & I2V_EPI_SCALE) t *= p.scale[n + c];
+                    if (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) t += p.shift[n + c];
+                    if (p.flags & I2V_EPI_RESIDUAL) t += p.res[o + c];
+                    if (p.flags & I2V_EPI_RELU) t = fmaxf(t, 0.f);
+                    p.y[o + c] = t;
+                }
+            }
+        }
+    } else if (split) {               // fallback: fp32 atomics into a zeroed y (64 lanes = 256 contiguous bytes)
         for (int e = gtid; e < BM * BN; e += NT) {
             const int row = e / BN, col = e % BN;
             const int m = m0 + row, n = n0 + col;
@@ -474,6 +585,54 @@ unsigned long long* g_clk = nullptr;   // i2v_conv_debug_clock()
 int g_spec_mode = [] { const char* e = getenv("I2V_CONV_SPEC"); return e ? atoi(e) : -1; }();
 int g_split_below = [] { const char* e = getenv("I2V_SPLIT_BELOW"); return e ? atoi(e) : NUM_CU; }();
 
+// Split-K workspace: one slab + one counter array per stream (up to kSplitSlots streams; beyond that, or for
+// partials larger than a slab, the kernel falls back to fp32 atomics into y).  Allocated once, on the first
+// split-K call made outside a graph capture; handing a slot to a new stream is host bookkeeping only, so it is
+// legal while that stream is capturing.
+constexpr size_t kSplitSlabBytes = 48u << 20;
+constexpr int kSplitSlots = 4, kSplitCounters = 1024;
+int g_split_atomics = [] { const char* e = getenv("I2V_SPLIT_ATOMICS"); return e ? atoi(e) : 0; }();
+char* g_split_base = nullptr;
+int* g_split_cnt = nullptr;
+hipStream_t g_split_owner[kSplitSlots];
+int g_split_used = 0;
+std::mutex g_split_mu;
+
+bool split_workspace(hipStream_t st, size_t need_bytes, long long tiles, float*& ws, int*& cnt) {
+    if (g_split_atomics || need_bytes > kSplitSlabBytes || tiles > kSplitCounters) return false;
+    std::lock_guard<std::mutex> lock(g_split_mu);
+    if (!g_split_base) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            return false;
+        }
+        char* base = nullptr;
+        int* c = nullptr;
+        if (hipMalloc((void**)&base, kSplitSlabBytes * kSplitSlots) != hipSuccess) { (void)hipGetLastError(); return false; }
+        if (hipMalloc((void**)&c, sizeof(int) * kSplitCounters * kSplitSlots) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(base);
+            return false;
+        }
+        (void)hipMemset(c, 0, sizeof(int) * kSplitCounters * kSplitSlots);
+        (void)hipDeviceSynchronize();
+        g_split_base = base;
+        g_split_cnt = c;
+    }
+    int slot = -1;
+    for (int i = 0; i < g_split_used; ++i)
+        if (g_split_owner[i] == st) slot = i;
+    if (slot < 0) {
+        if (g_split_used == kSplitSlots) return false;
+        slot = g_split_used++;
+        g_split_owner[slot] = st;
+    }
+    ws = reinterpret_cast<float*>(g_split_base + kSplitSlabBytes * slot);
+    cnt = g_split_cnt + kSplitCounters * slot;
+    return true;
+}
+
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 void launch_tile(const ConvP& p, bool spec, hipStream_t st) {
     constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
@@ -544,9 +703,19 @@ int run_conv(ConvP p, hipStream_t st) {
     p.splitk = splitk;
     p.k_per_split = i2v_cdiv(ksteps, splitk) * BKS;
     p.splitk = i2v_cdiv(p.K, p.k_per_split);
-    if (p.dry) return p.splitk;
+    const long long ntiles = (long long)i2v_cdiv(p.M, kTiles[cfg].bm) * i2v_cdiv(p.N, kTiles[cfg].bn);
+    p.ws = nullptr;
+    p.cnt = nullptr;
+    const size_t ws_need = (size_t)p.splitk * ntiles * kTiles[cfg].bm * kTiles[cfg].bn * sizeof(float);
+    // dry run: 0 = y needs no clear (no split, or the split is finished in-kernel), else the split factor
+    // in-kernel finish pays where the output is large (atomics and the extra epilogue pass scale with it);
+    // for the small FC outputs of the vrd head the atomics are cheap and a serial sum of many splits is not
+    const bool in_kernel = p.splitk > 1 && !g_split_atomics && p.splitk <= kSplitInKernelMax &&
+                           (long long)p.M * p.N >= (1 << 18) && ws_need <= kSplitSlabBytes && ntiles <= kSplitCounters;
+    if (p.dry) return (p.splitk > 1 && !in_kernel) ? p.splitk : 0;
+    if (in_kernel) split_workspace(st, ws_need, ntiles, p.ws, p.cnt);
     const long long ytotal = (long long)p.M * p.N;
-    if (p.splitk > 1 && !(p.flags & I2V_EPI_ZEROED)) hipMemsetAsync(p.y, 0, (size_t)ytotal * sizeof(float), st);
+    if (p.splitk > 1 && !p.ws && !(p.flags & I2V_EPI_ZEROED)) hipMemsetAsync(p.y, 0, (size_t)ytotal * sizeof(float), st);
     // wave specialisation pays where few workgroups share a CU (nothing else hides the staging)
     const long long nblocks = (long long)i2v_cdiv(p.M, kTiles[cfg].bm) * i2v_cdiv(p.N, kTiles[cfg].bn) * p.splitk;
     // measured neutral on the backbone shapes (l2 c2 +6 %, l3 ds -12 %): off unless forced
@@ -559,7 +728,7 @@ int run_conv(ConvP p, hipStream_t st) {
         case 4: launch_tile<2, 2, 2, 2>(p, spec, st); break;
         default: launch_tile<2, 2, 1, 2>(p, spec, st); break;
     }
-    if (p.splitk > 1 && (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS | I2V_EPI_RESIDUAL | I2V_EPI_RELU))) {
+    if (p.splitk > 1 && !p.ws && (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS | I2V_EPI_RESIDUAL | I2V_EPI_RELU))) {
         if (p.N % 4 == 0)
             conv_epilogue_kernel<<<(int)fmin((double)i2v_cdiv(ytotal / 4, 256), 4096.0), 256, 0, st>>>(
                 p.y, p.scale, p.shift, p.res, ytotal / 4, p.N, p.flags);

@@ -136,8 +136,12 @@ int32_t i2v_bbox_overlaps(const float* boxes, int32_t box_stride, int32_t box_of
 int32_t i2v_conv_fwd(const float* x, const float* w, const float* scale, const float* shift, const float* res,
                      float* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                      int32_t KH, int32_t KW, int32_t stride, int32_t pad, int32_t flags, void* stream);
-/* 1 if i2v_conv_fwd will use split-K atomics for this shape (y must start at zero: the call clears it unless
- * I2V_EPI_ZEROED is passed -- lets a caller batch many clears into one), 0 if not, < 0 on error */
+/* Small-M shapes split K over several workgroups per tile.  The partial tiles normally go through a per-stream
+ * workspace owned by the library and the last workgroup of a tile sums them in split order and applies the
+ * epilogue (deterministic, y needs no clear).  Returns 1 only when this shape would instead fall back to fp32
+ * atomics into y (partials larger than the 48 MiB slab, or I2V_SPLIT_ATOMICS=1): y must then start at zero --
+ * the call clears it unless I2V_EPI_ZEROED is passed, which lets a caller batch many clears into one.  0
+ * otherwise, < 0 on error. */
 int32_t i2v_conv_fwd_splits(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW,
                             int32_t stride, int32_t pad);
 /* tuning hook: cfg < 0 = cost model; else low byte = tile shape 0..5 (0xFF = cost model),

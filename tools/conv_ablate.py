@@ -7,15 +7,19 @@ os.environ["I2V_SPLIT_BELOW"] = os.environ.get("I2V_SPLIT_BELOW", "0")
 import torch
 from i2vsgg_amd import ops, _lib
 B = 2
+TILES = [int(t) for t in os.environ.get("TILES", "3").split(",")]
+BOUND = {0: 4096, 1: 2048, 2: 1536, 3: 1280, 4: 1024, 5: 512}   # MFMA issue cycles per 32-deep stage
 cases = [("l3 c2 3x3 256 (72 stages)", 256, 38, 63, 256, 3, 1, 1, 72), ("l3 c1 1024->256 (32 stages)", 1024, 38, 63, 256, 1, 1, 0, 32)]
 for name, cin, h, w, cout, k, s, p, stages in cases:
     x = torch.randn(B, cin, h, w, device="cuda").contiguous(memory_format=torch.channels_last)
     wt = (torch.randn(cout, cin, k, k, device="cuda") * 0.05).contiguous(memory_format=torch.channels_last)
-    for tile in (3,):
+    for tile in TILES:
         for label, cfg in (("plain", tile | (1 << 8)), ("plain, no staging", tile | (1 << 8) | (1 << 10)),
                            ("plain, no MFMA", tile | (1 << 8) | (2 << 10)), ("specialised", tile | (2 << 8)),
                            ("no staging, no barrier", tile | (1 << 8) | (5 << 10)),
                            ("no staging/barrier/ds_read", tile | (1 << 8) | (13 << 10))):
+            if tile != 3 and "no " in label:
+                continue                       # the ablated variants are only instantiated for the 80x64 tile
             buf = torch.zeros(8 * 8192, dtype=torch.int64, device="cuda")
             _lib.lib.i2v_conv_set_tile(cfg)
             for _ in range(50):
@@ -32,7 +36,7 @@ for name, cin, h, w, cout, k, s, p, stages in cases:
                 ops.conv2d(x, wt, None, None, None, s, p)
             e1.record(); torch.cuda.synchronize()
             print("%-28s tile %d %-28s WGs %4d  loop cycles/stage %6.0f (MFMA issue bound %d)  setup %6.0f cyc  kernel %6.1f us" % (
-                name, tile, label, v.shape[0], v[:, 0].double().median().item() / stages, 1280 if tile == 3 else 1024,
+                name, tile, label, v.shape[0], v[:, 0].double().median().item() / stages, BOUND[tile],
                 v[:, 2].double().median().item(), e0.elapsed_time(e1) / 20 * 1e3))
             if label == "specialised":
                 m = lambda i: v[:, i].double().median().item() / stages
