@@ -29,7 +29,7 @@ constexpr int KTAB_MAX = 2560;  // filter-tap table entries (K/4): KH*KW*Cin <= 
 constexpr int BKS = 32;         // k per LDS stage of the forward/dgrad kernel (= floats per LDS row)
 constexpr int LDS_ROW = 20;     // floats per staged row (16 + 4 pad)
 constexpr int THREADS = 256;
-constexpr int kSplitInKernelMax = 8;   // most splits the in-kernel split-K finish sums (else: atomics)
+constexpr int kSplitInKernelMax = 4;   // most splits the in-kernel split-K finish sums (else: atomics)
 
 struct ConvP {
     const float* x; const float* w; const float* scale; const float* shift; const float* res; float* y;
@@ -214,41 +214,54 @@ conv_igemm_f32(const ConvP p) {
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fg = lane >> 4;
-    auto compute = [&](int buf) {
+    // fragment reads of one 16-deep half (h = 0/1) of a stage, and the 4*TM*TN MFMAs that consume them
+    auto rd = [&](float4 (&av)[TM], float4 (&bv)[TN], int buf, int h) {
+        if constexpr (ABL & 8) {          // diagnostic: no LDS fragment reads (operands are lane constants)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            float4 av[TM], bv[TN];
-            if constexpr (ABL & 8) {          // diagnostic: no LDS fragment reads (operands are lane constants)
+            for (int i = 0; i < TM; ++i) av[i] = make_float4(1.f + lane, 2.f + buf, 3.f, 4.f);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) av[i] = make_float4(1.f + lane, 2.f + buf, 3.f, 4.f);
+            for (int j = 0; j < TN; ++j) bv[j] = make_float4(1.f, 2.f + lane, 3.f + buf, 4.f);
+        } else {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bv[j] = make_float4(1.f, 2.f + lane, 3.f + buf, 4.f);
-            } else {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int row = (wm * TM + i) * 16 + fr;
-                    av[i] = *(const float4*)&As[buf][row * BKS + (((s * 4 + fg) ^ ((row >> 1) & 7)) << 2)];
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int row = (wn * TN + j) * 16 + fr;
-                    bv[j] = *(const float4*)&Bs[buf][row * BKS + (((s * 4 + fg) ^ ((row >> 1) & 7)) << 2)];
-                }
+            for (int i = 0; i < TM; ++i) {
+                const int row = (wm * TM + i) * 16 + fr;
+                av[i] = *(const float4*)&As[buf][row * BKS + (((h * 4 + fg) ^ ((row >> 1) & 7)) << 2)];
             }
-            // k component outermost: consecutive MFMAs hit DIFFERENT accumulators (the 16x16x4 f32
-            // MFMA issues every 32 cycles but a dependent one waits 40)
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        const float a = t == 0 ? av[i].x : t == 1 ? av[i].y : t == 2 ? av[i].z : av[i].w;
-                        const float b = t == 0 ? bv[j].x : t == 1 ? bv[j].y : t == 2 ? bv[j].z : bv[j].w;
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i][j], 0, 0, 0);
-                    }
+            for (int j = 0; j < TN; ++j) {
+                const int row = (wn * TN + j) * 16 + fr;
+                bv[j] = *(const float4*)&Bs[buf][row * BKS + (((h * 4 + fg) ^ ((row >> 1) & 7)) << 2)];
+            }
         }
     };
+    auto mm = [&](const float4 (&av)[TM], const float4 (&bv)[TN]) {
+        // k component outermost: consecutive MFMAs hit DIFFERENT accumulators (the 16x16x4 f32
+        // MFMA issues every 32 cycles but a dependent one waits 40)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float a = t == 0 ? av[i].x : t == 1 ? av[i].y : t == 2 ? av[i].z : av[i].w;
+                    const float b = t == 0 ? bv[j].x : t == 1 ? bv[j].y : t == 2 ? bv[j].z : bv[j].w;
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i][j], 0, 0, 0);
+                }
+    };
+    auto compute = [&](int buf) {         // un-pipelined form (diagnostic variants only)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float4 av[TM], bv[TN];
+            rd(av, bv, buf, h);
+            mm(av, bv);
+        }
+    };
+    // Software-pipelined stage: two fragment register sets.  The reads of the second half are issued before
+    // the MFMAs of the first, and the first half of the NEXT stage is read right after the barrier that
+    // publishes it, before the MFMAs of this stage's second half -- every ds_read has ~20 MFMAs (640 cycles)
+    // to land.  (Reading and consuming a half back to back left the matrix pipe idle for one LDS round trip
+    // per half: 1580 instead of 1280 cycles per stage with nothing else running.)
+    float4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
     // residual tile: issued before the K loop so that its latency hides behind the MFMAs (small
     // tiles only: C_LD float4 registers per thread)
     constexpr int C_LD = (BM * (BN / 4) + NT - 1) / NT;
@@ -269,7 +282,6 @@ conv_igemm_f32(const ConvP p) {
     if (p.clk) t1c = __builtin_amdgcn_s_memtime();
     if constexpr (SPEC) {
         if (gtid >= THREADS) {                // ---- loader waves
-            __builtin_amdgcn_s_setprio(3);
             // four register sets: the loads of stages s+2 .. s+5 are in flight while stage s computes.  A CU
             // ingests only ~12 B/clk with one 18 KB stage in flight (L1 miss capacity x L2 latency; measured with
             // tools/conv_ablate.py) -- the matrix pipe needs ~14 B/clk at this tile shape -- so the loaders keep
@@ -347,11 +359,17 @@ conv_igemm_f32(const ConvP p) {
             __syncthreads();
             int buf = 0;
             unsigned long long c_mm = 0;
+            rd(fa0, fb0, 0, 0);
             for (int k0 = kbeg; k0 < kend; k0 += BKS) {
                 const unsigned long long a0 = p.clk ? __builtin_amdgcn_s_memtime() : 0ull;
-                compute(buf);
-                if (p.clk) c_mm += __builtin_amdgcn_s_memtime() - a0;
+                rd(fa1, fb1, buf, 1);
+                mm(fa0, fb0);
+                const unsigned long long a1 = p.clk ? __builtin_amdgcn_s_memtime() : 0ull;
                 __syncthreads();
+                const unsigned long long a2 = p.clk ? __builtin_amdgcn_s_memtime() : 0ull;
+                if (k0 + BKS < kend) rd(fa0, fb0, buf ^ 1, 0);
+                mm(fa1, fb1);
+                if (p.clk) c_mm += (__builtin_amdgcn_s_memtime() - a2) + (a1 - a0);
                 buf ^= 1;
             }
             if (p.clk && gtid == 0) p.clk[8 * (blockIdx.y * gridDim.x + blockIdx.x) + 7] = c_mm;
@@ -359,16 +377,35 @@ conv_igemm_f32(const ConvP p) {
     } else {
         gload(kbeg);
         sstore(0);
-        __syncthreads();
-        int buf = 0;
-        const bool no_stage = p.ablate & 1, no_mfma = p.ablate & 2;
-        for (int k0 = kbeg; k0 < kend; k0 += BKS) {
-            const bool more = k0 + BKS < kend && !no_stage;
-            if (more) gload(k0 + BKS);
-            if (!no_mfma) compute(buf);
-            if (more) sstore(buf ^ 1);
-            if constexpr (!(ABL & 4)) __syncthreads();
-            buf ^= 1;
+        if constexpr (ABL != 0) {
+            __syncthreads();
+            int buf = 0;
+            const bool no_stage = p.ablate & 1, no_mfma = p.ablate & 2;
+            for (int k0 = kbeg; k0 < kend; k0 += BKS) {
+                const bool more = k0 + BKS < kend && !no_stage;
+                if (more) gload(k0 + BKS);
+                if (!no_mfma) compute(buf);
+                if (more) sstore(buf ^ 1);
+                if constexpr (!(ABL & 4)) __syncthreads();
+                buf ^= 1;
+            }
+        } else {
+            const bool no_stage = p.ablate & 1, no_mfma = p.ablate & 2;
+            if (kbeg + BKS < kend && !no_stage) gload(kbeg + BKS);
+            __syncthreads();
+            rd(fa0, fb0, 0, 0);
+            int buf = 0;
+            for (int k0 = kbeg; k0 < kend; k0 += BKS) {
+                const bool more = k0 + BKS < kend && !no_stage;
+                rd(fa1, fb1, buf, 1);
+                if (more && !(p.ablate & 64)) sstore(buf ^ 1);  // stage s+1: its loads were issued a stage ago
+                if (k0 + 2 * BKS < kend && !no_stage && !(p.ablate & 128)) gload(k0 + 2 * BKS);
+                if (!no_mfma) mm(fa0, fb0);
+                __syncthreads();                              // stage s+1 published, stage s-1's buffer free
+                if (k0 + BKS < kend) rd(fa0, fb0, buf ^ 1, 0);
+                if (!no_mfma) mm(fa1, fb1);
+                buf ^= 1;
+            }
         }
     }
 
@@ -382,8 +419,8 @@ conv_igemm_f32(const ConvP p) {
     }
     // epilogue.  C/D map of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + r.  The tile goes
     // through LDS so that global stores (and the residual loads) are whole 16-B-per-lane rows
-    // instead of 64-B fragments of a line.  (The last loop iteration ended with a barrier: every
-    // wave is done reading the stage buffers.)
+    // instead of 64-B fragments of a line.  (Every wave's last fragment reads completed before the
+    // barrier of the last loop iteration, so the stage buffers are free.)
     if (!SPEC || gtid < THREADS) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -408,10 +445,10 @@ conv_igemm_f32(const ConvP p) {
         //
         // The 8 XCDs have private, mutually non-coherent L2s: a release/acquire fence pair at agent scope
         // writes back and invalidates a whole L2 per fence (measured: the layer3 3x3 went 65 -> 153 us with
-        // __threadfence()).  Instead the partials are stored and re-read with the sc0 sc1 cache bits --
-        // write-through to, and reads from, the memory side of the L2s -- so only these 20-64 KB tiles pay
+        // __threadfence()).  Instead the partials are stored and re-read at agent scope (sc1, the cache policy of
+        // a relaxed agent-scope atomic: coherent across the XCDs without fences) -- so only these 20-64 KB tiles pay
         // for coherence; s_waitcnt vmcnt(0) orders the stores before the (device-scope) arrival count.
-        constexpr int SC01 = 17;          // buffer aux: bit 0 = sc0, bit 4 = sc1
+        constexpr int SC01 = 16;          // buffer aux bit 4 = sc1: agent scope (sc0 sc1 = system scope is not needed)
         const size_t split_stride = (size_t)gridDim.x * (BM * BN);      // floats between splits of a tile
         const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(p.ws + (size_t)tile * (BM * BN)), 0, 0x7FFFFFF0, 0x00020000);
@@ -424,7 +461,8 @@ conv_igemm_f32(const ConvP p) {
         }
         __builtin_amdgcn_s_waitcnt(0);    // vmcnt(0): my stores have been acknowledged by memory
         __syncthreads();
-        int* flag = reinterpret_cast<int*>(smem);       // the staged tile is no longer needed
+        __shared__ int last_flag;
+        int* flag = &last_flag;
         if (gtid == 0) {
             const int arrived = __hip_atomic_fetch_add(p.cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int last = arrived == (int)gridDim.y - 1;
@@ -432,55 +470,77 @@ conv_igemm_f32(const ConvP p) {
             *flag = last;
         }
         __syncthreads();
-        if (!*flag) return;
-        const int nsplit = gridDim.y;
-        for (int e = gtid; e < BM * (BN / 4); e += NT) {
-            const int row = e / (BN / 4), col = (e % (BN / 4)) * 4;
-            const int m = m0 + row, n = n0 + col;
-            if (m >= p.M || n >= p.N) continue;
-            const unsigned off = (unsigned)(row * BN + col) * 4u;
-            // all partials of this element in flight at once (these reads come from beyond the L2), then
-            // summed in split order
-            float4 u[kSplitInKernelMax];
+        if (!*flag) {
+            if (p.clk && gtid == 0 && !SPEC)
+                p.clk[8 * (blockIdx.y * gridDim.x + blockIdx.x) + 4] = __builtin_amdgcn_s_memtime() - t0c;
+            return;
+        }
+        // The finisher's reads come from beyond the L2 (~2 us a round trip): every partial of up to FIN_CH
+        // elements per thread, and their residuals, are put in flight before the first sum.  Its own
+        // partial is still in LDS.  Summation is in split order whichever workgroup arrives last.
+        const int nsplit = gridDim.y, my = blockIdx.y;
+        constexpr int FIN_CH = C_LD < 6 ? C_LD : 6;
+        const bool vec = (p.N & 3) == 0;
+        for (int it0 = 0; it0 < C_LD; it0 += FIN_CH) {
+            float4 u[FIN_CH][kSplitInKernelMax], rr[FIN_CH];
 #pragma unroll
-            for (int sp = 0; sp < kSplitInKernelMax; ++sp)
-                u[sp] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-                    wsr, sp < nsplit ? off + (unsigned)(sp * split_stride * sizeof(float)) : 0xFFFFFFF0u, 0, SC01));
-            float4 v = u[0];
+            for (int c = 0; c < FIN_CH; ++c) {
+                const int e = gtid + (it0 + c) * NT;
+                const int row = e / (BN / 4), col = (e % (BN / 4)) * 4;
+                const int m = m0 + row, n = n0 + col;
+                const bool ok = e < BM * (BN / 4) && m < p.M && n < p.N;
+                const unsigned off = (unsigned)(row * BN + col) * 4u;
 #pragma unroll
-            for (int sp = 1; sp < kSplitInKernelMax; ++sp) {       // slots >= nsplit read out of range: zeros
-                v.x += u[sp].x; v.y += u[sp].y; v.z += u[sp].z; v.w += u[sp].w;
+                for (int sp = 0; sp < kSplitInKernelMax; ++sp)
+                    u[c][sp] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                        wsr, (ok && sp < nsplit && sp != my) ? off + (unsigned)(sp * split_stride * sizeof(float)) : 0xFFFFFFF0u,
+                        0, SC01));
+                rr[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok && vec && (p.flags & I2V_EPI_RESIDUAL)) rr[c] = *(const float4*)(p.res + (long long)m * p.N + n);
             }
-            const long long o = (long long)m * p.N + n;          // split-K only runs with ostride == 1
-            float vv[4] = {v.x, v.y, v.z, v.w};
-            if ((p.N & 3) == 0) {
-                if (p.flags & I2V_EPI_SCALE) {
-                    const float4 sc = *(const float4*)(p.scale + n);
-                    vv[0] *= sc.x; vv[1] *= sc.y; vv[2] *= sc.z; vv[3] *= sc.w;
-                }
-                if (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) {
-                    const float4 sh = *(const float4*)(p.shift + n);
-                    vv[0] += sh.x; vv[1] += sh.y; vv[2] += sh.z; vv[3] += sh.w;
-                }
-                if (p.flags & I2V_EPI_RESIDUAL) {
-                    const float4 rr = *(const float4*)(p.res + o);
-                    vv[0] += rr.x; vv[1] += rr.y; vv[2] += rr.z; vv[3] += rr.w;
-                }
-                if (p.flags & I2V_EPI_RELU) {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) vv[c] = fmaxf(vv[c], 0.f);
-                }
-                *(float4*)(p.y + o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
-            } else {
+            for (int c = 0; c < FIN_CH; ++c) {
+                const int e = gtid + (it0 + c) * NT;
+                const int row = e / (BN / 4), col = (e % (BN / 4)) * 4;
+                const int m = m0 + row, n = n0 + col;
+                if (e >= BM * (BN / 4) || m >= p.M || n >= p.N) continue;
+                const float4 mine4 = *(const float4*)&smem[row * CROW + col];
+                float4 v = my == 0 ? mine4 : u[c][0];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    if (n + c >= p.N) break;
-                    float t = vv[c];
-                    if (p.flags & I2V_EPI_SCALE) t *= p.scale[n + c];
-                    if (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) t += p.shift[n + c];
-                    if (p.flags & I2V_EPI_RESIDUAL) t += p.res[o + c];
-                    if (p.flags & I2V_EPI_RELU) t = fmaxf(t, 0.f);
-                    p.y[o + c] = t;
+                for (int sp = 1; sp < kSplitInKernelMax; ++sp) {   // slots >= nsplit were read out of range: zeros
+                    const float4 t = sp == my ? mine4 : u[c][sp];
+                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                }
+                const long long o = (long long)m * p.N + n;      // split-K only runs with ostride == 1
+                float vv[4] = {v.x, v.y, v.z, v.w};
+                if (vec) {
+                    if (p.flags & I2V_EPI_SCALE) {
+                        const float4 sc = *(const float4*)(p.scale + n);
+                        vv[0] *= sc.x; vv[1] *= sc.y; vv[2] *= sc.z; vv[3] *= sc.w;
+                    }
+                    if (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) {
+                        const float4 sh = *(const float4*)(p.shift + n);
+                        vv[0] += sh.x; vv[1] += sh.y; vv[2] += sh.z; vv[3] += sh.w;
+                    }
+                    if (p.flags & I2V_EPI_RESIDUAL) {
+                        vv[0] += rr[c].x; vv[1] += rr[c].y; vv[2] += rr[c].z; vv[3] += rr[c].w;
+                    }
+                    if (p.flags & I2V_EPI_RELU) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) vv[q] = fmaxf(vv[q], 0.f);
+                    }
+                    *(float4*)(p.y + o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (n + q >= p.N) break;
+                        float t = vv[q];
+                        if (p.flags & I2V_EPI_SCALE) t *= p.scale[n + q];
+                        if (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) t += p.shift[n + q];
+                        if (p.flags & I2V_EPI_RESIDUAL) t += p.res[o + q];
+                        if (p.flags & I2V_EPI_RELU) t = fmaxf(t, 0.f);
+                        p.y[o + q] = t;
+                    }
                 }
             }
         }
@@ -531,6 +591,12 @@ conv_igemm_f32(const ConvP p) {
             if (p.flags & I2V_EPI_RELU) v = fmaxf(v, 0.f);
             p.y[o] = v;
         }
+    }
+    if (p.clk && gtid == 0 && !SPEC) {
+        __builtin_amdgcn_s_waitcnt(0);
+        unsigned long long* o = p.clk + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
+        o[4] = __builtin_amdgcn_s_memtime() - t0c;           // whole kernel, this workgroup
+        o[5] = 1;                                            // this workgroup ran the epilogue (split-K: the last arrival)
     }
 }
 
@@ -1218,7 +1284,7 @@ extern "C" int32_t i2v_conv_set_tile(int32_t cfg) {
     if (cfg < 0) { g_force_tile = -1; g_spec_mode = -1; g_ablate = 0; return I2V_OK; }
     g_force_tile = (cfg & 0xFF) == 0xFF ? -1 : (cfg & 0xFF);
     g_spec_mode = ((cfg >> 8) & 3) - 1;
-    g_ablate = (cfg >> 10) & 15;
+    g_ablate = (cfg >> 10) & 255;
     return I2V_OK;
 }
 

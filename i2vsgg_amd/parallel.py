@@ -51,26 +51,43 @@ def shard_frames(n_global, rk=None, world=None):
     return start, start + per + (1 if rk < rem else 0)
 
 
-def all_reduce_grads(params, group=None):
-    """Sum-all-reduce ``p.grad`` of every parameter (loss was pre-scaled by 1/world)."""
+def all_reduce_grads_start(params, group=None):
+    """Launch the sum-all-reduce of every ``p.grad`` (loss was pre-scaled by 1/world) and return a token for
+    ``all_reduce_grads_finish``.  The collectives run on RCCL's own stream behind everything already queued
+    on the current stream; work queued on the current stream AFTER this call overlaps them."""
     if world_size() == 1:
-        return
+        return None
     grads = [p.grad for p in params if p.grad is not None]
     big = [g for g in grads if g.numel() * g.element_size() >= SMALL_BYTES]
     small = [g for g in grads if g.numel() * g.element_size() < SMALL_BYTES]
-    # largest first: the 822 MB fc6 gradient is produced last by backward and dominates the exchange
+    # largest first: the 822 MB fc6 gradient dominates the exchange
     handles = [dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True)
                for g in sorted(big, key=lambda t: -t.numel())]
+    flat = None
     if small:
         flat = torch.cat([g.reshape(-1) for g in small])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        handles.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True))
+    return handles, small, flat
+
+
+def all_reduce_grads_finish(token):
+    """Make the current stream wait for the exchange and scatter the small-tensor bucket back."""
+    if token is None:
+        return
+    handles, small, flat = token
+    for h in handles:
+        h.wait()
+    if flat is not None:
         off = 0
         for g in small:
             n = g.numel()
             g.copy_(flat[off:off + n].view_as(g))
             off += n
-    for h in handles:
-        h.wait()
+
+
+def all_reduce_grads(params, group=None):
+    """Sum-all-reduce ``p.grad`` of every parameter (loss was pre-scaled by 1/world)."""
+    all_reduce_grads_finish(all_reduce_grads_start(params, group))
 
 
 def max_over_ranks(value, device):

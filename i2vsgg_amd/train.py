@@ -103,6 +103,9 @@ class SGGEmbStep:
         self.graph = None
         self.use_graph = use_graph
         self.arena = ops.ZeroArena(1024, self.dev) if zero_arena else None    # sized after the first step
+        self.arena_bb = ops.ZeroArena(1024, self.dev) if zero_arena else None
+        self.fmap = None
+        self.pipelined = False
 
     def reseed(self, seed):
         """(Re)generate the synthetic minibatch: frames, pair tables, masks, labels -> static device inputs (the
@@ -134,82 +137,112 @@ class SGGEmbStep:
                 setattr(self, k, v)
         self.n_rows = int(self.boxes.shape[0] + self.relb.shape[0])
 
-    def _fwd_bwd(self):
-        net = self.net
-        if self.arena is not None:
-            self.arena.reset()          # one clear for every split-K output of this step
-        ops.ARENA = self.arena
+    # The step in two halves.  The backbone is frozen in this loop (the reference detaches it), so its
+    # forward does not depend on the head's weights: with data parallelism the backbone pass of the NEXT
+    # minibatch runs while the gradients of this one are exchanged (see __call__).
+    def _backbone(self):
+        ops.ARENA = self.arena_bb
         try:
-            self._fwd_bwd_inner()
+            if self.arena_bb is not None:
+                self.arena_bb.reset()
+            with torch.no_grad():
+                fmap = self.net.RCNN_base(self.im)
+            if self.fmap is None:
+                self.fmap = torch.empty_like(fmap)
+            self.fmap.copy_(fmap)           # static address for the head's graph; 20 MB, ~8 us
         finally:
             ops.ARENA = None
 
-    def _fwd_bwd_inner(self):
-        net = self.net
-        with torch.no_grad():
-            fmap = net.RCNN_base(self.im)
-        score, _ = net.vrd.forward_device(fmap, self.boxes, self.relb, self.masks, self.ixs, self.ixo)
-        per = torch.nn.functional.binary_cross_entropy_with_logits(score, self.labels, reduction="none").mean(1)
-        loss = (per * self.wrow).sum()
-        self.opt.zero_grad()
-        (loss / self.world).backward()
-        self.loss.copy_(loss.detach())
+    def _head(self):
+        ops.ARENA = self.arena
+        try:
+            if self.arena is not None:
+                self.arena.reset()          # one clear for every atomically accumulated output of this half
+            score, _ = self.net.vrd.forward_device(self.fmap, self.boxes, self.relb, self.masks, self.ixs, self.ixo)
+            per = torch.nn.functional.binary_cross_entropy_with_logits(score, self.labels, reduction="none").mean(1)
+            loss = (per * self.wrow).sum()
+            self.opt.zero_grad()
+            (loss / self.world).backward()
+            self.loss.copy_(loss.detach())
+        finally:
+            ops.ARENA = None
 
     def _body(self):
-        self._fwd_bwd()
+        self._backbone()
+        self._head()
         parallel.all_reduce_grads(self.opt.params())
         self.opt.step()
+
+    def _size_arenas(self):
+        for name in ("arena", "arena_bb"):
+            a = getattr(self, name)
+            if a is not None and a.wanted * 4 > a.buf.numel() * 4:
+                setattr(self, name, ops.ZeroArena(int(a.wanted * 4 * 1.05) + 4096, self.dev))
 
     def capture(self, warmup=2):
         """Warm up eagerly on a side stream, then capture the step into HIP graphs.
 
-        world == 1: one graph for the whole step.  world > 1 (or I2V_SPLIT_GRAPH=1): graph A =
-        forward + backward, the RCCL all-reduce of the (graph-static) gradient tensors runs eagerly
-        between, graph B = the SGD update -- the collective stays outside capture, the ~330 compute
-        launches do not go through Python."""
+        world == 1: one graph for the whole step.  world > 1 (or I2V_SPLIT_GRAPH=1): three graphs --
+        backbone forward / head forward+backward / SGD update -- with the RCCL all-reduce of the
+        (graph-static) gradient tensors launched eagerly between them: the collective stays outside
+        capture, the ~330 compute launches do not go through Python."""
         import os
         s = torch.cuda.Stream(self.dev)
         s.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(s):
             for i in range(warmup):
                 self._body()
-                if i == 0 and self.arena is not None and self.arena.wanted * 4 > self.arena.buf.numel() * 4:
-                    self.arena = ops.ZeroArena(int(self.arena.wanted * 4 * 1.05) + 4096, self.dev)
+                if i == 0:
+                    self._size_arenas()
         torch.cuda.current_stream(self.dev).wait_stream(s)
         torch.cuda.synchronize(self.dev)
         if not self.use_graph:
             return False
-        split = self.world > 1 or os.environ.get("I2V_SPLIT_GRAPH") == "1"
+        self.pipelined = self.world > 1 or os.environ.get("I2V_SPLIT_GRAPH") == "1"
         try:
-            if not split:
+            if not self.pipelined:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self._body()
                 self.graph = (g,)
             else:
-                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga):
-                    self._fwd_bwd()
-                self._grads = [p.grad for p in self.opt.params()]      # static tensors owned by graph A's pool
-                with torch.cuda.graph(gb, pool=ga.pool()):
+                gbb, gh, gs = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                # The backbone graph gets its OWN memory pool: it is replayed between the head graph and
+                # the SGD graph, and graphs that share a pool may reuse each other's freed blocks -- its
+                # activations would land on the gradients the update is about to read.
+                with torch.cuda.graph(gbb):
+                    self._backbone()
+                with torch.cuda.graph(gh):
+                    self._head()
+                self._grads = [p.grad for p in self.opt.params()]      # static tensors owned by the head graph's pool
+                with torch.cuda.graph(gs, pool=gh.pool()):
                     self.opt.step()
-                self.graph = (ga, gb)
+                self.graph = (gbb, gh, gs)
+                gbb.replay()                # feature map of the first timed step
             return True
         except Exception as e:      # report, fall back to eager launches
             self.graph = None
+            self.pipelined = False
             self.graph_error = repr(e)
             torch.cuda.synchronize(self.dev)
             return False
 
     def __call__(self):
+        """One step.  Pipelined form (world > 1): head fwd+bwd on the feature map computed during the previous
+        call -> launch the gradient exchange -> backbone forward of the next minibatch (overlaps the
+        exchange; the frames are static here, in a training loop this is where the next batch goes) ->
+        wait -> SGD.  Every call does exactly one backbone pass, one head pass, one exchange, one update."""
         if self.graph is None:
             self._body()
         elif len(self.graph) == 1:
             self.graph[0].replay()
         else:
-            self.graph[0].replay()
-            parallel.all_reduce_grads(self.opt.params())
-            self.graph[1].replay()
+            gbb, gh, gs = self.graph
+            gh.replay()
+            token = parallel.all_reduce_grads_start(self.opt.params())
+            gbb.replay()
+            parallel.all_reduce_grads_finish(token)
+            gs.replay()
         return self.loss
 
 

@@ -274,3 +274,28 @@ def test_fused_wgrad_sgd_equals_separate_update(cfg):
         res.append((w.detach().cpu().numpy().copy(), m.cpu().numpy().copy()))
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     assert not np.array_equal(res[0][0], w0)
+
+
+def test_sgg_step_pipelined_schedule_matches_single_graph(cfg, monkeypatch):
+    """The multi-GPU schedule (backbone graph / head graph / exchange / SGD graph, with the backbone pass of the
+    next step issued before the update) computes the same losses and weights as the one-graph step."""
+    from i2vsgg_amd import train
+    res = []
+    for split in ("0", "1"):
+        monkeypatch.setenv("I2V_SPLIT_GRAPH", split)
+        net = train.build_sgg_net(layers=50, seed=5, device=DEV)
+        net.vrd.dropout = False
+        step = train.SGGEmbStep(net, 1, seed=3, device=DEV, h=200, w=320, n_boxes=6, n_pairs=5, fuse_sgd=False)
+        assert step.capture(warmup=1), getattr(step, "graph_error", None)
+        assert step.pipelined == (split == "1")
+        losses = []
+        for _ in range(3):
+            losses.append(float(step().item()))
+        torch.cuda.synchronize()
+        res.append((losses, net.vrd.fc7.fc.weight.detach().cpu().numpy().copy()))
+        step.opt.unfuse()
+    (l0, w0), (l1, w1) = res
+    assert l0[0] != l0[2]                                                     # the weights do move
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 1e-5 * abs(a), (l0, l1)
+    assert _rel_err(w1, w0) < 1e-5

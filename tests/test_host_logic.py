@@ -97,7 +97,9 @@ y = torch.randn(8, 7)
 lo, hi = parallel.shard_frames(8, rk, world)
 loss = torch.nn.functional.mse_loss(lin(x[lo:hi]), y[lo:hi])          # per-rank mean over its 4 frames
 (loss / world).backward()
-parallel.all_reduce_grads(list(lin.parameters()))
+token = parallel.all_reduce_grads_start(list(lin.parameters()))       # the split form the pipelined step uses
+overlapped = (x * 2).sum()                                            # independent work between start and finish
+parallel.all_reduce_grads_finish(token)
 ref = torch.nn.Sequential(torch.nn.Linear(300, 2000), torch.nn.ReLU(), torch.nn.Linear(2000, 7))
 ref.load_state_dict(lin.state_dict())
 torch.nn.functional.mse_loss(ref(x), y).backward()                     # single-process, whole batch

@@ -16,6 +16,8 @@ for name, cin, h, w, cout, k, s, p, stages in cases:
     for tile in TILES:
         for label, cfg in (("plain", tile | (1 << 8)), ("plain, no staging", tile | (1 << 8) | (1 << 10)),
                            ("plain, no MFMA", tile | (1 << 8) | (2 << 10)), ("specialised", tile | (2 << 8)),
+                           ("plain, no LDS stores", tile | (1 << 8) | (64 << 10)),
+                           ("plain, no global loads", tile | (1 << 8) | (128 << 10)),
                            ("no staging, no barrier", tile | (1 << 8) | (5 << 10)),
                            ("no staging/barrier/ds_read", tile | (1 << 8) | (13 << 10))):
             if tile != 3 and "no " in label:
@@ -38,6 +40,12 @@ for name, cin, h, w, cout, k, s, p, stages in cases:
             print("%-28s tile %d %-28s WGs %4d  loop cycles/stage %6.0f (MFMA issue bound %d)  setup %6.0f cyc  kernel %6.1f us" % (
                 name, tile, label, v.shape[0], v[:, 0].double().median().item() / stages, BOUND[tile],
                 v[:, 2].double().median().item(), e0.elapsed_time(e1) / 20 * 1e3))
+            if label.startswith("plain"):
+                fin = v[v[:, 5] > 0]
+                post = (v[:, 4] - v[:, 3]).double()
+                postf = (fin[:, 4] - fin[:, 3]).double()
+                print("    after the K loop: all workgroups median %6.0f cyc (max %6.0f); epilogue-running ones median %6.0f (max %6.0f); last workgroup ends at %6.0f" % (
+                    post.median().item(), post.max().item(), postf.median().item(), postf.max().item(), v[:, 4].double().max().item()))
             if label == "specialised":
                 m = lambda i: v[:, i].double().median().item() / stages
                 print("    specialised per stage: loader LDS-store %5.0f  load-issue %5.0f  barrier-wait %5.0f | MFMA wave compute %5.0f" % (m(4), m(5), m(6), m(7)))
