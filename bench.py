@@ -140,6 +140,8 @@ def main():
                                "600x1000, 32 boxes + 32 pairs/frame, ResNet-%d C4" % (FRAMES_PER_RANK, a.layers),
                    "frames_per_gpu": FRAMES_PER_RANK, "global_frames": world * FRAMES_PER_RANK,
                    "hip_graph": bool(graphed), "graph_error": getattr(step, "graph_error", None), "parallelism": "dp%d (frames sharded, RCCL all-reduce of vrd grads)" % world,
+                   "schedule": ("pipelined: head fwd+bwd -> [gradient exchange || backbone fwd of the next minibatch] -> SGD"
+                                if getattr(step, "pipelined", False) else "one graph: backbone fwd, head fwd+bwd, fused wgrad+SGD"),
                    "loss": loss},
         "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (every i2v_conv_fwd/_dgrad call: kernel + its split-K helper kernels)", "achieved": achieved,
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,

@@ -1176,6 +1176,33 @@ __global__ void sgd_momentum_kernel(float* __restrict__ p, const float* __restri
     }
 }
 
+// Many small tensors in one launch (the per-tensor launch, not the bytes, is what a 300-float bias costs).  The
+// table travels by value in the kernel arguments; block b works on the tensor whose block range contains it.
+constexpr int SGD_MULTI_MAX = 48;
+struct SgdMulti {
+    float* p[SGD_MULTI_MAX]; const float* g[SGD_MULTI_MAX]; float* m[SGD_MULTI_MAX];
+    long long n[SGD_MULTI_MAX];
+    float lr[SGD_MULTI_MAX], wd[SGD_MULTI_MAX];
+    int first_block[SGD_MULTI_MAX + 1];
+    int count;
+    float mom;
+};
+constexpr int SGD_MULTI_PER_BLOCK = 256 * 16;     // elements per block
+__global__ void __launch_bounds__(256) sgd_momentum_multi_kernel(const SgdMulti t) {
+    int k = 0;
+    while (k + 1 < t.count && (int)blockIdx.x >= t.first_block[k + 1]) ++k;
+    const long long base = (long long)(blockIdx.x - t.first_block[k]) * SGD_MULTI_PER_BLOCK;
+    float* p = t.p[k]; const float* g = t.g[k]; float* m = t.m[k];
+    const float lr = t.lr[k], wd = t.wd[k], mom = t.mom;
+    for (int j = threadIdx.x; j < SGD_MULTI_PER_BLOCK; j += 256) {
+        const long long i = base + j;
+        if (i >= t.n[k]) break;
+        const float mv = mom * m[i] + (g[i] + wd * p[i]);       // same order as sgd_momentum_kernel
+        m[i] = mv;
+        p[i] -= lr * mv;
+    }
+}
+
 // g_pre = gy * (y > 0); g = g_pre * scale[n]; gbias[n] += sum_m g_pre.  One streaming pass: thread = 4 columns
 // (float4), a workgroup covers rows_per_blk rows x 1024 columns; either output may be NULL.
 __global__ void __launch_bounds__(256)
@@ -1446,6 +1473,31 @@ extern "C" int32_t i2v_maxpool3x3s2_fwd(const float* x, float* y, int32_t* argma
     maxpool3x3s2_kernel<<<(int)fmin((double)i2v_cdiv(total, 256), 8192.0), 256, 0, (hipStream_t)stream>>>(
         x, y, argmax, B, H, W, C, Ho, Wo);
     I2V_CHECK_LAUNCH("maxpool3x3s2");
+    return I2V_OK;
+}
+
+extern "C" int32_t i2v_sgd_momentum_multi(float* const* p, const float* const* g, float* const* m, const int64_t* n,
+                                          const float* lr, const float* weight_decay, int32_t count, float momentum,
+                                          void* stream) {
+    I2V_CHECK_ARG(count >= 0 && (count == 0 || (p && g && m && n && lr && weight_decay)), "sgd_momentum_multi: bad argument");
+    for (int32_t c0 = 0; c0 < count; c0 += SGD_MULTI_MAX) {
+        SgdMulti t;
+        t.count = 0;
+        t.mom = momentum;
+        int blocks = 0;
+        for (int32_t c = c0; c < count && t.count < SGD_MULTI_MAX; ++c) {
+            I2V_CHECK_ARG(p[c] && g[c] && m[c] && n[c] >= 0, "sgd_momentum_multi: bad tensor");
+            if (n[c] == 0) continue;
+            const int k = t.count++;
+            t.p[k] = p[c]; t.g[k] = g[c]; t.m[k] = m[c]; t.n[k] = n[c]; t.lr[k] = lr[c]; t.wd[k] = weight_decay[c];
+            t.first_block[k] = blocks;
+            blocks += (int)i2v_cdiv(n[c], (long long)SGD_MULTI_PER_BLOCK);
+        }
+        t.first_block[t.count] = blocks;
+        if (blocks == 0) continue;
+        sgd_momentum_multi_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(t);
+        I2V_CHECK_LAUNCH("sgd_momentum_multi");
+    }
     return I2V_OK;
 }
 

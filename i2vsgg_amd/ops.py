@@ -270,7 +270,19 @@ class ZeroArena:
         self.used = max(self.used, self.off)
         return t
 
+    def take_flat(self, n):
+        """n zeros, contiguous (bias-gradient sums, small filter gradients that are accumulated atomically)."""
+        n_al = (n + 63) // 64 * 64
+        self.wanted += n_al
+        if self.off + n_al > self.buf.numel():
+            return None
+        t = self.buf[self.off:self.off + n]
+        self.off += n_al
+        self.used = max(self.used, self.off)
+        return t
 
+
+SMALL_GW_BYTES = 16 << 20
 ARENA = None        # set by a training step object (train.SGGEmbStep) around its forward/backward
 
 
@@ -321,10 +333,19 @@ def _conv_dgrad_raw(g, w, in_shape, stride, pad):
 def _conv_wgrad_raw(x, g, w_shape, stride, pad):
     B, Cin, H, W = x.shape
     Cout, _, KH, KW = w_shape
-    gw = torch.empty(w_shape, device=x.device, dtype=torch.float32, memory_format=_CL)
+    # small filters: the pixel reduction is split over workgroups and accumulated with atomics, which needs a
+    # zeroed gw -- take it from the step's pre-zeroed arena and accumulate (beta = 1) instead of one clear per call
+    gw, beta = None, 0.0
+    n = Cout * Cin * KH * KW
+    if ARENA is not None and n * 4 <= SMALL_GW_BYTES:
+        flat = ARENA.take_flat(n)
+        if flat is not None:
+            gw, beta = flat.view(Cout, KH, KW, Cin).permute(0, 3, 1, 2), 1.0
+    if gw is None:
+        gw = torch.empty(w_shape, device=x.device, dtype=torch.float32, memory_format=_CL)
     with _Timed(2.0 * B * g.shape[2] * g.shape[3] * Cout * KH * KW * Cin, "wgrad",
                 "N%d K%d M%d" % (Cout, KH * KW * Cin, B * g.shape[2] * g.shape[3])):
-        check(lib.i2v_conv_wgrad(ptr(x), ptr(g), ptr(gw), B, H, W, Cin, Cout, KH, KW, stride, pad, 0.0, None, 0,
+        check(lib.i2v_conv_wgrad(ptr(x), ptr(g), ptr(gw), B, H, W, Cin, Cout, KH, KW, stride, pad, beta, None, 0,
                                  stream()), "conv_wgrad")
     return gw
 
@@ -378,7 +399,11 @@ class _ConvFn(torch.autograd.Function):
         gres = None
         need_bias = ctx.needs_input_grad[3] and has_shift and not has_scale
         need_res = has_res and ctx.needs_input_grad[4]
-        gbias = torch.zeros((N,), device=gy.device, dtype=torch.float32) if need_bias else None
+        gbias = None
+        if need_bias:
+            gbias = ARENA.take_flat(N) if ARENA is not None else None
+            if gbias is None:
+                gbias = torch.zeros((N,), device=gy.device, dtype=torch.float32)
 
         # one pass over gy: g_pre = gy*(y>0) feeds the residual branch and the bias sum, g = g_pre*scale feeds
         # dgrad / wgrad
@@ -461,6 +486,23 @@ def sgd_momentum_(p, g, m, lr, momentum, weight_decay):
     _need_cuda(p, g, m)
     check(lib.i2v_sgd_momentum(ptr(p), ptr(g), ptr(m), p.numel(), float(lr), float(momentum), float(weight_decay),
                                stream()), "sgd_momentum")
+
+
+def sgd_momentum_multi_(ps, gs, ms, lrs, wds, momentum):
+    """The same step for many (small) tensors in one launch; all flat, contiguous fp32."""
+    import ctypes
+    n = len(ps)
+    if n == 0:
+        return
+    _need_cuda(*ps, *gs, *ms)
+    arr_p = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ps])
+    arr_g = (ctypes.c_void_p * n)(*[t.data_ptr() for t in gs])
+    arr_m = (ctypes.c_void_p * n)(*[t.data_ptr() for t in ms])
+    arr_n = (ctypes.c_int64 * n)(*[t.numel() for t in ps])
+    arr_lr = (ctypes.c_float * n)(*[float(v) for v in lrs])
+    arr_wd = (ctypes.c_float * n)(*[float(v) for v in wds])
+    check(lib.i2v_sgd_momentum_multi(arr_p, arr_g, arr_m, arr_n, arr_lr, arr_wd, n, float(momentum), stream()),
+          "sgd_momentum_multi")
 
 
 class _DStylePoolFn(torch.autograd.Function):

@@ -19,6 +19,14 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def exchange_enabled():
+    """True when gradients are exchanged: world_size > 1, or a 1-rank group forced with I2V_FORCE_EXCHANGE=1
+    (rehearses the RCCL path and the pipelined step schedule on a single GPU)."""
+    if world_size() > 1:
+        return True
+    return os.environ.get("I2V_FORCE_EXCHANGE") == "1" and dist.is_available() and dist.is_initialized()
+
+
 def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
@@ -32,7 +40,7 @@ def init_from_env(backend=None):
     device = torch.device("cuda", local % max(torch.cuda.device_count(), 1)) if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("I2V_FORCE_EXCHANGE") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         kw = {}
@@ -55,7 +63,7 @@ def all_reduce_grads_start(params, group=None):
     """Launch the sum-all-reduce of every ``p.grad`` (loss was pre-scaled by 1/world) and return a token for
     ``all_reduce_grads_finish``.  The collectives run on RCCL's own stream behind everything already queued
     on the current stream; work queued on the current stream AFTER this call overlaps them."""
-    if world_size() == 1:
+    if not exchange_enabled():
         return None
     grads = [p.grad for p in params if p.grad is not None]
     big = [g for g in grads if g.numel() * g.element_size() >= SMALL_BYTES]

@@ -39,7 +39,7 @@ class FusedSGD:
         """Fuse the update of large filters into their wgrad epilogue (single-GPU only: with data
         parallelism the gradient must be all-reduced before the update).  Returns the fused names."""
         names = []
-        if parallel.world_size() > 1:
+        if parallel.exchange_enabled():
             return names
         for it in self.items:
             p = it["p"]
@@ -71,15 +71,24 @@ class FusedSGD:
         for it in self.items:
             it["lr"] *= k
 
+    MULTI_BELOW = 1 << 20       # tensors under 1 Mi elements share one launch
+
     @torch.no_grad()
     def step(self):
+        small = []
         for it in self.items:
             p, g = it["p"], it["p"].grad
             if g is None:
                 continue
             if g.stride() != p.stride():
                 g = torch.empty_like(p).copy_(g)
-            ops.sgd_momentum_(p, g, it["m"], it["lr"], self.momentum, it["wd"])
+            if p.numel() < self.MULTI_BELOW:
+                small.append((p, g, it))
+            else:
+                ops.sgd_momentum_(p, g, it["m"], it["lr"], self.momentum, it["wd"])
+        if small:
+            ops.sgd_momentum_multi_([p for p, _, _ in small], [g for _, g, _ in small], [it["m"] for _, _, it in small],
+                                    [it["lr"] for _, _, it in small], [it["wd"] for _, _, it in small], self.momentum)
 
 
 def synthetic_sgg_batch(seed, n_frames, n_boxes=32, n_pairs=32, n_rel=62, n_cls=16, h=600, w=1000):
@@ -198,7 +207,7 @@ class SGGEmbStep:
         torch.cuda.synchronize(self.dev)
         if not self.use_graph:
             return False
-        self.pipelined = self.world > 1 or os.environ.get("I2V_SPLIT_GRAPH") == "1"
+        self.pipelined = parallel.exchange_enabled() or os.environ.get("I2V_SPLIT_GRAPH") == "1"
         try:
             if not self.pipelined:
                 g = torch.cuda.CUDAGraph()

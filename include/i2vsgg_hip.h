@@ -194,6 +194,12 @@ int32_t i2v_dstyle_pool_bwd(const float* gz, const float* x1, const float* x2, f
  * zero-init, which equals torch's "buf = clone(g')" on the first step). */
 int32_t i2v_sgd_momentum(float* p, const float* g, float* m, int64_t n, float lr, float momentum,
                          float weight_decay, void* stream);
+/* The same update for `count` tensors in one launch (host arrays of device pointers / sizes / per-tensor lr and
+ * weight decay, read at call time): for the dozens of biases and small filters of the vrd head, where the launch
+ * is the cost.  Element order and rounding are those of i2v_sgd_momentum. */
+int32_t i2v_sgd_momentum_multi(float* const* p, const float* const* g, float* const* m, const int64_t* n,
+                               const float* lr, const float* weight_decay, int32_t count, float momentum,
+                               void* stream);
 
 #ifdef __cplusplus
 }

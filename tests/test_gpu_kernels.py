@@ -350,6 +350,22 @@ def test_sgd_momentum_matches_torch(ops):
     np.testing.assert_allclose(pd.cpu().numpy(), pt.detach().numpy(), rtol=1e-6, atol=1e-7)
 
 
+def test_sgd_momentum_multi_equals_per_tensor(ops):
+    """One launch for many small tensors == one launch per tensor, bitwise (60 tensors: two table chunks)."""
+    rng = np.random.default_rng(10)
+    sizes = [1, 3, 300, 4096, 4097, 65536 + 5, 256 * 16, 256 * 16 + 1] + [int(v) for v in rng.integers(1, 20000, 52)]
+    mk = lambda n: torch.from_numpy(rng.standard_normal(n, dtype=np.float32)).to(DEV)
+    ps, gs, ms = [mk(n) for n in sizes], [mk(n) for n in sizes], [mk(n) for n in sizes]
+    lrs = [0.01 * (1 + (i % 2)) for i in range(len(sizes))]
+    wds = [5e-4 * (i % 3 != 0) for i in range(len(sizes))]
+    p2, m2 = [t.clone() for t in ps], [t.clone() for t in ms]
+    for p, g, m, lr, wd in zip(ps, gs, ms, lrs, wds):
+        ops.sgd_momentum_(p, g, m, lr, 0.9, wd)
+    ops.sgd_momentum_multi_(p2, gs, m2, lrs, wds, 0.9)
+    for a, b, c, d in zip(ps, p2, ms, m2):
+        assert torch.equal(a, b) and torch.equal(c, d)
+
+
 def test_dstyle_pool(ops):
     rng = np.random.default_rng(4)
     x1 = torch.from_numpy(rng.standard_normal((2, 300, 2560), dtype=np.float32)).requires_grad_()

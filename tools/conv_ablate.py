@@ -41,6 +41,8 @@ for name, cin, h, w, cout, k, s, p, stages in cases:
                 name, tile, label, v.shape[0], v[:, 0].double().median().item() / stages, BOUND[tile],
                 v[:, 2].double().median().item(), e0.elapsed_time(e1) / 20 * 1e3))
             if label.startswith("plain"):
+                ghz = (v[:, 3].double() / v[:, 1].double()).median().item() * 0.1
+                print("    shader clock during the K loop: %.2f GHz (s_memtime cycles per 100 MHz s_memrealtime tick)" % ghz)
                 fin = v[v[:, 5] > 0]
                 post = (v[:, 4] - v[:, 3]).double()
                 postf = (fin[:, 4] - fin[:, 3]).double()

@@ -38,7 +38,7 @@ for name, cin, h, w, cout, k, s, p in SHAPES:
     fl = 2.0 * B * ho * wo * cout * k * k * cin
     res = []
     SP = int(os.environ.get("SPEC", "0"))
-    for cfg in list(range(6)) + [-1]:
+    for cfg in list(range(len(TILES))) + [-1]:
         _lib.lib.i2v_conv_set_tile((cfg if cfg >= 0 else 0xFF) | (SP << 8))
         for _ in range(2):
             ops.conv2d(x, wt, sc, sh, None, s, p, relu=True)
@@ -51,5 +51,5 @@ for name, cin, h, w, cout, k, s, p in SHAPES:
         torch.cuda.synchronize()
         res.append(e0.elapsed_time(e1) / n * 1e-3)
     _lib.lib.i2v_conv_set_tile(-1)
-    print("%-20s %9.2f | " % (name, fl / 1e9) + " ".join("%5.0fus/%3.0f" % (t * 1e6, fl / t / 1e12) for t in res[:6])
-          + " | %5.0fus/%3.0fTF" % (res[6] * 1e6, fl / res[6] / 1e12))
+    print("%-20s %9.2f | " % (name, fl / 1e9) + " ".join("%5.0fus/%3.0f" % (t * 1e6, fl / t / 1e12) for t in res[:len(TILES)])
+          + " | %5.0fus/%3.0fTF" % (res[-1] * 1e6, fl / res[-1] / 1e12))

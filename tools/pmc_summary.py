@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 passes of tools/profile_bench.sh into the files committed under profiles/.
+
+  pmc_summary.py <out_dir> <steps_in_run> <profiles_prefix>
+
+<out_dir>/fetch, <out_dir>/write: `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (csv); <out_dir>/trace: the
+`--kernel-trace --stats` pass.  FETCH_SIZE / WRITE_SIZE are KB; on gfx950 FETCH_SIZE reports half of the bytes of
+wide coalesced streaming reads (MI355X_MICROARCH.md, HBM section) and is doubled here."""
+import collections, csv, glob, json, re, sys
+
+out, steps, prefix = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "")
+    if name.startswith("void "):
+        name = name[5:]
+    return re.split(r"[<(]", name, 1)[0][:120]
+
+
+per = {}
+for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for f in glob.glob("%s/%s/**/*counter_collection.csv" % (out, sub), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            a = agg[short(r["Kernel_Name"])]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    per[counter] = {k: {"launches": n, "sum_kb": v} for k, (n, v) in sorted(agg.items(), key=lambda x: -x[1][1])[:12]}
+
+conv_f = per["FETCH_SIZE"].get("conv_igemm_f32", {"launches": 0, "sum_kb": 0.0})
+conv_w = per["WRITE_SIZE"].get("conv_igemm_f32", {"launches": 0, "sum_kb": 0.0})
+n = max(conv_f["launches"], 1)
+summary = {
+    "command": "rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps K --warmup W --no-cpu-baseline --no-graph",
+    "steps_in_run": steps,
+    "note": "FETCH_SIZE/WRITE_SIZE are KB. gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE reports 1/2 of wide coalesced streaming reads -> doubled.",
+    "conv_igemm_f32": {
+        "launches": conv_f["launches"], "fetch_kb_raw": conv_f["sum_kb"], "write_kb": conv_w["sum_kb"],
+        "hbm_bytes_per_launch_corrected": (2.0 * conv_f["sum_kb"] + conv_w["sum_kb"]) * 1024.0 / n,
+        "hbm_bytes_per_step_corrected": (2.0 * conv_f["sum_kb"] + conv_w["sum_kb"]) * 1024.0 / max(steps, 1),
+    },
+    "per_kernel": per,
+}
+json.dump(summary, open(prefix + "_pmc_summary.json", "w"), indent=1)
+print(json.dumps(summary["conv_igemm_f32"]))
+
+# kernel stats of the trace pass -> csv (name, calls, total ns, avg ns, %)
+rows = []
+for f in glob.glob("%s/trace/**/*kernel_stats.csv" % out, recursive=True):
+    rows = list(csv.reader(open(f)))
+if rows:
+    with open(prefix + "_bench_kernel_stats.csv", "w", newline="") as fo:
+        csv.writer(fo).writerows(rows)
+    print("kernel stats rows:", len(rows) - 1)
