@@ -168,7 +168,42 @@ conv_igemm_f32(const ConvP p) {
     // into the offset): with `cond ? offset : OOB` the compiler threads the condition into divergent
     // branches that each hold a copy of the load writing the same registers, and guards the second copy
     // with s_waitcnt vmcnt(0) -- which drains every stage still in flight.
+    // Fast path (whole stages of the 4-wave kernel): the k-dependent part of every address is UNIFORM across
+    // the workgroup -- k0*4 for 1x1 filters and for the weights, the tap's byte offset for KxK filters whose
+    // Cin is a multiple of 32 (a stage is then 32 channels of ONE tap) -- so it rides in the scalar offset
+    // operand of the buffer load and the per-lane offsets are loop invariants: no address VALU in the K loop
+    // (it was ~45 of the ~64 vector instructions per stage, and vector instructions of co-resident waves
+    // delay MFMA issue).  The buffer base is moved back by the largest negative halo offset so that the
+    // per-lane part is never negative (the hardware range-checks it before adding the scalar part).
+    const bool tap_uni = !is1x1 && (p.Cin % BKS) == 0 && p.KH * p.KW <= 32;
+    const unsigned halo = is1x1 ? 0u : (unsigned)((p.pad * p.W + p.pad) * p.Cin) * 4u;
+    const __amdgpu_buffer_rsrc_t xrb =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x - halo), 0, p.x_bytes + halo, 0x00020000);
+    unsigned a_vk[A_LD], b_vk[B_LD];
+#pragma unroll
+    for (int q = 0; q < A_LD; ++q) a_vk[q] = a_off4[q] == INV ? INV : a_off4[q] + halo + (unsigned)kg * 4u;
+#pragma unroll
+    for (int q = 0; q < B_LD; ++q) b_vk[q] = b_off4[q] == INV ? INV : b_off4[q] + (unsigned)kg * 4u;
     auto stage_load = [&](float4 (&A)[A_LD], float4 (&Bq)[B_LD], int k0) {
+        if constexpr (!SPEC) {
+            if (k0 + BKS <= kend && (is1x1 || tap_uni)) {
+                unsigned so_a = (unsigned)k0 * 4u, kp = 0;
+                if (!is1x1) {
+                    const unsigned e = __builtin_amdgcn_readfirstlane(ktab[k0 >> 2]);
+                    so_a = e >> 6;
+                    kp = e & 31u;
+                }
+#pragma unroll
+                for (int q = 0; q < A_LD; ++q) {
+                    const unsigned tinv = (((a_mlo[q] >> kp) & 1u) - 1u) & INV;     // 1x1: bit 0 is set for valid rows
+                    A[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrb, a_vk[q] | tinv, so_a, 0));
+                }
+#pragma unroll
+                for (int q = 0; q < B_LD; ++q)
+                    Bq[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, b_vk[q], (unsigned)k0 * 4u, 0));
+                return;
+            }
+        }
         const int k = k0 + kg;
         const unsigned kinv = ~(unsigned)((k - kend) >> 31) & INV;      // INV when k >= kend
         const unsigned k4 = (unsigned)k * 4u;
@@ -729,7 +764,8 @@ int run_conv(ConvP p, hipStream_t st) {
         }
     }
     const long long xb = (long long)p.B * p.H * p.W * p.Cin * 4, wb = (long long)p.N * p.K * 4;
-    if (xb >= (1ll << 31) || wb >= (1ll << 31)) {
+    const long long halo = (long long)(p.pad * p.W + p.pad) * p.Cin * 4;    // the kernel's descriptor starts this much earlier
+    if (xb + halo >= (1ll << 31) || wb >= (1ll << 31)) {
         i2v_set_error("conv: operand larger than 2 GiB (32-bit buffer offsets)");
         return I2V_ERR_UNSUPPORTED;
     }
@@ -1234,6 +1270,52 @@ epilogue_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, c
     }
 }
 
+// Narrow tensors (N <= 1024 columns, tall M: the conv_lo feature maps of the relation head are 16384 x 96):
+// the 256 threads split into N/4 column groups x row lanes, a lane strides over the rows of the block, and the
+// column sums are reduced across the lanes in LDS -> ONE atomic per column per workgroup.  (With one thread per
+// 4 columns only 24 of 256 threads had work and 512 workgroups hammered the same 96 addresses: 58 us.)
+__global__ void __launch_bounds__(256)
+epilogue_bwd_narrow_kernel(const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ scale,
+                           float* __restrict__ g, float* __restrict__ gpre, float* __restrict__ gbias, long long M,
+                           int N, int relu, int rows_per_blk) {
+    __shared__ float red[256 * 4];
+    const int cg = N >> 2;                       // column groups (<= 256)
+    const int lanes = 256 / cg;                  // row lanes (>= 1)
+    const int c = threadIdx.x % cg, lane = threadIdx.x / cg;
+    const int n = c * 4;
+    const long long r0 = (long long)blockIdx.x * rows_per_blk;
+    const long long r1 = r0 + rows_per_blk < M ? r0 + rows_per_blk : M;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < lanes) {
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (scale) sc = *(const float4*)(scale + n);
+#pragma unroll 4
+        for (long long r = r0 + lane; r < r1; r += lanes) {
+            float4 v = *(const float4*)(gy + r * N + n);
+            if (relu) {
+                const float4 yy = *(const float4*)(y + r * N + n);
+                v.x = yy.x > 0.f ? v.x : 0.f; v.y = yy.y > 0.f ? v.y : 0.f;
+                v.z = yy.z > 0.f ? v.z : 0.f; v.w = yy.w > 0.f ? v.w : 0.f;
+            }
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            if (gpre) *(float4*)(gpre + r * N + n) = v;
+            if (g) *(float4*)(g + r * N + n) = make_float4(v.x * sc.x, v.y * sc.y, v.z * sc.z, v.w * sc.w);
+        }
+    }
+    if (!gbias) return;
+    *(float4*)&red[threadIdx.x * 4] = s;
+    __syncthreads();
+    if (threadIdx.x < cg) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int l = 0; l < lanes; ++l) {
+            const float4 u = *(const float4*)&red[(l * cg + threadIdx.x) * 4];
+            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+        }
+        atomicAdd(gbias + n, t.x); atomicAdd(gbias + n + 1, t.y);
+        atomicAdd(gbias + n + 2, t.z); atomicAdd(gbias + n + 3, t.w);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 epilogue_bwd_scalar_kernel(const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ scale,
                            float* __restrict__ g, float* __restrict__ gpre, float* __restrict__ gbias, long long M,
@@ -1455,6 +1537,17 @@ extern "C" int32_t i2v_epilogue_bwd(const float* gy, const float* y, const float
     // enough workgroups to cover the chip even for the 64..128-row tensors of the relation head
     int rows = 64;
     while (rows > 4 && (long long)i2v_cdiv(M, rows) * i2v_cdiv(N, cols) < 2 * NUM_CU) rows >>= 1;
+    if (vec && N <= 512 && M >= 1024) {
+        // tall and narrow: all 256 threads on one row block, one atomic per column per workgroup
+        const int lanes = 256 / (N >> 2);
+        // few workgroups: same-address atomics retire one per ~150 ns, so 256 contenders cost more than the rows
+        int rpb = lanes * 64;
+        while (rpb > lanes && i2v_cdiv(M, rpb) < 48) rpb >>= 1;
+        epilogue_bwd_narrow_kernel<<<(unsigned)i2v_cdiv(M, rpb), 256, 0, (hipStream_t)stream>>>(gy, y, scale, g, gpre,
+                                                                                              gbias, M, N, relu, rpb);
+        I2V_CHECK_LAUNCH("epilogue_bwd");
+        return I2V_OK;
+    }
     dim3 grid(i2v_cdiv(M, rows), i2v_cdiv(N, cols));
     if (vec) epilogue_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(gy, y, scale, g, gpre, gbias, M, N, relu, rows);
     else epilogue_bwd_scalar_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(gy, y, scale, g, gpre, gbias, M, N, relu, rows);

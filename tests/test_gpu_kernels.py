@@ -306,7 +306,9 @@ def test_conv_bn_residual_backward(ops):
     np.testing.assert_allclose(rd.grad.cpu().numpy(), rt.grad.numpy(), **tol)
 
 
-@pytest.mark.parametrize("M,K,N", [(8, 50176, 64), (128, 4096, 300), (32, 600, 256), (62, 300, 1024), (5, 64, 1)])
+# the last three are tall-and-narrow: the epilogue backward's row-lane reduction (N/4 column groups x row lanes)
+@pytest.mark.parametrize("M,K,N", [(8, 50176, 64), (128, 4096, 300), (32, 600, 256), (62, 300, 1024), (5, 64, 1),
+                                   (16384, 100, 96), (4099, 64, 128), (1024, 32, 512)])
 def test_linear_fwd_bwd(ops, M, K, N):
     rng = np.random.default_rng(M + K + N)
     x = rng.standard_normal((M, K), dtype=np.float32)
