@@ -14,6 +14,7 @@
 // free.  K order inside a 8-deep step is permuted (lane half h owns k = 4h..4h+3) so a
 // fragment is ONE b128 read; A and B use the same permutation, so the sum is unchanged.
 #include "common.h"
+#include <algorithm>
 #include <mutex>
 #include <type_traits>
 #include <stdlib.h>
@@ -33,7 +34,8 @@ constexpr int kSplitInKernelMax = 4;   // most splits the in-kernel split-K fini
 
 struct ConvP {
     const float* x; const float* w; const float* scale; const float* shift; const float* res; float* y;
-    int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
+    int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;    // pad = top padding; may be negative (a crop)
+    int pad_x;                   // left padding (run_conv callers set both; the sub-filters of a strided dgrad differ)
     int M, N, K;                 // GEMM sizes
     int flags;
     int splitk, k_per_split;     // k_per_split multiple of BK
@@ -107,7 +109,7 @@ conv_igemm_f32(const ConvP p) {
 
     // staging roles: slot = tid + q*256 -> row = slot>>3, 16-B column = slot&7 (= tid&7 for every q)
     const int kc = tid & 7, kg = kc * 4;
-    const bool is1x1 = (p.KH == 1 && p.KW == 1 && p.pad == 0);
+    const bool is1x1 = (p.KH == 1 && p.KW == 1 && p.pad == 0 && p.pad_x == 0);
     const unsigned m1x1 = is1x1 ? 0xFFFFFFFFu : 0u;
     // filter-tap table (only for KHxKW > 1): entry e = k/4 -> (byte offset of tap (ky,kx,c)) << 6 | tap id.
     // Built once per workgroup, so the K loop has no integer division and no per-tap bounds math.
@@ -139,10 +141,13 @@ conv_igemm_f32(const ConvP p) {
         const bool ok = row < BM && m < p.M;
         const int mm = ok ? m : 0;
         const int ox = mm % p.Wo, t = mm / p.Wo, oy = t % p.Ho, b = t / p.Ho;
-        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-        a_off4[q] = ok ? (unsigned)(((b * p.H + iy0) * p.W + ix0) * p.Cin) * 4u : INV;
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad_x;
+        // 1x1 filters have no tap mask: a window that starts outside the input (possible for the sub-filters of
+        // a strided dgrad, whose output grid can overhang gy) reads zeros through an invalid row offset
+        const bool inside = !is1x1 || (iy0 >= 0 && ix0 >= 0 && iy0 < p.H && ix0 < p.W);
+        a_off4[q] = (ok && inside) ? (unsigned)(((b * p.H + iy0) * p.W + ix0) * p.Cin) * 4u : INV;
         unsigned long long mask = 0;
-        if (ok && is1x1) mask = 1;
+        if (ok && is1x1 && inside) mask = 1;
         if (ok && !is1x1) {
             // taps (ky,kx) inside the image form a rectangle: kx in [kx_lo,kx_hi) for ky in [ky_lo,ky_hi)
             const int kx_lo = max(0, -ix0), kx_hi = min(p.KW, p.W - ix0);
@@ -176,7 +181,7 @@ conv_igemm_f32(const ConvP p) {
     // delay MFMA issue).  The buffer base is moved back by the largest negative halo offset so that the
     // per-lane part is never negative (the hardware range-checks it before adding the scalar part).
     const bool tap_uni = !is1x1 && (p.Cin % BKS) == 0 && p.KH * p.KW <= 32;
-    const unsigned halo = is1x1 ? 0u : (unsigned)((p.pad * p.W + p.pad) * p.Cin) * 4u;
+    const unsigned halo = (unsigned)max(0, (p.pad * p.W + p.pad_x) * p.Cin) * 4u;
     const __amdgpu_buffer_rsrc_t xrb =
         __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x - halo), 0, p.x_bytes + halo, 0x00020000);
     unsigned a_vk[A_LD], b_vk[B_LD];
@@ -757,14 +762,14 @@ int run_conv(ConvP p, hipStream_t st) {
     p.N = p.Cout;
     p.K = p.KH * p.KW * p.Cin;
     p.lgCin = ilog2_exact(p.Cin);
-    if (!(p.KH == 1 && p.KW == 1 && p.pad == 0)) {
+    if (!(p.KH == 1 && p.KW == 1 && p.pad == 0 && p.pad_x == 0)) {
         if (p.K > KTAB_MAX * 4 || p.KH * p.KW > 64 || ((long long)(p.KH * p.W + p.KW) * p.Cin) >= (1ll << 24)) {
             i2v_set_error("conv: filter %dx%dx%d too large for the tap table", p.KH, p.KW, p.Cin);
             return I2V_ERR_UNSUPPORTED;
         }
     }
     const long long xb = (long long)p.B * p.H * p.W * p.Cin * 4, wb = (long long)p.N * p.K * 4;
-    const long long halo = (long long)(p.pad * p.W + p.pad) * p.Cin * 4;    // the kernel's descriptor starts this much earlier
+    const long long halo = std::max(0ll, (long long)(p.pad * p.W + p.pad_x) * p.Cin * 4);    // the kernel's descriptor starts this much earlier
     if (xb + halo >= (1ll << 31) || wb >= (1ll << 31)) {
         i2v_set_error("conv: operand larger than 2 GiB (32-bit buffer offsets)");
         return I2V_ERR_UNSUPPORTED;
@@ -855,6 +860,23 @@ __global__ void weight_dgrad_layout(const float* __restrict__ w, float* __restri
         int ky = t % KH;
         int c = t / KH;
         wt[i] = w[(((long long)n * KH + (KH - 1 - ky)) * KW + (KW - 1 - kx)) * Cin + c];
+    }
+}
+
+// Sub-filter of a strided dgrad: the input pixels of one parity class (iy % s, ix % s) only see the taps
+// ky = ky0 + s*t: wt[c][Ty-1-ty][Tx-1-tx][n] = w[n][ky0 + s*ty][kx0 + s*tx][c].
+__global__ void weight_dgrad_sub_layout(const float* __restrict__ w, float* __restrict__ wt, int Cout, int KH, int KW,
+                                        int Cin, int s, int ky0, int kx0, int Ty, int Tx) {
+    const long long total = (long long)Cin * Ty * Tx * Cout;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        int n = i % Cout;
+        long long t = i / Cout;
+        int ux = t % Tx; t /= Tx;
+        int uy = t % Ty;
+        int c = t / Ty;
+        const int ky = ky0 + s * (Ty - 1 - uy), kx = kx0 + s * (Tx - 1 - ux);
+        wt[i] = w[(((long long)n * KH + ky) * KW + kx) * Cin + c];
     }
 }
 
@@ -1405,7 +1427,7 @@ extern "C" int32_t i2v_conv_fwd_splits(int32_t B, int32_t H, int32_t W, int32_t 
     int rc = check_conv("conv_fwd_splits", &dummy, &dummy, &dummy, B, H, W, Cin, Cout, KH, KW, stride, pad);
     if (rc) return rc;
     ConvP p = {};
-    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.pad_x = pad;
     p.Ho = (H + 2 * pad - KH) / stride + 1;
     p.Wo = (W + 2 * pad - KW) / stride + 1;
     p.ostride = 1; p.force_tile = g_force_tile; p.dry = 1;
@@ -1424,7 +1446,7 @@ extern "C" int32_t i2v_conv_fwd(const float* x, const float* w, const float* sca
     I2V_CHECK_ARG(!(flags & I2V_EPI_RESIDUAL) || res, "conv_fwd: EPI_RESIDUAL needs res");
     ConvP p = {};
     p.x = x; p.w = w; p.scale = scale; p.shift = shift; p.res = res; p.y = y;
-    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.pad_x = pad;
     p.Ho = (H + 2 * pad - KH) / stride + 1;
     p.Wo = (W + 2 * pad - KW) / stride + 1;
     p.flags = flags; p.ostride = 1; p.Hy = p.Ho; p.Wy = p.Wo;
@@ -1447,36 +1469,80 @@ extern "C" size_t i2v_conv_dgrad_workspace_bytes(int32_t Cin, int32_t Cout, int3
 }
 
 // dgrad = forward conv of gy with the flipped/transposed filter (staged in the workspace).
+//
+// stride s > 1, KxK filter: an input pixel iy = s*a + r only receives taps ky = (r + pad) % s + s*t, from
+// output rows a + c0 - t with c0 = (r + pad - ky0) / s.  So every parity class (ry, rx) is its own stride-1
+// correlation of gy with a flipped sub-filter, written to every s-th pixel of gx: s*s launches whose MACs add up
+// to exactly the dense count (the zero-insertion form did s*s times that).
 extern "C" int32_t i2v_conv_dgrad(const float* gy, const float* w, float* gx, int32_t B, int32_t H, int32_t W,
                                      int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                                      void* ws, size_t ws_bytes, void* stream) {
     int rc = check_conv("conv_dgrad", gy, w, gx, B, H, W, Cin, Cout, KH, KW, stride, pad);
     if (rc) return rc;
     I2V_CHECK_ARG(Cout % 4 == 0, "conv_dgrad: Cout must be a multiple of 4");
-    I2V_CHECK_ARG(stride == 1 || (KH == 1 && KW == 1 && pad == 0), "conv_dgrad: strided dgrad only for 1x1 filters");
     if (!ws || ws_bytes < (size_t)Cout * KH * KW * Cin * sizeof(float)) {
         i2v_set_error("conv_dgrad: workspace too small");
         return I2V_ERR_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    const long long wn = (long long)Cout * KH * KW * Cin;
-    weight_dgrad_layout<<<(int)fmin((double)i2v_cdiv(wn, 256), 4096.0), 256, 0, st>>>(w, (float*)ws, Cout, KH, KW, Cin);
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
     ConvP p = {};
-    p.x = gy; p.w = (const float*)ws; p.y = gx;
-    p.B = B; p.H = Ho; p.W = Wo; p.Cin = Cout; p.Cout = Cin; p.KH = KH; p.KW = KW; p.stride = 1;
-    p.pad = KH - 1 - pad;
+    p.x = gy; p.y = gx;
+    p.B = B; p.H = Ho; p.W = Wo; p.Cin = Cout; p.Cout = Cin; p.stride = 1;
     p.flags = 0;
     p.force_tile = g_force_tile;
-    if (stride == 1) {
-        p.Ho = H; p.Wo = W; p.ostride = 1; p.Hy = H; p.Wy = W;
-        I2V_CHECK_ARG(KW - 1 - pad >= 0 && KH == KW, "conv_dgrad: unsupported padding");
-    } else {
-        p.pad = 0; p.Ho = Ho; p.Wo = Wo; p.ostride = stride; p.Hy = H; p.Wy = W;
-        hipMemsetAsync(gx, 0, (size_t)B * H * W * Cin * sizeof(float), st);
+    p.Hy = H; p.Wy = W;
+    const bool pointwise = KH == 1 && KW == 1 && pad == 0;
+    if (stride == 1 || pointwise) {
+        const long long wn = (long long)Cout * KH * KW * Cin;
+        weight_dgrad_layout<<<(int)fmin((double)i2v_cdiv(wn, 256), 4096.0), 256, 0, st>>>(w, (float*)ws, Cout, KH, KW, Cin);
+        p.w = (const float*)ws;
+        p.KH = KH; p.KW = KW;
+        if (stride == 1) {
+            I2V_CHECK_ARG(KH - 1 - pad >= 0 && KW - 1 - pad >= 0, "conv_dgrad: padding larger than the filter");
+            p.pad = KH - 1 - pad; p.pad_x = KW - 1 - pad;
+            p.Ho = H; p.Wo = W; p.ostride = 1;
+        } else {                    // strided 1x1: every s-th pixel gets a value, the rest are zero
+            p.pad = 0; p.pad_x = 0; p.Ho = Ho; p.Wo = Wo; p.ostride = stride;
+            hipMemsetAsync(gx, 0, (size_t)B * H * W * Cin * sizeof(float), st);
+        }
+        rc = run_conv(p, st);
+        if (rc) return rc;
+        I2V_CHECK_LAUNCH("conv_dgrad");
+        return I2V_OK;
     }
-    rc = run_conv(p, st);
-    if (rc) return rc;
+    // parity decomposition
+    bool all_written = true;
+    for (int r = 0; r < stride; ++r) {
+        if ((r + pad) % stride >= KH || (r + pad) % stride >= KW) all_written = false;
+    }
+    // pixels beyond the last window (iy + pad - ky > s*(Ho-1) for every tap) still get zeros from the masked taps
+    if (!all_written) hipMemsetAsync(gx, 0, (size_t)B * H * W * Cin * sizeof(float), st);
+    float* wsub = (float*)ws;
+    for (int ry = 0; ry < stride && ry < H; ++ry) {
+        const int ky0 = (ry + pad) % stride;
+        if (ky0 >= KH) continue;
+        const int Ty = (KH - ky0 + stride - 1) / stride, c0y = (ry + pad - ky0) / stride;
+        for (int rx = 0; rx < stride && rx < W; ++rx) {
+            const int kx0 = (rx + pad) % stride;
+            if (kx0 >= KW) continue;
+            const int Tx = (KW - kx0 + stride - 1) / stride, c0x = (rx + pad - kx0) / stride;
+            const long long wn = (long long)Cin * Ty * Tx * Cout;
+            weight_dgrad_sub_layout<<<(int)fmin((double)i2v_cdiv(wn, 256), 4096.0), 256, 0, st>>>(
+                w, wsub, Cout, KH, KW, Cin, stride, ky0, kx0, Ty, Tx);
+            ConvP q = p;
+            q.w = wsub;
+            q.KH = Ty; q.KW = Tx;
+            q.pad = Ty - 1 - c0y; q.pad_x = Tx - 1 - c0x;          // may be negative: the window starts inside gy
+            q.Ho = (H - ry + stride - 1) / stride;                    // pixels of this parity class
+            q.Wo = (W - rx + stride - 1) / stride;
+            q.ostride = stride;
+            q.y = gx + ((long long)ry * W + rx) * Cin;
+            rc = run_conv(q, st);
+            if (rc) return rc;
+            wsub += wn;
+        }
+    }
     I2V_CHECK_LAUNCH("conv_dgrad");
     return I2V_OK;
 }

@@ -315,12 +315,6 @@ def _conv_dgrad_raw(g, w, in_shape, stride, pad):
         g = torch.nn.functional.pad(g, (0, 0, 0, 0, 0, padc)).contiguous(memory_format=_CL)
         w = torch.cat([w, w.new_zeros((padc,) + tuple(w.shape[1:]))], 0).contiguous(memory_format=_CL)
         Cout += padc
-    if stride > 1 and not (KH == 1 and KW == 1 and pad == 0):
-        # zero-insertion: a strided conv's dgrad is the stride-1 dgrad of the dilated gradient map
-        Hd, Wd = H + 2 * pad - KH + 1, W + 2 * pad - KW + 1
-        gd = torch.empty((B, Cout, Hd, Wd), device=dev, dtype=torch.float32, memory_format=_CL).zero_()
-        gd[:, :, ::stride, ::stride][:, :, :g.shape[2], :g.shape[3]] = g
-        g, stride = gd, 1
     gx = torch.empty((B, Cin, H, W), device=dev, dtype=torch.float32, memory_format=_CL)
     ws = workspace(lib.i2v_conv_dgrad_workspace_bytes(Cin, Cout, KH, KW), dev, "dgrad")
     with _Timed(2.0 * B * g.shape[2] * g.shape[3] * Cout * KH * KW * Cin, "dgrad",

@@ -131,7 +131,8 @@ int32_t i2v_bbox_overlaps(const float* boxes, int32_t box_stride, int32_t box_of
  *   y   (B,Ho,Wo,Cout) NHWC                    res same shape as y (I2V_EPI_RESIDUAL)
  *   y = epi(sum_k x*w) with epi per flags: *scale[n] +shift[n], +res, relu.
  * dgrad: gx (B,H,W,Cin) = conv_transpose(gy, w) (overwrites gx); the workspace holds the
- *        flipped/transposed filter.  stride>1 is supported for 1x1 filters (all the path needs).
+ *        flipped/transposed filter(s).  stride>1: 1x1 filters scatter to every s-th pixel; KxK filters run
+ *        one sub-filter correlation per input-pixel parity class (s*s launches, dense MAC count).
  * wgrad: gw (Cout,KH,KW,Cin) (+)= gy^T * im2col(x); beta=0 overwrites, beta=1 accumulates. */
 int32_t i2v_conv_fwd(const float* x, const float* w, const float* scale, const float* shift, const float* res,
                      float* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,

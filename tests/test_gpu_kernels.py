@@ -239,6 +239,13 @@ CONV_CASES = [
     (3, 512, 7, 7, 18, 1, 1, 0),         # Cout not a multiple of 4
     (1, 96, 16, 16, 128, 5, 2, 2),       # vrd.conv_lo.1 (Cin not a power of two)
     (4, 128, 8, 8, 64, 8, 1, 0),         # vrd.conv_lo.2 -> 1x1 output, deep K (split-K)
+    # strided KxK: the dgrad runs one sub-filter correlation per input-pixel parity class
+    (2, 32, 17, 23, 64, 3, 2, 1),        # odd sizes: the last row/column has no window of its own
+    (1, 32, 16, 21, 32, 5, 2, 2),
+    (2, 16, 12, 10, 32, 2, 2, 0),        # sub-filters are single taps
+    (1, 16, 13, 14, 16, 3, 3, 0),
+    (1, 16, 14, 15, 32, 4, 2, 1),
+    (1, 16, 11, 11, 16, 2, 3, 0),        # filter smaller than the stride: one parity class receives nothing
 ]
 
 
