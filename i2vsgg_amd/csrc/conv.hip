@@ -1132,6 +1132,25 @@ conv_wgrad2_f32(const WgP p) {
         }
     };
 
+    // fused SGD: the filter and momentum tiles are fetched NOW, so their HBM latency hides behind the pixel
+    // reduction (read in the epilogue loop they cost one exposed round trip per iteration: the stores of one
+    // iteration alias the loads of the next as far as the compiler knows)
+    constexpr int W_LD = (BMW * (BNW / 4) + THREADS - 1) / THREADS;
+    constexpr bool PREFETCH_W = W_LD <= 4;
+    float4 pw[PREFETCH_W ? W_LD : 1], pm[PREFETCH_W ? W_LD : 1];
+    if (PREFETCH_W && p.sgd_m) {
+#pragma unroll
+        for (int it = 0; it < W_LD; ++it) {
+            const int e = tid + it * THREADS;
+            const int row = e / (BNW / 4), col = (e % (BNW / 4)) * 4;
+            const int n = n0 + row, k = k0 + col;
+            const bool ok = e < BMW * (BNW / 4) && n < p.N && k < p.K;
+            const long long o = (long long)n * p.K + k;
+            pw[it] = ok ? *(const float4*)(p.gw + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pm[it] = ok ? *(const float4*)(p.sgd_m + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+
     gload(mbeg);
     sstore(0);
     __syncthreads();
@@ -1154,7 +1173,23 @@ conv_wgrad2_f32(const WgP p) {
             for (int rr = 0; rr < 4; ++rr)
                 smem[((wm * TM + i) * 16 + 4 * fg + rr) * CROW + (wn * TN + j) * 16 + fr] = acc[i][j][rr];
     __syncthreads();
-    if (p.sgd_m || p.direct) {
+    if (PREFETCH_W && p.sgd_m) {
+#pragma unroll
+        for (int it = 0; it < W_LD; ++it) {
+            const int e = tid + it * THREADS;
+            const int row = e / (BNW / 4), col = (e % (BNW / 4)) * 4;
+            const int n = n0 + row, k = k0 + col;
+            if (e >= BMW * (BNW / 4) || n >= p.N || k >= p.K) continue;
+            const long long o = (long long)n * p.K + k;
+            const float4 g = *(const float4*)&smem[row * CROW + col];
+            float4 pv = pw[it], mv = pm[it];      // g' = g + wd*p ; m = mom*m + g' ; p -= lr*m   (same order as sgd_momentum_kernel)
+            mv.x = p.mom * mv.x + (g.x + p.wd * pv.x); mv.y = p.mom * mv.y + (g.y + p.wd * pv.y);
+            mv.z = p.mom * mv.z + (g.z + p.wd * pv.z); mv.w = p.mom * mv.w + (g.w + p.wd * pv.w);
+            pv.x -= p.lr * mv.x; pv.y -= p.lr * mv.y; pv.z -= p.lr * mv.z; pv.w -= p.lr * mv.w;
+            *(float4*)(p.sgd_m + o) = mv;
+            *(float4*)(p.gw + o) = pv;
+        }
+    } else if (p.sgd_m || p.direct) {
         for (int e = tid; e < BMW * (BNW / 4); e += THREADS) {
             const int row = e / (BNW / 4), col = (e % (BNW / 4)) * 4;
             const int n = n0 + row, k = k0 + col;

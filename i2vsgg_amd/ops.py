@@ -427,6 +427,14 @@ class _ConvFn(torch.autograd.Function):
 
 def conv2d(x, w, scale=None, shift=None, res=None, stride=1, pad=0, relu=False):
     """Implicit-GEMM conv with fused epilogue.  x (B,Cin,H,W), w (Cout,Cin,KH,KW); Cin % 4 == 0."""
+    B, Cin, H, W = x.shape
+    Cout, _, KH, KW = w.shape
+    if pad == 0 and KH == H and KW == W and (KH > 1 or KW > 1) and res is None:
+        # the filter covers the whole input (vrd.conv_lo's 8x8 layer): one output pixel, i.e. a linear layer
+        # over the NHWC-flattened map.  As a conv its dgrad is a full correlation with 63 of 64 taps masked.
+        xf = as_nhwc(x).permute(0, 2, 3, 1).reshape(B, H * W * Cin, 1, 1)
+        wf = w.contiguous(memory_format=_CL).permute(0, 2, 3, 1).reshape(Cout, KH * KW * Cin, 1, 1)
+        return _ConvFn.apply(xf, wf, scale, shift, None, 1, 0, bool(relu))
     return _ConvFn.apply(x, w, scale, shift, res, int(stride), int(pad), bool(relu))
 
 
