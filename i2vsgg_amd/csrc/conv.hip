@@ -134,12 +134,19 @@ conv_igemm_f32(const ConvP p) {
     constexpr unsigned INV = 0x80000000u, OOB = 0xFFFFFFF0u;
     unsigned a_off4[A_LD];            // byte offset of x[b][iy0][ix0][0] (mod 2^32: padded taps are masked)
     unsigned a_mlo[A_LD], a_mhi[A_LD];  // bit t: tap t of this output pixel reads inside the image
+    const bool ident = is1x1 && p.stride == 1 && p.Ho == p.H && p.Wo == p.W;      // no index arithmetic at all
 #pragma unroll
     for (int q = 0; q < A_LD; ++q) {
         const int row = (tid >> 3) + q * (THREADS / 8);
         const int m = m0 + row;
         const bool ok = row < BM && m < p.M;
         const int mm = ok ? m : 0;
+        if (ident) {                  // pointwise, stride 1, same grid: input pixel index == output pixel index
+            a_off4[q] = ok ? (unsigned)(mm * p.Cin) * 4u : INV;
+            a_mlo[q] = ok ? 1u : 0u;
+            a_mhi[q] = 0u;
+            continue;
+        }
         const int ox = mm % p.Wo, t = mm / p.Wo, oy = t % p.Ho, b = t / p.Ho;
         const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad_x;
         // 1x1 filters have no tap mask: a window that starts outside the input (possible for the sub-filters of
