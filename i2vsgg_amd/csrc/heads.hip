@@ -52,6 +52,205 @@ __global__ void dstyle_pool_bwd_kernel(const float* __restrict__ gz, const float
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// netD_pixel (resnet_instance_styleD_bilinear.py:38-83): per ROI pixel, 1024 -> 512 ReLU -> 128 ReLU -> 1 -> sigmoid,
+// no biases.  ONE kernel per direction: a workgroup owns 32 rows (ROI pixels); the 512- and 128-wide activations of
+// those rows never leave the CU between layers -- they stay in LDS in exactly the swizzled [k-stage][row][32] image
+// the MFMA fragment reads want, and are written to HBM once, for the backward.  The reference runs 3 convs + 3
+// pointwise kernels forward (and their autograd backward), each a round trip through HBM.
+//
+// Both directions are the same machine: rows x K  ->(GEMM, weights N x K streamed through LDS)->  rows x N, twice.
+//   forward :  x[.,1024] -> relu -> h1[.,512] -> relu -> h2[.,128] -> dot(w3) -> sigmoid
+//   backward:  gh2[.,128] -> (W2^T) mask(h1>0) -> gh1[.,512] -> (W1^T) * (-lambda) -> gx[.,1024]   (GRL folded in)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int DP_ROWS = 32, DP_BK = 32, DP_CHUNK = 128, DP_THREADS = 256;
+
+__device__ inline int dp_swz(int row, int kc) { return (kc ^ ((row >> 1) & 7)) << 2; }
+
+// One layer for the workgroup's 32 rows: out[32][N] = A[32][K] * Bw[N][K]^T, N in chunks of 128 columns (wave w owns
+// 32 of them).  A comes from global rows (A_LDS == false: `a_rows`, leading dimension K, rows >= m_valid read 0) or
+// from an LDS image [K/32][32][32] (swizzled).  epi(row, col, value) is called once per output element.
+template <int K, int N, bool A_LDS, class Epi>
+__device__ inline void dp_layer(const float* __restrict__ a_rows, int m_valid, const float* a_img,
+                                const float* __restrict__ Bw, float* stA, float* stB, Epi epi) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int srow = tid >> 3, kc = tid & 7;
+    constexpr int STAGES = K / DP_BK;
+    for (int n0 = 0; n0 < N; n0 += DP_CHUNK) {
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float4 ra, rb[4];
+        auto gload = [&](int s) {
+            const int k0 = s * DP_BK + kc * 4;
+            if (!A_LDS) ra = srow < m_valid ? *(const float4*)(a_rows + (long long)srow * K + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + srow + q * 32;
+                rb[q] = n < N ? *(const float4*)(Bw + (long long)n * K + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto sstore = [&](int buf) {
+            if (!A_LDS) *(float4*)&stA[buf * (DP_ROWS * DP_BK) + srow * DP_BK + dp_swz(srow, kc)] = ra;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int row = srow + q * 32;
+                *(float4*)&stB[buf * (DP_CHUNK * DP_BK) + row * DP_BK + dp_swz(row, kc)] = rb[q];
+            }
+        };
+        gload(0);
+        sstore(0);
+        __syncthreads();
+        int buf = 0;
+        for (int s = 0; s < STAGES; ++s) {
+            if (s + 1 < STAGES) gload(s + 1);
+            const float* As = A_LDS ? a_img + s * (DP_ROWS * DP_BK) : stA + buf * (DP_ROWS * DP_BK);
+            const float* Bs = stB + buf * (DP_CHUNK * DP_BK);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float4 av[2], bv[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = i * 16 + fr;
+                    av[i] = *(const float4*)&As[row * DP_BK + dp_swz(row, h * 4 + fg)];
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int row = wave * 32 + j * 16 + fr;
+                    bv[j] = *(const float4*)&Bs[row * DP_BK + dp_swz(row, h * 4 + fg)];
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const float a = t == 0 ? av[i].x : t == 1 ? av[i].y : t == 2 ? av[i].z : av[i].w;
+                            const float b = t == 0 ? bv[j].x : t == 1 ? bv[j].y : t == 2 ? bv[j].z : bv[j].w;
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i][j], 0, 0, 0);
+                        }
+            }
+            if (s + 1 < STAGES) sstore(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+        // C/D map of the 16x16 MFMA: col = lane&15, row = 4*(lane>>4) + r
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) epi(i * 16 + 4 * fg + r, n0 + wave * 32 + j * 16 + fr, acc[i][j][r]);
+        __syncthreads();          // the stage buffers are reused by the next chunk / layer
+    }
+}
+
+// LDS: stage A 2x4 KB | stage B 2x16 KB | image1 [16][32][32] 64 KB | image2 [4][32][32] 16 KB   = 120 KB
+constexpr int DP_LDS_FLOATS = 2 * DP_ROWS * DP_BK + 2 * DP_CHUNK * DP_BK + 16 * DP_ROWS * DP_BK + 4 * DP_ROWS * DP_BK;
+
+__device__ inline void dp_img_store(float* img, int row, int col, float v) {
+    img[((col >> 5) * DP_ROWS + row) * DP_BK + dp_swz(row, (col & 31) >> 2) + (col & 3)] = v;
+}
+__device__ inline float dp_img_load(const float* img, int row, int col) {
+    return img[((col >> 5) * DP_ROWS + row) * DP_BK + dp_swz(row, (col & 31) >> 2) + (col & 3)];
+}
+
+__global__ void __launch_bounds__(DP_THREADS)
+dpixel_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ w2,
+                  const float* __restrict__ w3, float* __restrict__ h1, float* __restrict__ h2, float* __restrict__ d,
+                  float* __restrict__ feat, int M, int pix_per_roi) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* stA = lds;
+    float* stB = stA + 2 * DP_ROWS * DP_BK;
+    float* img1 = stB + 2 * DP_CHUNK * DP_BK;
+    float* img2 = img1 + 16 * DP_ROWS * DP_BK;
+    const int m0 = blockIdx.x * DP_ROWS;
+    const int mv = min(DP_ROWS, M - m0);
+    dp_layer<1024, 512, false>(x + (long long)m0 * 1024, mv, nullptr, w1, stA, stB, [&](int row, int col, float v) {
+        v = fmaxf(v, 0.f);
+        dp_img_store(img1, row, col, v);
+        if (row < mv) h1[(long long)(m0 + row) * 512 + col] = v;
+    });
+    dp_layer<512, 128, true>(nullptr, mv, img1, w2, stA, stB, [&](int row, int col, float v) {
+        v = fmaxf(v, 0.f);
+        dp_img_store(img2, row, col, v);
+        if (row < mv) h2[(long long)(m0 + row) * 128 + col] = v;
+    });
+    // (dp_layer ended with a barrier: img2 is complete)  d = sigmoid(h2 . w3): 8 lanes per row, 16 columns each
+    const int row = threadIdx.x >> 3, part = threadIdx.x & 7;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const int col = part * 16 + c;
+        s += dp_img_load(img2, row, col) * w3[col];
+    }
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+    if (part == 0 && row < mv) d[m0 + row] = 1.f / (1.f + expf(-s));
+    if (feat) {                   // context vector: mean of h2 over the pixels of each ROI (:70-74)
+        const float inv = 1.f / (float)pix_per_roi;
+        for (int e = threadIdx.x; e < DP_ROWS * 128; e += DP_THREADS) {
+            const int r = e >> 7, col = e & 127;
+            if (r < mv) atomicAdd(feat + (long long)((m0 + r) / pix_per_roi) * 128 + col, dp_img_load(img2, r, col) * inv);
+        }
+    }
+}
+
+// backward chain.  w1t = W1^T (1024 x 512), w2t = W2^T (512 x 128): reduction-major copies made by the launcher.
+__global__ void __launch_bounds__(DP_THREADS)
+dpixel_bwd_kernel(const float* __restrict__ gd, const float* __restrict__ gfeat, const float* __restrict__ dsig,
+                  const float* __restrict__ h1, const float* __restrict__ h2, const float* __restrict__ w1t,
+                  const float* __restrict__ w2t, const float* __restrict__ w3, float* __restrict__ g3,
+                  float* __restrict__ gh2, float* __restrict__ gh1, float* __restrict__ gx, int M, int pix_per_roi,
+                  float neg_lambda) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* stA = lds;
+    float* stB = stA + 2 * DP_ROWS * DP_BK;
+    float* img1 = stB + 2 * DP_CHUNK * DP_BK;        // gh1 image
+    float* img2 = img1 + 16 * DP_ROWS * DP_BK;       // gh2 image
+    const int m0 = blockIdx.x * DP_ROWS;
+    const int mv = min(DP_ROWS, M - m0);
+    const float inv = 1.f / (float)pix_per_roi;
+    // g3 = gd * d * (1 - d);  gh2 = (g3 * w3 + gfeat / pixels) * (h2 > 0)
+    for (int e = threadIdx.x; e < DP_ROWS * 128; e += DP_THREADS) {
+        const int r = e >> 7, col = e & 127;
+        float v = 0.f;
+        if (r < mv) {
+            const int m = m0 + r;
+            const float ds = dsig[m];
+            const float g = (gd ? gd[m] : 0.f) * ds * (1.f - ds);
+            if (col == 0) g3[m] = g;
+            v = g * w3[col];
+            if (gfeat) v += gfeat[(long long)(m / pix_per_roi) * 128 + col] * inv;
+            v = h2[(long long)m * 128 + col] > 0.f ? v : 0.f;
+            gh2[(long long)m * 128 + col] = v;
+        }
+        dp_img_store(img2, r, col, v);
+    }
+    __syncthreads();
+    dp_layer<128, 512, true>(nullptr, mv, img2, w2t, stA, stB, [&](int row, int col, float v) {
+        const bool live = row < mv;
+        if (live) v = h1[(long long)(m0 + row) * 512 + col] > 0.f ? v : 0.f;
+        dp_img_store(img1, row, col, live ? v : 0.f);
+        if (live) gh1[(long long)(m0 + row) * 512 + col] = v;
+    });
+    dp_layer<512, 1024, true>(nullptr, mv, img1, w1t, stA, stB, [&](int row, int col, float v) {
+        if (row < mv) gx[(long long)(m0 + row) * 1024 + col] = v * neg_lambda;      // gradient reversal (net_utils.py:52-61)
+    });
+}
+
+// wt[k][n] = w[n][k]
+__global__ void dp_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int N, int K) {
+    const long long total = (long long)N * K;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % N), k = (int)(i / N);
+        wt[i] = w[(long long)n * K + k];
+    }
+}
+
 }  // namespace
 
 extern "C" int32_t i2v_dstyle_pool_fwd(const float* x1, const float* x2, float* z, int64_t rows, int32_t n_img,
@@ -75,5 +274,55 @@ extern "C" int32_t i2v_dstyle_pool_bwd(const float* gz, const float* x1, const f
     dstyle_pool_bwd_kernel<<<(int)fmin((double)i2v_cdiv(total, 256), 16384.0), 256, 0, (hipStream_t)stream>>>(
         gz, x1, x2, g1, g2, rows, n_img, dim, rank);
     I2V_CHECK_LAUNCH("dstyle_pool_bwd");
+    return I2V_OK;
+}
+
+// ---- netD_pixel, fused ------------------------------------------------------------------------------
+extern "C" int32_t i2v_dpixel_fwd(const float* x, const float* w1, const float* w2, const float* w3, float* h1, float* h2,
+                                  float* d, float* feat, int32_t M, int32_t pix_per_roi, void* stream) {
+    I2V_CHECK_ARG(x && w1 && w2 && w3 && h1 && h2 && d && M >= 0 && pix_per_roi > 0, "dpixel_fwd: bad argument");
+    I2V_CHECK_ARG(!feat || M % pix_per_roi == 0, "dpixel_fwd: M must be a whole number of ROIs when feat is requested");
+    if (M == 0) return I2V_OK;
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr = [] {
+        (void)hipFuncSetAttribute((const void*)dpixel_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS_FLOATS * 4);
+        (void)hipFuncSetAttribute((const void*)dpixel_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS_FLOATS * 4);
+        return true;
+    }();
+    (void)attr;
+    if (feat) hipMemsetAsync(feat, 0, sizeof(float) * (size_t)(M / pix_per_roi) * 128, st);
+    dpixel_fwd_kernel<<<i2v_cdiv(M, DP_ROWS), DP_THREADS, DP_LDS_FLOATS * 4, st>>>(x, w1, w2, w3, h1, h2, d, feat, M,
+                                                                                 pix_per_roi);
+    I2V_CHECK_LAUNCH("dpixel_fwd");
+    return I2V_OK;
+}
+
+extern "C" size_t i2v_dpixel_bwd_workspace_bytes(void) { return sizeof(float) * (size_t)(1024 * 512 + 512 * 128); }
+
+extern "C" int32_t i2v_dpixel_bwd(const float* gd, const float* gfeat, const float* d, const float* h1, const float* h2,
+                                  const float* w1, const float* w2, const float* w3, float* g3, float* gh2, float* gh1,
+                                  float* gx, int32_t M, int32_t pix_per_roi, float lambda, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    I2V_CHECK_ARG((gd || gfeat) && d && h1 && h2 && w1 && w2 && w3 && g3 && gh2 && gh1 && gx && M >= 0 && pix_per_roi > 0,
+                  "dpixel_bwd: bad argument");
+    if (!workspace || workspace_bytes < i2v_dpixel_bwd_workspace_bytes()) {
+        i2v_set_error("dpixel_bwd: workspace too small");
+        return I2V_ERR_WORKSPACE;
+    }
+    if (M == 0) return I2V_OK;
+    hipStream_t st = (hipStream_t)stream;
+    float* w1t = (float*)workspace;
+    float* w2t = w1t + 1024 * 512;
+    dp_transpose_kernel<<<512, 256, 0, st>>>(w1, w1t, 512, 1024);
+    dp_transpose_kernel<<<128, 256, 0, st>>>(w2, w2t, 128, 512);
+    static bool attr = [] {
+        (void)hipFuncSetAttribute((const void*)dpixel_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS_FLOATS * 4);
+        (void)hipFuncSetAttribute((const void*)dpixel_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS_FLOATS * 4);
+        return true;
+    }();
+    (void)attr;
+    dpixel_bwd_kernel<<<i2v_cdiv(M, DP_ROWS), DP_THREADS, DP_LDS_FLOATS * 4, st>>>(gd, gfeat, d, h1, h2, w1t, w2t, w3, g3,
+                                                                                 gh2, gh1, gx, M, pix_per_roi, -lambda);
+    I2V_CHECK_LAUNCH("dpixel_bwd");
     return I2V_OK;
 }

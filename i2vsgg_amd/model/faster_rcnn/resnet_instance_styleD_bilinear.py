@@ -28,6 +28,21 @@ class netD_pixel(nn.Module):
         self.context = context
 
     def forward(self, x, lamb=1.0):
+        if x.shape[1] != 1024 or not x.is_cuda:
+            return self._forward_layers(x, lamb)
+        # one fused kernel per direction (ops.dpixel): GRL, the three 1x1 convs, both ReLUs, the sigmoid and the
+        # context mean; the ROI pixels are rows of the NHWC map
+        R, C, H, W = x.shape
+        rows = ops.as_nhwc(x).permute(0, 2, 3, 1).reshape(R * H * W, C)
+        d, feat = ops.dpixel(rows, self.conv1.weight.reshape(512, 1024), self.conv2.weight.reshape(128, 512),
+                             self.conv3.weight.reshape(128), lamb, H * W, self.context)
+        d = d.view(R, H, W, 1).permute(0, 3, 1, 2)
+        if self.context:
+            return d, feat.view(R, 128, 1, 1)
+        return d
+
+    def _forward_layers(self, x, lamb=1.0):
+        """Layer-by-layer form (any channel count): three GEMM launches with the ReLU fused."""
         x = GradReverse.apply(x, lamb)
         x = ops.conv2d(x, self.conv1.weight, relu=True)
         x = ops.conv2d(x, self.conv2.weight, relu=True)

@@ -532,3 +532,50 @@ class _DStylePoolFn(torch.autograd.Function):
 def dstyle_pool(x1, x2, dim, rank):
     """z[b,d] = sum_pos sum_r x1[b,pos,d*rank+r]*x2[b,pos,d*rank+r] (x1,x2: (B,rows,dim*rank))."""
     return _DStylePoolFn.apply(x1, x2, int(dim), int(rank))
+
+
+class _DPixelFn(torch.autograd.Function):
+    """netD_pixel as one kernel per direction (i2v_dpixel_fwd / _bwd) + three 1x1 filter gradients."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, w3, lamb, pix_per_roi, want_feat):
+        _need_cuda(x, w1, w2, w3)
+        M = x.shape[0]
+        dev = x.device
+        h1 = torch.empty((M, 512), device=dev, dtype=torch.float32)
+        h2 = torch.empty((M, 128), device=dev, dtype=torch.float32)
+        d = torch.empty((M,), device=dev, dtype=torch.float32)
+        feat = torch.empty((M // pix_per_roi, 128), device=dev, dtype=torch.float32) if want_feat else None
+        check(lib.i2v_dpixel_fwd(ptr(x), ptr(w1), ptr(w2), ptr(w3), ptr(h1), ptr(h2), ptr(d), ptr(feat), M, pix_per_roi,
+                                 stream()), "dpixel_fwd")
+        ctx.save_for_backward(x, w1, w2, w3, h1, h2, d)
+        ctx.cfg = (float(lamb), int(pix_per_roi), want_feat)
+        return d, feat
+
+    @staticmethod
+    def backward(ctx, gd, gfeat):
+        x, w1, w2, w3, h1, h2, d = ctx.saved_tensors
+        lamb, pix, want_feat = ctx.cfg
+        M, dev = x.shape[0], x.device
+        gd = gd.contiguous() if gd is not None else None
+        gfeat = gfeat.contiguous() if (want_feat and gfeat is not None) else None
+        g3 = torch.empty((M,), device=dev, dtype=torch.float32)
+        gh2 = torch.empty((M, 128), device=dev, dtype=torch.float32)
+        gh1 = torch.empty((M, 512), device=dev, dtype=torch.float32)
+        gx = torch.empty((M, 1024), device=dev, dtype=torch.float32)
+        ws = workspace(lib.i2v_dpixel_bwd_workspace_bytes(), dev, "dpixel")
+        check(lib.i2v_dpixel_bwd(ptr(gd), ptr(gfeat), ptr(d), ptr(h1), ptr(h2), ptr(w1), ptr(w2), ptr(w3), ptr(g3), ptr(gh2),
+                                 ptr(gh1), ptr(gx), M, pix, lamb, ptr(ws), ws.numel(), stream()), "dpixel_bwd")
+        as4 = lambda t: t.view(M, -1, 1, 1)
+        gw1 = _conv_wgrad_raw(as4(x), as4(gh1), (512, 1024, 1, 1), 1, 0).view(512, 1024) if ctx.needs_input_grad[1] else None
+        gw2 = _conv_wgrad_raw(as4(h1), as4(gh2), (128, 512, 1, 1), 1, 0).view(128, 512) if ctx.needs_input_grad[2] else None
+        gw3 = _conv_wgrad_raw(as4(h2), as4(g3), (1, 128, 1, 1), 1, 0).view(128) if ctx.needs_input_grad[3] else None
+        return (gx if ctx.needs_input_grad[0] else None), gw1, gw2, gw3, None, None, None
+
+
+def dpixel(x_rows, w1, w2, w3, lamb=1.0, pix_per_roi=49, want_feat=False):
+    """Fused instance discriminator.  x_rows (M,1024) ROI pixels in NHWC order; w1 (512,1024), w2 (128,512), w3 (128).
+    Returns (d (M,), feat (M/pix_per_roi,128) or None).  The gradient w.r.t. x is reversed and scaled by ``lamb``."""
+    d, feat = _DPixelFn.apply(x_rows.contiguous(), w1.contiguous(), w2.contiguous(), w3.contiguous(), float(lamb),
+                              int(pix_per_roi), bool(want_feat))
+    return d, feat

@@ -189,6 +189,24 @@ int32_t i2v_dstyle_pool_fwd(const float* x1, const float* x2, float* z, int64_t 
 int32_t i2v_dstyle_pool_bwd(const float* gz, const float* x1, const float* x2, float* g1, float* g2,
                             int64_t rows, int32_t n_img, int32_t dim, int32_t rank, void* stream);
 
+/* ---- netD_pixel, fused (instance-level discriminator) ---------------------------------
+ * replaces netD_pixel.forward (resnet_instance_styleD_bilinear.py:38-83: GRL, conv1 1024->512 + ReLU, conv2
+ * 512->128 + ReLU, conv3 128->1, sigmoid, optional context vector = mean of the 128-d features over the ROI's
+ * pixels) and its autograd backward incl. GradReverse (net_utils.py:52-61) with one kernel per direction: the 512-
+ * and 128-wide activations of a 32-row tile stay in LDS between the layers.
+ *   x (M,1024) rows = ROI pixels (NHWC order, M = R * pix_per_roi); w1 (512,1024), w2 (128,512), w3 (128); no biases.
+ *   fwd writes h1 (M,512), h2 (M,128) (post-ReLU, kept for the backward), d (M) and, if feat != NULL, feat (R,128).
+ *   bwd takes gd (M) (may be NULL) and gfeat (R,128) (may be NULL) and writes g3 (M) = grad at the conv3 output,
+ *   gh2 (M,128), gh1 (M,512) -- the `gy` operands of the three filter gradients, which are plain
+ *   i2v_conv_wgrad calls with KH = KW = 1 -- and gx (M,1024) = -lambda * d loss / d x. */
+int32_t i2v_dpixel_fwd(const float* x, const float* w1, const float* w2, const float* w3, float* h1, float* h2,
+                       float* d, float* feat, int32_t M, int32_t pix_per_roi, void* stream);
+size_t  i2v_dpixel_bwd_workspace_bytes(void);
+int32_t i2v_dpixel_bwd(const float* gd, const float* gfeat, const float* d, const float* h1, const float* h2,
+                       const float* w1, const float* w2, const float* w3, float* g3, float* gh2, float* gh1,
+                       float* gx, int32_t M, int32_t pix_per_roi, float lambda, void* workspace,
+                       size_t workspace_bytes, void* stream);
+
 /* ---- fused SGD(momentum) step over a flat parameter buffer -------------------------
  * replaces torch.optim.SGD.step of trainval_net_SGG_emb.py:145-150,255 for one param
  * group: g' = g + wd*p ; m = mom*m + g' ; p -= lr*m   (m==first step handled by caller

@@ -468,3 +468,57 @@ def test_proposal_layer_fewer_survivors_than_post_nms_is_zero_padded(ops, oracle
         assert 0 < k <= 300
         assert torch.all(rois[b, :, 0] == b)
         assert torch.all(rois[b, k:, 1:] == 0) and torch.all(kept[b, k:] == -1)
+
+
+@pytest.mark.parametrize("R,ctx", [(5, False), (5, True), (32, True), (1, False)])
+def test_dpixel_fused_vs_torch(ops, R, ctx):
+    """netD_pixel in one kernel per direction (GRL, 3 pointwise convs, ReLUs, sigmoid, context mean) vs plain torch
+    fp32 autograd of resnet_instance_styleD_bilinear.py:38-83 + net_utils.py:52-61.  R*49 is not a multiple of the
+    32-row tile for R = 5 and R = 1."""
+    rng = np.random.default_rng(100 + R)
+    lamb = 0.3
+    x = rng.standard_normal((R, 1024, 7, 7), dtype=np.float32)
+    w1 = (rng.standard_normal((512, 1024), dtype=np.float32) * 0.03).astype(np.float32)
+    w2 = (rng.standard_normal((128, 512), dtype=np.float32) * 0.05).astype(np.float32)
+    w3 = (rng.standard_normal((128,), dtype=np.float32) * 0.2).astype(np.float32)
+    gd = rng.standard_normal((R, 1, 7, 7), dtype=np.float32)
+    gf = rng.standard_normal((R, 128, 1, 1), dtype=np.float32)
+
+    class GRL(torch.autograd.Function):
+        @staticmethod
+        def forward(c, t):
+            return t.view_as(t)
+
+        @staticmethod
+        def backward(c, g):
+            return g * -lamb
+
+    xt, w1t, w2t, w3t = (torch.from_numpy(a).requires_grad_() for a in (x, w1, w2, w3))
+    h = F.relu(F.conv2d(GRL.apply(xt), w1t.view(512, 1024, 1, 1)))
+    h = F.relu(F.conv2d(h, w2t.view(128, 512, 1, 1)))
+    d_ref = torch.sigmoid(F.conv2d(h, w3t.view(1, 128, 1, 1)))
+    f_ref = h.mean((2, 3), keepdim=True)
+    loss = (d_ref * torch.from_numpy(gd)).sum() + ((f_ref * torch.from_numpy(gf)).sum() if ctx else 0.0)
+    loss.backward()
+
+    xd = torch.from_numpy(x).to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+    w1d, w2d, w3d = (torch.from_numpy(a).to(DEV).requires_grad_() for a in (w1, w2, w3))
+    rows = xd.permute(0, 2, 3, 1).reshape(R * 49, 1024)
+    d, feat = ops.dpixel(rows, w1d, w2d, w3d, lamb, 49, ctx)
+    d4 = d.view(R, 7, 7, 1).permute(0, 3, 1, 2)
+    out = (d4 * torch.from_numpy(gd).to(DEV)).sum()
+    if ctx:
+        out = out + (feat.view(R, 128, 1, 1) * torch.from_numpy(gf).to(DEV)).sum()
+    out.backward()
+    tol = dict(rtol=3e-4, atol=3e-5)
+    np.testing.assert_allclose(d4.detach().cpu().numpy(), d_ref.detach().numpy(), **tol)
+    if ctx:
+        np.testing.assert_allclose(feat.detach().cpu().numpy().reshape(R, 128, 1, 1), f_ref.detach().numpy(), **tol)
+    np.testing.assert_allclose(xd.grad.cpu().numpy(), xt.grad.numpy(), **tol)
+    # filter gradients are sums over R*49 rows of O(1) products: compare against the tensor's scale (fp32 summation
+    # order differs).  A pre-activation within rounding of zero can take the other side of the ReLU in one of the two
+    # implementations, which moves one filter row by a visible amount: allow a handful of such elements.
+    for got, ref in ((w1d.grad, w1t.grad), (w2d.grad, w2t.grad), (w3d.grad, w3t.grad)):
+        g, r = got.cpu().numpy().astype(np.float64), ref.numpy().astype(np.float64)
+        err, scale = np.abs(g - r), np.abs(r).max()
+        assert (err > 1e-4 * scale).mean() < 1e-3 and err.max() < 2e-3 * scale, (err.max(), scale)
