@@ -7,6 +7,7 @@
 // -ffp-contract=off) so IoU threshold decisions match the reference's CPU path bit
 // for bit on the same boxes.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -428,6 +429,115 @@ int launch_nms(const float* dets, int n_img, int n, float thresh, int max_keep, 
     return 0;
 }
 
+
+// ------------------------------------------------------------------ detection post-processing (eval)
+// test_net_instance_styleD_bilinear.py:151-221 for one image, all foreground classes at once: de-normalise the
+// regression deltas, decode against the rois, clip, undo the image scale, per class threshold / sort / NMS, then the
+// image-wide top-`max_per_image` cut.  The reference does 1 + (n_classes-1) host NMS calls per frame.
+__global__ void det_decode_kernel(const float* __restrict__ rois, const float* __restrict__ prob,
+                                  const float* __restrict__ pred, int agnostic, int normalize, float4 stds, float4 means,
+                                  float im_h, float im_w, float scale, int R, int C, float thresh,
+                                  float4* __restrict__ boxes, float* __restrict__ keys, int* __restrict__ n_valid) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (C - 1) * R) return;
+    const int seg = idx / R, i = idx % R, j = seg + 1;
+    const float* d = pred + (long long)i * (agnostic ? 4 : 4 * C) + (agnostic ? 0 : 4 * j);
+    float d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3];
+    if (normalize) {          // box_deltas.view(-1, 4) * stds + means, one rounding per op (:158-163)
+        d0 = d0 * stds.x + means.x; d1 = d1 * stds.y + means.y;
+        d2 = d2 * stds.z + means.z; d3 = d3 * stds.w + means.w;
+    }
+    const float* a = rois + 5 * (long long)i + 1;
+    // bbox_transform.py:77-103
+    const float w = a[2] - a[0] + 1.0f, h = a[3] - a[1] + 1.0f;
+    const float cx = a[0] + 0.5f * w, cy = a[1] + 0.5f * h;
+    const float pcx = d0 * w + cx, pcy = d1 * h + cy;
+    const float pw = (float)exp((double)d2) * w, ph = (float)exp((double)d3) * h;
+    const float xmax = im_w - 1.0f, ymax = im_h - 1.0f;
+    float4 o;                  // clip_boxes :125-133, then pred_boxes /= scale (:171)
+    o.x = fminf(fmaxf(pcx - 0.5f * pw, 0.f), xmax) / scale;
+    o.y = fminf(fmaxf(pcy - 0.5f * ph, 0.f), ymax) / scale;
+    o.z = fminf(fmaxf(pcx + 0.5f * pw, 0.f), xmax) / scale;
+    o.w = fminf(fmaxf(pcy + 0.5f * ph, 0.f), ymax) / scale;
+    boxes[idx] = o;
+    const float sc = prob[(long long)i * C + j];
+    const bool ok = sc > thresh;                      // :182
+    keys[idx] = ok ? sc : -INFINITY;
+    if (ok) atomicAdd(n_valid + seg, 1);
+}
+
+// rows in descending-score order; rows past the class's valid count become far-away unit boxes that overlap nothing
+__global__ void det_gather_kernel(const float4* __restrict__ boxes, const float* __restrict__ keys,
+                                  const int* __restrict__ order, const int* __restrict__ n_valid, int R, int C,
+                                  float* __restrict__ dets) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (C - 1) * R) return;
+    const int seg = idx / R, r = idx % R;
+    float* o = dets + 5 * (long long)idx;
+    if (r < n_valid[seg]) {
+        const int src = seg * R + order[idx];
+        const float4 b = boxes[src];
+        o[0] = b.x; o[1] = b.y; o[2] = b.z; o[3] = b.w; o[4] = keys[src];
+    } else {
+        const float x = -1.0e8f - 64.0f * (float)r;
+        o[0] = x; o[1] = -1.0e8f; o[2] = x + 1.0f; o[3] = -1.0e8f + 1.0f; o[4] = -INFINITY;
+    }
+}
+
+// one workgroup per class: kept rows (in order) that are real detections -> tmp, their scores -> all_scores
+__global__ void det_compact_kernel(const float* __restrict__ dets, const int* __restrict__ keep,
+                                   const int* __restrict__ num, const int* __restrict__ n_valid, int R,
+                                   float* __restrict__ tmp, float* __restrict__ all_scores, int* __restrict__ cnt,
+                                   int* __restrict__ total) {
+    const int seg = blockIdx.x;
+    __shared__ int pos;
+    if (threadIdx.x == 0) pos = 0;
+    __syncthreads();
+    const int nk = num[seg], nv = n_valid[seg];
+    // keep[] is ascending (rows are visited in score order), so the real detections are a prefix of it
+    int mine = 0;
+    for (int t = threadIdx.x; t < nk; t += blockDim.x) mine += keep[(long long)seg * R + t] < nv;
+    atomicAdd(&pos, mine);
+    __syncthreads();
+    const int n = pos;
+    for (int t = threadIdx.x; t < R; t += blockDim.x) {
+        float sc = -INFINITY;
+        if (t < n) {
+            const float* src = dets + 5 * ((long long)seg * R + keep[(long long)seg * R + t]);
+            float* dst = tmp + 5 * ((long long)seg * R + t);
+            dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3]; dst[4] = src[4];
+            sc = src[4];
+        }
+        all_scores[(long long)seg * R + t] = sc;
+    }
+    if (threadIdx.x == 0) { cnt[seg] = n; atomicAdd(total, n); }
+}
+
+// image_thresh = the max_per_image-th largest kept score when more than that many were kept (:214-221)
+__global__ void det_final_kernel(const float* __restrict__ tmp, const int* __restrict__ cnt, const int* __restrict__ total,
+                                 const float* __restrict__ all_scores, const int* __restrict__ order2, int max_per_image,
+                                 int R, int C, float* __restrict__ out, int* __restrict__ counts) {
+    const int j = blockIdx.x;               // class, 0 = background (never reported)
+    if (j == 0) { if (threadIdx.x == 0) counts[0] = 0; return; }
+    const int seg = j - 1;
+    float image_thresh = -INFINITY;
+    if (max_per_image > 0 && *total > max_per_image) image_thresh = all_scores[order2[max_per_image - 1]];
+    __shared__ int n_out;
+    if (threadIdx.x == 0) n_out = 0;
+    __syncthreads();
+    const int n = cnt[seg];
+    // scores within a class are descending: the rows that pass are a prefix
+    int mine = 0;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) mine += tmp[5 * ((long long)seg * R + t) + 4] >= image_thresh;
+    atomicAdd(&n_out, mine);
+    __syncthreads();
+    for (int t = threadIdx.x; t < n_out; t += blockDim.x) {
+        const float* src = tmp + 5 * ((long long)seg * R + t);
+        float* dst = out + 5 * ((long long)j * R + t);
+        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3]; dst[4] = src[4];
+    }
+    if (threadIdx.x == 0) counts[j] = n_out;
+}
 }  // namespace
 
 extern "C" size_t i2v_nms_workspace_bytes(int32_t n_img, int32_t n) {
@@ -533,5 +643,71 @@ extern "C" int32_t i2v_bbox_overlaps(const float* boxes, int32_t box_stride, int
     bbox_overlaps_kernel<<<dim3(i2v_cdiv(N, 256), B), 256, (size_t)K * 24, (hipStream_t)stream>>>(
         boxes, box_stride, box_off, batched, gt, N, K, ov, max_ov, arg_ov);
     I2V_CHECK_LAUNCH("bbox_overlaps");
+    return I2V_OK;
+}
+
+namespace {
+struct DetWs {
+    float4* boxes; float* keys; int* order; float* dets; int* n_valid; int* keep; int* num; float* tmp;
+    float* all_scores; int* order2; int* cnt; int* total; void* sort_ws; size_t sort_ws_bytes; void* nms_ws;
+    size_t nms_ws_bytes; size_t bytes;
+};
+DetWs det_carve(char* base, int R, int C) {
+    DetWs w;
+    const size_t n = (size_t)(C - 1) * R;
+    size_t off = 0;
+    auto take = [&](size_t b) { char* p = base ? base + off : nullptr; off += i2v_align(b); return p; };
+    w.boxes = (float4*)take(n * 16); w.keys = (float*)take(n * 4); w.order = (int*)take(n * 4);
+    w.dets = (float*)take(n * 20); w.n_valid = (int*)take((size_t)C * 4); w.keep = (int*)take(n * 4);
+    w.num = (int*)take((size_t)C * 4); w.tmp = (float*)take(n * 20); w.all_scores = (float*)take(n * 4);
+    w.order2 = (int*)take(n * 4); w.cnt = (int*)take((size_t)C * 4); w.total = (int*)take(256);
+    w.sort_ws_bytes = std::max(i2v_sort_desc_workspace_bytes(C - 1, R), i2v_sort_desc_workspace_bytes(1, (int)n));
+    w.sort_ws = take(w.sort_ws_bytes);
+    w.nms_ws_bytes = i2v_nms_workspace_bytes(C - 1, R);
+    w.nms_ws = take(w.nms_ws_bytes);
+    w.bytes = off;
+    return w;
+}
+}  // namespace
+
+extern "C" size_t i2v_det_postprocess_workspace_bytes(int32_t R, int32_t C) {
+    if (R <= 0 || C <= 1) return 256;
+    return det_carve(nullptr, R, C).bytes;
+}
+
+extern "C" int32_t i2v_det_postprocess(const float* rois, const float* cls_prob, const float* bbox_pred,
+                                       int32_t class_agnostic, const float* stds, const float* means, float im_h,
+                                       float im_w, float im_scale, int32_t R, int32_t C, float score_thresh,
+                                       float nms_thresh, int32_t max_per_image, float* dets, int32_t* counts, void* ws,
+                                       size_t ws_bytes, void* stream) {
+    I2V_CHECK_ARG(rois && cls_prob && bbox_pred && dets && counts, "det_postprocess: null pointer");
+    I2V_CHECK_ARG(R > 0 && C > 1 && im_scale > 0.f, "det_postprocess: bad shape");
+    I2V_CHECK_ARG((stds == nullptr) == (means == nullptr), "det_postprocess: stds and means go together");
+    if (!ws || ws_bytes < i2v_det_postprocess_workspace_bytes(R, C)) {
+        i2v_set_error("det_postprocess: workspace too small");
+        return I2V_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    DetWs w = det_carve((char*)ws, R, C);
+    const int n = (C - 1) * R;
+    hipMemsetAsync(w.n_valid, 0, sizeof(int) * C, st);
+    hipMemsetAsync(w.total, 0, sizeof(int), st);
+    const float4 sd = stds ? make_float4(stds[0], stds[1], stds[2], stds[3]) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float4 mn = means ? make_float4(means[0], means[1], means[2], means[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    det_decode_kernel<<<i2v_cdiv(n, 256), 256, 0, st>>>(rois, cls_prob, bbox_pred, class_agnostic, stds != nullptr, sd, mn,
+                                                        im_h, im_w, im_scale, R, C, score_thresh, w.boxes, w.keys,
+                                                        w.n_valid);
+    int rc = i2v_sort_desc(w.keys, C - 1, R, w.order, w.sort_ws, w.sort_ws_bytes, stream);
+    if (rc) return rc;
+    det_gather_kernel<<<i2v_cdiv(n, 256), 256, 0, st>>>(w.boxes, w.keys, w.order, w.n_valid, R, C, w.dets);
+    rc = i2v_nms_sorted(w.dets, C - 1, R, nms_thresh, 0, w.keep, w.num, w.nms_ws, w.nms_ws_bytes, stream);
+    if (rc) return rc;
+    det_compact_kernel<<<C - 1, 256, 0, st>>>(w.dets, w.keep, w.num, w.n_valid, R, w.tmp, w.all_scores, w.cnt, w.total);
+    if (max_per_image > 0) {
+        rc = i2v_sort_desc(w.all_scores, 1, n, w.order2, w.sort_ws, w.sort_ws_bytes, stream);
+        if (rc) return rc;
+    }
+    det_final_kernel<<<C, 256, 0, st>>>(w.tmp, w.cnt, w.total, w.all_scores, w.order2, max_per_image, R, C, dets, counts);
+    I2V_CHECK_LAUNCH("det_postprocess");
     return I2V_OK;
 }

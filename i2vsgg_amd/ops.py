@@ -579,3 +579,31 @@ def dpixel(x_rows, w1, w2, w3, lamb=1.0, pix_per_roi=49, want_feat=False):
     d, feat = _DPixelFn.apply(x_rows.contiguous(), w1.contiguous(), w2.contiguous(), w3.contiguous(), float(lamb),
                               int(pix_per_roi), bool(want_feat))
     return d, feat
+
+
+def detection_postprocess(rois, cls_prob, bbox_pred, im_h, im_w, im_scale, class_agnostic=False, stds=None, means=None,
+                          score_thresh=0.0, nms_thresh=0.3, max_per_image=100):
+    """Per-class detection post-processing of one image on the device (test_net_instance_styleD_bilinear.py:151-221).
+
+    rois (R,5) [batch_idx,x1,y1,x2,y2]; cls_prob (R,C); bbox_pred (R,4) or (R,4C).  ``stds`` / ``means``: the
+    TRAIN.BBOX_NORMALIZE_STDS / _MEANS 4-tuples when the deltas are normalised, else None.
+    Returns (dets (C,R,5), counts (C,) int32), both on the device: rows ``dets[j, :counts[j]]`` are the reference's
+    ``all_boxes[j][i]``."""
+    import ctypes
+    _need_cuda(rois, cls_prob, bbox_pred)
+    rois = rois.reshape(-1, 5).float().contiguous()
+    cls_prob = cls_prob.reshape(rois.shape[0], -1).float().contiguous()
+    R, C = cls_prob.shape
+    bbox_pred = bbox_pred.reshape(R, -1).float().contiguous()
+    if bbox_pred.shape[1] != (4 if class_agnostic else 4 * C):
+        raise ValueError("bbox_pred has %d columns, expected %d" % (bbox_pred.shape[1], 4 if class_agnostic else 4 * C))
+    dev = rois.device
+    dets = torch.empty((C, R, 5), device=dev, dtype=torch.float32)
+    counts = torch.empty((C,), device=dev, dtype=torch.int32)
+    ws = workspace(lib.i2v_det_postprocess_workspace_bytes(R, C), dev, "det")
+    f4 = lambda v: (ctypes.c_float * 4)(*[float(t) for t in v]) if v is not None else None
+    check(lib.i2v_det_postprocess(ptr(rois), ptr(cls_prob), ptr(bbox_pred), int(bool(class_agnostic)), f4(stds), f4(means),
+                                  float(im_h), float(im_w), float(im_scale), R, C, float(score_thresh), float(nms_thresh),
+                                  int(max_per_image), ptr(dets), ptr(counts), ptr(ws), ws.numel(), stream()),
+          "det_postprocess")
+    return dets, counts

@@ -115,6 +115,22 @@ size_t  i2v_sort_desc_workspace_bytes(int32_t n_seg, int32_t n);
 int32_t i2v_sort_desc(const float* keys, int32_t n_seg, int32_t n, int32_t* order_out /* (n_seg,n) */,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- per-class detection post-processing (eval) --------------------
+ * replaces test_net_instance_styleD_bilinear.py:151-221 for one image: de-normalise the deltas with
+ * TRAIN.BBOX_NORMALIZE_STDS / _MEANS (host arrays of 4 floats, NULL = not normalised), bbox_transform_inv
+ * against rois (R,5), clip to the image, divide by the image scale, and for every class j >= 1: keep
+ * score > score_thresh, sort, NMS(nms_thresh); then, if more than max_per_image detections survive over all
+ * classes, keep those with score >= the max_per_image-th largest.  One asynchronous pass (the reference makes
+ * n_classes - 1 host NMS calls per frame).
+ *   cls_prob (R,C); bbox_pred (R,4) when class_agnostic else (R,4C)
+ *   dets (C,R,5) [x1,y1,x2,y2,score], rows of class j in descending score order, first counts[j] valid;
+ *   counts (C) int32, counts[0] = 0.  Ties: descending score, then ascending roi index. */
+size_t  i2v_det_postprocess_workspace_bytes(int32_t R, int32_t C);
+int32_t i2v_det_postprocess(const float* rois, const float* cls_prob, const float* bbox_pred, int32_t class_agnostic,
+                            const float* stds, const float* means, float im_h, float im_w, float im_scale,
+                            int32_t R, int32_t C, float score_thresh, float nms_thresh, int32_t max_per_image,
+                            float* dets, int32_t* counts, void* workspace, size_t workspace_bytes, void* stream);
+
 /* IoU of boxes (B,N,4 | stride_box floats per row, first 4 used after `box_off`) against
  * gt (B,K,5): bbox_transform.py:168-257 (bbox_overlaps_batch) incl. the zero-area
  * masks; also emits per-row max/argmax (first max).  overlaps may be NULL. */

@@ -238,3 +238,41 @@ def smooth_l1(pred, target, in_w, out_w, sigma=1.0, sum_dims=(1,)):
     for ax in sorted(sum_dims, reverse=True):
         loss = loss.sum(ax)
     return F32(loss.mean())
+
+
+def detection_postprocess(rois, cls_prob, bbox_pred, im_h, im_w, im_scale, class_agnostic=False, stds=None, means=None,
+                          score_thresh=0.0, nms_thresh=0.3, max_per_image=100):
+    """test_net_instance_styleD_bilinear.py:151-221 for one image.  Returns the reference's ``all_boxes[j][i]`` as a
+    list over classes (entry 0 = background, empty).  Sort rule on tied scores: descending score, ascending roi
+    index (torch.sort's order on exact ties is unspecified)."""
+    rois = np.asarray(rois, np.float32).reshape(-1, 5)
+    R = rois.shape[0]
+    scores = np.asarray(cls_prob, np.float32).reshape(R, -1)
+    C = scores.shape[1]
+    deltas = np.asarray(bbox_pred, np.float32).reshape(-1, 4)            # .view(-1, 4)  :158,:161
+    if stds is not None:
+        deltas = (deltas * np.asarray(stds, np.float32)).astype(np.float32) + np.asarray(means, np.float32)
+        deltas = deltas.astype(np.float32)
+    deltas = deltas.reshape(R, -1)
+    boxes = rois[:, 1:5]
+    out = [np.zeros((0, 5), np.float32)]
+    for j in range(1, C):
+        d = deltas if class_agnostic else deltas[:, 4 * j:4 * j + 4]
+        pred = decode_clip(boxes, d, im_h, im_w)                         # bbox_transform_inv + clip_boxes :165-166
+        pred = (pred / np.float32(im_scale)).astype(np.float32)          # :171
+        inds = np.nonzero(scores[:, j] > np.float32(score_thresh))[0]    # :182
+        if inds.size == 0:
+            out.append(np.zeros((0, 5), np.float32))
+            continue
+        cs = scores[inds, j]
+        order = np.argsort(-cs, kind="stable")
+        dets = np.concatenate([pred[inds], cs[:, None]], 1).astype(np.float32)[order]
+        keep = cops.nms_sorted(dets, nms_thresh)                         # nms(cls_dets, cfg.TEST.NMS) :195
+        out.append(dets[keep])
+    if max_per_image > 0:                                                # :214-221
+        image_scores = np.hstack([out[j][:, -1] for j in range(1, C)])
+        if len(image_scores) > max_per_image:
+            image_thresh = np.sort(image_scores)[-max_per_image]
+            for j in range(1, C):
+                out[j] = out[j][out[j][:, -1] >= image_thresh]
+    return out

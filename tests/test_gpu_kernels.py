@@ -522,3 +522,34 @@ def test_dpixel_fused_vs_torch(ops, R, ctx):
         g, r = got.cpu().numpy().astype(np.float64), ref.numpy().astype(np.float64)
         err, scale = np.abs(g - r), np.abs(r).max()
         assert (err > 1e-4 * scale).mean() < 1e-3 and err.max() < 2e-3 * scale, (err.max(), scale)
+
+
+@pytest.mark.parametrize("R,C,agnostic,thresh,maxdet", [(300, 16, False, 0.0, 100), (300, 16, True, 0.05, 100),
+                                                        (37, 5, False, 0.3, 0), (300, 36, False, 0.0, 100),
+                                                        (64, 3, False, 0.99, 100)])
+def test_detection_postprocess_vs_oracle(ops, oracle, R, C, agnostic, thresh, maxdet):
+    """the device pass == the numpy restatement of test_net_instance_styleD_bilinear.py:151-221
+    (whose pieces bbox_transform_inv / clip_boxes / nms_cpu are pinned by reference goldens): same detections, same
+    order, bit-equal boxes and scores."""
+    from oracle import rpn as orpn
+    rng = np.random.default_rng(R * 100 + C)
+    im_h, im_w, scale = 600.0, 1000.0, 1.6
+    xy = rng.uniform(0, 1, (R, 2)) * [im_w - 120, im_h - 120]
+    wh = rng.uniform(16, 300, (R, 2))
+    rois = np.concatenate([np.zeros((R, 1)), xy, np.minimum(xy + wh, [im_w - 1, im_h - 1])], 1).astype(np.float32)
+    # clustered rois so that the NMS has work to do
+    rois[R // 2:, 1:] = rois[:R - R // 2, 1:] + rng.uniform(-6, 6, (R - R // 2, 4)).astype(np.float32)
+    logits = rng.standard_normal((R, C)).astype(np.float32) * 2
+    prob = (np.exp(logits) / np.exp(logits).sum(1, keepdims=True)).astype(np.float32)
+    pred = (rng.standard_normal((R, 4 if agnostic else 4 * C)) * 0.5).astype(np.float32)
+    stds, means = (0.1, 0.1, 0.2, 0.2), (0.0, 0.0, 0.0, 0.0)
+    want = orpn.detection_postprocess(rois, prob, pred, im_h, im_w, scale, agnostic, stds, means, thresh, 0.3, maxdet)
+    dets, counts = ops.detection_postprocess(*(torch.from_numpy(a).to(DEV) for a in (rois, prob, pred)), im_h, im_w, scale,
+                                             agnostic, stds, means, thresh, 0.3, maxdet)
+    counts = counts.cpu().numpy()
+    dets = dets.cpu().numpy()
+    assert counts[0] == 0
+    assert sum(len(w) for w in want) > 0 or thresh > 0.9
+    for j in range(1, C):
+        assert counts[j] == len(want[j]), (j, counts[j], len(want[j]))
+        assert np.array_equal(dets[j, :counts[j]], want[j]), j

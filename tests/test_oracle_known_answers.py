@@ -58,3 +58,23 @@ def test_roi_pool_hand_worked():
     exp = np.zeros((4, 6), np.float32)
     exp[1, 2] = exp[1, 4] = exp[3, 2] = exp[3, 4] = 1
     assert np.array_equal(gin[0, 0], exp)
+
+
+def test_detection_postprocess_hand_worked():
+    """oracle.rpn.detection_postprocess (test_net_instance_styleD_bilinear.py:151-221) on a case small enough to do by
+    hand: zero deltas give x1' = ctr - w/2 = x1 and x2' = ctr + w/2 = x2 + 1 (the legacy +1 width convention of
+    bbox_transform.py:80-100), then / scale; two heavily overlapping rois of one class -> the lower
+    score is suppressed at NMS 0.3; the image-wide cut keeps scores >= the max_per_image-th largest."""
+    from oracle import rpn as orpn
+    rois = np.array([[0, 10, 10, 109, 109], [0, 12, 12, 111, 111], [0, 300, 200, 399, 299]], np.float32)
+    prob = np.array([[0.1, 0.9, 0.0], [0.2, 0.8, 0.0], [0.3, 0.1, 0.6]], np.float32)
+    pred = np.zeros((3, 12), np.float32)
+    out = orpn.detection_postprocess(rois, prob, pred, 600, 1000, 2.0, False, (0.1, 0.1, 0.2, 0.2), (0, 0, 0, 0), 0.05, 0.3, 100)
+    assert len(out) == 3 and out[0].shape == (0, 5)
+    # class 1: rois 0, 1, 2 pass the threshold (0.9, 0.8, 0.1); roi 1 overlaps roi 0 (IoU 0.92) and is suppressed
+    np.testing.assert_array_equal(out[1], np.array([[5, 5, 55, 55, 0.9], [150, 100, 200, 150, 0.1]], np.float32))
+    # class 2: only roi 2 (0.6)
+    np.testing.assert_array_equal(out[2], np.array([[150, 100, 200, 150, 0.6]], np.float32))
+    # top-2 over the image: threshold = 2nd largest kept score = 0.6
+    out = orpn.detection_postprocess(rois, prob, pred, 600, 1000, 2.0, False, (0.1, 0.1, 0.2, 0.2), (0, 0, 0, 0), 0.05, 0.3, 2)
+    assert [len(o) for o in out] == [0, 1, 1] and out[1][0, 4] == np.float32(0.9)

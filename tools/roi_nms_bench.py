@@ -62,3 +62,26 @@ for B in (1, 2, 4):
     for mode, pre, post in (("train", 12000, 2000), ("test", 6000, 300), ("target", 12000, 32)):
         t = timeit(lambda: ops.rpn_proposal(cls, box, info, base, 16, pre, post, 0.7))
         print("proposal layer B=%d %-6s (decode+sort+NMS+pad, 21546 anchors/frame): %7.1f us = %6.1f us/frame" % (B, mode, t * 1e6, t * 1e6 / B))
+
+# ---- per-class detection post-processing of one image (300 rois), device pass vs the numpy
+#      restatement of the reference's loop (1 + (C-1) host NMS calls) on this box's host
+import time
+from oracle import rpn as orpn
+for C in (16, 36):
+    R = 300
+    rng = np.random.default_rng(C)
+    xy = rng.uniform(0, 1, (R, 2)) * [880, 480]
+    wh = rng.uniform(16, 300, (R, 2))
+    rois = np.concatenate([np.zeros((R, 1)), xy, np.minimum(xy + wh, [999, 599])], 1).astype(np.float32)
+    logits = rng.standard_normal((R, C)).astype(np.float32) * 2
+    prob = (np.exp(logits) / np.exp(logits).sum(1, keepdims=True)).astype(np.float32)
+    pred = (rng.standard_normal((R, 4 * C)) * 0.5).astype(np.float32)
+    args = (600.0, 1000.0, 1.6, False, (0.1, 0.1, 0.2, 0.2), (0.0, 0.0, 0.0, 0.0), 0.0, 0.3, 100)
+    d = [torch.from_numpy(a).to(dev) for a in (rois, prob, pred)]
+    t = timeit(lambda: ops.detection_postprocess(*d, *args))
+    t0 = time.perf_counter()
+    for _ in range(3):
+        orpn.detection_postprocess(rois, prob, pred, *args)
+    tc = (time.perf_counter() - t0) / 3
+    print("detection post-processing R=300 C=%2d (decode + %2d x {threshold, sort, NMS 0.3} + top-100): %6.1f us on the device; "
+          "numpy restatement of the reference loop %7.1f us on the host" % (C, C - 1, t * 1e6, tc * 1e6))
