@@ -299,3 +299,28 @@ def test_sgg_step_pipelined_schedule_matches_single_graph(cfg, monkeypatch):
     for a, b in zip(l0, l1):
         assert abs(a - b) <= 1e-5 * abs(a), (l0, l1)
     assert _rel_err(w1, w0) < 1e-5
+
+
+def test_detect_frame_eval_loop_matches_oracle_postprocess(cfg):
+    """eval.detect_frame (test_net_instance_styleD_bilinear.py:140-221): eval forward (TEST proposal settings) + the
+    device post-processing pass == the oracle's restatement applied to the same network outputs."""
+    from i2vsgg_amd import eval as ev
+    from i2vsgg_amd.model.faster_rcnn.resnet_instance_styleD_bilinear import resnet
+    from oracle import rpn as orpn
+    torch.manual_seed(1)
+    net = resnet(tuple(range(16)), 50)
+    net.create_architecture()
+    net.to(DEV).eval()
+    im, info = syn.frames(11, 1, 320, 480)
+    imd, infod = torch.from_numpy(im).to(DEV), torch.from_numpy(info).to(DEV)
+    z = torch.zeros(1, 1, 5, device=DEV)
+    with torch.no_grad():
+        out = net(imd, infod, z, torch.zeros(1, device=DEV))
+    rois, cls_prob, bbox_pred = (t.cpu().numpy() for t in out[:3])
+    assert rois.shape[1] == cfg.TEST.RPN_POST_NMS_TOP_N
+    want = orpn.detection_postprocess(rois[0], cls_prob[0], bbox_pred[0], info[0, 0], info[0, 1], info[0, 2], False,
+                                      cfg.TRAIN.BBOX_NORMALIZE_STDS, cfg.TRAIN.BBOX_NORMALIZE_MEANS, 0.0, cfg.TEST.NMS, 100)
+    got = ev.detect_frame(net, imd, infod, z, torch.zeros(1, device=DEV), thresh=0.0, max_per_image=100)
+    assert len(got) == 16 and sum(len(g) for g in got) > 0
+    for j in range(16):
+        assert np.array_equal(got[j], want[j]), j
