@@ -142,8 +142,11 @@ class C4Base(nn.Sequential):
 
     def stem(self, im):
         B, C, H, W = im.shape
-        x4 = torch.zeros((B, 4, H, W), device=im.device, dtype=torch.float32).contiguous(memory_format=_CL)
-        x4[:, :3] = im
+        if C == 4:                    # the device front-end (ops.image_prep) already emits the zero-padded NHWC blob
+            x4 = ops.as_nhwc(im)
+        else:
+            x4 = torch.zeros((B, 4, H, W), device=im.device, dtype=torch.float32).contiguous(memory_format=_CL)
+            x4[:, :3] = im
         s, b = self[1].folded()
         x = ops.conv2d(x4, self._stem_weight(), s, b, None, 2, 3, relu=True)
         return ops.maxpool3x3s2(x)

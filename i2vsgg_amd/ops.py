@@ -9,6 +9,7 @@ Conventions
   * every function launches on torch's current stream and never synchronises;
   * no CPU fallback: non-CUDA tensors raise.
 """
+import numpy as np
 import torch
 
 from . import _lib
@@ -607,3 +608,25 @@ def detection_postprocess(rois, cls_prob, bbox_pred, im_h, im_w, im_scale, class
                                   int(max_per_image), ptr(dets), ptr(counts), ptr(ws), ws.numel(), stream()),
           "det_postprocess")
     return dets, counts
+
+
+def image_prep(img_u8, pixel_means, target_size, flipped=False, rgb=True, blob=None):
+    """Data-layer front-end of one image on the device (minibatch.py:60-90 + blob.py:35-52): img_u8 (H,W,3) uint8 on
+    the device, file channel order RGB (``rgb=True``) or BGR.  Writes the mean-subtracted, resized BGR image into
+    ``blob`` ((1,4,Hb,Wb) channels_last fp32, zero-initialised; allocated to fit when None -- channel 3 is the stem's
+    zero pad) and returns (blob, (Ho, Wo, im_scale))."""
+    import ctypes
+    if not img_u8.is_cuda or img_u8.dtype != torch.uint8 or img_u8.dim() != 3 or img_u8.shape[2] != 3:
+        raise ValueError("img_u8 must be a (H,W,3) uint8 CUDA tensor")
+    img_u8 = img_u8.contiguous()
+    H, W = int(img_u8.shape[0]), int(img_u8.shape[1])
+    ho, wo, sc = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_float()
+    check(lib.i2v_image_prep_size(H, W, int(target_size), ctypes.byref(ho), ctypes.byref(wo), ctypes.byref(sc)), "image_prep_size")
+    if blob is None:
+        blob = torch.zeros((1, 4, ho.value, wo.value), device=img_u8.device, dtype=torch.float32).contiguous(memory_format=_CL)
+    if blob.dim() != 4 or blob.shape[1] != 4 or not blob.is_contiguous(memory_format=_CL):
+        raise ValueError("blob must be a (1,4,H,W) channels_last tensor")
+    means = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(pixel_means).reshape(-1)[:3]])
+    check(lib.i2v_image_prep(ptr(img_u8), H, W, int(bool(rgb)), int(bool(flipped)), means, int(target_size), ptr(blob),
+                             int(blob.shape[2]), int(blob.shape[3]), stream()), "image_prep")
+    return blob, (ho.value, wo.value, float(sc.value))

@@ -115,6 +115,18 @@ size_t  i2v_sort_desc_workspace_bytes(int32_t n_seg, int32_t n);
 int32_t i2v_sort_desc(const float* keys, int32_t n_seg, int32_t n, int32_t* order_out /* (n_seg,n) */,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- image front-end of the data layer ------------------------------
+ * replaces, per image, roi_data_layer/minibatch.py:60-90 + model/utils/blob.py:35-52 and :19-33: RGB->BGR,
+ * optional horizontal flip, float conversion, PIXEL_MEANS subtraction, cv2.resize(fx=fy=target/shorter side,
+ * INTER_LINEAR) and the placement into the zero-padded batch blob.  img: decoded uint8 H x W x 3 on the device
+ * (rgb_order != 0: file order R,G,B); pixel_means_bgr: 3 host floats (cfg.PIXEL_MEANS); blob: (blob_h, blob_w, 4)
+ * fp32 NHWC slice of the batch tensor, caller-zeroed, channel 3 stays 0 (the stem's Cin % 4 pad, folded in).
+ * i2v_image_prep_size gives the resized size and im_scale (im_info = [Ho, Wo, scale], minibatch.py:49-51). */
+int32_t i2v_image_prep_size(int32_t H, int32_t W, int32_t target_size, int32_t* Ho, int32_t* Wo, float* scale);
+int32_t i2v_image_prep(const uint8_t* img, int32_t H, int32_t W, int32_t rgb_order, int32_t flipped,
+                       const float* pixel_means_bgr, int32_t target_size, float* blob, int32_t blob_h,
+                       int32_t blob_w, void* stream);
+
 /* ---- per-class detection post-processing (eval) --------------------
  * replaces test_net_instance_styleD_bilinear.py:151-221 for one image: de-normalise the deltas with
  * TRAIN.BBOX_NORMALIZE_STDS / _MEANS (host arrays of 4 floats, NULL = not normalised), bbox_transform_inv

@@ -553,3 +553,46 @@ def test_detection_postprocess_vs_oracle(ops, oracle, R, C, agnostic, thresh, ma
     for j in range(1, C):
         assert counts[j] == len(want[j]), (j, counts[j], len(want[j]))
         assert np.array_equal(dets[j, :counts[j]], want[j]), j
+
+
+@pytest.mark.parametrize("H,W,target,flip,rgb", [(375, 500, 600, False, True), (480, 640, 600, True, True),
+                                                 (720, 1280, 600, False, False), (500, 375, 600, True, True),
+                                                 (33, 47, 20, False, True)])
+def test_image_prep_vs_oracle(ops, H, W, target, flip, rgb):
+    """the device front-end (uint8 in, mean-subtracted resized BGR NHWC4 blob out) is bit-equal to
+    the numpy restatement of minibatch.py:60-90 + blob.py:35-52."""
+    from oracle import data as odata
+    rng = np.random.default_rng(H + W)
+    u8 = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    means = np.array([102.9801, 115.9465, 122.7717], np.float32)
+    src = u8 if rgb else np.ascontiguousarray(u8[:, :, ::-1])          # the oracle takes RGB file order
+    want, scale = odata.minibatch_image(u8, means, target, flipped=flip)
+    blob, (ho, wo, sc) = ops.image_prep(torch.from_numpy(src).to(DEV), means, target, flipped=flip, rgb=rgb)
+    assert (ho, wo) == want.shape[:2] and abs(sc - scale) < 1e-6
+    got = blob[0].permute(1, 2, 0).cpu().numpy()
+    assert np.array_equal(got[:, :, :3], want)
+    assert not got[:, :, 3].any()
+    # into a larger zero-padded batch blob (blob.py:19-33)
+    big = torch.zeros((1, 4, ho + 5, wo + 9), device=DEV).contiguous(memory_format=torch.channels_last)
+    ops.image_prep(torch.from_numpy(src).to(DEV), means, target, flipped=flip, rgb=rgb, blob=big)
+    b = big[0].permute(1, 2, 0).cpu().numpy()
+    assert np.array_equal(b[:ho, :wo, :3], want) and not b[ho:].any() and not b[:, wo:].any()
+
+
+def test_get_minibatch_device_equals_host(ops):
+    """roi_data_layer: the device front-end produces the blob of the host path (same im_info, gt_boxes, pixels)."""
+    import numpy.random as npr
+    from i2vsgg_amd.model.utils import config as c
+    from i2vsgg_amd.roi_data_layer import minibatch as mb
+    from i2vsgg_amd.roi_data_layer.roidb import combined_roidb
+    c.cfg_from_file(c.default_cfg_file("res101"))
+    c.cfg.TRAIN.USE_FLIPPED = True
+    _, roidb, _, _ = combined_roidb("synthetic_8", training=True)
+    for e in (roidb[0], roidb[-1]):                       # the last half of the list are the flipped copies
+        npr.seed(0)
+        host = mb.get_minibatch([e], 16)
+        npr.seed(0)
+        dev = mb.get_minibatch_device([e], 16, DEV)
+        assert np.array_equal(host["im_info"], dev["im_info"]) and np.array_equal(host["gt_boxes"], dev["gt_boxes"])
+        d = dev["data"][0].permute(1, 2, 0).cpu().numpy()
+        assert np.array_equal(d[:, :, :3], host["data"][0]) and not d[:, :, 3].any()

@@ -128,3 +128,16 @@ def test_gradient_exchange_world_size_2_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert "rank %d ok" % r in o
+
+
+def test_host_front_end_equals_oracle_restatement():
+    """roi_data_layer.minibatch.prep_im_for_blob (product, host) == oracle.data (checker) bit for bit."""
+    from i2vsgg_amd.roi_data_layer import minibatch as mb
+    from oracle import data as odata
+    rng = np.random.default_rng(1)
+    means = np.array([[[102.9801, 115.9465, 122.7717]]])
+    for (h, w), target in (((37, 53), 60), ((375, 500), 600), ((60, 40), 30)):
+        u8 = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        a, sa = mb.prep_im_for_blob(u8[:, :, ::-1], means, target)
+        b, sb = odata.minibatch_image(u8, means.reshape(-1), target)
+        assert sa == sb and a.shape == b.shape and np.array_equal(a, b)

@@ -78,3 +78,31 @@ def test_detection_postprocess_hand_worked():
     # top-2 over the image: threshold = 2nd largest kept score = 0.6
     out = orpn.detection_postprocess(rois, prob, pred, 600, 1000, 2.0, False, (0.1, 0.1, 0.2, 0.2), (0, 0, 0, 0), 0.05, 0.3, 2)
     assert [len(o) for o in out] == [0, 1, 1] and out[1][0, 4] == np.float32(0.9)
+
+
+def test_image_front_end_restatement():
+    """oracle.data (blob.py:35-52 with cv2's float INTER_LINEAR restated): identity at f = 1, a hand-worked 2x upscale
+    (half-pixel centres: output 0 sits at source -0.25 -> clamped to pixel 0; output 1 at 0.25 -> 0.75*p0 + 0.25*p1),
+    and agreement with an independent implementation of the same sampling rule (torch bilinear, align_corners=False)."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import data as odata
+    rng = np.random.default_rng(0)
+    im = rng.uniform(-120, 140, (7, 9, 3)).astype(np.float32)
+    assert np.array_equal(odata.resize_linear(im, 1.0), im)
+    row = np.array([[[0.0], [8.0]]], np.float32)                       # 1 x 2 x 1
+    up = odata.resize_linear(np.repeat(row, 2, 0), 2.0)[0, :, 0]
+    np.testing.assert_array_equal(up, np.array([0.0, 2.0, 6.0, 8.0], np.float32))
+    for f in (1.6, 600.0 / 375.0, 0.75):
+        got = odata.resize_linear(im, f)
+        t = torch.from_numpy(im).permute(2, 0, 1)[None]
+        ref = F.interpolate(t, size=got.shape[:2], scale_factor=None, mode="bilinear", align_corners=False)
+        ref = F.interpolate(t, scale_factor=f, mode="bilinear", align_corners=False, recompute_scale_factor=False)
+        assert tuple(ref.shape[2:]) == got.shape[:2] or abs(ref.shape[2] - got.shape[0]) <= 1
+        if tuple(ref.shape[2:]) == got.shape[:2]:
+            np.testing.assert_allclose(got, ref[0].permute(1, 2, 0).numpy(), atol=2e-4)
+    u8 = rng.integers(0, 256, (30, 40, 3), dtype=np.uint8)
+    out, scale = odata.minibatch_image(u8, (102.9801, 115.9465, 122.7717), 60)
+    assert out.shape == (60, 80, 3) and scale == 2.0
+    out_f, _ = odata.minibatch_image(u8, (102.9801, 115.9465, 122.7717), 60, flipped=True)
+    np.testing.assert_array_equal(out_f, out[:, ::-1])                   # the sampling grid is symmetric
