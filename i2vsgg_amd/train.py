@@ -134,7 +134,10 @@ class SGGEmbStep:
             boxes.append(b5); relb.append(r5); bounds.append(bnd); labels.append(lab)
             ixs.append(s + off); ixo.append(o + off); counts.append(lab.shape[0]); off += gt.shape[0]
         t = lambda a, dt=torch.float32: torch.from_numpy(np.concatenate(a)).to(self.dev, dt)
-        new = dict(im=torch.from_numpy(im).to(self.dev), info=torch.from_numpy(info).to(self.dev), boxes=t(boxes),
+        # frames in the layout the device front-end emits (ops.image_prep): NHWC with the stem's zero fourth channel
+        im4 = torch.zeros((im.shape[0], 4) + tuple(im.shape[2:]), device=self.dev).contiguous(memory_format=torch.channels_last)
+        im4[:, :3] = torch.from_numpy(im).to(self.dev)
+        new = dict(im=im4, info=torch.from_numpy(info).to(self.dev), boxes=t(boxes),
                    relb=t(relb), labels=t(labels), ixs=t(ixs, torch.long), ixo=t(ixo, torch.long),
                    masks=rasterize_masks(np.concatenate(bounds), self.dev),
                    wrow=torch.cat([torch.full((c,), 1.0 / (c * len(counts))) for c in counts]).to(self.dev))
