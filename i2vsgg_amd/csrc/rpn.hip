@@ -538,6 +538,29 @@ __global__ void det_final_kernel(const float* __restrict__ tmp, const int* __res
     }
     if (threadIdx.x == 0) counts[j] = n_out;
 }
+
+// ------------------------------------------------------------------ relation triplet ranking (eval)
+// lib/utils.py:584-628 (detection_output): rel_prob[i][r] * conf[ixs[i]] * conf[ixo[i]] (two fp32 roundings, as numpy
+// evaluates float32_row * python_float * python_float), then the top k of the flattened (pair, predicate) grid.
+__global__ void rel_scale_kernel(const float* __restrict__ rel, const float* __restrict__ conf,
+                                 const long long* __restrict__ ixs, const long long* __restrict__ ixo, int n_pairs,
+                                 int n_rel, float* __restrict__ prob) {
+    const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (idx >= (long long)n_pairs * n_rel) return;
+    const int i = (int)(idx / n_rel);
+    float v = rel[idx] * conf[ixs[i]];
+    v = v * conf[ixo[i]];
+    prob[idx] = v;
+}
+__global__ void rel_emit_kernel(const float* __restrict__ prob, const int* __restrict__ order, int k, int n_rel,
+                                int* __restrict__ pair, int* __restrict__ pred, float* __restrict__ out_conf) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= k) return;
+    const int flat = order[t];
+    pair[t] = flat / n_rel;
+    pred[t] = flat % n_rel;
+    out_conf[t] = prob[flat];
+}
 }  // namespace
 
 extern "C" size_t i2v_nms_workspace_bytes(int32_t n_img, int32_t n) {
@@ -709,5 +732,36 @@ extern "C" int32_t i2v_det_postprocess(const float* rois, const float* cls_prob,
     }
     det_final_kernel<<<C, 256, 0, st>>>(w.tmp, w.cnt, w.total, w.all_scores, w.order2, max_per_image, R, C, dets, counts);
     I2V_CHECK_LAUNCH("det_postprocess");
+    return I2V_OK;
+}
+
+extern "C" size_t i2v_relation_topk_workspace_bytes(int32_t n_pairs, int32_t n_rel) {
+    if (n_pairs <= 0 || n_rel <= 0) return 256;
+    const size_t n = (size_t)n_pairs * n_rel;
+    return i2v_align(n * 4) + i2v_align(n * 4) + i2v_sort_desc_workspace_bytes(1, (int)n);
+}
+
+extern "C" int32_t i2v_relation_topk(const float* rel_score, const float* conf, const int64_t* ixs, const int64_t* ixo,
+                                     int32_t n_pairs, int32_t n_rel, int32_t k, int32_t* pair_out, int32_t* pred_out,
+                                     float* conf_out, void* ws, size_t ws_bytes, void* stream) {
+    I2V_CHECK_ARG(rel_score && conf && ixs && ixo && pair_out && pred_out && conf_out, "relation_topk: null pointer");
+    I2V_CHECK_ARG(n_pairs > 0 && n_rel > 0 && k > 0 && (long long)n_pairs * n_rel <= (1 << 24), "relation_topk: bad shape");
+    I2V_CHECK_ARG((long long)k <= (long long)n_pairs * n_rel, "relation_topk: k exceeds the number of (pair, predicate) cells");
+    if (!ws || ws_bytes < i2v_relation_topk_workspace_bytes(n_pairs, n_rel)) {
+        i2v_set_error("relation_topk: workspace too small");
+        return I2V_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int n = n_pairs * n_rel;
+    char* base = (char*)ws;
+    float* prob = (float*)base;
+    int* order = (int*)(base + i2v_align((size_t)n * 4));
+    void* sws = base + 2 * i2v_align((size_t)n * 4);
+    rel_scale_kernel<<<i2v_cdiv(n, 256), 256, 0, st>>>(rel_score, conf, (const long long*)ixs, (const long long*)ixo, n_pairs,
+                                                       n_rel, prob);
+    int rc = i2v_sort_desc(prob, 1, n, order, sws, i2v_sort_desc_workspace_bytes(1, n), stream);
+    if (rc) return rc;
+    rel_emit_kernel<<<i2v_cdiv(k, 256), 256, 0, st>>>(prob, order, k, n_rel, pair_out, pred_out, conf_out);
+    I2V_CHECK_LAUNCH("relation_topk");
     return I2V_OK;
 }

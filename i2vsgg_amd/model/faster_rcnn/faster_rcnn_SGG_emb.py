@@ -49,6 +49,28 @@ def build_pair_tables(anno, im_scale, ih, iw, n_rel, margin=10):
     return gt, union, np.stack([bounds(sb), bounds(ob)], 1).astype(np.int32), labels, ixs, ixo
 
 
+def build_eval_pair_tables(boxes_scaled, ih, iw, margin=10):
+    """Eval branch of forward_relation (:597-652): ALL ordered pairs i != j of the frame's boxes (i-major), their union
+    boxes (+margin, clipped to (iw, ih)) and the integer bounds of the 32x32 dual masks.  float64 like the reference."""
+    b = np.asarray(boxes_scaled, np.float64).reshape(-1, 4)
+    n = b.shape[0]
+    ii, jj = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    keep = ii != jj
+    ixs, ixo = ii[keep].astype(np.int64), jj[keep].astype(np.int64)
+    sb, ob = b[ixs], b[ixo]
+    union = np.stack([np.maximum(0, np.minimum(sb[:, 0], ob[:, 0]) - margin),
+                      np.maximum(0, np.minimum(sb[:, 1], ob[:, 1]) - margin),
+                      np.minimum(iw, np.maximum(sb[:, 2], ob[:, 2]) + margin),
+                      np.minimum(ih, np.maximum(sb[:, 3], ob[:, 3]) + margin)], 1)
+
+    def bounds(bb):          # _getDualMask (resnet_SGG_emb.py:246-256)
+        rh, rw = 32.0 / ih, 32.0 / iw
+        return np.stack([np.maximum(0, np.floor(bb[:, 0] * rw)), np.maximum(0, np.floor(bb[:, 1] * rh)),
+                         np.minimum(32, np.ceil(bb[:, 2] * rw)), np.minimum(32, np.ceil(bb[:, 3] * rh))], 1)
+
+    return union, np.stack([bounds(sb), bounds(ob)], 1).astype(np.int32), ixs, ixo
+
+
 def rasterize_masks(bounds, device):
     """(n,2,4) int [x1,y1,x2,y2) -> (n,2,32,32) float masks on the device."""
     b = torch.as_tensor(bounds, device=device).view(-1, 2, 4, 1, 1)
@@ -73,9 +95,48 @@ class _fasterRCNN(nn.Module):
         if task != "pre_det":
             raise NotImplementedError("vrd_task=%r: only pre_det is live in the reference (SURVEY.md A10)" % task)
         if not self.training:
-            raise NotImplementedError("eval forward_predicate is broken in the reference (SURVEY.md A9, A11); "
-                                      "relation scoring is listed as next (SURVEY.md 8f row f3)")
+            # eval forward_predicate is broken in the reference; the live eval path is the
+            # relation branch on the target annotations (forward_relation :583-697)
+            return self.forward_relation_eval(base_feat, im_info, im_path if isinstance(im_path, str) else im_path[0])
         return self.forward_predicate(base_feat, im_info, im_path)
+
+    @torch.no_grad()
+    def forward_relation_eval(self, fmap, im_info, im_path):
+        """Eval branch of forward_relation (:583-697) for ONE frame: the annotated boxes of ``target_gt_rels[im_path]``
+        (confidence 1), every ordered pair, union boxes, dual masks, the subject/object prior rows, the relation head
+        in eval mode (softmax over predicates) -> the reference's ``vrd_data`` dict, with ``rel_score`` / ``pre_feat``
+        left on the device.  The feature map never visits the host (the reference copies it down and up, :148)."""
+        anno = self.vrd.target_gt_rels[im_path]
+        info = im_info.detach().cpu().numpy().reshape(-1, 3)
+        ih, iw, sc = float(info[0][0]), float(info[0][1]), float(info[0][2])
+        detected = anno["boxes"]
+        classes = list(anno["box_classes"])
+        scores = [1 for _ in classes]
+        if len(detected) == 0:
+            return {"bboxes": [], "classes": [], "scores": []}
+        if len(detected) == 1:
+            return {"bboxes": detected, "classes": classes, "scores": scores}
+        boxes = np.array(detected, np.float64).reshape(-1, 4) * sc
+        union, bnd, ixs, ixo = build_eval_pair_tables(boxes, ih, iw)
+        dev = fmap.device
+        cls = np.asarray(classes, np.int64)
+        n_rel = self.vrd.n_rel
+        so_prior = self.vrd._so_prior
+        rel_so_prior = np.asarray(so_prior)[cls[ixs] - 1, cls[ixo] - 1] if so_prior is not None else np.zeros((ixs.size, n_rel))
+        b5 = np.zeros((boxes.shape[0], 5), np.float32)
+        b5[:, 1:] = boxes
+        r5 = np.zeros((union.shape[0], 5), np.float32)
+        r5[:, 1:] = union
+        was_training = self.vrd.training
+        self.vrd.eval()
+        try:
+            rel_score, pre_feat = self.vrd.forward_device(fmap[:1], torch.from_numpy(b5).to(dev), torch.from_numpy(r5).to(dev),
+                                                          rasterize_masks(bnd, dev), torch.from_numpy(ixs).to(dev),
+                                                          torch.from_numpy(ixo).to(dev))
+        finally:
+            self.vrd.train(was_training)
+        return {"ixs": ixs, "ixo": ixo, "bboxes": detected, "classes": classes, "scores": scores, "rel_score": rel_score,
+                "pre_feat": pre_feat, "rel_so_prior": rel_so_prior}
 
     def forward_predicate(self, fmap, im_info, im_path):
         paths = [im_path] if isinstance(im_path, str) else list(im_path)

@@ -630,3 +630,22 @@ def image_prep(img_u8, pixel_means, target_size, flipped=False, rgb=True, blob=N
     check(lib.i2v_image_prep(ptr(img_u8), H, W, int(bool(rgb)), int(bool(flipped)), means, int(target_size), ptr(blob),
                              int(blob.shape[2]), int(blob.shape[3]), stream()), "image_prep")
     return blob, (ho.value, wo.value, float(sc.value))
+
+
+def relation_topk(rel_score, conf, ixs, ixo, k=100):
+    """Top-k (pair, predicate) cells of ``rel_score * conf[ixs] * conf[ixo]`` (lib/utils.py:584-628), on the device.
+    rel_score (n_pairs, n_rel) fp32, conf (n_boxes,) fp32, ixs / ixo (n_pairs,) int64.  Returns (pair, pred, conf):
+    int32, int32, fp32 tensors of length min(k, n_pairs * n_rel), descending."""
+    _need_cuda(rel_score, conf, ixs, ixo)
+    rel_score, conf = rel_score.float().contiguous(), conf.float().contiguous()
+    ixs, ixo = ixs.long().contiguous(), ixo.long().contiguous()
+    n_pairs, n_rel = rel_score.shape
+    k = min(int(k), n_pairs * n_rel)
+    dev = rel_score.device
+    pair = torch.empty((k,), device=dev, dtype=torch.int32)
+    pred = torch.empty((k,), device=dev, dtype=torch.int32)
+    out = torch.empty((k,), device=dev, dtype=torch.float32)
+    ws = workspace(lib.i2v_relation_topk_workspace_bytes(n_pairs, n_rel), dev, "reltopk")
+    check(lib.i2v_relation_topk(ptr(rel_score), ptr(conf), ptr(ixs), ptr(ixo), n_pairs, n_rel, k, ptr(pair), ptr(pred), ptr(out),
+                                ptr(ws), ws.numel(), stream()), "relation_topk")
+    return pair, pred, out

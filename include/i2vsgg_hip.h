@@ -143,6 +143,15 @@ int32_t i2v_det_postprocess(const float* rois, const float* cls_prob, const floa
                             int32_t R, int32_t C, float score_thresh, float nms_thresh, int32_t max_per_image,
                             float* dets, int32_t* counts, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- relation triplet ranking (eval) -----------------------------------
+ * replaces the scoring loop and the argsort of detection_output (lib/utils.py:584-628): cell (i, r) of rel_score
+ * (n_pairs, n_rel) is multiplied by conf[ixs[i]] and conf[ixo[i]] (two fp32 roundings) and the k largest cells are
+ * returned in descending order (ties: ascending flat index): pair_out (k) = i, pred_out (k) = r, conf_out (k). */
+size_t  i2v_relation_topk_workspace_bytes(int32_t n_pairs, int32_t n_rel);
+int32_t i2v_relation_topk(const float* rel_score, const float* conf, const int64_t* ixs, const int64_t* ixo,
+                          int32_t n_pairs, int32_t n_rel, int32_t k, int32_t* pair_out, int32_t* pred_out,
+                          float* conf_out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* IoU of boxes (B,N,4 | stride_box floats per row, first 4 used after `box_off`) against
  * gt (B,K,5): bbox_transform.py:168-257 (bbox_overlaps_batch) incl. the zero-area
  * masks; also emits per-row max/argmax (first max).  overlaps may be NULL. */

@@ -190,3 +190,47 @@ def build_pairs(anno_boxes, rels, im_scale, ih, iw, n_rel):
     boxes = np.zeros((gt.shape[0], 5), np.float32)
     boxes[:, 1:5] = gt
     return boxes, rel_boxes, spatial, labels, ixs, ixo
+
+
+def detection_output(vrd_data, k=100):
+    """lib/utils.py:584-628 with ``rel_score`` given as a numpy array.  Tie rule of the argsort: descending value,
+    ascending flat index (numpy's default quicksort leaves ties unspecified)."""
+    if len(vrd_data["bboxes"]) <= 1:
+        return None, None, None, None, None
+    ixs, ixo = np.asarray(vrd_data["ixs"]), np.asarray(vrd_data["ixo"])
+    boxes, classes, confs = vrd_data["bboxes"], vrd_data["classes"], vrd_data["scores"]
+    rel_prob = np.array(vrd_data["rel_score"], np.float32)
+    rlp = np.zeros((k, 3), np.float64)
+    sub = np.zeros((k, 4), np.float64)
+    obj = np.zeros((k, 4), np.float64)
+    for i in range(rel_prob.shape[0]):
+        rel_prob[i] = rel_prob[i] * float(confs[ixs[i]]) * float(confs[ixo[i]])     # float32 row x python floats (:613)
+    order = np.argsort(-rel_prob.ravel(), kind="stable")
+    rel_res = np.dstack(np.unravel_index(order, rel_prob.shape))[0][:k]
+    tconf, ridx = [], []
+    for ii in range(rel_res.shape[0]):
+        t, rel = rel_res[ii, 0], rel_res[ii, 1]
+        sub[ii], obj[ii] = boxes[ixs[t]], boxes[ixo[t]]
+        rlp[ii] = [classes[ixs[t]], rel, classes[ixo[t]]]
+        tconf.append(rel_prob[t, rel])
+        ridx.append(t)
+    return rlp, np.array(tconf), sub, obj, np.array(ridx)
+
+
+def eval_pair_tables(boxes_scaled, ih, iw, union_fn, mask_fn):
+    """Eval branch of forward_relation (faster_rcnn_SGG_emb.py:597-652), the reference's double loop as written:
+    all ordered pairs i != j, union boxes via ``_getUnionBBox``, dual masks via ``_getDualMask``."""
+    n = len(boxes_scaled)
+    ixs, ixo = [], []
+    for i in range(n):
+        for j in range(n):
+            if i != j:
+                ixs.append(i)
+                ixo.append(j)
+    rel_boxes = np.zeros((len(ixs), 5))
+    masks = np.zeros((len(ixs), 2, 32, 32))
+    for t in range(len(ixs)):
+        s, o = boxes_scaled[ixs[t]], boxes_scaled[ixo[t]]
+        rel_boxes[t, 1:5] = np.array(union_fn(s, o, ih, iw))
+        masks[t] = [mask_fn(ih, iw, s), mask_fn(ih, iw, o)]
+    return np.array(ixs), np.array(ixo), rel_boxes, masks

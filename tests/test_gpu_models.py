@@ -328,3 +328,61 @@ def test_detect_frame_eval_loop_matches_oracle_postprocess(cfg):
     assert len(got) == 16 and sum(len(g) for g in got) > 0
     for j in range(16):
         assert np.array_equal(got[j], want[j]), j
+
+
+def test_relation_eval_branch_and_topk_vs_oracle(cfg):
+    """eval branch of forward_relation (faster_rcnn_SGG_emb.py:583-697: all ordered pairs, union
+    boxes, dual masks, relation head with softmax) and detection_output (lib/utils.py:584-628: confidence scaling +
+    top-100 triplets) against the oracle's restatements."""
+    from i2vsgg_amd import eval as ev
+    from i2vsgg_amd.model.faster_rcnn.faster_rcnn_SGG_emb import build_eval_pair_tables
+    from i2vsgg_amd.model.faster_rcnn.resnet_SGG_emb import resnet
+    from oracle import nets
+    n_rel, n_cls = 62, 16
+    torch.manual_seed(0)
+    prd = syn.word_vectors(21, n_rel)
+    net = resnet(tuple(range(n_cls)), _vrd_args(), 50, obj_vecs=syn.word_vectors(22, n_cls), prd_vecs=prd)
+    net.create_architecture()
+    params = syn.vrd_params(13)
+    _load(net.vrd, params, "vrd.")
+    net.to(DEV).eval()
+    anno = syn.relation_annotation(31, 7, 8, n_rel, n_cls)
+    net.vrd.target_gt_rels = {"t0": anno}
+    ih, iw, sc = 600.0, 1000.0, 1.25
+    # (1) pair tables == the reference's double loop over _getUnionBBox / _getDualMask
+    boxes = np.array(anno["boxes"], np.float64) * sc
+    union, bnd, ixs, ixo = build_eval_pair_tables(boxes, ih, iw)
+    o_ixs, o_ixo, o_rel, o_masks = nets.eval_pair_tables(boxes, ih, iw, nets.union_box, nets.dual_mask)
+    assert np.array_equal(ixs, o_ixs) and np.array_equal(ixo, o_ixo) and ixs.size == 7 * 6
+    assert np.array_equal(union, o_rel[:, 1:])
+    from i2vsgg_amd.model.faster_rcnn.faster_rcnn_SGG_emb import rasterize_masks
+    assert np.array_equal(rasterize_masks(bnd, DEV).cpu().numpy(), o_masks.astype(np.float32))
+    # (2) relation scores of the eval branch == oracle head in eval mode (softmax over predicates)
+    fmap = np.abs(np.random.default_rng(32).standard_normal((1, 1024, 38, 63), dtype=np.float32))
+    fm = torch.from_numpy(fmap).to(DEV).contiguous(memory_format=torch.channels_last)
+    info = torch.tensor([[ih, iw, sc]], device=DEV)
+    vrd_data = net.forward_relation_eval(fm, info, "t0")
+    b5 = np.zeros((boxes.shape[0], 5), np.float32)
+    b5[:, 1:] = boxes
+    want, _ = nets.vrd_head(fmap, b5, o_rel.astype(np.float32), o_masks, o_ixs, o_ixo, prd,
+                            {k: torch.as_tensor(v) for k, v in params.items()}, training=False)
+    got = vrd_data["rel_score"].cpu().numpy()
+    assert got.shape == (42, n_rel) and abs(got.sum(1) - 1).max() < 1e-5
+    assert _rel_err(got, want.numpy()) < REL
+    assert vrd_data["scores"] == [1] * 7 and vrd_data["bboxes"] == anno["boxes"]
+    # (3) detection_output on the SAME scores: identical triplets, in order
+    host = dict(vrd_data, rel_score=got)
+    o = nets.detection_output(host, 100)
+    g = ev.detection_output(vrd_data, 100)
+    for a, b in zip(g, o):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    # non-trivial confidences
+    vrd_data["scores"] = list(np.random.default_rng(5).uniform(0.3, 1.0, 7).astype(np.float32))
+    host = dict(vrd_data, rel_score=got)
+    for a, b in zip(ev.detection_output(vrd_data, 100), nets.detection_output(host, 100)):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+    # degenerate frames (:588-594)
+    net.vrd.target_gt_rels = {"one": {"boxes": [[1, 2, 30, 40]], "box_classes": [3], "rels": []},
+                              "none": {"boxes": [], "box_classes": [], "rels": []}}
+    assert ev.detection_output(net.forward_relation_eval(fm, info, "one")) == (None,) * 5
+    assert net.forward_relation_eval(fm, info, "none") == {"bboxes": [], "classes": [], "scores": []}
