@@ -266,8 +266,9 @@ class InstanceStyleDStep:
     with the reference's np.random stream, which needs two small D2H copies per step)."""
 
     def __init__(self, net, n_frames, lr=5e-4, eta=0.1, eta_style=0.001, style_lambda=1.0, seed=3, device="cuda:0",
-                 h=600, w=1000, n_gt=8):
+                 h=600, w=1000, n_gt=8, cr=False):
         self.net, self.dev = net, torch.device(device)
+        self.cr = cr                  # --cr: consistency regularisation between instance- and image-level D (:299-312)
         self.world = parallel.world_size()
         self.eta, self.eta_style, self.style_lambda = eta, eta_style, style_lambda
         ims, info = syn.frames(seed, n_frames, h, w)
@@ -292,13 +293,32 @@ class InstanceStyleDStep:
         dloss_t = 0.5 * torch.mean((1 - d_inst_t) ** 2)
         dloss_t_style = 0.5 * torch.mean((1 - d_style_t) ** 2)
         total = loss + dloss_s + dloss_t + self.style_lambda * (dloss_s_style + dloss_t_style)
+        cst = {}
+        if self.cr:
+            cst = consistency_terms(d_inst, d_style, d_inst_t, d_style_t)
+            total = total + cst["source_adv_cst"] + cst["target_adv_cst"]
         self.opt.zero_grad()
         (total / self.world).backward()
         parallel.all_reduce_grads(self.opt.params())
         self.opt.step()
         self.losses = dict(total=total.detach(), det=loss.detach(), dloss_s=dloss_s.detach(), dloss_t=dloss_t.detach(),
-                           dloss_s_style=dloss_s_style.detach(), dloss_t_style=dloss_t_style.detach())
+                           dloss_s_style=dloss_s_style.detach(), dloss_t_style=dloss_t_style.detach(),
+                           **{k: v.detach() for k, v in cst.items()})
         return self.losses["total"]
+
+
+def consistency_terms(d_inst, d_style, d_inst_t, d_style_t):
+    """trainval_net_instance_styleD_bilinear.py:299-311 (``--cr``): MSE between the per-ROI mean of the instance
+    discriminator map and the (detached) image-level discriminator output repeated once per ROI.  The reference
+    hard-codes 128 ROIs per image (``repeat(1,128)``); here the repeat count is the actual
+    number of ROIs per frame, which is the same thing at TRAIN.BATCH_SIZE = 128."""
+    out = {}
+    for name, di, ds in (("source_adv_cst", d_inst, d_style), ("target_adv_cst", d_inst_t, d_style_t)):
+        per_roi = di.mean(3).mean(2)                                  # (B*R, 1)
+        rois_per_frame = per_roi.shape[0] // ds.shape[0]
+        prob = ds.reshape(ds.shape[0], -1)[:, :1].repeat(1, rois_per_frame).view(-1, 1)
+        out[name] = torch.nn.functional.mse_loss(per_roi, prob.detach())
+    return out
 
 
 def build_instance_styled_net(layers=101, n_cls=16, seed=0, device="cuda:0"):

@@ -386,3 +386,17 @@ def test_relation_eval_branch_and_topk_vs_oracle(cfg):
                               "none": {"boxes": [], "box_classes": [], "rels": []}}
     assert ev.detection_output(net.forward_relation_eval(fm, info, "one")) == (None,) * 5
     assert net.forward_relation_eval(fm, info, "none") == {"bboxes": [], "classes": [], "scores": []}
+
+
+def test_consistency_terms_match_reference_formula(cfg):
+    """--cr (trainval_net_instance_styleD_bilinear.py:299-311) with the reference's literal expressions at 128 ROIs."""
+    from i2vsgg_amd import train
+    g = torch.Generator().manual_seed(3)
+    B, R = 2, 128
+    d_inst, d_inst_t = torch.rand(B * R, 1, 7, 7, generator=g), torch.rand(B * R, 1, 7, 7, generator=g)
+    d_style, d_style_t = torch.rand(B, 1, generator=g), torch.rand(B, 1, generator=g)
+    mse = torch.nn.MSELoss()
+    want_s = mse(torch.mean(torch.mean(d_inst, dim=3), dim=2), d_style.repeat(1, 128).view(-1, 1).detach())
+    want_t = mse(torch.mean(torch.mean(d_inst_t, dim=3), dim=2), d_style_t.repeat(1, 128).view(-1, 1).detach())
+    got = train.consistency_terms(d_inst, d_style, d_inst_t, d_style_t)
+    assert torch.equal(got["source_adv_cst"], want_s) and torch.equal(got["target_adv_cst"], want_t)
