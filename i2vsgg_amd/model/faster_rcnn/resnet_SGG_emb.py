@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from i2vsgg_amd import ops
 from ..roi_layers import ROIPool
 from ..utils.config import cfg
 from .faster_rcnn_SGG_emb import _fasterRCNN
@@ -96,7 +97,9 @@ class vrd(nn.Module):
         if self._prd_dev is None or self._prd_dev.device != x.device:
             self._prd_dev = torch.from_numpy(np.asarray(self.prd_vecs, np.float32)).to(x.device)
         sem = F.normalize(self.prd_sem_embeddings(self._prd_dev), p=2, dim=1)
-        scores = torch.mm(F.normalize(x, p=2, dim=1), sem.t())
+        # logits = V . S^T through the same implicit-GEMM kernel as every other layer (a torch.mm here drags a
+        # hipBLASLt launch with its device-side argument upload into the captured step)
+        scores = ops.linear(F.normalize(x, p=2, dim=1), sem)
         if not self.training:
             scores = F.softmax(scores, dim=1)
         return scores, x

@@ -10,6 +10,8 @@ B = 2
 TILES = [int(t) for t in os.environ.get("TILES", "3").split(",")]
 BOUND = {0: 4096, 1: 2048, 2: 1536, 3: 1280, 4: 1024, 5: 512}   # MFMA issue cycles per 32-deep stage
 cases = [("l3 c2 3x3 256 (72 stages)", 256, 38, 63, 256, 3, 1, 1, 72), ("l3 c1 1024->256 (32 stages)", 1024, 38, 63, 256, 1, 1, 0, 32)]
+if os.environ.get("CASES") == "c3":         # layer3 conv3: K = 256 (8 stages), N = 1024: 960 workgroups, two rounds
+    cases = [("l3 c3 256->1024 (8 stages)", 256, 38, 63, 1024, 1, 1, 0, 8)]
 if os.environ.get("CASES") == "smallk":     # the HBM-bound layers: K = 64 / 128, two to four stages per workgroup
     cases = [("l1 c3 64->256 (2 stages)", 64, 150, 250, 256, 1, 1, 0, 2), ("l2 c3 128->512 (4 stages)", 128, 75, 125, 512, 1, 1, 0, 4)]
 for name, cin, h, w, cout, k, s, p, stages in cases:
