@@ -64,6 +64,26 @@ class vrd(nn.Module):
         self.prd_sem_embeddings = nn.Sequential(Linear(300, 1024), nn.LeakyReLU(0.1), Linear(1024, self.emb_dim))
         self.dropout = True          # F.dropout(training=self.training) of the reference (:149-163)
         self._prd_dev = None
+        self.tp = None               # (rank, world) once enable_fc6_tp() has cut fc6 by output columns
+
+    def enable_fc6_tp(self, rank, world):
+        """Cut fc6 (50176 -> 4096, 822 MB) by output columns across the data-parallel ranks (i2vsgg_amd.parallel:
+        the layer's gradient never crosses xGMI and its update stays fused).  ``fc6.fc.weight`` / ``.bias`` become this
+        rank's (4096/world, 50176) / (4096/world,) shards; ``gather_fc6()`` reassembles the full tensors."""
+        from i2vsgg_amd import parallel
+        w, b = self.fc6.fc.weight.data, self.fc6.fc.bias.data
+        assert self.tp is None and w.shape[0] % world == 0
+        n = w.shape[0] // world
+        self.fc6.fc.weight = parallel.mark_local(nn.Parameter(w[rank * n:(rank + 1) * n].clone()))
+        self.fc6.fc.bias = parallel.mark_local(nn.Parameter(b[rank * n:(rank + 1) * n].clone()))
+        self.tp = (rank, world)
+
+    def gather_fc6(self):
+        """Full (4096, 50176) weight and (4096,) bias from the column shards (checkpointing)."""
+        from i2vsgg_amd import parallel
+        if self.tp is None:
+            return self.fc6.fc.weight.data, self.fc6.fc.bias.data
+        return parallel.gather_rows(self.fc6.fc.weight.data), parallel.gather_rows(self.fc6.fc.bias.data.view(-1, 1)).view(-1)
 
     def _dev(self, x, dtype=torch.float32):
         if isinstance(x, np.ndarray):
@@ -85,7 +105,12 @@ class vrd(nn.Module):
         nb = boxes.size(0)
         rois = torch.cat((boxes, rel_boxes), 0)
         pooled = self.roi_pool(fmap, rois)                       # (nb+nr, 1024, 7, 7), NCHW flatten order
-        h = self.fc6(pooled.view(pooled.size(0), -1))            # one pass over the 822 MB weight
+        x6 = pooled.view(pooled.size(0), -1)
+        if self.tp is None:
+            h = self.fc6(x6)                                     # one pass over the 822 MB weight
+        else:                                                    # column-parallel fc6: everybody's rows, my columns
+            from i2vsgg_amd import parallel
+            h = parallel.ColShardToOwnRows.apply(self.fc6(parallel.gather_rows(x6.detach())))
         h = self.fc7(self._drop(h))
         h = self._drop(h)
         obj = self.so_vis_embeddings(h[:nb])

@@ -39,10 +39,10 @@ class FusedSGD:
         """Fuse the update of large filters into their wgrad epilogue (single-GPU only: with data
         parallelism the gradient must be all-reduced before the update).  Returns the fused names."""
         names = []
-        if parallel.exchange_enabled():
-            return names
         for it in self.items:
             p = it["p"]
+            if parallel.exchange_enabled() and not parallel.is_local(p):
+                continue              # its gradient has to cross the ranks first
             if p.dim() >= 2 and p.numel() >= min_numel:
                 ops.FUSED_SGD[p.data_ptr()] = (it["m"], it["lr"], self.momentum, it["wd"])
                 self._fused_keys.append(p.data_ptr())
@@ -106,6 +106,13 @@ class SGGEmbStep:
         self.world = parallel.world_size()
         self.geom = (h, w, n_boxes, n_pairs)
         self.reseed(seed)
+        # data parallelism for everything except vrd.fc6, which is cut by output columns (parallel.py): its 822 MB
+        # gradient -- 91 % of the exchange -- stays local and its SGD update stays fused into the wgrad epilogue
+        import os
+        self.tp = parallel.exchange_enabled() and os.environ.get("I2V_TP_FC6", "1") != "0" and \
+            net.vrd.fc6.fc.weight.shape[0] % max(self.world, 1) == 0
+        if self.tp and net.vrd.tp is None:
+            net.vrd.enable_fc6_tp(parallel.rank(), self.world)
         self.opt = FusedSGD([(n, p) for n, p in net.named_parameters() if n.startswith("vrd.")], vrd_lr)
         self.fused = self.opt.fuse_wgrad() if fuse_sgd else []
         self.loss = torch.zeros((), device=self.dev)

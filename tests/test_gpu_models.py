@@ -2,6 +2,7 @@
 golden vectors the reference itself produced (tools/gen_golden.py) and against the CPU oracle.
 Tolerance for floating point: 1e-3 relative (BASELINE.json north_star), written per assert."""
 import argparse
+import os
 
 import numpy as np
 import pytest
@@ -400,3 +401,39 @@ def test_consistency_terms_match_reference_formula(cfg):
     want_t = mse(torch.mean(torch.mean(d_inst_t, dim=3), dim=2), d_style_t.repeat(1, 128).view(-1, 1).detach())
     got = train.consistency_terms(d_inst, d_style, d_inst_t, d_style_t)
     assert torch.equal(got["source_adv_cst"], want_s) and torch.equal(got["target_adv_cst"], want_t)
+
+
+def test_sgg_step_tensor_parallel_fc6_rehearsal_matches_single_graph(cfg, monkeypatch):
+    """The multi-GPU form of the step on ONE rank (1-rank RCCL group, I2V_FORCE_EXCHANGE=1): column-parallel fc6 with
+    its three collectives captured in the head graph, fused fc6 update, pipelined backbone -- same losses and weights
+    as the plain one-graph step.  (The 2-rank numerics of the column cut are checked on CPU under gloo.)"""
+    import torch.distributed as dist
+    from i2vsgg_amd import parallel, train
+    res = []
+    for forced in (False, True):
+        if forced:
+            monkeypatch.setenv("I2V_FORCE_EXCHANGE", "1")
+            monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+            monkeypatch.setenv("MASTER_PORT", str(29600 + os.getpid() % 300))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+        try:
+            net = train.build_sgg_net(layers=50, seed=5, device=DEV)
+            net.vrd.dropout = False
+            step = train.SGGEmbStep(net, 1, seed=3, device=DEV, h=200, w=320, n_boxes=6, n_pairs=5)
+            assert step.tp == forced and (net.vrd.tp is not None) == forced
+            assert "vrd.fc6.fc.weight" in step.fused           # the fc6 update stays fused in both forms
+            assert step.capture(warmup=1), getattr(step, "graph_error", None)
+            assert step.pipelined == forced
+            losses = [float(step().item()) for _ in range(3)]
+            torch.cuda.synchronize()
+            w6, _ = net.vrd.gather_fc6()
+            res.append((losses, w6.detach().cpu().numpy().copy(), net.vrd.fc7.fc.weight.detach().cpu().numpy().copy()))
+            step.opt.unfuse()
+        finally:
+            if forced:
+                dist.destroy_process_group()
+    (l0, a0, b0), (l1, a1, b1) = res
+    assert l0[0] != l0[2]
+    for x, y in zip(l0, l1):
+        assert abs(x - y) <= 1e-5 * abs(x), (l0, l1)
+    assert _rel_err(a1, a0) < 1e-5 and _rel_err(b1, b0) < 1e-5

@@ -141,3 +141,61 @@ def test_host_front_end_equals_oracle_restatement():
         a, sa = mb.prep_im_for_blob(u8[:, :, ::-1], means, target)
         b, sb = odata.minibatch_image(u8, means.reshape(-1), target)
         assert sa == sb and a.shape == b.shape and np.array_equal(a, b)
+
+
+TP_WORKER = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+import torch.nn.functional as F
+from i2vsgg_amd import parallel
+rk, world, dev = parallel.init_from_env("gloo")
+assert world == 2
+R, K, C = 5, 24, 8                        # rows per rank, input features, output features (C %% world == 0)
+g = torch.Generator().manual_seed(0)
+W = torch.randn(C, K, generator=g); b = torch.randn(C, generator=g)
+xs = [torch.randn(R, K, generator=g) for _ in range(world)]
+ts = [torch.randn(R, C, generator=g) for _ in range(world)]
+# ---- data parallel reference: full layer on every rank, gradient all-reduced
+Wd, bd = W.clone().requires_grad_(), b.clone().requires_grad_()
+h_dp = F.relu(F.linear(xs[rk], Wd, bd))
+((h_dp * ts[rk]).sum() / world).backward()
+dist.all_reduce(Wd.grad); dist.all_reduce(bd.grad)
+# ---- column-parallel: my output columns for everybody's rows; nothing of W crosses the ranks
+n = C // world
+Ws = parallel.mark_local(W[rk * n:(rk + 1) * n].clone().requires_grad_())
+bs = parallel.mark_local(b[rk * n:(rk + 1) * n].clone().requires_grad_())
+x_all = parallel.gather_rows(xs[rk])
+assert torch.equal(x_all, torch.cat(xs))
+h = parallel.ColShardToOwnRows.apply(F.relu(F.linear(x_all, Ws, bs)))
+assert torch.allclose(h, h_dp.detach(), rtol=1e-6, atol=1e-6)
+((h * ts[rk]).sum() / world).backward()
+assert torch.allclose(Ws.grad, Wd.grad[rk * n:(rk + 1) * n], rtol=1e-5, atol=1e-6), (Ws.grad - Wd.grad[rk * n:(rk + 1) * n]).abs().max()
+assert torch.allclose(bs.grad, bd.grad[rk * n:(rk + 1) * n], rtol=1e-5, atol=1e-6)
+# local shards are exempt from the exchange
+other = torch.nn.Parameter(torch.ones(3)); other.grad = torch.full((3,), float(rk + 1))
+before = Ws.grad.clone()
+parallel.all_reduce_grads([Ws, bs, other])
+assert torch.equal(Ws.grad, before) and torch.equal(other.grad, torch.full((3,), 3.0))
+parallel.barrier()
+dist.destroy_process_group()
+print("rank", rk, "ok")
+"""
+
+
+def test_column_parallel_fc6_equals_data_parallel_world_size_2_gloo(tmp_path):
+    """vrd.fc6 cut by output columns (parallel.gather_rows + ColShardToOwnRows): same activations and the same weight
+    gradient as the data-parallel layer with an all-reduce -- without moving the weight gradient."""
+    script = tmp_path / "tp_worker.py"
+    script.write_text(TP_WORKER % ROOT)
+    port = 31500 + (os.getpid() % 2000)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="2", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, o
+        assert "rank %d ok" % r in o
