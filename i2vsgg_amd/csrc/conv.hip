@@ -30,6 +30,7 @@ constexpr int KTAB_MAX = 2560;  // filter-tap table entries (K/4): KH*KW*Cin <= 
 constexpr int BKS = 32;         // k per LDS stage of the forward/dgrad kernel (= floats per LDS row)
 constexpr int LDS_ROW = 20;     // floats per staged row (16 + 4 pad)
 constexpr int THREADS = 256;
+constexpr bool PIPE_FRAGS = false;   // software-pipelined fragment reads in the 4-wave K loop (costs 20 VGPRs)
 constexpr int kSplitInKernelMax = 4;   // most splits the in-kernel split-K finish sums (else: atomics)
 
 struct ConvP {
@@ -45,6 +46,7 @@ struct ConvP {
     int force_tile;              // >=0: tile config override (tuning / tests), -1: cost model
     unsigned x_bytes, w_bytes;   // sizes of x and w for the buffer descriptors (< 2 GiB each)
     int ablate;                  // diagnostic (i2v_conv_set_tile bits 10-11): 1 = skip staging in the K loop, 2 = skip MFMAs
+    int ktab_entries;            // tap-table entries in LDS (>= 1; K/4 rounded up to whole stages for KxK filters)
     int dry;                     // plan only: run_conv returns the chosen split-K factor instead of launching
     unsigned long long* clk;     // diagnostic only (i2v_conv_debug_clock): per-workgroup {shader cycles, 100 MHz ticks}
     float* ws;                   // split-K partial tiles [split][tile][BM*BN] (nullptr: fp32 atomics into y)
@@ -79,10 +81,12 @@ conv_igemm_f32(const ConvP p) {
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     // one LDS block: [A stage 0 | A stage 1 | B stage 0 | B stage 1 | tap table]; after the K loop the
     // same bytes stage the BM x BN output tile (row stride BN+4 floats) for a coalesced epilogue
-    constexpr int STAGE_FLOATS = 2 * (BM + BN) * BKS + KTAB_MAX;
+    constexpr int STAGE_FLOATS = 2 * (BM + BN) * BKS;       // + the tap table (p.ktab_entries), dynamic
     constexpr int CROW = BN + 4;
     constexpr int SMEM_FLOATS = STAGE_FLOATS > BM * CROW ? STAGE_FLOATS : BM * CROW;
-    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    // dynamic: max(stage buffers + tap table of THIS filter, epilogue tile).  A 3x3x256 filter needs 2.3 KB of
+    // table, not the 10 KB worst case: 39 KB per workgroup instead of 47 -> four workgroups per CU instead of three
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     float (*As)[BM * BKS] = reinterpret_cast<float (*)[BM * BKS]>(smem);
     float (*Bs)[BN * BKS] = reinterpret_cast<float (*)[BN * BKS]>(smem + 2 * BM * BKS);
     unsigned* ktab = reinterpret_cast<unsigned*>(smem + 2 * (BM + BN) * BKS);
@@ -114,7 +118,7 @@ conv_igemm_f32(const ConvP p) {
     // filter-tap table (only for KHxKW > 1): entry e = k/4 -> (byte offset of tap (ky,kx,c)) << 6 | tap id.
     // Built once per workgroup, so the K loop has no integer division and no per-tap bounds math.
     if (!is1x1) {
-        const int n_e = min(KTAB_MAX, ((p.K + BKS - 1) / BKS) * (BKS / 4));
+        const int n_e = p.ktab_entries;
         for (int e = gtid; e < n_e; e += NT) {
             unsigned v = 0;
             if ((e << 2) < p.K) {
@@ -222,7 +226,7 @@ conv_igemm_f32(const ConvP p) {
         // 1x1 filters have no tap table: their "entry" is (k*4) << 6 | tap 0.  One load sequence serves
         // both cases (selected by mask arithmetic, not a branch: two copies of the loads under a branch
         // write the same registers and cost a vmcnt(0) each)
-        const unsigned e = ktab[(unsigned)min(k >> 2, KTAB_MAX - 1) & ~m1x1];
+        const unsigned e = ktab[(unsigned)min(k >> 2, p.ktab_entries - 1) & ~m1x1];
         const unsigned ee = (e & ~m1x1) | ((k4 << 6) & m1x1);
         const unsigned d4 = ee >> 6, kp = ee & 63u;
 #pragma unroll
@@ -434,6 +438,18 @@ conv_igemm_f32(const ConvP p) {
                 if (!no_mfma) compute(buf);
                 if (more) sstore(buf ^ 1);
                 if constexpr (!(ABL & 4)) __syncthreads();
+                buf ^= 1;
+            }
+        } else if constexpr (!PIPE_FRAGS) {
+            // one fragment register set: 118 VGPRs -> four waves per SIMD (the pipelined form below needs 138 -> three)
+            __syncthreads();
+            int buf = 0;
+            for (int k0 = kbeg; k0 < kend; k0 += BKS) {
+                const bool more = k0 + BKS < kend;
+                if (more) gload(k0 + BKS);
+                compute(buf);
+                if (more) sstore(buf ^ 1);
+                __syncthreads();
                 buf ^= 1;
             }
         } else {
@@ -696,6 +712,7 @@ int g_ablate = 0;
 unsigned long long* g_clk = nullptr;   // i2v_conv_debug_clock()
 // -1 / 0: plain 4-wave kernel, 1: loader/MFMA specialised 8-wave kernel, 2: specialised when <= 3 workgroups per CU
 int g_spec_mode = [] { const char* e = getenv("I2V_CONV_SPEC"); return e ? atoi(e) : -1; }();
+int g_split_target = [] { const char* e = getenv("I2V_SPLIT_TARGET"); return e ? atoi(e) : 2; }();
 int g_split_below = [] { const char* e = getenv("I2V_SPLIT_BELOW"); return e ? atoi(e) : NUM_CU; }();
 
 // Split-K workspace: one slab + one counter array per stream (up to kSplitSlots streams; beyond that, or for
@@ -746,16 +763,34 @@ bool split_workspace(hipStream_t st, size_t need_bytes, long long tiles, float*&
     return true;
 }
 
+template <class K>
+void set_max_lds(K kernel) {
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+}
+
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 void launch_tile(const ConvP& p, bool spec, hipStream_t st) {
     constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
     const int tiles = i2v_cdiv(p.M, BM) * i2v_cdiv(p.N, BN);
+    const size_t stage = (size_t)(2 * (BM + BN) * BKS + p.ktab_entries) * sizeof(float);
+    const size_t epi = (size_t)BM * (BN + 4) * sizeof(float);
+    const size_t lds = stage > epi ? stage : epi;
+    static bool once = [] {
+        set_max_lds(conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, true>);
+        set_max_lds(conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false>);
+        if constexpr (WAVES_M == 1) {
+            set_max_lds(conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false, 4>);
+            set_max_lds(conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false, 12>);
+        }
+        return true;
+    }();
+    (void)once;
     if constexpr (WAVES_M == 1) {      // diagnostic instantiations (tools/conv_ablate.py), 80x64 tile only
-        if ((p.ablate & 12) == 4) { conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false, 4><<<dim3(tiles, p.splitk), THREADS, 0, st>>>(p); return; }
-        if ((p.ablate & 12) == 12) { conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false, 12><<<dim3(tiles, p.splitk), THREADS, 0, st>>>(p); return; }
+        if ((p.ablate & 12) == 4) { conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false, 4><<<dim3(tiles, p.splitk), THREADS, lds, st>>>(p); return; }
+        if ((p.ablate & 12) == 12) { conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false, 12><<<dim3(tiles, p.splitk), THREADS, lds, st>>>(p); return; }
     }
-    if (spec) conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, true><<<dim3(tiles, p.splitk), 2 * THREADS, 0, st>>>(p);
-    else conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false><<<dim3(tiles, p.splitk), THREADS, 0, st>>>(p);
+    if (spec) conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, true><<<dim3(tiles, p.splitk), 2 * THREADS, lds, st>>>(p);
+    else conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false><<<dim3(tiles, p.splitk), THREADS, lds, st>>>(p);
 }
 
 struct TileCfg { int bm, bn; float eff; };
@@ -775,6 +810,7 @@ int run_conv(ConvP p, hipStream_t st) {
             return I2V_ERR_UNSUPPORTED;
         }
     }
+    p.ktab_entries = (p.KH == 1 && p.KW == 1 && p.pad == 0 && p.pad_x == 0) ? 4 : ((p.K + BKS - 1) / BKS) * (BKS / 4);
     const long long xb = (long long)p.B * p.H * p.W * p.Cin * 4, wb = (long long)p.N * p.K * 4;
     const long long halo = std::max(0ll, (long long)(p.pad * p.W + p.pad_x) * p.Cin * 4);    // the kernel's descriptor starts this much earlier
     if (xb + halo >= (1ll << 31) || wb >= (1ll << 31)) {
@@ -794,7 +830,7 @@ int run_conv(ConvP p, hipStream_t st) {
         const long long t = (long long)i2v_cdiv(p.M, kTiles[c].bm) * i2v_cdiv(p.N, kTiles[c].bn);
         splitk = 1;
         if (t < g_split_below && ksteps >= 8 && p.ostride == 1) {
-            splitk = (int)((2 * NUM_CU + t - 1) / t);
+            splitk = (int)((g_split_target * NUM_CU + t - 1) / t);
             splitk = splitk > ksteps / 4 ? ksteps / 4 : splitk;
             if (splitk < 1) splitk = 1;
         }
