@@ -1053,7 +1053,9 @@ conv_wgrad_f32(const WgP p) {
 // stage, swizzled 128-B LDS rows, register prefetch + double-buffered LDS.  Both operands arrive
 // reduction-major, so every thread owns 4x4 blocks (4 consecutive pixels x 4 columns): four 16-B loads,
 // an in-register transpose, four ds_write_b128 -- no scalar LDS traffic, no bank-conflicted transposes.
-template <int TM, int TN>       // tile = (2*TM*16) filters x (2*TN*16) taps, 4 waves as 2x2
+// FUSED_SGD: the instantiation that runs the SGD update in its epilogue (prefetches the filter / momentum tiles:
+// +34 VGPRs, four waves per SIMD instead of five -- which the plain gradient kernel should not pay)
+template <int TM, int TN, bool FUSED_SGD = false>       // tile = (2*TM*16) filters x (2*TN*16) taps, 4 waves as 2x2
 __global__ void __launch_bounds__(THREADS)
 conv_wgrad2_f32(const WgP p) {
     constexpr int BMW = 2 * TM * 16, BNW = 2 * TN * 16;
@@ -1179,7 +1181,7 @@ conv_wgrad2_f32(const WgP p) {
     // reduction (read in the epilogue loop they cost one exposed round trip per iteration: the stores of one
     // iteration alias the loads of the next as far as the compiler knows)
     constexpr int W_LD = (BMW * (BNW / 4) + THREADS - 1) / THREADS;
-    constexpr bool PREFETCH_W = W_LD <= 4;
+    constexpr bool PREFETCH_W = FUSED_SGD && W_LD <= 4;
     float4 pw[PREFETCH_W ? W_LD : 1], pm[PREFETCH_W ? W_LD : 1];
     if (PREFETCH_W && p.sgd_m) {
 #pragma unroll
@@ -1469,6 +1471,7 @@ static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st) {
     if (!v2) conv_wgrad_f32<64, 64><<<grid, THREADS, 0, st>>>(p);
     else if (tm == 128 && tk == 128) conv_wgrad2_f32<4, 4><<<grid, THREADS, 0, st>>>(p);
     else if (tm == 128) conv_wgrad2_f32<4, 2><<<grid, THREADS, 0, st>>>(p);
+    else if (fused) conv_wgrad2_f32<2, 2, true><<<grid, THREADS, 0, st>>>(p);
     else conv_wgrad2_f32<2, 2><<<grid, THREADS, 0, st>>>(p);
     return true;
 }
