@@ -242,6 +242,69 @@ dpixel_bwd_kernel(const float* __restrict__ gd, const float* __restrict__ gfeat,
     });
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small fused pieces of the relation head's tail (resnet_SGG_emb.py:207-215, faster_rcnn_SGG_emb.py:269): these tensors
+// are 64 x 300, so every aten op is one launch-bound kernel; F.normalize + its autograd backward are ~9 launches, the
+// BCE-with-logits + per-frame mean + weighting ~12.
+//
+// y = x / max(||x||_2, eps) per row (F.normalize(p=2, dim=1)); one wave per row.
+__global__ void __launch_bounds__(256)
+l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ inv_norm, int rows, int cols,
+                  float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (long long)row * cols;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) s += xr[c] * xr[c];
+    for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh);
+    const float inv = 1.f / fmaxf(sqrtf(s), eps);
+    if (lane == 0) inv_norm[row] = inv;
+    for (int c = lane; c < cols; c += 64) y[(long long)row * cols + c] = xr[c] * inv;
+}
+// gx = (g - y * (g . y)) * inv   (norm > eps; at the clamp the reference's gradient is g / eps, which this also gives
+// because inv = 1/eps and the projection term is dropped only when ||x|| <= eps)
+__global__ void __launch_bounds__(256)
+l2norm_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ inv_norm,
+                  float* __restrict__ gx, int rows, int cols, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* gr = g + (long long)row * cols;
+    const float* yr = y + (long long)row * cols;
+    float d = 0.f;
+    for (int c = lane; c < cols; c += 64) d += gr[c] * yr[c];
+    for (int sh = 32; sh > 0; sh >>= 1) d += __shfl_xor(d, sh);
+    const float inv = inv_norm[row];
+    const bool clamped = inv >= 1.f / eps;
+    for (int c = lane; c < cols; c += 64)
+        gx[(long long)row * cols + c] = clamped ? gr[c] * inv : (gr[c] - yr[c] * d) * inv;
+}
+
+// loss = sum_r w[r] * mean_c bce(z[r][c], t[r][c]),  bce = max(z,0) - z*t + log1p(exp(-|z|))   (BCEWithLogitsLoss)
+__global__ void __launch_bounds__(256)
+bce_rows_fwd_kernel(const float* __restrict__ z, const float* __restrict__ t, const float* __restrict__ w,
+                    float* __restrict__ loss, int rows, int cols) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane; c < cols; c += 64) {
+        const float zz = z[(long long)row * cols + c], tt = t[(long long)row * cols + c];
+        s += fmaxf(zz, 0.f) - zz * tt + log1pf(expf(-fabsf(zz)));
+    }
+    for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh);
+    if (lane == 0) atomicAdd(loss, s / (float)cols * w[row]);
+}
+__global__ void bce_rows_bwd_kernel(const float* __restrict__ z, const float* __restrict__ t, const float* __restrict__ w,
+                                    const float* __restrict__ gloss, float* __restrict__ gz, int rows, int cols) {
+    const long long n = (long long)rows * cols;
+    const float gl = gloss[0];
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / cols);
+        const float zz = z[i];
+        const float sg = 1.f / (1.f + expf(-zz));
+        gz[i] = (sg - t[i]) * (w[row] / (float)cols) * gl;
+    }
+}
+
 // wt[k][n] = w[n][k]
 __global__ void dp_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int N, int K) {
     const long long total = (long long)N * K;
@@ -324,5 +387,42 @@ extern "C" int32_t i2v_dpixel_bwd(const float* gd, const float* gfeat, const flo
     dpixel_bwd_kernel<<<i2v_cdiv(M, DP_ROWS), DP_THREADS, DP_LDS_FLOATS * 4, st>>>(gd, gfeat, d, h1, h2, w1t, w2t, w3, g3,
                                                                                  gh2, gh1, gx, M, pix_per_roi, -lambda);
     I2V_CHECK_LAUNCH("dpixel_bwd");
+    return I2V_OK;
+}
+
+// ---- small fused pieces of the relation head's tail ------------------------------------------------
+extern "C" int32_t i2v_l2norm_rows_fwd(const float* x, float* y, float* inv_norm, int32_t rows, int32_t cols, float eps,
+                                       void* stream) {
+    I2V_CHECK_ARG(x && y && inv_norm && rows >= 0 && cols > 0 && eps > 0.f, "l2norm_rows_fwd: bad argument");
+    if (rows == 0) return I2V_OK;
+    l2norm_fwd_kernel<<<i2v_cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>(x, y, inv_norm, rows, cols, eps);
+    I2V_CHECK_LAUNCH("l2norm_rows_fwd");
+    return I2V_OK;
+}
+extern "C" int32_t i2v_l2norm_rows_bwd(const float* g, const float* y, const float* inv_norm, float* gx, int32_t rows,
+                                       int32_t cols, float eps, void* stream) {
+    I2V_CHECK_ARG(g && y && inv_norm && gx && rows >= 0 && cols > 0 && eps > 0.f, "l2norm_rows_bwd: bad argument");
+    if (rows == 0) return I2V_OK;
+    l2norm_bwd_kernel<<<i2v_cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>(g, y, inv_norm, gx, rows, cols, eps);
+    I2V_CHECK_LAUNCH("l2norm_rows_bwd");
+    return I2V_OK;
+}
+extern "C" int32_t i2v_bce_rows_fwd(const float* z, const float* t, const float* w, float* loss, int32_t rows,
+                                    int32_t cols, void* stream) {
+    I2V_CHECK_ARG(z && t && w && loss && rows >= 0 && cols > 0, "bce_rows_fwd: bad argument");
+    hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream);
+    if (rows == 0) return I2V_OK;
+    bce_rows_fwd_kernel<<<i2v_cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>(z, t, w, loss, rows, cols);
+    I2V_CHECK_LAUNCH("bce_rows_fwd");
+    return I2V_OK;
+}
+extern "C" int32_t i2v_bce_rows_bwd(const float* z, const float* t, const float* w, const float* gloss, float* gz,
+                                    int32_t rows, int32_t cols, void* stream) {
+    I2V_CHECK_ARG(z && t && w && gloss && gz && rows >= 0 && cols > 0, "bce_rows_bwd: bad argument");
+    if (rows == 0) return I2V_OK;
+    const long long n = (long long)rows * cols;
+    bce_rows_bwd_kernel<<<(int)fmin((double)i2v_cdiv(n, 256), 4096.0), 256, 0, (hipStream_t)stream>>>(z, t, w, gloss, gz,
+                                                                                                   rows, cols);
+    I2V_CHECK_LAUNCH("bce_rows_bwd");
     return I2V_OK;
 }

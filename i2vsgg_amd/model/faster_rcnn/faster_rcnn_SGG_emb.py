@@ -166,9 +166,9 @@ class _fasterRCNN(nn.Module):
                                            t(ixs, torch.long), t(ixo, torch.long))
         target = t(labels)
         # mean over frames of the per-frame BCE mean (== reference run per frame, averaged)
-        per = nn.functional.binary_cross_entropy_with_logits(score, target, reduction="none").mean(1)
         w = torch.cat([torch.full((c,), 1.0 / (c * len(counts))) for c in counts]).to(dev)
-        return (per * w).sum()
+        from i2vsgg_amd import ops
+        return ops.bce_rows(score, target, w)
 
     def _init_weights(self):
         def normal_init(m, mean, std):

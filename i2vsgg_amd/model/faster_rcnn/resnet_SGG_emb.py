@@ -113,18 +113,21 @@ class vrd(nn.Module):
             h = parallel.ColShardToOwnRows.apply(self.fc6(parallel.gather_rows(x6.detach())))
         h = self.fc7(self._drop(h))
         h = self._drop(h)
-        obj = self.so_vis_embeddings(h[:nb])
-        x = self.fc8(h[nb:])
-        x_so = self.fc_so(torch.cat((obj.index_select(0, ix1), obj.index_select(0, ix2)), 1))
+        h_box, h_rel = torch.split(h, [nb, h.size(0) - nb])      # one cat in the backward (two slices = 2 fills + 2 copies + add)
+        obj = self.so_vis_embeddings(h_box)
+        x = self.fc8(h_rel)
+        nr = ix1.numel()
+        so = obj.index_select(0, torch.cat((ix1, ix2)))          # one gather / one index_add instead of two each
+        x_so = self.fc_so(torch.cat((so[:nr], so[nr:]), 1))
         lo = self.conv_lo(spatial)
         lo = self.fc_lov(lo.reshape(lo.size(0), -1))
         x = self.fc_rel(self.fc_fusion(torch.cat((x, x_so, lo), 1)))
         if self._prd_dev is None or self._prd_dev.device != x.device:
             self._prd_dev = torch.from_numpy(np.asarray(self.prd_vecs, np.float32)).to(x.device)
-        sem = F.normalize(self.prd_sem_embeddings(self._prd_dev), p=2, dim=1)
+        sem = ops.l2norm_rows(self.prd_sem_embeddings(self._prd_dev))       # F.normalize(p=2, dim=1), one kernel each way
         # logits = V . S^T through the same implicit-GEMM kernel as every other layer (a torch.mm here drags a
         # hipBLASLt launch with its device-side argument upload into the captured step)
-        scores = ops.linear(F.normalize(x, p=2, dim=1), sem)
+        scores = ops.linear(ops.l2norm_rows(x), sem)
         if not self.training:
             scores = F.softmax(scores, dim=1)
         return scores, x

@@ -51,6 +51,7 @@ class Conv2d(nn.Module):
         w = c.weight
         if c.cin % 4:       # e.g. the 2-channel dual mask: pad the channel axis to a float4 boundary
             padc = 4 - c.cin % 4
-            x = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, padc))
+            if x.shape[1] == c.cin:                      # a caller may hand the input already padded with zero channels
+                x = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, padc))
             w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, padc))
         return ops.conv2d(x, w, None, c.bias, None, c.stride, c.pad, relu=self.relu)

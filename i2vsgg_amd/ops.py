@@ -649,3 +649,55 @@ def relation_topk(rel_score, conf, ixs, ixo, k=100):
     check(lib.i2v_relation_topk(ptr(rel_score), ptr(conf), ptr(ixs), ptr(ixo), n_pairs, n_rel, k, ptr(pair), ptr(pred), ptr(out),
                                 ptr(ws), ws.numel(), stream()), "relation_topk")
     return pair, pred, out
+
+
+class _L2NormRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        _need_cuda(x)
+        x = x.contiguous()
+        rows, cols = x.shape
+        y = torch.empty_like(x)
+        inv = torch.empty((rows,), device=x.device, dtype=torch.float32)
+        check(lib.i2v_l2norm_rows_fwd(ptr(x), ptr(y), ptr(inv), rows, cols, float(eps), stream()), "l2norm_rows_fwd")
+        ctx.save_for_backward(y, inv)
+        ctx.eps = float(eps)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        y, inv = ctx.saved_tensors
+        g = g.contiguous()
+        gx = torch.empty_like(g)
+        check(lib.i2v_l2norm_rows_bwd(ptr(g), ptr(y), ptr(inv), ptr(gx), y.shape[0], y.shape[1], ctx.eps, stream()),
+              "l2norm_rows_bwd")
+        return gx, None
+
+
+def l2norm_rows(x, eps=1e-12):
+    """F.normalize(x, p=2, dim=1) for a 2-D fp32 tensor, forward and backward one kernel each."""
+    return _L2NormRowsFn.apply(x, eps)
+
+
+class _BceRowsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, t, w):
+        _need_cuda(z, t, w)
+        z, t, w = z.contiguous(), t.contiguous(), w.contiguous()
+        loss = torch.empty((), device=z.device, dtype=torch.float32)
+        check(lib.i2v_bce_rows_fwd(ptr(z), ptr(t), ptr(w), ptr(loss), z.shape[0], z.shape[1], stream()), "bce_rows_fwd")
+        ctx.save_for_backward(z, t, w)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        z, t, w = ctx.saved_tensors
+        gz = torch.empty_like(z)
+        check(lib.i2v_bce_rows_bwd(ptr(z), ptr(t), ptr(w), ptr(gl.contiguous()), ptr(gz), z.shape[0], z.shape[1], stream()),
+              "bce_rows_bwd")
+        return gz, None, None
+
+
+def bce_rows(z, t, w):
+    """sum_r w[r] * mean_c BCEWithLogits(z[r,c], t[r,c]) as one device scalar (forward and backward one kernel each)."""
+    return _BceRowsFn.apply(z, t, w)

@@ -146,7 +146,7 @@ class SGGEmbStep:
         im4[:, :3] = torch.from_numpy(im).to(self.dev)
         new = dict(im=im4, info=torch.from_numpy(info).to(self.dev), boxes=t(boxes),
                    relb=t(relb), labels=t(labels), ixs=t(ixs, torch.long), ixo=t(ixo, torch.long),
-                   masks=rasterize_masks(np.concatenate(bounds), self.dev),
+                   masks=torch.nn.functional.pad(rasterize_masks(np.concatenate(bounds), self.dev), (0, 0, 0, 0, 0, 2)),  # 2 zero channels: the float4 pad of conv_lo.0, done once by the data side
                    wrow=torch.cat([torch.full((c,), 1.0 / (c * len(counts))) for c in counts]).to(self.dev))
         for k, v in new.items():
             cur = getattr(self, k, None)
@@ -178,8 +178,7 @@ class SGGEmbStep:
             if self.arena is not None:
                 self.arena.reset()          # one clear for every atomically accumulated output of this half
             score, _ = self.net.vrd.forward_device(self.fmap, self.boxes, self.relb, self.masks, self.ixs, self.ixo)
-            per = torch.nn.functional.binary_cross_entropy_with_logits(score, self.labels, reduction="none").mean(1)
-            loss = (per * self.wrow).sum()
+            loss = ops.bce_rows(score, self.labels, self.wrow)     # sum_r wrow[r] * mean_c BCE: one kernel each way
             self.opt.zero_grad()
             (loss / self.world).backward()
             self.loss.copy_(loss.detach())

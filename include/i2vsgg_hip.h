@@ -226,6 +226,20 @@ int32_t i2v_dstyle_pool_fwd(const float* x1, const float* x2, float* z, int64_t 
 int32_t i2v_dstyle_pool_bwd(const float* gz, const float* x1, const float* x2, float* g1, float* g2,
                             int64_t rows, int32_t n_img, int32_t dim, int32_t rank, void* stream);
 
+/* ---- small fused pieces of the relation head's tail ---------------------------------------------
+ * rows here are 64 x 300, so each aten op of the reference expression is one launch-bound kernel.
+ * l2norm_rows: y = x / max(||x||_2, eps) per row = F.normalize(x, p=2, dim=1) (resnet_SGG_emb.py:210-213) and its
+ *   backward gx = (g - y (g.y)) / max(||x||, eps); inv_norm (rows) is kept for the backward.
+ * bce_rows: loss = sum_r w[r] * mean_c BCEWithLogits(z[r][c], t[r][c]) (faster_rcnn_SGG_emb.py:269 with the per-frame
+ *   mean folded into w) -> one device scalar; backward gz = (sigmoid(z) - t) * w[r] / cols * gloss[0]. */
+int32_t i2v_l2norm_rows_fwd(const float* x, float* y, float* inv_norm, int32_t rows, int32_t cols, float eps, void* stream);
+int32_t i2v_l2norm_rows_bwd(const float* g, const float* y, const float* inv_norm, float* gx, int32_t rows, int32_t cols,
+                            float eps, void* stream);
+int32_t i2v_bce_rows_fwd(const float* z, const float* t, const float* w, float* loss, int32_t rows, int32_t cols,
+                         void* stream);
+int32_t i2v_bce_rows_bwd(const float* z, const float* t, const float* w, const float* gloss, float* gz, int32_t rows,
+                         int32_t cols, void* stream);
+
 /* ---- netD_pixel, fused (instance-level discriminator) ---------------------------------
  * replaces netD_pixel.forward (resnet_instance_styleD_bilinear.py:38-83: GRL, conv1 1024->512 + ReLU, conv2
  * 512->128 + ReLU, conv3 128->1, sigmoid, optional context vector = mean of the 128-d features over the ROI's

@@ -596,3 +596,31 @@ def test_get_minibatch_device_equals_host(ops):
         assert np.array_equal(host["im_info"], dev["im_info"]) and np.array_equal(host["gt_boxes"], dev["gt_boxes"])
         d = dev["data"][0].permute(1, 2, 0).cpu().numpy()
         assert np.array_equal(d[:, :, :3], host["data"][0]) and not d[:, :, 3].any()
+
+
+def test_l2norm_rows_and_bce_rows_vs_torch(ops):
+    """The two fused tail ops == F.normalize / BCEWithLogits expressions of resnet_SGG_emb.py:210-213 and
+    faster_rcnn_SGG_emb.py:269 (forward and autograd backward)."""
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((64, 300), dtype=np.float32)
+    x[3] = 0.0                                              # a zero row: the eps clamp
+    g = rng.standard_normal((64, 300), dtype=np.float32)
+    xt = torch.from_numpy(x).requires_grad_()
+    F.normalize(xt, p=2, dim=1).backward(torch.from_numpy(g))
+    xd = torch.from_numpy(x).to(DEV).requires_grad_()
+    y = ops.l2norm_rows(xd)
+    y.backward(torch.from_numpy(g).to(DEV))
+    np.testing.assert_allclose(y.detach().cpu().numpy(), F.normalize(torch.from_numpy(x), p=2, dim=1).numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(xd.grad[np.arange(64) != 3].cpu().numpy(), xt.grad[np.arange(64) != 3].numpy(), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(xd.grad[3].cpu().numpy(), xt.grad[3].numpy(), rtol=1e-5)          # g / eps
+    z = (rng.standard_normal((42, 62)) * 3).astype(np.float32)
+    t = (rng.uniform(size=(42, 62)) < 0.1).astype(np.float32)
+    w = rng.uniform(0.01, 0.05, 42).astype(np.float32)
+    zt = torch.from_numpy(z).requires_grad_()
+    ref = (F.binary_cross_entropy_with_logits(zt, torch.from_numpy(t), reduction="none").mean(1) * torch.from_numpy(w)).sum()
+    (ref * 0.5).backward()
+    zd = torch.from_numpy(z).to(DEV).requires_grad_()
+    loss = ops.bce_rows(zd, torch.from_numpy(t).to(DEV), torch.from_numpy(w).to(DEV))
+    (loss * 0.5).backward()
+    assert abs(loss.item() - ref.item()) <= 2e-6 * abs(ref.item())
+    np.testing.assert_allclose(zd.grad.cpu().numpy(), zt.grad.numpy(), rtol=2e-5, atol=1e-8)

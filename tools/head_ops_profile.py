@@ -17,3 +17,8 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     step.opt.step()
     torch.cuda.synchronize()
 print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=60, max_name_column_width=40, max_shapes_column_width=60))
+print("---- aten ops that launch device work (count, self device time) ----")
+rows = [(e.key, e.count, e.self_device_time_total) for e in prof.key_averages() if e.key.startswith("aten::") and e.self_device_time_total > 0]
+for k, c, t in sorted(rows, key=lambda r: -r[2]):
+    print("%-44s %4d calls %9.1f us" % (k, c, t))
+print("total aten device time %.1f us in %d launching calls" % (sum(r[2] for r in rows), sum(r[1] for r in rows)))
