@@ -118,7 +118,7 @@ class vrd(nn.Module):
         x = self.fc8(h_rel)
         nr = ix1.numel()
         so = obj.index_select(0, torch.cat((ix1, ix2)))          # one gather / one index_add instead of two each
-        x_so = self.fc_so(torch.cat((so[:nr], so[nr:]), 1))
+        x_so = self.fc_so(so.view(2, nr, -1).permute(1, 0, 2).reshape(nr, -1))     # [subject | object] per pair: one copy
         lo = self.conv_lo(spatial)
         lo = self.fc_lov(lo.reshape(lo.size(0), -1))
         x = self.fc_rel(self.fc_fusion(torch.cat((x, x_so, lo), 1)))
