@@ -1191,8 +1191,10 @@ conv_wgrad2_f32(const WgP p) {
             const int n = n0 + row, k = k0 + col;
             const bool ok = e < BMW * (BNW / 4) && n < p.N && k < p.K;
             const long long o = (long long)n * p.K + k;
-            pw[it] = ok ? *(const float4*)(p.gw + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-            pm[it] = ok ? *(const float4*)(p.sgd_m + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            // streamed once: non-temporal, so the filter / momentum tiles do not evict the x and gy slices that the
+            // other workgroups of this XCD re-read from L2
+            pw[it] = ok ? __builtin_bit_cast(float4, __builtin_nontemporal_load((const f32x4*)(p.gw + o))) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pm[it] = ok ? __builtin_bit_cast(float4, __builtin_nontemporal_load((const f32x4*)(p.sgd_m + o))) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
 
@@ -1231,8 +1233,8 @@ conv_wgrad2_f32(const WgP p) {
             mv.x = p.mom * mv.x + (g.x + p.wd * pv.x); mv.y = p.mom * mv.y + (g.y + p.wd * pv.y);
             mv.z = p.mom * mv.z + (g.z + p.wd * pv.z); mv.w = p.mom * mv.w + (g.w + p.wd * pv.w);
             pv.x -= p.lr * mv.x; pv.y -= p.lr * mv.y; pv.z -= p.lr * mv.z; pv.w -= p.lr * mv.w;
-            *(float4*)(p.sgd_m + o) = mv;
-            *(float4*)(p.gw + o) = pv;
+            __builtin_nontemporal_store(__builtin_bit_cast(f32x4, mv), (f32x4*)(p.sgd_m + o));
+            __builtin_nontemporal_store(__builtin_bit_cast(f32x4, pv), (f32x4*)(p.gw + o));
         }
     } else if (p.sgd_m || p.direct) {
         for (int e = tid; e < BMW * (BNW / 4); e += THREADS) {
