@@ -325,8 +325,10 @@ conv_igemm_f32(const ConvP p) {
             const int e = gtid + it * NT;
             const int row = e / (BN / 4), col = (e % (BN / 4)) * 4;
             const int m = m0 + row, n = n0 + col;
-            rres[it] = (e < BM * (BN / 4) && m < p.M && n < p.N) ? *(const float4*)(p.res + (long long)m * p.N + n)
-                                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            // non-temporal: in a bottleneck this is the last use of the block input
+            rres[it] = (e < BM * (BN / 4) && m < p.M && n < p.N)
+                           ? __builtin_bit_cast(float4, __builtin_nontemporal_load((const f32x4*)(p.res + (long long)m * p.N + n)))
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     unsigned long long t1c = 0;
@@ -559,7 +561,7 @@ conv_igemm_f32(const ConvP p) {
                         wsr, (ok && sp < nsplit && sp != my) ? off + (unsigned)(sp * split_stride * sizeof(float)) : 0xFFFFFFF0u,
                         0, SC01));
                 rr[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok && vec && (p.flags & I2V_EPI_RESIDUAL)) rr[c] = *(const float4*)(p.res + (long long)m * p.N + n);
+                if (ok && vec && (p.flags & I2V_EPI_RESIDUAL)) rr[c] = __builtin_bit_cast(float4, __builtin_nontemporal_load((const f32x4*)(p.res + (long long)m * p.N + n)));
             }
 #pragma unroll
             for (int c = 0; c < FIN_CH; ++c) {
