@@ -142,7 +142,10 @@ def main():
                    "hip_graph": bool(graphed), "graph_error": getattr(step, "graph_error", None), "parallelism": ("dp%d (frames sharded) + vrd.fc6 cut by output columns across the ranks: RCCL all-reduce of the other "
                                    "84 MB of gradients, 30 MB of activation gathers for fc6" % world) if getattr(step, "tp", False)
                    else "dp%d (frames sharded, RCCL all-reduce of vrd grads)" % world,
-                   "schedule": ("pipelined: head fwd+bwd -> [gradient exchange || backbone fwd of the next minibatch] -> SGD"
+                   "schedule": ("two streams: [head fwd+bwd (+ gradient exchange) + SGD] beside [backbone fwd of the next minibatch]; "
+                                "every step = 1 backbone pass + 1 head pass + 1 update, all inside the timed region"
+                                if getattr(step, "overlap", False) else
+                                "pipelined: head fwd+bwd -> [gradient exchange || backbone fwd of the next minibatch] -> SGD"
                                 if getattr(step, "pipelined", False) else "one graph: backbone fwd, head fwd+bwd, fused wgrad+SGD"),
                    "loss": loss},
         "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (every i2v_conv_fwd/_dgrad call: kernel + its split-K helper kernels)", "achieved": achieved,

@@ -722,12 +722,13 @@ int g_split_below = [] { const char* e = getenv("I2V_SPLIT_BELOW"); return e ? a
 // split-K call made outside a graph capture; handing a slot to a new stream is host bookkeeping only, so it is
 // legal while that stream is capturing.
 constexpr size_t kSplitSlabBytes = 48u << 20;
-constexpr int kSplitSlots = 4, kSplitCounters = 1024;
+constexpr int kSplitSlots = 6, kSplitCounters = 1024;
 int g_split_atomics = [] { const char* e = getenv("I2V_SPLIT_ATOMICS"); return e ? atoi(e) : 0; }();
 char* g_split_base = nullptr;
 int* g_split_cnt = nullptr;
 hipStream_t g_split_owner[kSplitSlots];
 int g_split_used = 0;
+int g_split_pin = -1;             // i2v_conv_set_split_slot(): >= 0 pins the slot (counted from the top) instead of keying by stream
 std::mutex g_split_mu;
 
 bool split_workspace(hipStream_t st, size_t need_bytes, long long tiles, float*& ws, int*& cnt) {
@@ -753,12 +754,19 @@ bool split_workspace(hipStream_t st, size_t need_bytes, long long tiles, float*&
         g_split_cnt = c;
     }
     int slot = -1;
-    for (int i = 0; i < g_split_used; ++i)
-        if (g_split_owner[i] == st) slot = i;
-    if (slot < 0) {
-        if (g_split_used == kSplitSlots) return false;
-        slot = g_split_used++;
-        g_split_owner[slot] = st;
+    if (g_split_pin >= 0) {
+        // pinned by the caller: graphs that are captured on the same stream but replayed CONCURRENTLY on different
+        // streams (the overlapped backbone / head graphs) must not share a slab
+        slot = kSplitSlots - 1 - g_split_pin;
+        if (slot < g_split_used) return false;          // would collide with a stream-assigned slot
+    } else {
+        for (int i = 0; i < g_split_used; ++i)
+            if (g_split_owner[i] == st) slot = i;
+        if (slot < 0) {
+            if (g_split_used >= kSplitSlots - 2) return false;       // the top two slots are reserved for pins
+            slot = g_split_used++;
+            g_split_owner[slot] = st;
+        }
     }
     ws = reinterpret_cast<float*>(g_split_base + kSplitSlabBytes * slot);
     cnt = g_split_cnt + kSplitCounters * slot;
@@ -1493,6 +1501,13 @@ static int check_conv(const char* who, const void* a, const void* b, const void*
 
 extern "C" int32_t i2v_conv_debug_clock(void* buf) {
     g_clk = (unsigned long long*)buf;      // device buffer of 2 u64 per workgroup, or NULL to switch off
+    return I2V_OK;
+}
+
+extern "C" int32_t i2v_conv_set_split_slot(int32_t pin) {
+    I2V_CHECK_ARG(pin >= -1 && pin <= 1, "conv_set_split_slot: pin must be -1 (by stream), 0 or 1");
+    std::lock_guard<std::mutex> lock(g_split_mu);
+    g_split_pin = pin;
     return I2V_OK;
 }
 

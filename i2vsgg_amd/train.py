@@ -121,7 +121,10 @@ class SGGEmbStep:
         self.arena = ops.ZeroArena(1024, self.dev) if zero_arena else None    # sized after the first step
         self.arena_bb = ops.ZeroArena(1024, self.dev) if zero_arena else None
         self.fmap = None
+        self.fmap_head = None
         self.pipelined = False
+        import os as _os
+        self.overlap = _os.environ.get("I2V_OVERLAP", "1") != "0" and use_graph
 
     def reseed(self, seed):
         """(Re)generate the synthetic minibatch: frames, pair tables, masks, labels -> static device inputs (the
@@ -177,7 +180,8 @@ class SGGEmbStep:
         try:
             if self.arena is not None:
                 self.arena.reset()          # one clear for every atomically accumulated output of this half
-            score, _ = self.net.vrd.forward_device(self.fmap, self.boxes, self.relb, self.masks, self.ixs, self.ixo)
+            fmap = self.fmap_head if self.overlap else self.fmap
+            score, _ = self.net.vrd.forward_device(fmap, self.boxes, self.relb, self.masks, self.ixs, self.ixo)
             loss = ops.bce_rows(score, self.labels, self.wrow)     # sum_r wrow[r] * mean_c BCE: one kernel each way
             self.opt.zero_grad()
             (loss / self.world).backward()
@@ -187,6 +191,10 @@ class SGGEmbStep:
 
     def _body(self):
         self._backbone()
+        if self.overlap:
+            if self.fmap_head is None:
+                self.fmap_head = torch.empty_like(self.fmap)
+            self.fmap_head.copy_(self.fmap)
         self._head()
         parallel.all_reduce_grads(self.opt.params())
         self.opt.step()
@@ -218,7 +226,9 @@ class SGGEmbStep:
             return False
         self.pipelined = parallel.exchange_enabled() or os.environ.get("I2V_SPLIT_GRAPH") == "1"
         try:
-            if not self.pipelined:
+            if self.overlap:
+                self._capture_overlapped()
+            elif not self.pipelined:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self._body()
@@ -240,18 +250,70 @@ class SGGEmbStep:
             return True
         except Exception as e:      # report, fall back to eager launches
             self.graph = None
-            self.pipelined = False
+            self.pipelined = self.overlap = False
             self.graph_error = repr(e)
             torch.cuda.synchronize(self.dev)
             return False
 
+    def _capture_overlapped(self):
+        """Two streams.  The backbone is frozen, so the backbone pass of the NEXT minibatch does not depend on this
+        step's update: it runs on its own stream BESIDE this step's head (whose long kernels -- the fused fc6
+        wgrad+SGD, ROI pooling -- are HBM- or latency-bound, and whose ~100 small kernels leave most CUs idle) and
+        beside the gradient exchange, instead of after them.  The feature map is handed over through a copy at the
+        top of each step.  The graphs pin different split-K workspace slabs (they are captured on one stream but
+        replayed concurrently).  Single GPU: head graph = head fwd+bwd + SGD.  Multi-GPU: head graph (with the
+        column-parallel fc6 collectives captured), eager all-reduce of the remaining gradients, SGD graph."""
+        from ._lib import lib
+        self.s_bb = torch.cuda.Stream(self.dev)
+        self.ev_bb, self.ev_copy = torch.cuda.Event(), torch.cuda.Event()
+        gbb, gh = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        gs = torch.cuda.CUDAGraph() if self.pipelined else None
+        try:
+            lib.i2v_conv_set_split_slot(1)
+            with torch.cuda.graph(gbb):
+                self._backbone()
+            lib.i2v_conv_set_split_slot(0)
+            with torch.cuda.graph(gh):
+                self._head()
+                if not self.pipelined:
+                    self.opt.step()
+            if self.pipelined:
+                self._grads = [p.grad for p in self.opt.params()]      # static tensors owned by the head graph's pool
+                with torch.cuda.graph(gs, pool=gh.pool()):
+                    self.opt.step()
+        finally:
+            lib.i2v_conv_set_split_slot(-1)
+        self.graph = (gbb, gh, gs) if self.pipelined else (gbb, gh)
+        with torch.cuda.stream(self.s_bb):
+            self.s_bb.wait_stream(torch.cuda.current_stream(self.dev))
+            gbb.replay()                    # feature map of the first timed step
+            self.ev_bb.record(self.s_bb)
+
+    def _call_overlapped(self):
+        gbb, gh = self.graph[0], self.graph[1]
+        cur = torch.cuda.current_stream(self.dev)
+        cur.wait_event(self.ev_bb)          # backbone(i) done
+        self.fmap_head.copy_(self.fmap)     # hand-off: 20 MB
+        self.ev_copy.record(cur)
+        with torch.cuda.stream(self.s_bb):
+            self.s_bb.wait_event(self.ev_copy)
+            gbb.replay()                    # backbone(i+1), beside ...
+            self.ev_bb.record(self.s_bb)
+        gh.replay()                         # ... head(i) fwd + bwd (+ SGD on one GPU)
+        if self.pipelined:
+            parallel.all_reduce_grads(self.opt.params())      # the exchange also runs beside the backbone stream
+            self.graph[2].replay()
+        return self.loss
+
     def __call__(self):
-        """One step.  Pipelined form (world > 1): head fwd+bwd on the feature map computed during the previous
-        call -> launch the gradient exchange -> backbone forward of the next minibatch (overlaps the
-        exchange; the frames are static here, in a training loop this is where the next batch goes) ->
-        wait -> SGD.  Every call does exactly one backbone pass, one head pass, one exchange, one update."""
+        """One step = one backbone pass, one head pass, one exchange (world > 1), one update.  Default: the backbone
+        pass is the NEXT minibatch's, on its own stream beside this step's head (``_capture_overlapped``; the frames
+        are static here, in a training loop that is where the next batch goes).  I2V_OVERLAP=0: everything on one
+        stream -- one graph on one GPU; head -> [exchange || backbone] -> SGD with world > 1."""
         if self.graph is None:
             self._body()
+        elif self.overlap:
+            return self._call_overlapped()
         elif len(self.graph) == 1:
             self.graph[0].replay()
         else:

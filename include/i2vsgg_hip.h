@@ -182,6 +182,10 @@ int32_t i2v_conv_fwd(const float* x, const float* w, const float* scale, const f
  * otherwise, < 0 on error. */
 int32_t i2v_conv_fwd_splits(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW,
                             int32_t stride, int32_t pad);
+/* The split-K workspace is one slab per stream.  Work that is captured on one stream but REPLAYED concurrently on
+ * several (two HIP graphs overlapped on two streams) must not share a slab: pin = 0 / 1 selects one of two reserved
+ * slabs for every following call of this process until pin = -1 restores keying by stream. */
+int32_t i2v_conv_set_split_slot(int32_t pin);
 /* tuning hook: cfg < 0 = cost model; else low byte = tile shape 0..5 (0xFF = cost model),
  * bits 8-9 = 0 auto / 1 plain 4-wave kernel / 2 loader+MFMA specialised 8-wave kernel */
 int32_t i2v_conv_set_tile(int32_t cfg);

@@ -277,29 +277,32 @@ def test_fused_wgrad_sgd_equals_separate_update(cfg):
     assert not np.array_equal(res[0][0], w0)
 
 
-def test_sgg_step_pipelined_schedule_matches_single_graph(cfg, monkeypatch):
-    """The multi-GPU schedule (backbone graph / head graph / exchange / SGD graph, with the backbone pass of the
-    next step issued before the update) computes the same losses and weights as the one-graph step."""
+def test_sgg_step_schedules_match_single_graph(cfg, monkeypatch):
+    """Every schedule of the step computes the losses and weights of the plain one-graph step:
+    overlap (default, one GPU): backbone graph of the next minibatch on its own stream beside the head+SGD graph;
+    split: the multi-GPU graph cut (backbone / head / SGD graphs, exchange launched eagerly between them), sequential
+    (I2V_OVERLAP=0: head -> [exchange || backbone] -> SGD) and overlapped (two streams)."""
     from i2vsgg_amd import train
-    res = []
-    for split in ("0", "1"):
+    res = {}
+    for overlap, split in (("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")):
+        monkeypatch.setenv("I2V_OVERLAP", overlap)
         monkeypatch.setenv("I2V_SPLIT_GRAPH", split)
         net = train.build_sgg_net(layers=50, seed=5, device=DEV)
         net.vrd.dropout = False
-        step = train.SGGEmbStep(net, 1, seed=3, device=DEV, h=200, w=320, n_boxes=6, n_pairs=5, fuse_sgd=False)
+        step = train.SGGEmbStep(net, 2, seed=3, device=DEV, h=200, w=320, n_boxes=6, n_pairs=5, fuse_sgd=(split == "0"))
         assert step.capture(warmup=1), getattr(step, "graph_error", None)
-        assert step.pipelined == (split == "1")
-        losses = []
-        for _ in range(3):
-            losses.append(float(step().item()))
+        assert step.pipelined == (split == "1") and step.overlap == (overlap == "1")
+        assert len(step.graph) == {("0", "0"): 1, ("1", "0"): 2, ("0", "1"): 3, ("1", "1"): 3}[(overlap, split)]
+        losses = [float(step().item()) for _ in range(4)]
         torch.cuda.synchronize()
-        res.append((losses, net.vrd.fc7.fc.weight.detach().cpu().numpy().copy()))
+        res[(overlap, split)] = (losses, net.vrd.fc7.fc.weight.detach().cpu().numpy().copy())
         step.opt.unfuse()
-    (l0, w0), (l1, w1) = res
-    assert l0[0] != l0[2]                                                     # the weights do move
-    for a, b in zip(l0, l1):
-        assert abs(a - b) <= 1e-5 * abs(a), (l0, l1)
-    assert _rel_err(w1, w0) < 1e-5
+    l0, w0 = res[("0", "0")]
+    assert l0[0] != l0[3]                                                     # the weights do move
+    for key, (l1, w1) in res.items():
+        for a, b in zip(l0, l1):
+            assert abs(a - b) <= 1e-5 * abs(a), (key, l0, l1)
+        assert _rel_err(w1, w0) < 1e-5, key
 
 
 def test_detect_frame_eval_loop_matches_oracle_postprocess(cfg):
