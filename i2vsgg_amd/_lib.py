@@ -36,6 +36,10 @@ SIGNATURES = {
     "i2v_bbox_overlaps": (_i, [_p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p]),
     "i2v_conv_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "i2v_conv_fwd_splits": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "i2v_gemm_nt_batched": (_i, [_p, _p, _p, _i, _i, _i, _i, _l, _l, _l, _p]),
+    "i2v_winograd_filter": (_i, [_p, _p, _i, _i, _p]),
+    "i2v_conv3x3_winograd_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
+    "i2v_conv3x3_winograd_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "i2v_conv_set_split_slot": (_i, [_i]),
     "i2v_conv_set_tile": (_i, [_i]),
     "i2v_conv_debug_clock": (_i, [_p]),

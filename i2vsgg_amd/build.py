@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libi2vsgg_hip.so")
-SOURCES = ["api.cpp", "roi_ops.hip", "rpn.hip", "conv.hip", "heads.hip", "image.hip"]
+SOURCES = ["api.cpp", "roi_ops.hip", "rpn.hip", "conv.hip", "heads.hip", "image.hip", "winograd.hip"]
 # -ffp-contract=off: box / IoU / ROIAlign arithmetic must round once per operation like the
 # reference's CPU path (no FMA contraction), or NMS threshold decisions can flip.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",

@@ -51,6 +51,8 @@ struct ConvP {
     unsigned long long* clk;     // diagnostic only (i2v_conv_debug_clock): per-workgroup {shader cycles, 100 MHz ticks}
     float* ws;                   // split-K partial tiles [split][tile][BM*BN] (nullptr: fp32 atomics into y)
     int* cnt;                    // split-K arrival counters, one per tile, zero between launches
+    int nbatch;                  // > 1: blockIdx.z selects one of nbatch independent GEMMs (Winograd planes)
+    long long bsx, bsw, bsy;     // element strides between the batches of x, w and y
 };
 
 __device__ inline void split_k(const ConvP& p, int k, int& ky, int& kx, int& c) {
@@ -74,7 +76,13 @@ __device__ inline void split_k(const ConvP& p, int k, int& ky, int& kx, int& c) 
 // beside its MFMA wave (VALU/VMEM and the matrix pipe issue independently).
 template <int WAVES_M, int WAVES_N, int TM, int TN, bool SPEC, int ABL = 0>
 __global__ void __launch_bounds__(SPEC ? 2 * THREADS : THREADS)
-conv_igemm_f32(const ConvP p) {
+conv_igemm_f32(const ConvP p_in) {
+    ConvP p = p_in;
+    if (p.nbatch > 1) {              // batched GEMM: same shapes, different operands (uniform: blockIdx.z)
+        p.x += (long long)blockIdx.z * p.bsx;
+        p.w += (long long)blockIdx.z * p.bsw;
+        p.y += (long long)blockIdx.z * p.bsy;
+    }
     constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
     constexpr int NT = SPEC ? 2 * THREADS : THREADS;      // threads per workgroup
     constexpr int A_LD = (BM * 8 + THREADS - 1) / THREADS, B_LD = (BN * 8 + THREADS - 1) / THREADS;
@@ -796,11 +804,12 @@ void launch_tile(const ConvP& p, bool spec, hipStream_t st) {
     }();
     (void)once;
     if constexpr (WAVES_M == 1) {      // diagnostic instantiations (tools/conv_ablate.py), 80x64 tile only
-        if ((p.ablate & 12) == 4) { conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false, 4><<<dim3(tiles, p.splitk), THREADS, lds, st>>>(p); return; }
-        if ((p.ablate & 12) == 12) { conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false, 12><<<dim3(tiles, p.splitk), THREADS, lds, st>>>(p); return; }
+        if ((p.ablate & 12) == 4) { conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false, 4><<<dim3(tiles, p.splitk, p.nbatch > 1 ? p.nbatch : 1), THREADS, lds, st>>>(p); return; }
+        if ((p.ablate & 12) == 12) { conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false, 12><<<dim3(tiles, p.splitk, p.nbatch > 1 ? p.nbatch : 1), THREADS, lds, st>>>(p); return; }
     }
-    if (spec) conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, true><<<dim3(tiles, p.splitk), 2 * THREADS, lds, st>>>(p);
-    else conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false><<<dim3(tiles, p.splitk), THREADS, lds, st>>>(p);
+    const dim3 grid(tiles, p.splitk, p.nbatch > 1 ? p.nbatch : 1);
+    if (spec) conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, true><<<grid, 2 * THREADS, lds, st>>>(p);
+    else conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false><<<grid, THREADS, lds, st>>>(p);
 }
 
 struct TileCfg { int bm, bn; float eff; };
@@ -837,9 +846,9 @@ int run_conv(ConvP p, hipStream_t st) {
     // The M of a 600x1000 frame pair at stride 16 is only 4788 rows, so wave quantisation decides
     // the shape; skinny GEMMs (vrd FCs: M = 128 rows) fill the chip by splitting K.
     auto plan = [&](int c, int& splitk) {
-        const long long t = (long long)i2v_cdiv(p.M, kTiles[c].bm) * i2v_cdiv(p.N, kTiles[c].bn);
+        const long long t = (long long)i2v_cdiv(p.M, kTiles[c].bm) * i2v_cdiv(p.N, kTiles[c].bn) * (p.nbatch > 1 ? p.nbatch : 1);
         splitk = 1;
-        if (t < g_split_below && ksteps >= 8 && p.ostride == 1) {
+        if (t < g_split_below && ksteps >= 8 && p.ostride == 1 && p.nbatch <= 1) {
             splitk = (int)((g_split_target * NUM_CU + t - 1) / t);
             splitk = splitk > ksteps / 4 ? ksteps / 4 : splitk;
             if (splitk < 1) splitk = 1;
@@ -1554,6 +1563,24 @@ extern "C" int32_t i2v_conv_fwd(const float* x, const float* w, const float* sca
     rc = run_conv(p, (hipStream_t)stream);
     if (rc) return rc;
     I2V_CHECK_LAUNCH("conv_fwd");
+    return I2V_OK;
+}
+
+// nbatch independent GEMMs of one shape in ONE launch: C_z (M x N) = A_z (M x K) * B_z (N x K)^T, fp32, operand z at
+// base + z * stride (elements).  The 16 element-wise planes of a Winograd convolution are such a batch.
+extern "C" int32_t i2v_gemm_nt_batched(const float* a, const float* b, float* c, int32_t M, int32_t N, int32_t K,
+                                       int32_t nbatch, int64_t stride_a, int64_t stride_b, int64_t stride_c, void* stream) {
+    I2V_CHECK_ARG(a && b && c && M > 0 && N > 0 && K > 0 && nbatch > 0 && nbatch <= 65535, "gemm_nt_batched: bad argument");
+    I2V_CHECK_ARG(K % 4 == 0, "gemm_nt_batched: K must be a multiple of 4");
+    ConvP p = {};
+    p.x = a; p.w = b; p.y = c;
+    p.B = 1; p.H = M; p.W = 1; p.Cin = K; p.Cout = N; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0; p.pad_x = 0;
+    p.Ho = M; p.Wo = 1; p.flags = 0; p.ostride = 1; p.Hy = M; p.Wy = 1;
+    p.force_tile = g_force_tile;
+    p.nbatch = nbatch; p.bsx = stride_a; p.bsw = stride_b; p.bsy = stride_c;
+    int rc = run_conv(p, (hipStream_t)stream);
+    if (rc) return rc;
+    I2V_CHECK_LAUNCH("gemm_nt_batched");
     return I2V_OK;
 }
 

@@ -1,0 +1,163 @@
+// Winograd F(2x2, 3x3) for the stride-1 / pad-1 3x3 convolutions of a FROZEN backbone (SGG_emb: the reference detaches
+// it, so the filters need no gradient and are transformed once).  The step is MFMA-throughput bound and the 23 layer3
+// 3x3 convolutions are 29 % of its MACs; Winograd does them with 2.25x fewer: per 2x2 output tile 16 multiplies per
+// (cin, cout) pair instead of 36.  fp32 throughout; the transform constants are 0, +-1, +-0.5, so the result differs
+// from the direct convolution by a few ulp-scale roundings (measured ~1e-6 relative).
+//
+//   U[xi][n][c]  = (G g G^T)[xi]            filter transform, once per filter (i2v_winograd_filter)
+//   V[xi][t][c]  = (B^T d B)[xi]            input transform of the 4x4 patch of tile t  (HBM/L2 streaming)
+//   M[xi][t][n]  = sum_c V[xi][t][c] U[xi][n][c]      16 independent (T x Cin) x (Cin x Cout) GEMMs, ONE launch
+//   y(tile t)    = A^T M[.][t][n] A          output transform + BN scale/shift + ReLU  (streaming)
+// xi = 4*row + col of the 4x4 transform domain.  Only the GEMM uses the matrix cores; the two transforms are
+// streaming kernels that overlap with MFMA work of the other stream.
+#include "common.h"
+
+extern "C" int32_t i2v_gemm_nt_batched(const float* a, const float* b, float* c, int32_t M, int32_t N, int32_t K,
+                                       int32_t nbatch, int64_t stride_a, int64_t stride_b, int64_t stride_c, void* stream);
+
+namespace {
+
+__device__ inline float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ inline float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+// one thread per (filter n, channel c): 9 taps -> 16 transform-domain values
+__global__ void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin) {
+    const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (idx >= (long long)Cout * Cin) return;
+    const int c = (int)(idx % Cin), n = (int)(idx / Cin);
+    float g[3][3];
+    for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) g[ky][kx] = w[(((long long)n * 3 + ky) * 3 + kx) * Cin + c];
+    float t[4][3];                      // G g : G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]
+    for (int kx = 0; kx < 3; ++kx) {
+        t[0][kx] = g[0][kx];
+        t[1][kx] = 0.5f * (g[0][kx] + g[1][kx] + g[2][kx]);
+        t[2][kx] = 0.5f * (g[0][kx] - g[1][kx] + g[2][kx]);
+        t[3][kx] = g[2][kx];
+    }
+    for (int r = 0; r < 4; ++r) {       // (G g) G^T
+        const float u0 = t[r][0], u1 = 0.5f * (t[r][0] + t[r][1] + t[r][2]), u2 = 0.5f * (t[r][0] - t[r][1] + t[r][2]),
+                    u3 = t[r][2];
+        const long long plane = (long long)Cout * Cin;
+        float* o = U + (long long)(4 * r) * plane + (long long)n * Cin + c;
+        o[0] = u0; o[plane] = u1; o[2 * plane] = u2; o[3 * plane] = u3;
+    }
+}
+
+// one thread per (tile, 4 channels): V = B^T d B,  B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+__global__ void __launch_bounds__(256)
+wino_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H, int W, int C, int th, int tw) {
+    const int c4n = C >> 2;
+    const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const long long T = (long long)B * th * tw;
+    if (idx >= T * c4n) return;
+    const int c = (int)(idx % c4n) * 4;
+    const long long t = idx / c4n;
+    const int tx = (int)(t % tw), ty = (int)((t / tw) % th), b = (int)(t / ((long long)tw * th));
+    float4 d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int iy = 2 * ty - 1 + r;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ix = 2 * tx - 1 + q;
+            d[r][q] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? *(const float4*)(x + (((long long)b * H + iy) * W + ix) * C + c)
+                                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    float4 m[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {       // B^T d (rows)
+        m[0][q] = f4sub(d[0][q], d[2][q]);
+        m[1][q] = f4add(d[1][q], d[2][q]);
+        m[2][q] = f4sub(d[2][q], d[1][q]);
+        m[3][q] = f4sub(d[1][q], d[3][q]);
+    }
+    const long long plane = T * C;
+    float* o = V + t * C + c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {       // (B^T d) B (columns)
+        *(float4*)(o + (long long)(4 * r + 0) * plane) = f4sub(m[r][0], m[r][2]);
+        *(float4*)(o + (long long)(4 * r + 1) * plane) = f4add(m[r][1], m[r][2]);
+        *(float4*)(o + (long long)(4 * r + 2) * plane) = f4sub(m[r][2], m[r][1]);
+        *(float4*)(o + (long long)(4 * r + 3) * plane) = f4sub(m[r][1], m[r][3]);
+    }
+}
+
+// one thread per (tile, 4 filters): Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1]; then scale/shift (frozen BN) and ReLU
+__global__ void __launch_bounds__(256)
+wino_output_kernel(const float* __restrict__ Mx, const float* __restrict__ scale, const float* __restrict__ shift,
+                   float* __restrict__ y, int B, int H, int W, int N, int th, int tw, int relu) {
+    const int n4n = N >> 2;
+    const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const long long T = (long long)B * th * tw;
+    if (idx >= T * n4n) return;
+    const int n = (int)(idx % n4n) * 4;
+    const long long t = idx / n4n;
+    const int tx = (int)(t % tw), ty = (int)((t / tw) % th), b = (int)(t / ((long long)tw * th));
+    const long long plane = T * N;
+    const float* src = Mx + t * N + n;
+    float4 s[2][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {       // A^T M (rows)
+        const float4 m0 = *(const float4*)(src + (long long)(0 + q) * plane), m1 = *(const float4*)(src + (long long)(4 + q) * plane);
+        const float4 m2 = *(const float4*)(src + (long long)(8 + q) * plane), m3 = *(const float4*)(src + (long long)(12 + q) * plane);
+        s[0][q] = f4add(f4add(m0, m1), m2);
+        s[1][q] = f4sub(f4sub(m1, m2), m3);
+    }
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (scale) sc = *(const float4*)(scale + n);
+    if (shift) sh = *(const float4*)(shift + n);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int oy = 2 * ty + r;
+        if (oy >= H) continue;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int ox = 2 * tx + q;
+            if (ox >= W) continue;
+            float4 v = q == 0 ? f4add(f4add(s[r][0], s[r][1]), s[r][2]) : f4sub(f4sub(s[r][1], s[r][2]), s[r][3]);
+            v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+            if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            *(float4*)(y + (((long long)b * H + oy) * W + ox) * N + n) = v;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int32_t i2v_winograd_filter(const float* w, float* U, int32_t Cout, int32_t Cin, void* stream) {
+    I2V_CHECK_ARG(w && U && Cout > 0 && Cin > 0, "winograd_filter: bad argument");
+    const long long n = (long long)Cout * Cin;
+    wino_filter_kernel<<<(unsigned)i2v_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(w, U, Cout, Cin);
+    I2V_CHECK_LAUNCH("winograd_filter");
+    return I2V_OK;
+}
+
+extern "C" size_t i2v_conv3x3_winograd_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 256;
+    const size_t T = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2);
+    return i2v_align(16 * T * Cin * sizeof(float)) + i2v_align(16 * T * Cout * sizeof(float));
+}
+
+extern "C" int32_t i2v_conv3x3_winograd_fwd(const float* x, const float* U, const float* scale, const float* shift,
+                                            float* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                                            int32_t relu, void* ws, size_t ws_bytes, void* stream) {
+    I2V_CHECK_ARG(x && U && y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_winograd_fwd: bad argument");
+    I2V_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0, "conv3x3_winograd_fwd: Cin and Cout must be multiples of 4");
+    if (!ws || ws_bytes < i2v_conv3x3_winograd_workspace_bytes(B, H, W, Cin, Cout)) {
+        i2v_set_error("conv3x3_winograd_fwd: workspace too small");
+        return I2V_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int th = (H + 1) / 2, tw = (W + 1) / 2;
+    const long long T = (long long)B * th * tw;
+    float* V = (float*)ws;
+    float* Mx = (float*)((char*)ws + i2v_align(16 * (size_t)T * Cin * sizeof(float)));
+    wino_input_kernel<<<(unsigned)i2v_cdiv(T * (Cin / 4), 256), 256, 0, st>>>(x, V, B, H, W, Cin, th, tw);
+    int rc = i2v_gemm_nt_batched(V, U, Mx, (int32_t)T, Cout, Cin, 16, T * Cin, (long long)Cout * Cin, T * Cout, stream);
+    if (rc) return rc;
+    wino_output_kernel<<<(unsigned)i2v_cdiv(T * (Cout / 4), 256), 256, 0, st>>>(Mx, scale, shift, y, B, H, W, Cout, th, tw, relu);
+    I2V_CHECK_LAUNCH("conv3x3_winograd_fwd");
+    return I2V_OK;
+}

@@ -7,6 +7,7 @@ K-major (Cout,KH,KW,Cin) filter layout of the GEMM.  Frozen BatchNorm (eval mode
 reference: resnet_instance_styleD_bilinear.py:405-411,433-439) is a per-channel scale/shift fused
 into the conv epilogue together with the residual add and the ReLU."""
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -72,6 +73,10 @@ class FrozenBN(nn.Module):
         return super()._apply(fn, *a, **k)
 
 
+WINOGRAD = os.environ.get("I2V_WINOGRAD", "1") != "0"
+WINOGRAD_MIN_CIN = 128           # layer2 / layer3 / layer4 (measured: the 64-channel layer1 3x3 is faster direct)
+
+
 class Bottleneck(nn.Module):
     """resnet_instance_styleD_bilinear.py:181-217: stride on the first 1x1 (caffe style)."""
     expansion = 4
@@ -87,12 +92,25 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
         self.stride = stride
 
+    def _winograd_filter(self):
+        w = self.conv2.weight
+        key = (w.data_ptr(), w._version, w.device)
+        if getattr(self, "_wino_key", None) != key:
+            with torch.no_grad():
+                self._wino_u, self._wino_key = ops.winograd_filter(w.detach()), key
+        return self._wino_u
+
     def forward(self, x):
         s1, b1 = self.bn1.folded()
         s2, b2 = self.bn2.folded()
         s3, b3 = self.bn3.folded()
         out = ops.conv2d(x, self.conv1.weight, s1, b1, None, self.stride, 0, relu=True)
-        out = ops.conv2d(out, self.conv2.weight, s2, b2, None, 1, 1, relu=True)
+        if WINOGRAD and not torch.is_grad_enabled() and self.conv2.cin >= WINOGRAD_MIN_CIN:
+            # no gradient is being recorded (the detached SGG_emb backbone, eval): the 3x3 runs as Winograd F(2x2,3x3)
+            # with the filter transformed once -- 2.25x fewer MACs (layer3: 63 -> 43 us per layer)
+            out = ops.conv3x3_winograd(out, self._winograd_filter(), s2, b2, relu=True)
+        else:
+            out = ops.conv2d(out, self.conv2.weight, s2, b2, None, 1, 1, relu=True)
         res = x
         if self.downsample is not None:
             sd, bd = self.downsample[1].folded()

@@ -701,3 +701,29 @@ class _BceRowsFn(torch.autograd.Function):
 def bce_rows(z, t, w):
     """sum_r w[r] * mean_c BCEWithLogits(z[r,c], t[r,c]) as one device scalar (forward and backward one kernel each)."""
     return _BceRowsFn.apply(z, t, w)
+
+
+def winograd_filter(w):
+    """(Cout,Cin,3,3) filter -> (16,Cout,Cin) Winograd-domain filter (done once for a frozen filter)."""
+    _need_cuda(w)
+    Cout, Cin, KH, KW = w.shape
+    if (KH, KW) != (3, 3):
+        raise ValueError("winograd_filter needs a 3x3 filter")
+    w = w.contiguous(memory_format=_CL)
+    U = torch.empty((16, Cout, Cin), device=w.device, dtype=torch.float32)
+    check(lib.i2v_winograd_filter(ptr(w), ptr(U), Cout, Cin, stream()), "winograd_filter")
+    return U
+
+
+def conv3x3_winograd(x, U, scale=None, shift=None, relu=False):
+    """stride-1 / pad-1 3x3 convolution with a pre-transformed frozen filter U (ops.winograd_filter); forward only."""
+    _need_cuda(x, U)
+    x = as_nhwc(x)
+    B, Cin, H, W = x.shape
+    Cout = U.shape[1]
+    y = torch.empty((B, Cout, H, W), device=x.device, dtype=torch.float32, memory_format=_CL)
+    ws = workspace(lib.i2v_conv3x3_winograd_workspace_bytes(B, H, W, Cin, Cout), x.device, "winograd")
+    with _Timed(2.0 * B * H * W * Cout * 9 * Cin, "fwd", "M%d N%d K%d (3x3 winograd)" % (B * H * W, Cout, 9 * Cin)):
+        check(lib.i2v_conv3x3_winograd_fwd(ptr(x), ptr(U), ptr(scale), ptr(shift), ptr(y), B, H, W, Cin, Cout, int(bool(relu)),
+                                           ptr(ws), ws.numel(), stream()), "conv3x3_winograd_fwd")
+    return y

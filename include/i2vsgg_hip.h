@@ -203,6 +203,22 @@ int32_t i2v_conv_wgrad(const float* x, const float* gy, float* gw, int32_t B, in
                        int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                        float beta, void* workspace, size_t workspace_bytes, void* stream);
 
+/* nbatch independent GEMMs of one shape in one launch: C_z (M x N) = A_z (M x K) * B_z (N x K)^T (fp32; operand z at
+ * base + z * stride elements; K % 4 == 0). */
+int32_t i2v_gemm_nt_batched(const float* a, const float* b, float* c, int32_t M, int32_t N, int32_t K, int32_t nbatch,
+                            int64_t stride_a, int64_t stride_b, int64_t stride_c, void* stream);
+
+/* Winograd F(2x2,3x3) forward for stride-1 / pad-1 3x3 convolutions whose filter is FROZEN (the SGG_emb backbone:
+ * resnet_instance_styleD_bilinear.py:197-217 under the detach of faster_rcnn_SGG_emb.py:148): 2.25x fewer MACs than
+ * the direct form.  i2v_winograd_filter transforms w (Cout,3,3,Cin) into U (16,Cout,Cin) once; the forward runs the
+ * input transform, ONE batched GEMM launch over the 16 planes and the output transform with the frozen-BN
+ * scale/shift (either may be NULL) and optional ReLU.  Same result as i2v_conv_fwd up to fp32 rounding (~1e-6 rel). */
+int32_t i2v_winograd_filter(const float* w, float* U, int32_t Cout, int32_t Cin, void* stream);
+size_t  i2v_conv3x3_winograd_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
+int32_t i2v_conv3x3_winograd_fwd(const float* x, const float* U, const float* scale, const float* shift, float* y,
+                                 int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t relu,
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
 /* wgrad with the SGD(momentum) step of that filter fused into the epilogue: w and m are updated in place and
  * the gradient is never written (g' = g + wd*w; m = mom*m + g'; w -= lr*m).  Only for shapes whose pixel
  * reduction needs no split (M <= 4096 and >= 512 filter tiles), else I2V_ERR_UNSUPPORTED. */

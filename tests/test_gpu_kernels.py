@@ -624,3 +624,27 @@ def test_l2norm_rows_and_bce_rows_vs_torch(ops):
     (loss * 0.5).backward()
     assert abs(loss.item() - ref.item()) <= 2e-6 * abs(ref.item())
     np.testing.assert_allclose(zd.grad.cpu().numpy(), zt.grad.numpy(), rtol=2e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("B,C,N,H,W", [(2, 256, 256, 38, 63), (1, 128, 128, 75, 125), (3, 64, 128, 7, 7), (1, 32, 16, 5, 6),
+                                        (2, 16, 32, 1, 1)])
+def test_winograd_3x3_vs_torch_fp32(ops, B, C, N, H, W):
+    """Winograd F(2x2,3x3) forward (frozen-filter 3x3 stride-1 pad-1 convolutions) == torch fp32 conv2d + frozen-BN
+    scale/shift + ReLU, on even / odd / tiny spatial sizes (the last tile row / column is partial when H or W is odd)."""
+    rng = np.random.default_rng(B * 1000 + C + H)
+    x = rng.standard_normal((B, C, H, W), dtype=np.float32)
+    w = (rng.standard_normal((N, C, 3, 3), dtype=np.float32) / np.sqrt(9 * C)).astype(np.float32)
+    sc = rng.uniform(0.5, 1.5, N).astype(np.float32)
+    sh = rng.uniform(-0.5, 0.5, N).astype(np.float32)
+    ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), padding=1)
+    xd = torch.from_numpy(x).to(DEV)
+    U = ops.winograd_filter(torch.from_numpy(w).to(DEV))
+    assert U.shape == (16, N, C)
+    y = ops.conv3x3_winograd(xd, U)
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), rtol=2e-5, atol=2e-5)
+    y = ops.conv3x3_winograd(xd, U, torch.from_numpy(sc).to(DEV), torch.from_numpy(sh).to(DEV), relu=True)
+    r2 = F.relu(ref * torch.from_numpy(sc).view(1, -1, 1, 1) + torch.from_numpy(sh).view(1, -1, 1, 1))
+    np.testing.assert_allclose(y.cpu().numpy(), r2.numpy(), rtol=2e-5, atol=2e-5)
+    # and the same numbers as the direct implicit-GEMM path, to rounding
+    d = ops.conv2d(xd, torch.from_numpy(w).to(DEV), torch.from_numpy(sc).to(DEV), torch.from_numpy(sh).to(DEV), None, 1, 1, relu=True)
+    np.testing.assert_allclose(y.cpu().numpy(), d.cpu().numpy(), rtol=2e-5, atol=2e-5)
