@@ -113,8 +113,9 @@ def main():
         d = by_tag.setdefault(tag, [0.0, 0.0, 0])
         d[0] += e0.elapsed_time(e1) * 1e-3; d[1] += fl; d[2] += 1
     achieved = f_conv / t_conv / 1e12
-    # the same calls counted by the MACs the matrix cores actually execute (Winograd F(2x2,3x3): 16/36 of the direct count)
-    f_exec = sum((fl * 16.0 / 36.0 if "winograd" in d else fl) for e0, e1, fl, tag, d in rec if tag in ("fwd", "dgrad"))
+    # the same calls counted by the MACs the matrix cores actually execute (Winograd F(4x4,3x3): 9/36 of the direct count)
+    f_exec = sum((fl * (9.0 / 36.0 if "winograd F4" in d else 16.0 / 36.0 if "winograd" in d else 1.0))
+                 for e0, e1, fl, tag, d in rec if tag in ("fwd", "dgrad"))
     achieved_exec = f_exec / t_conv / 1e12
     if a.dump_launches and rank == 0:
         per = len(rec) // n_prof
@@ -155,8 +156,8 @@ def main():
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "note": ("achieved = ALGORITHMIC FLOPs (2*M*N*K of the direct convolution / linear layer) of every i2v_conv_fwd, "
-                              "_dgrad and Winograd call / their summed durations; the 27 frozen 3x3 layers of layer2-3 run as "
-                              "Winograd F(2x2,3x3) (transforms + one batched conv_igemm_f32 launch) and execute 2.25x fewer MACs "
+                              "_dgrad and Winograd call / their summed durations; the 30 frozen 3x3 layers of layer1-3 run as "
+                              "Winograd F(4x4,3x3) (transforms + one batched conv_igemm_f32 launch) and execute 4x fewer MACs "
                               "than that count"),
                      "executed_mfma_tflops": achieved_exec, "executed_mfma_frac": achieved_exec / MFMA_F32_PEAK_TFLOPS,
                      "algorithmic_bytes_per_launch": 4.8e9 / 117,

@@ -124,6 +124,124 @@ wino_output_kernel(const float* __restrict__ Mx, const float* __restrict__ scale
     }
 }
 
+
+// ---------------------------------------------------------------- F(4x4, 3x3): 36 multiplies per 16 outputs (4x fewer
+// than direct).  Lavin & Gray's matrices; fp32 error ~1e-5 relative (measured on the backbone shapes) because the
+// transform constants reach 8 and 1/24.  One thread per (tile, channel): a 6x6 patch held as scalars.
+__device__ inline void bt6(const float d[6], float t[6]) {           // B^T d
+    t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+    t[1] = -4.f * d[1] - 4.f * d[2] + d[3] + d[4];
+    t[2] = 4.f * d[1] - 4.f * d[2] - d[3] + d[4];
+    t[3] = -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
+    t[4] = 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
+    t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+__device__ inline void at6(const float m[6], float s[4]) {           // A^T m
+    s[0] = m[0] + m[1] + m[2] + m[3] + m[4];
+    s[1] = m[1] - m[2] + 2.f * m[3] - 2.f * m[4];
+    s[2] = m[1] + m[2] + 4.f * m[3] + 4.f * m[4];
+    s[3] = m[1] - m[2] + 8.f * m[3] - 8.f * m[4] + m[5];
+}
+__device__ inline void g6(const float g[3], float u[6]) {            // G g
+    u[0] = 0.25f * g[0];
+    u[1] = (-1.f / 6.f) * (g[0] + g[1] + g[2]);
+    u[2] = (-1.f / 6.f) * (g[0] - g[1] + g[2]);
+    u[3] = (1.f / 24.f) * g[0] + (1.f / 12.f) * g[1] + (1.f / 6.f) * g[2];
+    u[4] = (1.f / 24.f) * g[0] - (1.f / 12.f) * g[1] + (1.f / 6.f) * g[2];
+    u[5] = g[2];
+}
+
+__global__ void wino4_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin) {
+    const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (idx >= (long long)Cout * Cin) return;
+    const int c = (int)(idx % Cin), n = (int)(idx / Cin);
+    float t[6][3];
+    for (int kx = 0; kx < 3; ++kx) {
+        float g[3], u[6];
+        for (int ky = 0; ky < 3; ++ky) g[ky] = w[(((long long)n * 3 + ky) * 3 + kx) * Cin + c];
+        g6(g, u);
+        for (int r = 0; r < 6; ++r) t[r][kx] = u[r];
+    }
+    const long long plane = (long long)Cout * Cin;
+    for (int r = 0; r < 6; ++r) {
+        float u[6];
+        g6(t[r], u);
+        for (int q = 0; q < 6; ++q) U[(long long)(6 * r + q) * plane + (long long)n * Cin + c] = u[q];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+wino4_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H, int W, int C, int th, int tw) {
+    const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const long long T = (long long)B * th * tw;
+    if (idx >= T * C) return;
+    const int c = (int)(idx % C);
+    const long long t = idx / C;
+    const int tx = (int)(t % tw), ty = (int)((t / tw) % th), b = (int)(t / ((long long)tw * th));
+    float m[6][6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {               // column q of the patch through B^T (rows)
+        const int ix = 4 * tx - 1 + q;
+        float d[6], tt[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int iy = 4 * ty - 1 + r;
+            d[r] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((long long)b * H + iy) * W + ix) * C + c] : 0.f;
+        }
+        bt6(d, tt);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) m[r][q] = tt[r];
+    }
+    const long long plane = T * C;
+    float* o = V + t * C + c;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        float v[6];
+        bt6(m[r], v);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) o[(long long)(6 * r + q) * plane] = v[q];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+wino4_output_kernel(const float* __restrict__ Mx, const float* __restrict__ scale, const float* __restrict__ shift,
+                    float* __restrict__ y, int B, int H, int W, int N, int th, int tw, int relu) {
+    const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const long long T = (long long)B * th * tw;
+    if (idx >= T * N) return;
+    const int n = (int)(idx % N);
+    const long long t = idx / N;
+    const int tx = (int)(t % tw), ty = (int)((t / tw) % th), b = (int)(t / ((long long)tw * th));
+    const long long plane = T * N;
+    const float* src = Mx + t * N + n;
+    float s[4][6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        float m[6], ss[4];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) m[r] = src[(long long)(6 * r + q) * plane];
+        at6(m, ss);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r][q] = ss[r];
+    }
+    const float sc = scale ? scale[n] : 1.f, sh = shift ? shift[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int oy = 4 * ty + r;
+        float o[4];
+        at6(s[r], o);
+        if (oy >= H) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int ox = 4 * tx + q;
+            if (ox >= W) continue;
+            float v = o[q] * sc + sh;
+            if (relu) v = fmaxf(v, 0.f);
+            y[(((long long)b * H + oy) * W + ox) * N + n] = v;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int32_t i2v_winograd_filter(const float* w, float* U, int32_t Cout, int32_t Cin, void* stream) {
@@ -159,5 +277,42 @@ extern "C" int32_t i2v_conv3x3_winograd_fwd(const float* x, const float* U, cons
     if (rc) return rc;
     wino_output_kernel<<<(unsigned)i2v_cdiv(T * (Cout / 4), 256), 256, 0, st>>>(Mx, scale, shift, y, B, H, W, Cout, th, tw, relu);
     I2V_CHECK_LAUNCH("conv3x3_winograd_fwd");
+    return I2V_OK;
+}
+
+// ---- F(4x4,3x3) entry points (variant = 4): same contract, U is (36, Cout, Cin)
+extern "C" int32_t i2v_winograd4_filter(const float* w, float* U, int32_t Cout, int32_t Cin, void* stream) {
+    I2V_CHECK_ARG(w && U && Cout > 0 && Cin > 0, "winograd4_filter: bad argument");
+    const long long n = (long long)Cout * Cin;
+    wino4_filter_kernel<<<(unsigned)i2v_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(w, U, Cout, Cin);
+    I2V_CHECK_LAUNCH("winograd4_filter");
+    return I2V_OK;
+}
+
+extern "C" size_t i2v_conv3x3_winograd4_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 256;
+    const size_t T = (size_t)B * ((H + 3) / 4) * ((W + 3) / 4);
+    return i2v_align(36 * T * Cin * sizeof(float)) + i2v_align(36 * T * Cout * sizeof(float));
+}
+
+extern "C" int32_t i2v_conv3x3_winograd4_fwd(const float* x, const float* U, const float* scale, const float* shift,
+                                             float* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                                             int32_t relu, void* ws, size_t ws_bytes, void* stream) {
+    I2V_CHECK_ARG(x && U && y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_winograd4_fwd: bad argument");
+    I2V_CHECK_ARG(Cin % 4 == 0, "conv3x3_winograd4_fwd: Cin must be a multiple of 4");
+    if (!ws || ws_bytes < i2v_conv3x3_winograd4_workspace_bytes(B, H, W, Cin, Cout)) {
+        i2v_set_error("conv3x3_winograd4_fwd: workspace too small");
+        return I2V_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int th = (H + 3) / 4, tw = (W + 3) / 4;
+    const long long T = (long long)B * th * tw;
+    float* V = (float*)ws;
+    float* Mx = (float*)((char*)ws + i2v_align(36 * (size_t)T * Cin * sizeof(float)));
+    wino4_input_kernel<<<(unsigned)i2v_cdiv(T * Cin, 256), 256, 0, st>>>(x, V, B, H, W, Cin, th, tw);
+    int rc = i2v_gemm_nt_batched(V, U, Mx, (int32_t)T, Cout, Cin, 36, T * Cin, (long long)Cout * Cin, T * Cout, stream);
+    if (rc) return rc;
+    wino4_output_kernel<<<(unsigned)i2v_cdiv(T * Cout, 256), 256, 0, st>>>(Mx, scale, shift, y, B, H, W, Cout, th, tw, relu);
+    I2V_CHECK_LAUNCH("conv3x3_winograd4_fwd");
     return I2V_OK;
 }

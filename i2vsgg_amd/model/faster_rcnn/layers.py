@@ -73,8 +73,10 @@ class FrozenBN(nn.Module):
         return super()._apply(fn, *a, **k)
 
 
-WINOGRAD = os.environ.get("I2V_WINOGRAD", "1") != "0"
-WINOGRAD_MIN_CIN = 128           # layer2 / layer3 / layer4 (measured: the 64-channel layer1 3x3 is faster direct)
+# I2V_WINOGRAD: 0 = direct 3x3, 2 = F(2x2,3x3) (fp32 error ~1e-6 like the direct kernel), 4 (default) = F(4x4,3x3) (4x fewer
+# MACs, error ~1e-5 per layer: what cuDNN's fp32 WINOGRAD_NONFUSED does for the reference's 3x3 layers)
+WINOGRAD = int(os.environ.get("I2V_WINOGRAD", "4"))
+WINOGRAD_MIN_CIN = {0: 1 << 30, 2: 128, 4: 64}[WINOGRAD]      # measured: F(2x2) loses to direct at 64 channels, F(4x4) wins
 
 
 class Bottleneck(nn.Module):
@@ -97,7 +99,7 @@ class Bottleneck(nn.Module):
         key = (w.data_ptr(), w._version, w.device)
         if getattr(self, "_wino_key", None) != key:
             with torch.no_grad():
-                self._wino_u, self._wino_key = ops.winograd_filter(w.detach()), key
+                self._wino_u, self._wino_key = ops.winograd_filter(w.detach(), WINOGRAD), key
         return self._wino_u
 
     def forward(self, x):
@@ -107,7 +109,7 @@ class Bottleneck(nn.Module):
         out = ops.conv2d(x, self.conv1.weight, s1, b1, None, self.stride, 0, relu=True)
         if WINOGRAD and not torch.is_grad_enabled() and self.conv2.cin >= WINOGRAD_MIN_CIN:
             # no gradient is being recorded (the detached SGG_emb backbone, eval): the 3x3 runs as Winograd F(2x2,3x3)
-            # with the filter transformed once -- 2.25x fewer MACs (layer3: 63 -> 43 us per layer)
+            # with the filter transformed once -- 4x fewer MACs with F(4x4,3x3) (layer3: 63 -> 37 us per layer)
             out = ops.conv3x3_winograd(out, self._winograd_filter(), s2, b2, relu=True)
         else:
             out = ops.conv2d(out, self.conv2.weight, s2, b2, None, 1, 1, relu=True)

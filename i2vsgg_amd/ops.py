@@ -703,15 +703,17 @@ def bce_rows(z, t, w):
     return _BceRowsFn.apply(z, t, w)
 
 
-def winograd_filter(w):
-    """(Cout,Cin,3,3) filter -> (16,Cout,Cin) Winograd-domain filter (done once for a frozen filter)."""
+def winograd_filter(w, m=2):
+    """(Cout,Cin,3,3) filter -> Winograd-domain filter, done once for a frozen filter: (16,Cout,Cin) for F(2x2,3x3)
+    (``m=2``), (36,Cout,Cin) for F(4x4,3x3) (``m=4``)."""
     _need_cuda(w)
     Cout, Cin, KH, KW = w.shape
-    if (KH, KW) != (3, 3):
-        raise ValueError("winograd_filter needs a 3x3 filter")
+    if (KH, KW) != (3, 3) or m not in (2, 4):
+        raise ValueError("winograd_filter needs a 3x3 filter and m in (2, 4)")
     w = w.contiguous(memory_format=_CL)
-    U = torch.empty((16, Cout, Cin), device=w.device, dtype=torch.float32)
-    check(lib.i2v_winograd_filter(ptr(w), ptr(U), Cout, Cin, stream()), "winograd_filter")
+    U = torch.empty(((m + 2) ** 2, Cout, Cin), device=w.device, dtype=torch.float32)
+    fn = lib.i2v_winograd_filter if m == 2 else lib.i2v_winograd4_filter
+    check(fn(ptr(w), ptr(U), Cout, Cin, stream()), "winograd_filter")
     return U
 
 
@@ -722,8 +724,12 @@ def conv3x3_winograd(x, U, scale=None, shift=None, relu=False):
     B, Cin, H, W = x.shape
     Cout = U.shape[1]
     y = torch.empty((B, Cout, H, W), device=x.device, dtype=torch.float32, memory_format=_CL)
-    ws = workspace(lib.i2v_conv3x3_winograd_workspace_bytes(B, H, W, Cin, Cout), x.device, "winograd")
-    with _Timed(2.0 * B * H * W * Cout * 9 * Cin, "fwd", "M%d N%d K%d (3x3 winograd)" % (B * H * W, Cout, 9 * Cin)):
-        check(lib.i2v_conv3x3_winograd_fwd(ptr(x), ptr(U), ptr(scale), ptr(shift), ptr(y), B, H, W, Cin, Cout, int(bool(relu)),
-                                           ptr(ws), ws.numel(), stream()), "conv3x3_winograd_fwd")
+    four = U.shape[0] == 36          # F(4x4,3x3)
+    wsb = (lib.i2v_conv3x3_winograd4_workspace_bytes if four else lib.i2v_conv3x3_winograd_workspace_bytes)(B, H, W, Cin, Cout)
+    ws = workspace(wsb, x.device, "winograd")
+    fn = lib.i2v_conv3x3_winograd4_fwd if four else lib.i2v_conv3x3_winograd_fwd
+    with _Timed(2.0 * B * H * W * Cout * 9 * Cin, "fwd",
+                "M%d N%d K%d (3x3 winograd F%d)" % (B * H * W, Cout, 9 * Cin, 4 if four else 2)):
+        check(fn(ptr(x), ptr(U), ptr(scale), ptr(shift), ptr(y), B, H, W, Cin, Cout, int(bool(relu)), ptr(ws), ws.numel(),
+                 stream()), "conv3x3_winograd_fwd")
     return y

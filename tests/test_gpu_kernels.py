@@ -648,3 +648,8 @@ def test_winograd_3x3_vs_torch_fp32(ops, B, C, N, H, W):
     # and the same numbers as the direct implicit-GEMM path, to rounding
     d = ops.conv2d(xd, torch.from_numpy(w).to(DEV), torch.from_numpy(sc).to(DEV), torch.from_numpy(sh).to(DEV), None, 1, 1, relu=True)
     np.testing.assert_allclose(y.cpu().numpy(), d.cpu().numpy(), rtol=2e-5, atol=2e-5)
+    # F(4x4,3x3): 4x fewer MACs, transform constants up to 8 and 1/24 -> ~1e-5 of the output scale
+    U4 = ops.winograd_filter(torch.from_numpy(w).to(DEV), 4)
+    assert U4.shape == (36, N, C)
+    y4 = ops.conv3x3_winograd(xd, U4, torch.from_numpy(sc).to(DEV), torch.from_numpy(sh).to(DEV), relu=True)
+    assert np.abs(y4.cpu().numpy() - r2.numpy()).max() <= 1e-4 * max(np.abs(r2.numpy()).max(), 1.0)
