@@ -239,6 +239,114 @@ __global__ void roi_pool_bwd_kernel(const float* __restrict__ gout, const int* _
     }
 }
 
+// ---------------------------------------------------------------- ROIAlign, sampled (model._C)
+// roi_layers.ROIAlign of the SGG_emb model (roi_layers/roi_align.py:20,:31 -> model._C, the maskrcnn-benchmark
+// csrc; source absent from the reference tree, algorithm restated from the published ROIAlign_cuda.cu): no +1 on
+// the ROI extent, extent clamped to >= 1, each bin is the mean of a gh x gw grid of bilinear samples (gh =
+// sampling_ratio, or ceil(extent / pooled) when sampling_ratio <= 0), a sample more than a pixel outside the map
+// contributes 0 and coordinates clamp at the borders.  fp32 throughout, one rounding per op.
+struct RasGeom { float y0, x0, bh, bw; int gh, gw; };
+
+__device__ inline RasGeom ras_geometry(const float* roi, float scale, int PH, int PW, int sampling) {
+    RasGeom g;
+    const float x1 = roi[1] * scale, y1 = roi[2] * scale, x2 = roi[3] * scale, y2 = roi[4] * scale;
+    const float rw = fmaxf(x2 - x1, 1.f), rh = fmaxf(y2 - y1, 1.f);
+    g.x0 = x1; g.y0 = y1;
+    g.bh = rh / (float)PH; g.bw = rw / (float)PW;
+    g.gh = sampling > 0 ? sampling : (int)ceilf(rh / (float)PH);
+    g.gw = sampling > 0 ? sampling : (int)ceilf(rw / (float)PW);
+    return g;
+}
+
+struct RasTaps { int ok, yl, xl, yh, xh; float w0, w1, w2, w3; };
+
+__device__ inline RasTaps ras_taps(int H, int W, float y, float x) {
+    RasTaps t;
+    t.ok = !(y < -1.0f || y > (float)H || x < -1.0f || x > (float)W);
+    if (y <= 0) y = 0;
+    if (x <= 0) x = 0;
+    t.yl = (int)y; t.xl = (int)x;
+    if (t.yl >= H - 1) { t.yh = t.yl = H - 1; y = (float)t.yl; } else t.yh = t.yl + 1;
+    if (t.xl >= W - 1) { t.xh = t.xl = W - 1; x = (float)t.xl; } else t.xh = t.xl + 1;
+    const float ly = y - (float)t.yl, lx = x - (float)t.xl, hy = 1.f - ly, hx = 1.f - lx;
+    t.w0 = hy * hx; t.w1 = hy * lx; t.w2 = ly * hx; t.w3 = ly * lx;
+    if (!t.ok) t.yl = t.xl = t.yh = t.xh = 0;
+    return t;
+}
+
+// grid = R*PH*PW blocks (one output bin), lanes run over channels (VEC = 4: NHWC map, 16 B per lane and tap).
+template <int VEC>
+__global__ void __launch_bounds__(256)
+roi_align_sampled_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
+                             int B, int C, int H, int W, int PH, int PW, float scale, int sampling, Strides fs,
+                             Strides os) {
+    const int pw = blockIdx.x % PW, ph = (blockIdx.x / PW) % PH, r = blockIdx.x / (PW * PH);
+    const float* roi = rois + 5 * (long long)r;
+    const int b = (int)roi[0];
+    const bool live = b >= 0 && b < B;
+    const RasGeom g = ras_geometry(roi, scale, PH, PW, sampling);
+    const float count = (float)(g.gh * g.gw);
+    const float* fb = feat + (long long)(live ? b : 0) * fs.b;
+    for (int c = threadIdx.x * VEC; c < C; c += blockDim.x * VEC) {
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+        for (int iy = 0; live && iy < g.gh; ++iy) {
+            const float y = g.y0 + (float)ph * g.bh + ((float)iy + .5f) * g.bh / (float)g.gh;
+            for (int ix = 0; ix < g.gw; ++ix) {
+                const float x = g.x0 + (float)pw * g.bw + ((float)ix + .5f) * g.bw / (float)g.gw;
+                const RasTaps t = ras_taps(H, W, y, x);
+                if (!t.ok) continue;
+                const float* p = fb + c * fs.c;
+                float v0[VEC], v1[VEC], v2[VEC], v3[VEC];
+                if (VEC == 4) {
+                    *(float4*)v0 = *(const float4*)(p + t.yl * fs.h + t.xl * fs.w);
+                    *(float4*)v1 = *(const float4*)(p + t.yl * fs.h + t.xh * fs.w);
+                    *(float4*)v2 = *(const float4*)(p + t.yh * fs.h + t.xl * fs.w);
+                    *(float4*)v3 = *(const float4*)(p + t.yh * fs.h + t.xh * fs.w);
+                } else {
+                    v0[0] = p[t.yl * fs.h + t.xl * fs.w]; v1[0] = p[t.yl * fs.h + t.xh * fs.w];
+                    v2[0] = p[t.yh * fs.h + t.xl * fs.w]; v3[0] = p[t.yh * fs.h + t.xh * fs.w];
+                }
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) acc[k] += t.w0 * v0[k] + t.w1 * v1[k] + t.w2 * v2[k] + t.w3 * v3[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) out[r * os.b + (c + k) * os.c + ph * os.h + pw * os.w] = acc[k] / count;
+    }
+}
+
+// backward: same decomposition, fp32 atomics on the map gradient (RoIAlignBackwardFeature); summation order free.
+__global__ void __launch_bounds__(256)
+roi_align_sampled_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gfeat,
+                             int B, int C, int H, int W, int PH, int PW, float scale, int sampling, Strides fs,
+                             Strides os) {
+    const int pw = blockIdx.x % PW, ph = (blockIdx.x / PW) % PH, r = blockIdx.x / (PW * PH);
+    const float* roi = rois + 5 * (long long)r;
+    const int b = (int)roi[0];
+    if (b < 0 || b >= B) return;
+    const RasGeom g = ras_geometry(roi, scale, PH, PW, sampling);
+    const float count = (float)(g.gh * g.gw);
+    float* fb = gfeat + (long long)b * fs.b;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float top = gout[r * os.b + c * os.c + ph * os.h + pw * os.w];
+        float* p = fb + c * fs.c;
+        for (int iy = 0; iy < g.gh; ++iy) {
+            const float y = g.y0 + (float)ph * g.bh + ((float)iy + .5f) * g.bh / (float)g.gh;
+            for (int ix = 0; ix < g.gw; ++ix) {
+                const float x = g.x0 + (float)pw * g.bw + ((float)ix + .5f) * g.bw / (float)g.gw;
+                const RasTaps t = ras_taps(H, W, y, x);
+                if (!t.ok) continue;
+                atomicAdd(p + t.yl * fs.h + t.xl * fs.w, top * t.w0 / count);
+                atomicAdd(p + t.yl * fs.h + t.xh * fs.w, top * t.w1 / count);
+                atomicAdd(p + t.yh * fs.h + t.xl * fs.w, top * t.w2 / count);
+                atomicAdd(p + t.yh * fs.h + t.xh * fs.w, top * t.w3 / count);
+            }
+        }
+    }
+}
+
 inline Strides out_strides(int layout, int C, int PH, int PW) {
     Strides s;
     if (layout == I2V_LAYOUT_NHWC) { s.c = 1; s.w = C; s.h = (long long)PW * C; s.b = (long long)PH * PW * C; }
@@ -316,5 +424,40 @@ extern "C" int32_t i2v_roi_pool_bwd(const float* gout, const int32_t* argmax, in
     roi_pool_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(gout, argmax, rois, gfeat, total, C, W, PH * PW, fs,
                                                                 out_layout == I2V_LAYOUT_NCHW);
     I2V_CHECK_LAUNCH("roi_pool_bwd");
+    return I2V_OK;
+}
+
+extern "C" int32_t i2v_roi_align_sampled_fwd(const float* feat, int32_t feat_layout, int32_t B, int32_t C, int32_t H,
+                                             int32_t W, const float* rois, int32_t R, int32_t PH, int32_t PW,
+                                             float scale, int32_t sampling_ratio, float* out, int32_t out_layout,
+                                             void* stream) {
+    if (R == 0) return I2V_OK;
+    I2V_CHECK_ARG(feat && rois && out, "roi_align_sampled_fwd: null pointer");
+    I2V_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && R >= 0 && PH > 0 && PW > 0, "roi_align_sampled_fwd: bad shape");
+    I2V_CHECK_ARG((long long)R * PH * PW < (1ll << 31), "roi_align_sampled_fwd: too many bins for one launch");
+    Strides fs = feat_strides(feat_layout, C, H, W), os = out_strides(out_layout, C, PH, PW);
+    const int grid = R * PH * PW;
+    if (feat_layout == I2V_LAYOUT_NHWC && (C % 4) == 0)
+        roi_align_sampled_fwd_kernel<4><<<grid, 256, 0, (hipStream_t)stream>>>(feat, rois, out, B, C, H, W, PH, PW, scale,
+                                                                               sampling_ratio, fs, os);
+    else
+        roi_align_sampled_fwd_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(feat, rois, out, B, C, H, W, PH, PW, scale,
+                                                                               sampling_ratio, fs, os);
+    I2V_CHECK_LAUNCH("roi_align_sampled_fwd");
+    return I2V_OK;
+}
+
+extern "C" int32_t i2v_roi_align_sampled_bwd(const float* gout, int32_t out_layout, const float* rois, int32_t R,
+                                             int32_t PH, int32_t PW, float scale, int32_t sampling_ratio, float* gfeat,
+                                             int32_t feat_layout, int32_t B, int32_t C, int32_t H, int32_t W,
+                                             void* stream) {
+    if (R == 0) return I2V_OK;
+    I2V_CHECK_ARG(gout && rois && gfeat, "roi_align_sampled_bwd: null pointer");
+    I2V_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && R >= 0 && PH > 0 && PW > 0, "roi_align_sampled_bwd: bad shape");
+    I2V_CHECK_ARG((long long)R * PH * PW < (1ll << 31), "roi_align_sampled_bwd: too many bins for one launch");
+    Strides fs = feat_strides(feat_layout, C, H, W), os = out_strides(out_layout, C, PH, PW);
+    roi_align_sampled_bwd_kernel<<<R * PH * PW, 256, 0, (hipStream_t)stream>>>(gout, rois, gfeat, B, C, H, W, PH, PW, scale,
+                                                                              sampling_ratio, fs, os);
+    I2V_CHECK_LAUNCH("roi_align_sampled_bwd");
     return I2V_OK;
 }

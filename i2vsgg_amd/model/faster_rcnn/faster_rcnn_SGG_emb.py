@@ -10,7 +10,9 @@ reference's arithmetic) and the dual masks are rasterised on the device from the
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
+from ..roi_layers import ROIAlign, ROIPool
 from ..rpn.proposal_target_layer_cascade import _ProposalTargetLayer
 from ..rpn.rpn import _RPN
 from ..utils.config import cfg
@@ -87,6 +89,8 @@ class _fasterRCNN(nn.Module):
         self.args = args
         self.RCNN_rpn = _RPN(self.dout_base_model)       # constructed, unused by forward (as in the reference)
         self.RCNN_proposal_target = _ProposalTargetLayer(self.n_classes)
+        self.RCNN_roi_pool = ROIPool((cfg.POOLING_SIZE, cfg.POOLING_SIZE), 1.0 / 16.0, out_nchw=False)    # :46
+        self.RCNN_roi_align = ROIAlign((cfg.POOLING_SIZE, cfg.POOLING_SIZE), 1.0 / 16.0, 0)               # :47
 
     def forward(self, im_data, im_info, gt_boxes, num_boxes, im_path, target=False):
         with torch.no_grad():                            # base_feat.detach() of the reference (:148)
@@ -137,6 +141,30 @@ class _fasterRCNN(nn.Module):
             self.vrd.train(was_training)
         return {"ixs": ixs, "ixo": ixo, "bboxes": detected, "classes": classes, "scores": scores, "rel_score": rel_score,
                 "pre_feat": pre_feat, "rel_so_prior": rel_so_prior}
+
+    def _rois_of(self, bboxes, device):
+        b = bboxes.detach().float().cpu().numpy() if torch.is_tensor(bboxes) else np.asarray(bboxes, np.float32)
+        b = b.reshape(-1, 4)
+        return torch.from_numpy(np.hstack((np.zeros((b.shape[0], 1), np.float32), b.astype(np.float32)))).to(device)
+
+    @torch.no_grad()
+    def _extract_feature(self, base_feat, bboxes):
+        """:381-392: ROIAlign (sampling grid, ``roi_layers.ROIAlign``) of frame 0 at ``bboxes`` (n,4, network-input
+        pixels) -> layer4 -> spatial mean; returns the (n,2048) features as a numpy array like the reference."""
+        if not torch.is_tensor(base_feat):
+            base_feat = torch.from_numpy(np.asarray(base_feat, np.float32)).to(self.RCNN_cls_score.weight.device)
+        pooled = self.RCNN_roi_align(base_feat, self._rois_of(bboxes, base_feat.device))
+        return self._head_to_tail(pooled).detach().cpu().numpy()
+
+    @torch.no_grad()
+    def classify_boxes(self, base_feat, bboxes):
+        """Box classification of the eval branch of forward_predicate (:278-291): ROIAlign -> ``_head_to_tail`` ->
+        ``RCNN_cls_score`` -> softmax with the background column zeroed -> (classes, confs) per box."""
+        pooled = self.RCNN_roi_align(base_feat, self._rois_of(bboxes, base_feat.device))
+        prob = F.softmax(self.RCNN_cls_score(self._head_to_tail(pooled)), 1)
+        prob[:, 0] = 0.0
+        conf, cls = prob.max(1)
+        return cls.cpu().numpy(), conf.cpu().numpy()
 
     def forward_predicate(self, fmap, im_info, im_path):
         paths = [im_path] if isinstance(im_path, str) else list(im_path)

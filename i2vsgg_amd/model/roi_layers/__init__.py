@@ -1,8 +1,8 @@
-"""maskrcnn-benchmark style names used by the SGG_emb model (lib/model/roi_layers): ``ROIPool`` and ``nms``.
+"""maskrcnn-benchmark style names used by the SGG_emb model (lib/model/roi_layers): ``ROIPool``, ``ROIAlign``, ``nms``.
 
-``ROIAlign(output_size, scale, sampling_ratio)`` of the same package is only reached by the
-reference's (broken) eval branches and its source (``model._C``) is absent from the
-reference tree; it is listed as "next"  and raises here rather than guess."""
+``ROIAlign(output_size, scale, sampling_ratio)`` is the sub-bin sampling variant bound to ``model._C`` in the reference
+(roi_layers/roi_align.py:20); that source is absent from the reference tree, so the published maskrcnn-benchmark
+algorithm is what ``i2v_roi_align_sampled_*`` implements (parity unpinned)."""
 from torch import nn
 
 from i2vsgg_amd import ops
@@ -25,10 +25,15 @@ class ROIPool(nn.Module):
 
 
 class ROIAlign(nn.Module):
-    def __init__(self, output_size, spatial_scale, sampling_ratio):
+    def __init__(self, output_size, spatial_scale, sampling_ratio, out_nchw=False):
         super().__init__()
         self.output_size, self.spatial_scale, self.sampling_ratio = output_size, spatial_scale, sampling_ratio
+        self.out_nchw = out_nchw     # channels-last by default: what layer4's convolutions consume
 
     def forward(self, input, rois):
-        raise NotImplementedError("roi_layers.ROIAlign (sub-bin sampling variant) is out of scope for this round: "
-                                  "its reference source (model._C) is absent; see DESIGN.md 'Out of scope'")
+        h, w = (self.output_size if isinstance(self.output_size, (tuple, list)) else (self.output_size,) * 2)
+        return ops.roi_align_sampled(input, rois, h, w, self.spatial_scale, self.sampling_ratio, out_nchw=self.out_nchw)
+
+    def __repr__(self):
+        return "ROIAlign(output_size=%s, spatial_scale=%s, sampling_ratio=%s)" % (self.output_size, self.spatial_scale,
+                                                                               self.sampling_ratio)

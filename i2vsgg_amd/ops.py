@@ -98,6 +98,46 @@ def roi_align(feat, rois, pooled_h, pooled_w, spatial_scale, avg=True, out_nchw=
     return _RoIAlignFn.apply(feat, rois, int(pooled_h), int(pooled_w), float(spatial_scale), bool(avg), bool(out_nchw))
 
 
+class _RoIAlignSampledFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, rois, ph, pw, scale, sampling, out_nchw):
+        _need_cuda(feat, rois)
+        rois = _rois_f32(rois)
+        nhwc = _is_nhwc(feat)
+        if not nhwc:
+            feat = feat.contiguous()
+        B, C, H, W = feat.shape
+        R = rois.size(0)
+        out = torch.empty((R, C, ph, pw), device=feat.device, dtype=torch.float32,
+                          memory_format=torch.contiguous_format if out_nchw else _CL)
+        check(lib.i2v_roi_align_sampled_fwd(ptr(feat), LAYOUT_NHWC if nhwc else LAYOUT_NCHW, B, C, H, W, ptr(rois), R, ph, pw,
+                                            scale, sampling, ptr(out), LAYOUT_NCHW if out_nchw else LAYOUT_NHWC, stream()),
+              "roi_align_sampled_fwd")
+        ctx.save_for_backward(rois)
+        ctx.meta = (feat.shape, nhwc, ph, pw, scale, sampling, out_nchw)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (rois,) = ctx.saved_tensors
+        shape, nhwc, ph, pw, scale, sampling, out_nchw = ctx.meta
+        B, C, H, W = shape
+        gout = gout.contiguous() if out_nchw else gout.contiguous(memory_format=_CL)
+        gfeat = torch.empty(shape, device=gout.device, dtype=torch.float32,
+                            memory_format=_CL if nhwc else torch.contiguous_format).zero_()
+        check(lib.i2v_roi_align_sampled_bwd(ptr(gout), LAYOUT_NCHW if out_nchw else LAYOUT_NHWC, ptr(rois), rois.size(0), ph,
+                                            pw, scale, sampling, ptr(gfeat), LAYOUT_NHWC if nhwc else LAYOUT_NCHW, B, C, H, W,
+                                            stream()), "roi_align_sampled_bwd")
+        return gfeat, None, None, None, None, None, None
+
+
+def roi_align_sampled(feat, rois, pooled_h, pooled_w, spatial_scale, sampling_ratio=0, out_nchw=False):
+    """``roi_layers.ROIAlign`` (maskrcnn-benchmark definition: mean of a sampling grid per bin); differentiable w.r.t.
+    ``feat`` only, as roi_layers/roi_align.py:44 returns ``grad_input, None, ...``."""
+    return _RoIAlignSampledFn.apply(feat, rois, int(pooled_h), int(pooled_w), float(spatial_scale), int(sampling_ratio),
+                                    bool(out_nchw))
+
+
 class _RoIPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, rois, ph, pw, scale, out_nchw):

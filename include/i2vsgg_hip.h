@@ -63,6 +63,24 @@ int32_t i2v_roi_align_bwd(const float* grad_out, int32_t out_layout, const float
                           float* grad_feat, int32_t feat_layout, int32_t B, int32_t C, int32_t H, int32_t W,
                           void* stream);
 
+/* ---- ROIAlign, sampled variant (roi_layers.ROIAlign) ------------------------------
+ * replaces model._C.roi_align_forward / roi_align_backward as bound by roi_layers/roi_align.py:20,:31-42
+ * (called as (input, rois, spatial_scale, pooled_h, pooled_w, sampling_ratio) and
+ * (grad, rois, spatial_scale, pooled_h, pooled_w, B, C, H, W, sampling_ratio)); constructed with
+ * sampling_ratio 0 at faster_rcnn_SGG_emb.py:47.  model._C is the maskrcnn-benchmark csrc, absent from the
+ * reference tree: the published algorithm is restated (no +1 on the extent, extent >= 1, mean of a
+ * sampling_ratio^2 -- or ceil(extent/pooled)^2 when sampling_ratio <= 0 -- grid of bilinear samples per bin,
+ * samples more than a pixel outside the map contribute 0).  A roi whose batch index is outside [0,B) yields
+ * zeros / no gradient.  bwd accumulates into grad_feat (caller pre-zeroes), fp32 atomics. */
+int32_t i2v_roi_align_sampled_fwd(const float* feat, int32_t feat_layout, int32_t B, int32_t C, int32_t H, int32_t W,
+                                  const float* rois, int32_t R, int32_t pooled_h, int32_t pooled_w,
+                                  float spatial_scale, int32_t sampling_ratio, float* out, int32_t out_layout,
+                                  void* stream);
+int32_t i2v_roi_align_sampled_bwd(const float* grad_out, int32_t out_layout, const float* rois, int32_t R,
+                                  int32_t pooled_h, int32_t pooled_w, float spatial_scale, int32_t sampling_ratio,
+                                  float* grad_feat, int32_t feat_layout, int32_t B, int32_t C, int32_t H, int32_t W,
+                                  void* stream);
+
 /* ---- ROIPool (Caffe max pooling) ----------------------------------------------
  * replaces roi_pooling/src/roi_pooling_cuda.c:7-8,49-50 and model._C.roi_pool_forward /
  * roi_pool_backward (roi_layers/roi_pool.py:17,30).  argmax holds h*W+w of the winning

@@ -18,6 +18,12 @@
  *                       line from roi_align.c:80-136 / roi_align_kernel.cu:94-143.
  *   roi_pool_*          UNPINNED: model._C source is absent from the reference tree;
  *                       restated from roi_pooling_kernel.cu:24-93,128-203.
+ *   roi_align_sampled_* UNPINNED: model._C (roi_layers/roi_align.py:20,:31) is the csrc of
+ *                       facebookresearch/maskrcnn-benchmark via jwyang/faster-rcnn.pytorch
+ *                       (pytorch-1.0 branch), no commit pinned, source absent from the
+ *                       reference tree; its published algorithm
+ *                       (ROIAlign_cuda.cu: RoIAlignForward / bilinear_interpolate /
+ *                       RoIAlignBackwardFeature) is restated here in fp32.
  */
 #include <math.h>
 #include <float.h>
@@ -126,6 +132,98 @@ void oracle_roi_align_bwd(const float* gout, const float* rois, int R, int C, in
                     p[W]     += (float)(g * hr * (1 - wr));
                     p[W + 1] += (float)(g * hr * wr);
                 }
+    }
+}
+
+/* ------------------------------------------- ROIAlign, sampled (model._C) ---- */
+/* maskrcnn-benchmark bilinear_interpolate: a sample more than one pixel outside the
+ * map contributes 0; coordinates are clamped at 0 and at the last row / column.
+ * Returns 0 for an outside sample, else the four tap weights and the two corners. */
+static int ras_taps(int H, int W, float y, float x, int* yl, int* xl, int* yh, int* xh, float w[4])
+{
+    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return 0;
+    if (y <= 0) y = 0;
+    if (x <= 0) x = 0;
+    *yl = (int)y; *xl = (int)x;
+    if (*yl >= H - 1) { *yh = *yl = H - 1; y = (float)*yl; } else *yh = *yl + 1;
+    if (*xl >= W - 1) { *xh = *xl = W - 1; x = (float)*xl; } else *xh = *xl + 1;
+    float ly = y - (float)*yl, lx = x - (float)*xl, hy = 1.f - ly, hx = 1.f - lx;
+    w[0] = hy * hx; w[1] = hy * lx; w[2] = ly * hx; w[3] = ly * lx;
+    return 1;
+}
+
+struct ras_geom { float y0, x0, bh, bw; int gh, gw; };
+
+/* RoIAlignForward prologue: no +1 on the extent, extent clamped to >= 1, bin = extent / pooled,
+ * sampling grid = sampling_ratio or ceil(extent / pooled) when sampling_ratio <= 0. */
+static struct ras_geom ras_geometry(const float* roi, float scale, int PH, int PW, int sampling)
+{
+    struct ras_geom g;
+    float x1 = roi[1] * scale, y1 = roi[2] * scale, x2 = roi[3] * scale, y2 = roi[4] * scale;
+    float rw = fmaxf(x2 - x1, 1.f), rh = fmaxf(y2 - y1, 1.f);
+    g.x0 = x1; g.y0 = y1;
+    g.bh = rh / (float)PH; g.bw = rw / (float)PW;
+    g.gh = sampling > 0 ? sampling : (int)ceilf(rh / (float)PH);
+    g.gw = sampling > 0 ? sampling : (int)ceilf(rw / (float)PW);
+    return g;
+}
+
+/* feat NCHW (B,C,H,W), rois (R,5) -> out (R,C,PH,PW): mean of the gh x gw bilinear samples of a bin. */
+void oracle_roi_align_sampled_fwd(const float* feat, const float* rois, int R, int C, int H, int W,
+                                  int PH, int PW, float scale, int sampling, float* out)
+{
+    for (int n = 0; n < R; ++n) {
+        struct ras_geom g = ras_geometry(rois + 5 * n, scale, PH, PW, sampling);
+        int b = (int)rois[5 * n];
+        float count = (float)(g.gh * g.gw);
+        for (int c = 0; c < C; ++c) {
+            const float* f = feat + ((size_t)b * C + c) * H * W;
+            for (int ph = 0; ph < PH; ++ph)
+                for (int pw = 0; pw < PW; ++pw) {
+                    float acc = 0.f;
+                    for (int iy = 0; iy < g.gh; ++iy) {
+                        float y = g.y0 + (float)ph * g.bh + ((float)iy + .5f) * g.bh / (float)g.gh;
+                        for (int ix = 0; ix < g.gw; ++ix) {
+                            float x = g.x0 + (float)pw * g.bw + ((float)ix + .5f) * g.bw / (float)g.gw;
+                            int yl, xl, yh, xh; float w[4];
+                            if (!ras_taps(H, W, y, x, &yl, &xl, &yh, &xh, w)) continue;
+                            acc += w[0] * f[yl * W + xl] + w[1] * f[yl * W + xh] + w[2] * f[yh * W + xl]
+                                 + w[3] * f[yh * W + xh];
+                        }
+                    }
+                    out[(((size_t)n * C + c) * PH + ph) * PW + pw] = acc / count;
+                }
+        }
+    }
+}
+
+/* RoIAlignBackwardFeature in serial (n,c,ph,pw,iy,ix) order; gin NCHW pre-zeroed by the caller. */
+void oracle_roi_align_sampled_bwd(const float* gout, const float* rois, int R, int C, int H, int W,
+                                  int PH, int PW, float scale, int sampling, float* gin)
+{
+    for (int n = 0; n < R; ++n) {
+        struct ras_geom g = ras_geometry(rois + 5 * n, scale, PH, PW, sampling);
+        int b = (int)rois[5 * n];
+        float count = (float)(g.gh * g.gw);
+        for (int c = 0; c < C; ++c) {
+            float* f = gin + ((size_t)b * C + c) * H * W;
+            for (int ph = 0; ph < PH; ++ph)
+                for (int pw = 0; pw < PW; ++pw) {
+                    float top = gout[(((size_t)n * C + c) * PH + ph) * PW + pw];
+                    for (int iy = 0; iy < g.gh; ++iy) {
+                        float y = g.y0 + (float)ph * g.bh + ((float)iy + .5f) * g.bh / (float)g.gh;
+                        for (int ix = 0; ix < g.gw; ++ix) {
+                            float x = g.x0 + (float)pw * g.bw + ((float)ix + .5f) * g.bw / (float)g.gw;
+                            int yl, xl, yh, xh; float w[4];
+                            if (!ras_taps(H, W, y, x, &yl, &xl, &yh, &xh, w)) continue;
+                            f[yl * W + xl] += top * w[0] / count;
+                            f[yl * W + xh] += top * w[1] / count;
+                            f[yh * W + xl] += top * w[2] / count;
+                            f[yh * W + xh] += top * w[3] / count;
+                        }
+                    }
+                }
+        }
     }
 }
 

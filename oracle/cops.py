@@ -87,6 +87,31 @@ def avgpool2x2_bwd(gy):
     return gx
 
 
+def roi_align_sampled_fwd(feat, rois, ph, pw, scale, sampling_ratio):
+    """``model._C.roi_align_forward`` (roi_layers/roi_align.py:20; maskrcnn-benchmark ROIAlign_cuda.cu, source absent
+    from the reference tree): feat NCHW, rois (R,5) -> (R,C,ph,pw).  Parity unpinned."""
+    feat, pf = _f(feat)
+    rois, pr = _f(rois)
+    B, C, H, W = feat.shape
+    R = rois.shape[0]
+    out = np.zeros((R, C, ph, pw), dtype=np.float32)
+    lib().oracle_roi_align_sampled_fwd(pf, pr, R, C, H, W, ph, pw, ctypes.c_float(scale), int(sampling_ratio),
+                                       out.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return out
+
+
+def roi_align_sampled_bwd(gout, rois, feat_shape, scale, sampling_ratio):
+    """``model._C.roi_align_backward`` (roi_layers/roi_align.py:31-42) in serial order.  Parity unpinned."""
+    gout, pg = _f(gout)
+    rois, pr = _f(rois)
+    B, C, H, W = feat_shape
+    R, _, ph, pw = gout.shape
+    gin = np.zeros(feat_shape, dtype=np.float32)
+    lib().oracle_roi_align_sampled_bwd(pg, pr, R, C, H, W, ph, pw, ctypes.c_float(scale), int(sampling_ratio),
+                                       gin.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return gin
+
+
 def roi_align_avg_fwd(feat, rois, ph, pw, scale):
     """RoIAlignAvg (roi_align/modules/roi_align.py:18-29): align to (ph+1,pw+1), 2x2 s1 mean."""
     return avgpool2x2_fwd(roi_align_fwd(feat, rois, ph + 1, pw + 1, scale))

@@ -92,6 +92,52 @@ def test_roi_align_bwd(ops, oracle, C, H, W, B, avg):
         np.testing.assert_allclose(feat.grad.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("C,H,W,B", [(4, 9, 11, 2), (6, 9, 11, 2), (64, 19, 32, 2), (1024, 38, 63, 1)])
+@pytest.mark.parametrize("sampling", [0, 2])
+def test_roi_align_sampled_fwd_bwd(ops, oracle, C, H, W, B, sampling):
+    """roi_layers.ROIAlign (sampling grid): forward bit-exact against the C restatement for both map layouts and both
+    output layouts; backward within the tolerance fp32 atomics allow; a roi of another batch gives zeros."""
+    cops, _ = oracle
+    rng = np.random.default_rng(3 * C + H + sampling)
+    feat = rng.standard_normal((B, C, H, W), dtype=np.float32)
+    rois = _rois_cases(rng, B, H, W)
+    ref = cops.roi_align_sampled_fwd(feat, rois, 7, 7, 1.0 / 16.0, sampling)
+    gout = rng.standard_normal(ref.shape, dtype=np.float32)
+    refg = cops.roi_align_sampled_bwd(gout, rois, feat.shape, 1.0 / 16.0, sampling)
+    rt = torch.from_numpy(rois).to(DEV)
+    for nhwc in (True, False):
+        for out_nchw in (True, False):
+            ft = torch.from_numpy(feat).to(DEV).requires_grad_()
+            f = ft.contiguous(memory_format=torch.channels_last) if nhwc else ft
+            out = ops.roi_align_sampled(f, rt, 7, 7, 1.0 / 16.0, sampling, out_nchw=out_nchw)
+            got = out.detach().cpu().numpy()
+            assert np.array_equal(got, ref), "nhwc=%s out_nchw=%s maxdiff=%g" % (nhwc, out_nchw, np.abs(got - ref).max())
+            out.backward(torch.from_numpy(gout).to(DEV))
+            np.testing.assert_allclose(ft.grad.cpu().numpy(), refg, rtol=2e-5, atol=2e-5)
+    bad = rt.clone()
+    bad[:, 0] = B + 3
+    assert torch.all(ops.roi_align_sampled(torch.from_numpy(feat).to(DEV), bad, 7, 7, 1.0 / 16.0, sampling) == 0)
+
+
+def test_roi_layers_roialign_module(ops, oracle):
+    """The module with the reference's constructor (faster_rcnn_SGG_emb.py:47) and an affine map: every bin returns
+    the map at its centre."""
+    from i2vsgg_amd.model.roi_layers import ROIAlign
+    cops, _ = oracle
+    H, W = 38, 63
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    feat = torch.stack([0.5 * yy + 0.25 * xx, 1.0 - 0.125 * yy + 0.5 * xx])[None].to(DEV)
+    rois = torch.tensor([[0, 32.0, 48.0, 480.0, 400.0]], device=DEV)
+    m = ROIAlign((7, 7), 1.0 / 16.0, 0, out_nchw=True)
+    out = m(feat, rois)
+    cy = 3.0 + (torch.arange(7) + 0.5) * (22.0 / 7)
+    cx = 2.0 + (torch.arange(7) + 0.5) * (28.0 / 7)
+    want = 0.5 * cy[:, None] + 0.25 * cx[None, :]
+    assert torch.allclose(out[0, 0].cpu(), want, atol=2e-5)
+    assert np.array_equal(out.cpu().numpy(), cops.roi_align_sampled_fwd(feat.cpu().numpy(), rois.cpu().numpy(), 7, 7, 1 / 16.0, 0))
+    assert "sampling_ratio=0" in repr(m)
+
+
 @pytest.mark.parametrize("C,H,W,B", [(4, 9, 11, 2), (100, 19, 32, 2), (1024, 38, 63, 1)])
 def test_roi_pool_fwd_bwd(ops, oracle, C, H, W, B):
     cops, _ = oracle

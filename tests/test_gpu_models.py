@@ -392,6 +392,35 @@ def test_relation_eval_branch_and_topk_vs_oracle(cfg):
     assert net.forward_relation_eval(fm, info, "none") == {"bboxes": [], "classes": [], "scores": []}
 
 
+def test_extract_feature_and_box_classification_vs_oracle(cfg):
+    """``_extract_feature`` (faster_rcnn_SGG_emb.py:381-392) and the box classification of the eval branch (:278-291):
+    roi_layers.ROIAlign -> layer4 -> mean -> RCNN_cls_score -> softmax with the background column zeroed."""
+    from i2vsgg_amd.model.faster_rcnn.resnet_SGG_emb import resnet
+    from oracle import cops, nets
+    n_cls = 16
+    torch.manual_seed(0)
+    net = resnet(tuple(range(n_cls)), _vrd_args(), 101, obj_vecs=syn.word_vectors(22, n_cls), prd_vecs=syn.word_vectors(21, 62))
+    net.create_architecture()
+    p = dict(syn.backbone_params(0, 101), **syn.det_head_params(11, n_cls))
+    _load(net.RCNN_top, p, "RCNN_top.")
+    _load(net.RCNN_cls_score, p, "RCNN_cls_score.")
+    net.to(DEV).eval()
+    fmap = np.abs(np.random.default_rng(5).standard_normal((1, 1024, 38, 63), dtype=np.float32))
+    boxes = syn.boxes(9, 6, 600, 1000)
+    fm = torch.from_numpy(fmap).to(DEV).contiguous(memory_format=torch.channels_last)
+    got = net._extract_feature(fm, boxes)
+    r5 = np.hstack((np.zeros((6, 1), np.float32), boxes.astype(np.float32)))
+    tp = {k: torch.as_tensor(v) for k, v in p.items()}
+    pooled = torch.from_numpy(cops.roi_align_sampled_fwd(fmap, r5, 7, 7, 1.0 / 16.0, 0))
+    want = nets.head_to_tail(pooled, tp)
+    assert got.shape == (6, 2048) and _rel_err(got, want.numpy()) < REL
+    assert _rel_err(net._extract_feature(fmap, boxes), want.numpy()) < REL           # numpy map in, as the reference passes it
+    prob = torch.softmax(want @ tp["RCNN_cls_score.weight"].t() + tp["RCNN_cls_score.bias"], 1)
+    prob[:, 0] = 0
+    cls, conf = net.classify_boxes(fm, boxes)
+    assert np.array_equal(cls, prob.argmax(1).numpy()) and np.allclose(conf, prob.max(1).values.numpy(), atol=1e-5)
+
+
 def test_consistency_terms_match_reference_formula(cfg):
     """--cr (trainval_net_instance_styleD_bilinear.py:299-311) with the reference's literal expressions at 128 ROIs."""
     from i2vsgg_amd import train

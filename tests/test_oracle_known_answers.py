@@ -37,6 +37,51 @@ def test_roi_align_hand_worked():
     assert gin[0, 0, 2, 3] == 0.5 and gin[0, 0, 3, 3] == 0.5 and gin.sum() == 1.0
 
 
+def test_roi_align_sampled_properties():
+    """roi_layers.ROIAlign restatement (model._C source absent, parity unpinned): properties derivable by hand from the
+    published definition.  (1) bilinear sampling reproduces an affine map exactly and the sample grid of a bin is
+    symmetric about the bin centre, so every output equals the map at its bin centre; (2) sampling_ratio 0 uses
+    ceil(extent / pooled) samples per side; (3) a ROI more than a pixel outside gives zeros; (4) backward is the
+    adjoint of forward."""
+    from oracle import cops
+    H, W, C = 12, 17, 2
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    feat = np.stack([0.25 * yy + 0.5 * xx + 1.0, 2.0 - 0.125 * yy + 0.75 * xx])[None].astype(np.float32)
+    rois = np.array([[0, 16.0, 24.0, 208.0, 152.0]], np.float32)           # map coords x 1..13, y 1.5..9.5
+    for sr in (0, 1, 2, 3):
+        out = cops.roi_align_sampled_fwd(feat, rois, 4, 3, 1 / 16.0, sr)
+        bh, bw = 8.0 / 4, 12.0 / 3
+        cy = 1.5 + (np.arange(4) + 0.5) * bh
+        cx = 1.0 + (np.arange(3) + 0.5) * bw
+        want0 = 0.25 * cy[:, None] + 0.5 * cx[None, :] + 1.0
+        want1 = 2.0 - 0.125 * cy[:, None] + 0.75 * cx[None, :]
+        np.testing.assert_allclose(out[0, 0], want0, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(out[0, 1], want1, rtol=0, atol=2e-6)
+    # (2) adaptive grid: a 6-px-tall bin row over a map that is 1 on row 3 only.  Bin 0 of a 1x1 pooling of the box
+    # y in [0,6] is sampled at gh = ceil(6/1) = 6 rows y = 0.5, 1.5, ... 5.5: rows 2.5 and 3.5 see 0.5 each -> 1/6.
+    f = np.zeros((1, 1, 8, 8), np.float32)
+    f[0, 0, 3, :] = 1.0
+    r = np.array([[0, 0, 0, 6, 6]], np.float32)
+    assert abs(cops.roi_align_sampled_fwd(f, r, 1, 1, 1.0, 0)[0, 0, 0, 0] - 1.0 / 6.0) < 1e-7
+    assert abs(cops.roi_align_sampled_fwd(f, r, 1, 1, 1.0, 1)[0, 0, 0, 0] - 1.0) < 1e-7     # one sample at y = 3
+    assert abs(cops.roi_align_sampled_fwd(f, r, 1, 1, 1.0, 2)[0, 0, 0, 0] - 0.0) < 1e-7     # samples at y = 1.5, 4.5
+    # (3) outside: everything beyond W+1 / below -1
+    far = np.array([[0, 400, 400, 500, 500], [0, -300, -300, -40, -40]], np.float32)
+    assert np.all(cops.roi_align_sampled_fwd(feat, far, 3, 3, 1 / 16.0, 0) == 0)
+    # degenerate extent is clamped to one pixel, not zero: a point ROI returns the interpolated value around it
+    pt = np.array([[0, 64, 48, 64, 48]], np.float32)                       # (x,y) = (4,3), 1x1 extent
+    out = cops.roi_align_sampled_fwd(feat, pt, 1, 1, 1 / 16.0, 0)
+    assert abs(out[0, 0, 0, 0] - (0.25 * 3.5 + 0.5 * 4.5 + 1.0)) < 1e-6
+    # (4) adjoint
+    rng = np.random.default_rng(0)
+    fr = rng.standard_normal((2, 3, H, W), dtype=np.float32)
+    rr = np.array([[0, 5, 9, 180, 120], [1, -20, 30, 300, 100], [1, 100, 100, 130, 190]], np.float32)
+    g = rng.standard_normal((3, 3, 5, 4), dtype=np.float32)
+    lhs = float((cops.roi_align_sampled_fwd(fr, rr, 5, 4, 1 / 16.0, 0).astype(np.float64) * g).sum())
+    rhs = float((cops.roi_align_sampled_bwd(g, rr, fr.shape, 1 / 16.0, 0).astype(np.float64) * fr).sum())
+    assert abs(lhs - rhs) < 1e-4 * max(1.0, abs(lhs))
+
+
 def test_roi_pool_hand_worked():
     # 1 channel 4x6 map, values row-major 0..23; scale 1
     feat = np.arange(24, dtype=np.float32).reshape(1, 1, 4, 6)
