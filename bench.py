@@ -81,6 +81,9 @@ def main():
     c.cfg_from_list(["ANCHOR_SCALES", "[8, 16, 32]", "ANCHOR_RATIOS", "[0.5,1,2]", "MAX_NUM_GT_BOXES", "30",
                      "TRAIN.BATCH_SIZE", "32", "TRAIN.RPN_POST_NMS_TOP_N_TARGET", "32"])
 
+    # work on a stream of our own: HIP's legacy default stream does not keep back-to-back graph launches ordered once
+    # the host runs ahead, and every operation on it drags the other streams in (i2vsgg_amd/train.py, __call__)
+    torch.cuda.set_stream(torch.cuda.Stream(dev))
     net = train.build_sgg_net(a.layers, device=dev)
     step = train.SGGEmbStep(net, FRAMES_PER_RANK, seed=1 + rank, device=dev, use_graph=not a.no_graph)
     graphed = step.capture(warmup=2)

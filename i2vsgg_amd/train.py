@@ -224,6 +224,7 @@ class SGGEmbStep:
         torch.cuda.synchronize(self.dev)
         if not self.use_graph:
             return False
+        self.s_main = torch.cuda.Stream(self.dev)       # every replay runs here (see __call__)
         self.pipelined = parallel.exchange_enabled() or os.environ.get("I2V_SPLIT_GRAPH") == "1"
         try:
             if self.overlap:
@@ -246,7 +247,9 @@ class SGGEmbStep:
                 with torch.cuda.graph(gs, pool=gh.pool()):
                     self.opt.step()
                 self.graph = (gbb, gh, gs)
-                gbb.replay()                # feature map of the first timed step
+                self.s_main.wait_stream(torch.cuda.current_stream(self.dev))
+                with torch.cuda.stream(self.s_main):
+                    gbb.replay()            # feature map of the first timed step
             return True
         except Exception as e:      # report, fall back to eager launches
             self.graph = None
@@ -284,8 +287,8 @@ class SGGEmbStep:
         finally:
             lib.i2v_conv_set_split_slot(-1)
         self.graph = (gbb, gh, gs) if self.pipelined else (gbb, gh)
+        self.s_bb.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self.s_bb):
-            self.s_bb.wait_stream(torch.cuda.current_stream(self.dev))
             gbb.replay()                    # feature map of the first timed step
             self.ev_bb.record(self.s_bb)
 
@@ -312,17 +315,33 @@ class SGGEmbStep:
         stream -- one graph on one GPU; head -> [exchange || backbone] -> SGD with world > 1."""
         if self.graph is None:
             self._body()
-        elif self.overlap:
-            return self._call_overlapped()
-        elif len(self.graph) == 1:
-            self.graph[0].replay()
-        else:
-            gbb, gh, gs = self.graph
-            gh.replay()
-            token = parallel.all_reduce_grads_start(self.opt.params())
-            gbb.replay()
-            parallel.all_reduce_grads_finish(token)
-            gs.replay()
+            return self.loss
+        # Graph replays never go to HIP's legacy default stream.  Measured (tools/loss_trace.py, bench.py): with the
+        # two-stream step replayed back to back on the default stream, about half of the 23-step runs end with a
+        # different, an all-zero-logit or a NaN loss; a host-side synchronize of that stream before every step removes
+        # it, and so does replaying on an ordinary stream -- there every run reproduces the one-graph / eager
+        # trajectory to the last bit or two (tests/test_gpu_models.py::test_sgg_step_back_to_back_replays_are_ordered).
+        # A caller that is on the default stream gets the replays on a stream of this object, ordered against its own
+        # stream on both sides: correct, but those waits on the default stream cost the overlap (6.0 instead of
+        # 5.3 ms per step), so bench.py and the training script set an ordinary current stream.
+        caller = torch.cuda.current_stream(self.dev)
+        detour = caller == torch.cuda.default_stream(self.dev)
+        if detour:
+            self.s_main.wait_stream(caller)
+        with torch.cuda.stream(self.s_main if detour else caller):
+            if self.overlap:
+                self._call_overlapped()
+            elif len(self.graph) == 1:
+                self.graph[0].replay()
+            else:
+                gbb, gh, gs = self.graph
+                gh.replay()
+                token = parallel.all_reduce_grads_start(self.opt.params())
+                gbb.replay()
+                parallel.all_reduce_grads_finish(token)
+                gs.replay()
+        if detour:
+            caller.wait_stream(self.s_main)
         return self.loss
 
 

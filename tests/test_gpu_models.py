@@ -305,6 +305,45 @@ def test_sgg_step_schedules_match_single_graph(cfg, monkeypatch):
         assert _rel_err(w1, w0) < 1e-5, key
 
 
+def test_sgg_step_back_to_back_replays_are_ordered(cfg):
+    """The two-stream step replayed back to back WITHOUT a host synchronisation between steps (the bench loop: the
+    host runs several steps ahead of the device) follows the same loss trajectory as the same step synchronised after
+    every replay -- from the default stream (replays detour through the step's own stream) and from an ordinary
+    stream (replays go to the caller's stream).  Full configs[1] shapes: the ordering failure this guards against
+    (train.SGGEmbStep.__call__) only shows when a step is long enough for the host to run ahead."""
+    from i2vsgg_amd import train
+    n = 20
+
+    def run(own_stream, sync):
+        net = train.build_sgg_net(101, device=DEV)
+        step = train.SGGEmbStep(net, 2, seed=1, device=DEV)
+        prev = torch.cuda.current_stream()
+        if own_stream:
+            s = torch.cuda.Stream()
+            s.wait_stream(prev)
+            torch.cuda.set_stream(s)
+        try:
+            assert step.capture(warmup=2) and step.overlap, getattr(step, "graph_error", None)
+            for i in range(3):
+                step()
+            torch.cuda.synchronize()            # bench.py's shape: warm-up, synchronise, timed steps back to back
+            for i in range(n):
+                step()
+                if sync:
+                    torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            return float(step.loss), net.vrd.fc7.fc.weight.detach().double().abs().sum().item()
+        finally:
+            torch.cuda.set_stream(prev)
+            step.opt.unfuse()
+
+    want = run(True, True)
+    for own in (True, False):
+        for _rep in range(2):
+            got = run(own, False)
+            assert abs(got[0] - want[0]) < 1e-5 and abs(got[1] - want[1]) < 1e-6 * want[1], (own, got, want)
+
+
 def test_detect_frame_eval_loop_matches_oracle_postprocess(cfg):
     """eval.detect_frame (test_net_instance_styleD_bilinear.py:140-221): eval forward (TEST proposal settings) + the
     device post-processing pass == the oracle's restatement applied to the same network outputs."""

@@ -53,6 +53,8 @@ def main():
     net = train.build_sgg_net(101 if a.net == "res101" else 50, a.num_relations, a.num_classes, device=dev)
     vrd_lr = a.vrd_lr
     # eager steps: the minibatch changes every iteration (the data layer's role is played by reseed())
+    if dev.type == "cuda":
+        torch.cuda.set_stream(torch.cuda.Stream(dev))      # not the legacy default stream (train.SGGEmbStep.__call__)
     step = train.SGGEmbStep(net, a.batch_size, vrd_lr=vrd_lr, seed=rank, device=dev, h=a.height, w=a.width,
                             use_graph=False, fuse_sgd=False)
     for epoch in range(1, a.max_epochs + 1):
