@@ -1125,24 +1125,44 @@ conv_wgrad2_f32(const WgP p) {
         }
     }
     float4 r[NBLK][4];
+    const bool lin = p.H == 1 && p.W == 1 && p.KH == 1 && p.KW == 1 && p.pad == 0 && p.stride == 1;     // uniform
+    // No divergent control flow around the loads: the A/B role of a block is uniform per wave (A_BLK is a multiple of
+    // 128), so the descriptor is picked with a scalar select, and a masked element gets the 2 GiB bit OR-ed into its
+    // offset (the buffer returns 0) -- written as `cond ? off : OOB` the compiler wraps every load in its own branch.
     auto gload = [&](int ms) {
 #pragma unroll
         for (int q = 0; q < NBLK; ++q) {
+            const bool a_u = __builtin_amdgcn_readfirstlane((int)is_a[q]) != 0;
+            const __amdgpu_buffer_rsrc_t rs = a_u ? gr : xr;
+            const int m0 = ms + 4 * m4[q];
+            int ox = 0, oy = 0, b = 0;
+            if (!a_u && !lin) {             // one division pair per 4 consecutive pixels, the rest by carry
+                ox = m0 % p.Wo;
+                const int tt = m0 / p.Wo;
+                oy = tt % p.Ho;
+                b = tt / p.Ho;
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int m = ms + 4 * m4[q] + t;
-                unsigned off = OOB;
-                if (live[q] && m < mend) {
-                    if (is_a[q]) {
-                        off = (unsigned)(m * p.N + coff[q]) * 4u;
-                    } else {
-                        const int ox = m % p.Wo, tt = m / p.Wo, oy = tt % p.Ho, b = tt / p.Ho;
-                        const int iy = oy * p.stride - p.pad + ky[q], ix = ox * p.stride - p.pad + kx[q];
-                        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                            off = (unsigned)(((b * p.H + iy) * p.W + ix) * p.Cin + coff[q]) * 4u;
-                    }
+                const int m = m0 + t;
+                unsigned off;
+                if (a_u) {
+                    off = (unsigned)(m * p.N + coff[q]) * 4u;
+                } else if (lin) {
+                    off = (unsigned)(m * p.Cin + coff[q]) * 4u;         // linear layer: row m of x, no pixel arithmetic
+                } else {
+                    const int iy = oy * p.stride - p.pad + ky[q], ix = ox * p.stride - p.pad + kx[q];
+                    const bool inside = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                    off = (unsigned)(((b * p.H + iy) * p.W + ix) * p.Cin + coff[q]) * 4u;
+                    off |= inside ? 0u : 0x80000000u;
+                    const bool wx = ox + 1 == p.Wo;
+                    const bool wy = wx && oy + 1 == p.Ho;
+                    ox = wx ? 0 : ox + 1;
+                    oy = wy ? 0 : (wx ? oy + 1 : oy);
+                    b += wy ? 1 : 0;
                 }
-                r[q][t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(is_a[q] ? gr : xr, off, 0, 0));
+                off |= (live[q] && m < mend) ? 0u : 0x80000000u;
+                r[q][t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
             }
         }
     };
