@@ -242,6 +242,119 @@ wino4_output_kernel(const float* __restrict__ Mx, const float* __restrict__ scal
     }
 }
 
+// ---- row-split forms of the two F(4x4,3x3) transforms.  One thread per (tile, channel) is 320 x 256 threads on
+// layer3 -- five waves per CU, each with 36 loads and 36 stores: one exposed round trip each way and nothing to hide it
+// behind (10 + 7 us per layer, 30 layers per step).  Here blockIdx.y picks ONE row of the transformed tile: a thread
+// loads only the patch rows that row's B^T (A^T) coefficients touch (3-4 of 6 for the input, 4-5 of 6 for the output),
+// the launch has 6x (4x) the threads, and every value is computed by the same expression as in the one-thread form.
+template <int R> __device__ inline float bt6_row(const float d[6]) {
+    if (R == 0) return 4.f * d[0] - 5.f * d[2] + d[4];
+    if (R == 1) return -4.f * d[1] - 4.f * d[2] + d[3] + d[4];
+    if (R == 2) return 4.f * d[1] - 4.f * d[2] - d[3] + d[4];
+    if (R == 3) return -2.f * d[1] - d[2] + 2.f * d[3] + d[4];
+    if (R == 4) return 2.f * d[1] - d[2] - 2.f * d[3] + d[4];
+    return 4.f * d[1] - 5.f * d[3] + d[5];
+}
+template <int R> __device__ inline bool bt6_needs(int k) {
+    return R == 0 ? (k == 0 || k == 2 || k == 4) : R == 5 ? (k == 1 || k == 3 || k == 5) : (k >= 1 && k <= 4);
+}
+template <int R> __device__ inline float at6_row(const float m[6]) {
+    if (R == 0) return m[0] + m[1] + m[2] + m[3] + m[4];
+    if (R == 1) return m[1] - m[2] + 2.f * m[3] - 2.f * m[4];
+    if (R == 2) return m[1] + m[2] + 4.f * m[3] + 4.f * m[4];
+    return m[1] - m[2] + 8.f * m[3] - 8.f * m[4] + m[5];
+}
+template <int R> __device__ inline bool at6_needs(int k) {
+    return R == 0 ? k <= 4 : R == 3 ? k >= 1 : (k >= 1 && k <= 4);
+}
+
+template <int R>
+__device__ inline void wino4_input_row(const float* __restrict__ x, float* __restrict__ V, int H, int W, int C, int b,
+                                       int ty, int tx, long long t, int c, long long plane) {
+    float mrow[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int ix = 4 * tx - 1 + q;
+        float d[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            d[k] = 0.f;
+            if (!bt6_needs<R>(k)) continue;
+            const int iy = 4 * ty - 1 + k;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) d[k] = x[(((long long)b * H + iy) * W + ix) * C + c];
+        }
+        mrow[q] = bt6_row<R>(d);
+    }
+    float v[6];
+    bt6(mrow, v);
+    float* o = V + t * C + c;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) o[(long long)(6 * R + q) * plane] = v[q];
+}
+
+__global__ void __launch_bounds__(256)
+wino4_input_rows_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H, int W, int C, int th, int tw) {
+    const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const long long T = (long long)B * th * tw;
+    if (idx >= T * C) return;
+    const int c = (int)(idx % C);
+    const long long t = idx / C;
+    const int tx = (int)(t % tw), ty = (int)((t / tw) % th), b = (int)(t / ((long long)tw * th));
+    const long long plane = T * C;
+    switch (blockIdx.y) {                   // uniform per workgroup
+    case 0: wino4_input_row<0>(x, V, H, W, C, b, ty, tx, t, c, plane); break;
+    case 1: wino4_input_row<1>(x, V, H, W, C, b, ty, tx, t, c, plane); break;
+    case 2: wino4_input_row<2>(x, V, H, W, C, b, ty, tx, t, c, plane); break;
+    case 3: wino4_input_row<3>(x, V, H, W, C, b, ty, tx, t, c, plane); break;
+    case 4: wino4_input_row<4>(x, V, H, W, C, b, ty, tx, t, c, plane); break;
+    default: wino4_input_row<5>(x, V, H, W, C, b, ty, tx, t, c, plane); break;
+    }
+}
+
+template <int R>
+__device__ inline void wino4_output_row(const float* __restrict__ src, long long plane, float s[6]) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        float m[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) m[k] = at6_needs<R>(k) ? src[(long long)(6 * k + q) * plane] : 0.f;
+        s[q] = at6_row<R>(m);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+wino4_output_rows_kernel(const float* __restrict__ Mx, const float* __restrict__ scale, const float* __restrict__ shift,
+                         float* __restrict__ y, int B, int H, int W, int N, int th, int tw, int relu) {
+    const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const long long T = (long long)B * th * tw;
+    if (idx >= T * N) return;
+    const int n = (int)(idx % N);
+    const long long t = idx / N;
+    const int tx = (int)(t % tw), ty = (int)((t / tw) % th), b = (int)(t / ((long long)tw * th));
+    const int r = blockIdx.y, oy = 4 * ty + r;
+    if (oy >= H) return;
+    const long long plane = T * N;
+    const float* src = Mx + t * N + n;
+    float s[6];
+    switch (r) {                            // uniform per workgroup
+    case 0: wino4_output_row<0>(src, plane, s); break;
+    case 1: wino4_output_row<1>(src, plane, s); break;
+    case 2: wino4_output_row<2>(src, plane, s); break;
+    default: wino4_output_row<3>(src, plane, s); break;
+    }
+    float o[4];
+    at6(s, o);
+    const float sc = scale ? scale[n] : 1.f, sh = shift ? shift[n] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ox = 4 * tx + q;
+        if (ox >= W) continue;
+        float v = o[q] * sc + sh;
+        if (relu) v = fmaxf(v, 0.f);
+        y[(((long long)b * H + oy) * W + ox) * N + n] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" int32_t i2v_winograd_filter(const float* w, float* U, int32_t Cout, int32_t Cin, void* stream) {
@@ -309,10 +422,16 @@ extern "C" int32_t i2v_conv3x3_winograd4_fwd(const float* x, const float* U, con
     const long long T = (long long)B * th * tw;
     float* V = (float*)ws;
     float* Mx = (float*)((char*)ws + i2v_align(36 * (size_t)T * Cin * sizeof(float)));
-    wino4_input_kernel<<<(unsigned)i2v_cdiv(T * Cin, 256), 256, 0, st>>>(x, V, B, H, W, Cin, th, tw);
+    // row-split transforms only where the one-thread-per-(tile, channel) launch cannot fill the chip (layer3: 34 vs
+    // 37 us per layer); on layer1/2 their redundant loads cost more than the parallelism buys (79 vs 57 us)
+    static const int rows_env = [] { const char* e = getenv("I2V_WINO_ROWS"); return e ? atoi(e) : -1; }();   // bit 0: input, bit 1: output
+    const int rows = rows_env >= 0 ? rows_env : (T * (Cin > Cout ? Cin : Cout) <= 98304 ? 3 : 0);
+    if (rows & 1) wino4_input_rows_kernel<<<dim3((unsigned)i2v_cdiv(T * Cin, 256), 6), 256, 0, st>>>(x, V, B, H, W, Cin, th, tw);
+    else wino4_input_kernel<<<(unsigned)i2v_cdiv(T * Cin, 256), 256, 0, st>>>(x, V, B, H, W, Cin, th, tw);
     int rc = i2v_gemm_nt_batched(V, U, Mx, (int32_t)T, Cout, Cin, 36, T * Cin, (long long)Cout * Cin, T * Cout, stream);
     if (rc) return rc;
-    wino4_output_kernel<<<(unsigned)i2v_cdiv(T * Cout, 256), 256, 0, st>>>(Mx, scale, shift, y, B, H, W, Cout, th, tw, relu);
+    if (rows & 2) wino4_output_rows_kernel<<<dim3((unsigned)i2v_cdiv(T * Cout, 256), 4), 256, 0, st>>>(Mx, scale, shift, y, B, H, W, Cout, th, tw, relu);
+    else wino4_output_kernel<<<(unsigned)i2v_cdiv(T * Cout, 256), 256, 0, st>>>(Mx, scale, shift, y, B, H, W, Cout, th, tw, relu);
     I2V_CHECK_LAUNCH("conv3x3_winograd4_fwd");
     return I2V_OK;
 }
