@@ -43,6 +43,7 @@ SIGNATURES = {
     "i2v_conv3x3_winograd_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "i2v_conv3x3_winograd_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "i2v_winograd4_filter": (_i, [_p, _p, _i, _i, _p]),
+    "i2v_winograd4_filter_dgrad": (_i, [_p, _p, _i, _i, _p]),
     "i2v_conv3x3_winograd4_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "i2v_conv3x3_winograd4_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "i2v_conv_set_split_slot": (_i, [_i]),

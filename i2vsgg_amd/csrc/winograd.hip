@@ -170,6 +170,28 @@ __global__ void wino4_filter_kernel(const float* __restrict__ w, float* __restri
     }
 }
 
+// Filter of the DATA-GRADIENT convolution in the Winograd domain: gx = conv3x3(gy, w') with w'[c][ky][kx][n] =
+// w[n][2-ky][2-kx][c] (taps flipped, channels swapped) -> U'[36][Cin][Cout].  n is the fast thread index: the 36 plane
+// stores are coalesced, the 9 tap reads are strided (the filter is the small side).
+__global__ void wino4_filter_dgrad_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin) {
+    const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (idx >= (long long)Cout * Cin) return;
+    const int n = (int)(idx % Cout), c = (int)(idx / Cout);
+    float t[6][3];
+    for (int kx = 0; kx < 3; ++kx) {
+        float g[3], u[6];
+        for (int ky = 0; ky < 3; ++ky) g[ky] = w[(((long long)n * 3 + (2 - ky)) * 3 + (2 - kx)) * Cin + c];
+        g6(g, u);
+        for (int r = 0; r < 6; ++r) t[r][kx] = u[r];
+    }
+    const long long plane = (long long)Cout * Cin;
+    for (int r = 0; r < 6; ++r) {
+        float u[6];
+        g6(t[r], u);
+        for (int q = 0; q < 6; ++q) U[(long long)(6 * r + q) * plane + (long long)c * Cout + n] = u[q];
+    }
+}
+
 __global__ void __launch_bounds__(256)
 wino4_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H, int W, int C, int th, int tw) {
     const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -399,6 +421,14 @@ extern "C" int32_t i2v_winograd4_filter(const float* w, float* U, int32_t Cout, 
     const long long n = (long long)Cout * Cin;
     wino4_filter_kernel<<<(unsigned)i2v_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(w, U, Cout, Cin);
     I2V_CHECK_LAUNCH("winograd4_filter");
+    return I2V_OK;
+}
+
+extern "C" int32_t i2v_winograd4_filter_dgrad(const float* w, float* U, int32_t Cout, int32_t Cin, void* stream) {
+    I2V_CHECK_ARG(w && U && Cout > 0 && Cin > 0, "winograd4_filter_dgrad: bad argument");
+    const long long n = (long long)Cout * Cin;
+    wino4_filter_dgrad_kernel<<<(unsigned)i2v_cdiv(n, 256), 256, 0, (hipStream_t)stream>>>(w, U, Cout, Cin);
+    I2V_CHECK_LAUNCH("winograd4_filter_dgrad");
     return I2V_OK;
 }
 

@@ -112,7 +112,7 @@ class Bottleneck(nn.Module):
             # with the filter transformed once -- 4x fewer MACs with F(4x4,3x3) (layer3: 63 -> 37 us per layer)
             out = ops.conv3x3_winograd(out, self._winograd_filter(), s2, b2, relu=True)
         else:
-            out = ops.conv2d(out, self.conv2.weight, s2, b2, None, 1, 1, relu=True)
+            out = ops.conv2d(out, self.conv2.weight, s2, b2, None, 1, 1, relu=True, winograd=bool(WINOGRAD))   # trained: F(4x4) fwd + dgrad
         res = x
         if self.downsample is not None:
             sd, bd = self.downsample[1].folded()

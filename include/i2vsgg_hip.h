@@ -240,6 +240,11 @@ int32_t i2v_conv3x3_winograd_fwd(const float* x, const float* U, const float* sc
 /* The same with F(4x4,3x3): 4x fewer MACs than direct, U is (36,Cout,Cin), fp32 error ~1e-5 relative (transform
  * constants up to 8 and 1/24) instead of ~1e-6. */
 int32_t i2v_winograd4_filter(const float* w, float* U, int32_t Cout, int32_t Cin, void* stream);
+/* Winograd-domain filter of the data gradient of the same layer: U'[36][Cin][Cout] from w (Cout,3,3,Cin), taps flipped
+ * and channels swapped, so that gx = i2v_conv3x3_winograd4_fwd(gy, U', NULL, NULL, gx, B, H, W, Cout, Cin, 0, ...) is
+ * the dgrad of a stride-1 / pad-1 3x3 convolution (the 3x3 of Bottleneck.backward when the layer is trained,
+ * resnet_instance_styleD_bilinear.py:203-205 under autograd). */
+int32_t i2v_winograd4_filter_dgrad(const float* w, float* U, int32_t Cout, int32_t Cin, void* stream);
 size_t  i2v_conv3x3_winograd4_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
 int32_t i2v_conv3x3_winograd4_fwd(const float* x, const float* U, const float* scale, const float* shift, float* y,
                                   int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t relu,

@@ -360,6 +360,35 @@ def test_conv_bn_residual_backward(ops):
 
 
 # the last three are tall-and-narrow: the epilogue backward's row-lane reduction (N/4 column groups x row lanes)
+@pytest.mark.parametrize("B,C,N,H,W", [(2, 256, 256, 38, 63), (3, 64, 128, 9, 7), (5, 512, 512, 4, 4)])
+def test_trained_3x3_winograd_fwd_and_dgrad_vs_torch_autograd(ops, B, C, N, H, W):
+    """A stride-1 / pad-1 3x3 layer under autograd runs forward and data gradient as Winograd F(4x4,3x3) (wgrad stays
+    direct): output, input gradient and filter gradient against torch's fp32 conv in float64."""
+    assert ops.WINOGRAD_TRAIN
+    g = torch.Generator(device="cpu").manual_seed(B * C + H)
+    x = torch.randn(B, C, H, W, generator=g).to(DEV).requires_grad_()
+    w = (torch.randn(N, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5).to(DEV).requires_grad_()
+    sc, sh = (torch.rand(N, generator=g) + 0.5).to(DEV), (torch.rand(N, generator=g) - 0.5).to(DEV)
+    gy = torch.randn(B, N, H, W, generator=g).to(DEV)
+    y = ops.conv2d(x, w, sc, sh, None, 1, 1, relu=True, winograd=True)
+    y.backward(gy)
+    xd, wd = x.detach().double().requires_grad_(), w.detach().double().requires_grad_()
+    pre = F.conv2d(xd, wd, padding=1) * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1)
+    rel = lambda a, b: ((a.double() - b).abs().max() / b.abs().max()).item()
+    assert rel(y, torch.relu(pre.detach())) < 1e-4
+    # the ReLU mask is the kernel's own: an output within ~1e-5 of zero may sit on the other side of the ReLU in fp32,
+    # and one flipped element moves the input gradient by a whole tap -- masks must agree everywhere else
+    mask = y.detach() > 0
+    flips = (mask != (pre.detach() > 0))
+    assert not bool((flips & (pre.detach().abs() > 1e-4 * pre.detach().abs().max())).any())
+    (pre * mask * gy.double()).sum().backward()
+    assert rel(x.grad, xd.grad) < 1e-4 and rel(w.grad, wd.grad) < 1e-4
+    # the same layer with the direct kernels (the default of ops.conv2d)
+    x2, w2 = x.detach().clone().requires_grad_(), w.detach().clone().requires_grad_()
+    y2 = ops.conv2d(x2, w2, sc, sh, None, 1, 1, relu=True)
+    assert rel(y, y2.double()) < 1e-4 and not torch.equal(y, y2)
+
+
 @pytest.mark.parametrize("M,K,N", [(8, 50176, 64), (128, 4096, 300), (32, 600, 256), (62, 300, 1024), (5, 64, 1),
                                    (16384, 100, 96), (4099, 64, 128), (1024, 32, 512)])
 def test_linear_fwd_bwd(ops, M, K, N):
