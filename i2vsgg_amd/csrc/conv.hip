@@ -1491,7 +1491,7 @@ static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st) {
     int tm = 64, tk = 64;
     if (v2 && g_wgrad_v2 >= 2) {
         if (p.N >= 128) tm = 128;
-        if (p.K >= 128 && tm == 128) tk = 128;
+        if (p.K >= 128 && tm == 128 && g_wgrad_v2 == 2) tk = 128;
     }
     const long long tiles = (long long)i2v_cdiv(p.N, tm) * i2v_cdiv(p.K, tk);
     const int rs = v2 ? BKS : 16;
