@@ -154,6 +154,8 @@ def main():
                                 if getattr(step, "overlap", False) else
                                 "pipelined: head fwd+bwd -> [gradient exchange || backbone fwd of the next minibatch] -> SGD"
                                 if getattr(step, "pipelined", False) else "one graph: backbone fwd, head fwd+bwd, fused wgrad+SGD"),
+                   "backbone_stream_priority": getattr(step, "bb_priority", None),
+                   "backbone_stream_tuning_ms": getattr(step, "bb_tuning_ms", None),
                    "loss": loss},
         "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (every i2v_conv_fwd/_dgrad call: kernel + its split-K helper kernels)", "achieved": achieved,
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,

@@ -298,8 +298,12 @@ class ZeroArena:
         self.off = self.used = self.wanted = 0
 
     def reset(self):
-        if self.used:
-            self.buf[:self.used].zero_()
+        # while a graph is being captured the clear must cover everything the captured step will take, whatever the
+        # eager steps before it used (an arena that was just re-sized has used == 0: a captured step without a clear
+        # node would accumulate into its own outputs of the previous replay)
+        n = self.buf.numel() if torch.cuda.is_current_stream_capturing() else self.used
+        if n:
+            self.buf[:n].zero_()
         self.off = self.wanted = 0
 
     def take(self, B, C, H, W):

@@ -229,6 +229,7 @@ class SGGEmbStep:
         try:
             if self.overlap:
                 self._capture_overlapped()
+                self._tune_for(torch.cuda.current_stream(self.dev))
             elif not self.pipelined:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
@@ -267,7 +268,7 @@ class SGGEmbStep:
         replayed concurrently).  Single GPU: head graph = head fwd+bwd + SGD.  Multi-GPU: head graph (with the
         column-parallel fc6 collectives captured), eager all-reduce of the remaining gradients, SGD graph."""
         from ._lib import lib
-        self.s_bb = torch.cuda.Stream(self.dev)
+        self.s_bb = torch.cuda.Stream(self.dev)          # capture() -> _tune_side_stream() settles its priority
         self.ev_bb, self.ev_copy = torch.cuda.Event(), torch.cuda.Event()
         gbb, gh = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         gs = torch.cuda.CUDAGraph() if self.pipelined else None
@@ -287,10 +288,72 @@ class SGGEmbStep:
         finally:
             lib.i2v_conv_set_split_slot(-1)
         self.graph = (gbb, gh, gs) if self.pipelined else (gbb, gh)
-        self.s_bb.wait_stream(torch.cuda.current_stream(self.dev))
-        with torch.cuda.stream(self.s_bb):
-            gbb.replay()                    # feature map of the first timed step
-            self.ev_bb.record(self.s_bb)
+
+    def _host_stream(self, caller):
+        """The stream that carries the head graph for this caller: the caller's own, unless that is HIP's legacy
+        default stream (see __call__)."""
+        return self.s_main if caller == torch.cuda.default_stream(self.dev) else caller
+
+    def _tune_for(self, caller):
+        """Settle the side stream for the stream the replays will run on: which priority interleaves depends on the
+        PAIR of streams (measured: the same high-priority side stream gives 5.1 ms beside one stream and 10.3 beside
+        another), so the measurement runs on the hosting stream itself and is repeated when a later call arrives on a
+        different one.  Snapshot, steps and restore all run there -- never on the default stream."""
+        host = self._host_stream(caller)
+        self._tuned_for = host                      # the tuning steps below go through __call__
+        if host != caller:
+            torch.cuda.synchronize(self.dev)
+            host.wait_stream(caller)
+        with torch.cuda.stream(host):
+            self._tune_side_stream()
+        if host != caller:
+            caller.wait_stream(host)
+            torch.cuda.synchronize(self.dev)
+
+    def _prime(self, stream):
+        """Backbone pass of the first step on ``stream`` (the feature map the first head replay consumes)."""
+        self.s_bb = stream
+        torch.cuda.synchronize(self.dev)
+        with torch.cuda.stream(stream):
+            self.graph[0].replay()
+            self.ev_bb.record(stream)
+
+    def _tune_side_stream(self):
+        """Which stream carries the backbone graph is settled by measurement.  How HIP maps streams to hardware queues
+        decides whether the two graphs interleave at all, and it depends on things this object does not control.
+        Measured on MI355X / ROCm 7.2 (ms per step): without a process group a normal-priority side stream gives 5.1
+        and a high-priority one 10.3; with an RCCL process group alive it is 6.1 (the side stream shares an in-order
+        queue: no interleaving) against 5.1.  So: run three steps with each, keep the faster, and put parameters,
+        momentum and the RNG state back exactly as they were -- the tuning steps leave no trace in the trajectory.
+        I2V_BB_PRIORITY=0/-1 pins the choice."""
+        import os
+        import time
+        pin = os.environ.get("I2V_BB_PRIORITY")
+        if pin is not None:
+            self.bb_priority = int(pin)
+            self._prime(torch.cuda.Stream(self.dev, priority=self.bb_priority))
+            return
+        state = [it["p"].data for it in self.opt.items] + [it["m"] for it in self.opt.items]
+        saved = [t.clone() for t in state]
+        rng = torch.cuda.get_rng_state(self.dev)
+        timing = {}
+        for prio in (0, -1):
+            stream = torch.cuda.Stream(self.dev, priority=prio)
+            self._prime(stream)
+            self()                                    # settle
+            torch.cuda.synchronize(self.dev)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                self()
+            torch.cuda.synchronize(self.dev)
+            timing[prio] = (time.perf_counter() - t0, stream)
+        self.bb_priority = min(timing, key=lambda k: timing[k][0])
+        self.bb_tuning_ms = {k: v[0] / 3 * 1e3 for k, v in timing.items()}
+        with torch.no_grad():
+            for t, sv in zip(state, saved):
+                t.copy_(sv)
+        torch.cuda.set_rng_state(rng, self.dev)
+        self._prime(timing[self.bb_priority][1])
 
     def _call_overlapped(self):
         gbb, gh = self.graph[0], self.graph[1]
@@ -322,13 +385,18 @@ class SGGEmbStep:
         # it, and so does replaying on an ordinary stream -- there every run reproduces the one-graph / eager
         # trajectory to the last bit or two (tests/test_gpu_models.py::test_sgg_step_back_to_back_replays_are_ordered).
         # A caller that is on the default stream gets the replays on a stream of this object, ordered against its own
-        # stream on both sides: correct, but those waits on the default stream cost the overlap (6.0 instead of
-        # 5.3 ms per step), so bench.py and the training script set an ordinary current stream.
+        # stream on both sides and with a device synchronize before each step (event waits alone were not enough once
+        # the side stream had a priority): correct, but it costs the overlap across steps (6.0 instead of 5.1 ms per
+        # step), so bench.py and the training script set an ordinary current stream.
         caller = torch.cuda.current_stream(self.dev)
-        detour = caller == torch.cuda.default_stream(self.dev)
+        host = self._host_stream(caller)
+        detour = host != caller
+        if self.overlap and getattr(self, "_tuned_for", None) != host:
+            self._tune_for(caller)                  # first call from this stream
         if detour:
+            torch.cuda.synchronize(self.dev)        # nothing of the previous step in flight: the conservative form
             self.s_main.wait_stream(caller)
-        with torch.cuda.stream(self.s_main if detour else caller):
+        with torch.cuda.stream(host):
             if self.overlap:
                 self._call_overlapped()
             elif len(self.graph) == 1:
