@@ -1220,7 +1220,7 @@ conv_wgrad2_f32(const WgP p) {
     // reduction (read in the epilogue loop they cost one exposed round trip per iteration: the stores of one
     // iteration alias the loads of the next as far as the compiler knows)
     constexpr int W_LD = (BMW * (BNW / 4) + THREADS - 1) / THREADS;
-    constexpr bool PREFETCH_W = FUSED_SGD && W_LD <= 4;
+    constexpr bool PREFETCH_W = FUSED_SGD && W_LD <= 8;
     float4 pw[PREFETCH_W ? W_LD : 1], pm[PREFETCH_W ? W_LD : 1];
     if (PREFETCH_W && p.sgd_m) {
 #pragma unroll
@@ -1489,6 +1489,8 @@ static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st) {
     const bool v2 = (p.N % 4 == 0) && xb < (1ll << 31) && gb < (1ll << 31) && g_wgrad_v2;
     // bigger tiles raise the FLOP per staged byte (the reduction dim is streamed): 128x128 = 32 FLOP/B vs 16
     int tm = 64, tk = 64;
+    static const int fused_tile = [] { const char* e = getenv("I2V_WGRAD_FUSED_TILE"); return e ? atoi(e) : 64; }();
+    if (v2 && fused && fused_tile == 128 && p.N >= 128) tm = 128;      // 128 filters x 64 taps: the x tile is shared by twice the filters
     if (v2 && g_wgrad_v2 >= 2) {
         if (p.N >= 128) tm = 128;
         if (p.K >= 128 && tm == 128 && g_wgrad_v2 == 2) tk = 128;
@@ -1510,6 +1512,7 @@ static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st) {
     p.gy_bytes = (unsigned)gb;
     const dim3 grid((unsigned)tiles, splits);
     if (!v2) conv_wgrad_f32<64, 64><<<grid, THREADS, 0, st>>>(p);
+    else if (fused && tm == 128 && tk == 64) conv_wgrad2_f32<4, 2, true><<<grid, THREADS, 0, st>>>(p);
     else if (tm == 128 && tk == 128) conv_wgrad2_f32<4, 4><<<grid, THREADS, 0, st>>>(p);
     else if (tm == 128) conv_wgrad2_f32<4, 2><<<grid, THREADS, 0, st>>>(p);
     else if (fused) conv_wgrad2_f32<2, 2, true><<<grid, THREADS, 0, st>>>(p);
