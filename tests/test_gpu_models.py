@@ -344,6 +344,29 @@ def test_sgg_step_back_to_back_replays_are_ordered(cfg):
             assert abs(got[0] - want[0]) < 1e-5 and abs(got[1] - want[1]) < 1e-6 * want[1], (own, got, want)
 
 
+def test_captured_backbone_graph_is_idempotent_after_one_warmup(cfg, monkeypatch):
+    """A graph captured right after ONE warm-up step (the arena of atomically accumulated outputs has just been
+    re-sized and has recorded no use yet) still carries its clear: replaying the backbone graph again and again gives
+    the eager feature map every time.  (Without the clear each replay accumulates into the previous one's outputs.)"""
+    from i2vsgg_amd import train
+    monkeypatch.setenv("I2V_BB_PRIORITY", "0")
+    net = train.build_sgg_net(layers=50, seed=5, device=DEV)
+    step = train.SGGEmbStep(net, 2, seed=3, device=DEV, h=200, w=320, n_boxes=6, n_pairs=5)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        assert step.capture(warmup=1) and step.overlap, getattr(step, "graph_error", None)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            want = net.RCNN_base(step.im).clone()
+        for _ in range(3):
+            step.graph[0].replay()
+            torch.cuda.synchronize()
+            assert _rel_err(step.fmap.cpu().numpy(), want.cpu().numpy()) < 1e-5
+    torch.cuda.current_stream().wait_stream(s)
+    step.opt.unfuse()
+
+
 def test_detect_frame_eval_loop_matches_oracle_postprocess(cfg):
     """eval.detect_frame (test_net_instance_styleD_bilinear.py:140-221): eval forward (TEST proposal settings) + the
     device post-processing pass == the oracle's restatement applied to the same network outputs."""
