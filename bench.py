@@ -108,7 +108,10 @@ def main():
     torch.cuda.synchronize(dev)
     rec = ops.PROFILE
     ops.PROFILE = None
-    fwd = [(e0.elapsed_time(e1) * 1e-3, fl) for e0, e1, fl, tag, _d in rec if tag in ("fwd", "dgrad")]
+    # the calls that run on conv_igemm_f32: every forward and the convolution data gradients (linear-layer data
+    # gradients run on the wgrad kernel with the roles swapped and are reported under by_kind only)
+    on_igemm = lambda tag, d: tag in ("fwd", "dgrad") and "(wgrad form)" not in d
+    fwd = [(e0.elapsed_time(e1) * 1e-3, fl) for e0, e1, fl, tag, d in rec if on_igemm(tag, d)]
     t_conv = sum(t for t, _ in fwd)
     f_conv = sum(f for _, f in fwd)
     by_tag = {}
@@ -118,7 +121,7 @@ def main():
     achieved = f_conv / t_conv / 1e12
     # the same calls counted by the MACs the matrix cores actually execute (Winograd F(4x4,3x3): 9/36 of the direct count)
     f_exec = sum((fl * (9.0 / 36.0 if "winograd F4" in d else 16.0 / 36.0 if "winograd" in d else 1.0))
-                 for e0, e1, fl, tag, d in rec if tag in ("fwd", "dgrad"))
+                 for e0, e1, fl, tag, d in rec if on_igemm(tag, d))
     achieved_exec = f_exec / t_conv / 1e12
     if a.dump_launches and rank == 0:
         per = len(rec) // n_prof
@@ -157,15 +160,16 @@ def main():
                    "backbone_stream_priority": getattr(step, "bb_priority", None),
                    "backbone_stream_tuning_ms": getattr(step, "bb_tuning_ms", None),
                    "loss": loss},
-        "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (every i2v_conv_fwd/_dgrad call: kernel + its split-K helper kernels)", "achieved": achieved,
+        "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (every i2v_conv_fwd call and every convolution _dgrad call: kernel + its split-K helper kernels)", "achieved": achieved,
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "note": ("achieved = ALGORITHMIC FLOPs (2*M*N*K of the direct convolution / linear layer) of every i2v_conv_fwd, "
-                              "_dgrad and Winograd call / their summed durations; the 30 frozen 3x3 layers of layer1-3 run as "
+                              "convolution _dgrad and Winograd call / their summed durations (linear-layer data gradients run on the "
+                              "wgrad kernel and are listed under by_kind only); the 30 frozen 3x3 layers of layer1-3 run as "
                               "Winograd F(4x4,3x3) (transforms + one batched conv_igemm_f32 launch) and execute 4x fewer MACs "
                               "than that count"),
                      "executed_mfma_tflops": achieved_exec, "executed_mfma_frac": achieved_exec / MFMA_F32_PEAK_TFLOPS,
-                     "algorithmic_bytes_per_launch": 4.8e9 / 117,
+                     "algorithmic_bytes_per_launch": 4.8e9 / max(len(fwd) // n_prof, 1),
                      "launches_per_step": len(fwd) // n_prof,
                      "avg_launch_us": 1e6 * t_conv / max(len(fwd), 1),
                      "gflop_per_step": f_conv / n_prof / 1e9,
