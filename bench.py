@@ -184,8 +184,15 @@ def main():
                                "sample": "1 frame 600x1000: ResNet-101 C4 fwd + vrd head fwd/bwd/SGD for 32 boxes + "
                                          "32 pairs, best of 2 (%.2f s)" % sec}
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+        print(json.dumps(out), flush=True)
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        # the graphs that captured RCCL kernels go first: tearing the communicator down under them can abort
+        import gc
+        torch.cuda.synchronize(dev)
+        step.opt.unfuse()
+        del step, net
+        gc.collect()
+        torch.cuda.synchronize(dev)
         torch.distributed.destroy_process_group()
 
 

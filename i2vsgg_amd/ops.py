@@ -389,7 +389,9 @@ def _conv_wgrad_raw(x, g, w_shape, stride, pad, tag="wgrad"):
     # zeroed gw -- take it from the step's pre-zeroed arena and accumulate (beta = 1) instead of one clear per call
     gw, beta = None, 0.0
     n = Cout * Cin * KH * KW
-    if ARENA is not None and n * 4 <= SMALL_GW_BYTES:
+    # up to 224 pixels the launcher never splits the reduction (fewer than 8 stages of 32): one workgroup per tile
+    # stores its result directly -- no zeroed output, no atomics
+    if ARENA is not None and n * 4 <= SMALL_GW_BYTES and B * g.shape[2] * g.shape[3] > 224:
         flat = ARENA.take_flat(n)
         if flat is not None:
             gw, beta = flat.view(Cout, KH, KW, Cin).permute(0, 3, 1, 2), 1.0

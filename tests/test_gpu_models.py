@@ -524,6 +524,11 @@ def test_sgg_step_tensor_parallel_fc6_rehearsal_matches_single_graph(cfg, monkey
             res.append((losses, w6.detach().cpu().numpy().copy(), net.vrd.fc7.fc.weight.detach().cpu().numpy().copy()))
             step.opt.unfuse()
         finally:
+            # the graphs that captured RCCL kernels go before the communicator
+            step = net = None
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
             if forced:
                 dist.destroy_process_group()
     (l0, a0, b0), (l1, a1, b1) = res
