@@ -224,6 +224,65 @@ roi_pool_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ ro
     }
 }
 
+// NHWC map, C % 128 == 0: a workgroup owns 128 channels of one ROI; a 32-lane group takes one bin at a time with four
+// channels per lane (one 16-B load per window cell instead of four 4-B ones), eight bins in flight per workgroup.  Window
+// cells are visited in the same (h, w) order per channel as above: same maxima, same first-maximum argmax.
+__global__ void __launch_bounds__(256)
+roi_pool_fwd_c128_kernel(const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
+                         int* __restrict__ argmax, int C, int H, int W, int PH, int PW, float scale, int out_nchw) {
+    extern __shared__ float lds[];
+    const int P = PH * PW;
+    float* sval = lds;
+    int* sarg = (int*)(lds + 128 * P);
+    const int chunks = C / 128;
+    const int r = blockIdx.x / chunks, c0 = (blockIdx.x % chunks) * 128;
+    const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const float* roi = rois + 5 * (long long)r;
+    const int b = (int)roi[0];
+    const int x1 = (int)roundf(roi[1] * scale), y1 = (int)roundf(roi[2] * scale);
+    const int x2 = (int)roundf(roi[3] * scale), y2 = (int)roundf(roi[4] * scale);
+    const int rw = max(x2 - x1 + 1, 1), rh = max(y2 - y1 + 1, 1);
+    const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+    const float* fb = feat + (long long)b * H * W * C + c0 + 4 * l32;
+    for (int p = grp; p < P; p += 8) {
+        const int ph = p / PW, pw = p - ph * PW;
+        int hs = (int)floorf((float)ph * bh), he = (int)ceilf((float)(ph + 1) * bh);
+        hs = min(max(hs + y1, 0), H); he = min(max(he + y1, 0), H);
+        int ws = (int)floorf((float)pw * bw), we = (int)ceilf((float)(pw + 1) * bw);
+        ws = min(max(ws + x1, 0), W); we = min(max(we + x1, 0), W);
+        const bool empty = (he <= hs) || (we <= ws);
+        float4 m = empty ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+        int4 mi = make_int4(-1, -1, -1, -1);
+        for (int h = hs; h < he; ++h) {
+            const float* row = fb + (long long)h * W * C;
+            for (int w = ws; w < we; ++w) {
+                const float4 v = *(const float4*)(row + (long long)w * C);
+                const int id = h * W + w;
+                if (v.x > m.x) { m.x = v.x; mi.x = id; }
+                if (v.y > m.y) { m.y = v.y; mi.y = id; }
+                if (v.z > m.z) { m.z = v.z; mi.z = id; }
+                if (v.w > m.w) { m.w = v.w; mi.w = id; }
+            }
+        }
+        const int e = (4 * l32) * P + p;
+        sval[e] = m.x; sval[e + P] = m.y; sval[e + 2 * P] = m.z; sval[e + 3 * P] = m.w;
+        sarg[e] = mi.x; sarg[e + P] = mi.y; sarg[e + 2 * P] = mi.z; sarg[e + 3 * P] = mi.w;
+    }
+    __syncthreads();
+    if (out_nchw) {                      // (r, c0..c0+128, :, :) is contiguous
+        float* o = out + (long long)r * C * P + (long long)c0 * P;
+        int* a = argmax + (long long)r * C * P + (long long)c0 * P;
+        for (int e = threadIdx.x; e < 128 * P; e += 256) { o[e] = sval[e]; a[e] = sarg[e]; }
+    } else {                             // NHWC: (r, p, c) with c contiguous
+        for (int e = threadIdx.x; e < 128 * P; e += 256) {
+            const int p = e >> 7, ch = e & 127;
+            const long long o = (long long)r * P * C + (long long)p * C + c0 + ch;
+            out[o] = sval[ch * P + p];
+            argmax[o] = sarg[ch * P + p];
+        }
+    }
+}
+
 __global__ void roi_pool_bwd_kernel(const float* __restrict__ gout, const int* __restrict__ argmax,
                                     const float* __restrict__ rois, float* __restrict__ gfeat, long long total,
                                     int C, int W, int P, Strides fs, int out_nchw) {
@@ -404,6 +463,13 @@ extern "C" int32_t i2v_roi_pool_fwd(const float* feat, int32_t feat_layout, int3
     I2V_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && R >= 0 && PH > 0 && PW > 0, "roi_pool_fwd: bad shape");
     I2V_CHECK_ARG(PH * PW <= 256, "roi_pool_fwd: pooled grid too large for the LDS stage");
     Strides fs = feat_strides(feat_layout, C, H, W), os = out_strides(out_layout, C, PH, PW);
+    static const int c128 = [] { const char* e = getenv("I2V_ROIPOOL_C128"); return e ? atoi(e) : 1; }();
+    if (c128 && feat_layout == I2V_LAYOUT_NHWC && C % 128 == 0 && (size_t)128 * PH * PW * 8 <= 64 * 1024) {
+        roi_pool_fwd_c128_kernel<<<R * (C / 128), 256, (size_t)128 * PH * PW * 8, (hipStream_t)stream>>>(
+            feat, rois, out, argmax, C, H, W, PH, PW, scale, out_layout == I2V_LAYOUT_NCHW);
+        I2V_CHECK_LAUNCH("roi_pool_fwd");
+        return I2V_OK;
+    }
     size_t lds = (size_t)64 * PH * PW * 8;
     roi_pool_fwd_kernel<<<R * ((C + 63) / 64), 256, lds, (hipStream_t)stream>>>(
         feat, rois, out, argmax, C, H, W, PH, PW, scale, fs, os, out_layout == I2V_LAYOUT_NCHW);
