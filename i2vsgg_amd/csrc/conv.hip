@@ -1390,7 +1390,7 @@ __global__ void __launch_bounds__(256) sgd_momentum_multi_kernel(const SgdMulti 
 __global__ void __launch_bounds__(256)
 epilogue_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ scale,
                     float* __restrict__ g, float* __restrict__ gpre, float* __restrict__ gbias, long long M, int N,
-                    int relu, int rows_per_blk) {
+                    int relu, int rows_per_blk, float* __restrict__ g_t) {
     const int n = (blockIdx.y * 256 + threadIdx.x) * 4;
     if (n >= N) return;
     const long long r0 = (long long)blockIdx.x * rows_per_blk;
@@ -1409,6 +1409,10 @@ epilogue_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, c
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         if (gpre) *(float4*)(gpre + r * N + n) = v;
         if (g) *(float4*)(g + r * N + n) = make_float4(v.x * sc.x, v.y * sc.y, v.z * sc.z, v.w * sc.w);
+        if (g_t) {          // the same gradient column-major, (N x M): what a linear layer's dgrad on the wgrad kernel reads
+            g_t[(long long)n * M + r] = v.x * sc.x; g_t[(long long)(n + 1) * M + r] = v.y * sc.y;
+            g_t[(long long)(n + 2) * M + r] = v.z * sc.z; g_t[(long long)(n + 3) * M + r] = v.w * sc.w;
+        }
     }
     if (gbias) {
         atomicAdd(gbias + n, s.x); atomicAdd(gbias + n + 1, s.y);
@@ -1465,7 +1469,7 @@ epilogue_bwd_narrow_kernel(const float* __restrict__ gy, const float* __restrict
 __global__ void __launch_bounds__(256)
 epilogue_bwd_scalar_kernel(const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ scale,
                            float* __restrict__ g, float* __restrict__ gpre, float* __restrict__ gbias, long long M,
-                           int N, int relu, int rows_per_blk) {
+                           int N, int relu, int rows_per_blk, float* __restrict__ g_t) {
     const int n = blockIdx.y * 256 + threadIdx.x;
     if (n >= N) return;
     const long long r0 = (long long)blockIdx.x * rows_per_blk;
@@ -1478,6 +1482,7 @@ epilogue_bwd_scalar_kernel(const float* __restrict__ gy, const float* __restrict
         s += v;
         if (gpre) gpre[r * N + n] = v;
         if (g) g[r * N + n] = v * sc;
+        if (g_t) g_t[(long long)n * M + r] = v * sc;
     }
     if (gbias) atomicAdd(gbias + n, s);
 }
@@ -1747,7 +1752,7 @@ extern "C" int32_t i2v_conv_wgrad_sgd(const float* x, const float* gy, float* w,
 }
 
 extern "C" int32_t i2v_epilogue_bwd(const float* gy, const float* y, const float* scale, float* g, float* gpre,
-                                    float* gbias, int64_t M, int32_t N, int32_t relu, void* stream) {
+                                    float* gbias, int64_t M, int32_t N, int32_t relu, float* g_t, void* stream) {
     I2V_CHECK_ARG(gy && M >= 0 && N > 0, "epilogue_bwd: bad argument");
     I2V_CHECK_ARG(!relu || y, "epilogue_bwd: relu needs y");
     if (M == 0) return I2V_OK;
@@ -1756,7 +1761,7 @@ extern "C" int32_t i2v_epilogue_bwd(const float* gy, const float* y, const float
     // enough workgroups to cover the chip even for the 64..128-row tensors of the relation head
     int rows = 64;
     while (rows > 4 && (long long)i2v_cdiv(M, rows) * i2v_cdiv(N, cols) < 2 * NUM_CU) rows >>= 1;
-    if (vec && N <= 512 && M >= 1024) {
+    if (vec && N <= 512 && M >= 1024 && !g_t) {
         // tall and narrow: all 256 threads on one row block, one atomic per column per workgroup
         const int lanes = 256 / (N >> 2);
         // few workgroups: same-address atomics retire one per ~150 ns, so 256 contenders cost more than the rows
@@ -1768,8 +1773,8 @@ extern "C" int32_t i2v_epilogue_bwd(const float* gy, const float* y, const float
         return I2V_OK;
     }
     dim3 grid(i2v_cdiv(M, rows), i2v_cdiv(N, cols));
-    if (vec) epilogue_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(gy, y, scale, g, gpre, gbias, M, N, relu, rows);
-    else epilogue_bwd_scalar_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(gy, y, scale, g, gpre, gbias, M, N, relu, rows);
+    if (vec) epilogue_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(gy, y, scale, g, gpre, gbias, M, N, relu, rows, g_t);
+    else epilogue_bwd_scalar_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(gy, y, scale, g, gpre, gbias, M, N, relu, rows, g_t);
     I2V_CHECK_LAUNCH("epilogue_bwd");
     return I2V_OK;
 }

@@ -355,11 +355,17 @@ def _conv_fwd_raw(x, w, scale, shift, res, stride, pad, flags):
 LINEAR_DGRAD_AS_WGRAD = int(os.environ.get("I2V_LINEAR_DGRAD_AS_WGRAD", "0"))     # filter elements from which a linear layer's dgrad goes through the wgrad kernel
 
 
+def _linear_dgrad_as_wgrad(in_shape, w_shape, stride, pad):
+    B, Cin, H, W = in_shape
+    Cout, _, KH, KW = w_shape
+    return (H, W, KH, KW, stride, pad) == (1, 1, 1, 1, 1, 0) and B <= Cin and (Cout * Cin >= LINEAR_DGRAD_AS_WGRAD or Cout % 4 != 0)
+
+
 def _conv_dgrad_raw(g, w, in_shape, stride, pad):
     B, Cin, H, W = in_shape
     Cout, _, KH, KW = w.shape
     dev = g.device
-    if (H, W, KH, KW, stride, pad) == (1, 1, 1, 1, 1, 0) and B <= Cin and (Cout * Cin >= LINEAR_DGRAD_AS_WGRAD or Cout % 4):
+    if _linear_dgrad_as_wgrad(in_shape, w.shape, stride, pad):
         # linear layer: gx[m][k] = sum_n g[m][n] w[n][k] is a 'filter gradient' whose pixel axis is n, whose activations
         # are w as stored (n x k) and whose output gradient is g^T (n x m) -- only the small g is transposed, where the
         # implicit-GEMM form re-lays the whole filter out first (fc7: 134 -> 48 us in the step, the 64-row layers
@@ -466,7 +472,7 @@ class _ConvFn(torch.autograd.Function):
         stride, pad, relu, has_scale, has_shift, has_res = ctx.cfg
         gy = as_nhwc(gy)
         M, N = gy.shape[0] * gy.shape[2] * gy.shape[3], gy.shape[1]
-        gres = None
+        gres = g_t = None
         need_bias = ctx.needs_input_grad[3] and has_shift and not has_scale
         need_res = has_res and ctx.needs_input_grad[4]
         gbias = None
@@ -482,8 +488,12 @@ class _ConvFn(torch.autograd.Function):
             want_g = has_scale or relu
             g = torch.empty_like(gy) if want_g else None
             gpre = torch.empty_like(gy) if (want_pre and has_scale) else None
+            # a linear layer whose data gradient will run on the wgrad kernel wants g column-major as well: written by
+            # this pass instead of a transpose kernel of its own
+            if ctx.needs_input_grad[0] and not ctx.wino and _linear_dgrad_as_wgrad(x.shape, w.shape, stride, pad):
+                g_t = torch.empty((N, M, 1, 1), device=gy.device, dtype=torch.float32)
             check(lib.i2v_epilogue_bwd(ptr(gy), ptr(y), ptr(scale) if has_scale else None, ptr(g), ptr(gpre), ptr(gbias),
-                                       M, N, int(relu), stream()), "epilogue_bwd")
+                                       M, N, int(relu), ptr(g_t), stream()), "epilogue_bwd")
             if g is None:
                 g = gy
             if need_res:
@@ -493,7 +503,12 @@ class _ConvFn(torch.autograd.Function):
             gres = gy if need_res else None
         gx = None
         if ctx.needs_input_grad[0]:
-            gx = conv3x3_winograd(g, winograd_filter_dgrad(w), tag="dgrad") if ctx.wino else _conv_dgrad_raw(g, w, x.shape, stride, pad)
+            if ctx.wino:
+                gx = conv3x3_winograd(g, winograd_filter_dgrad(w), tag="dgrad")
+            elif g_t is not None:
+                gx = _conv_wgrad_raw(w, g_t, (x.shape[0], x.shape[1], 1, 1), 1, 0, tag="dgrad")
+            else:
+                gx = _conv_dgrad_raw(g, w, x.shape, stride, pad)
         gw = None
         if ctx.needs_input_grad[1]:
             fused = FUSED_SGD.get(w.data_ptr())

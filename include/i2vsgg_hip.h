@@ -258,9 +258,11 @@ int32_t i2v_conv_wgrad_sgd(const float* x, const float* gy, float* w, float* m, 
                            float lr, float momentum, float weight_decay, void* stream);
 
 /* epilogue backward, one streaming pass: g_pre = gy * (y>0) [relu]; g = g_pre * scale[n] (scale may be NULL);
- * gbias[n] += column sums of g_pre.  g, gpre and gbias may each be NULL; in-place (g == gy or gpre == gy) allowed. */
+ * gbias[n] += column sums of g_pre.  g, gpre and gbias may each be NULL; in-place (g == gy or gpre == gy) allowed.
+ * g_t (may be NULL): g once more, column-major (N x M) -- the operand a linear layer's data gradient reads when it
+ * runs on the filter-gradient kernel with the roles swapped (saves the separate transpose of the small gradient). */
 int32_t i2v_epilogue_bwd(const float* gy, const float* y, const float* scale, float* g, float* gpre, float* gbias,
-                         int64_t M, int32_t N, int32_t relu, void* stream);
+                         int64_t M, int32_t N, int32_t relu, float* g_t, void* stream);
 
 /* 3x3 / stride 2 / pad 0 / ceil_mode max pool of the stem (resnet_instance...:228), NHWC */
 int32_t i2v_maxpool3x3s2_fwd(const float* x, float* y, int32_t* argmax, int32_t B, int32_t H, int32_t W, int32_t C,
