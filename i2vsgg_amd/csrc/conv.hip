@@ -722,7 +722,7 @@ int g_ablate = 0;
 unsigned long long* g_clk = nullptr;   // i2v_conv_debug_clock()
 // -1 / 0: plain 4-wave kernel, 1: loader/MFMA specialised 8-wave kernel, 2: specialised when <= 3 workgroups per CU
 int g_spec_mode = [] { const char* e = getenv("I2V_CONV_SPEC"); return e ? atoi(e) : -1; }();
-int g_split_target = [] { const char* e = getenv("I2V_SPLIT_TARGET"); return e ? atoi(e) : 2; }();
+int g_split_target = [] { const char* e = getenv("I2V_SPLIT_TARGET"); return e ? atoi(e) : 3; }();     // 3: 4.88 ms per step against 4.94 with 2 and 5.21 with 4
 int g_split_below = [] { const char* e = getenv("I2V_SPLIT_BELOW"); return e ? atoi(e) : NUM_CU; }();
 
 // Split-K workspace: one slab + one counter array per stream (up to kSplitSlots streams; beyond that, or for

@@ -347,7 +347,9 @@ class SGGEmbStep:
                 self()
             torch.cuda.synchronize(self.dev)
             timing[prio] = (time.perf_counter() - t0, stream)
-        self.bb_priority = min(timing, key=lambda k: timing[k][0])
+        # normal priority unless the high-priority stream is clearly faster (it is by ~17 % when an RCCL process group is
+        # alive): when the two measure alike, the high-priority stream has been seen to fall into the 10 ms mode later
+        self.bb_priority = -1 if timing[-1][0] < 0.92 * timing[0][0] else 0
         self.bb_tuning_ms = {k: v[0] / 3 * 1e3 for k, v in timing.items()}
         with torch.no_grad():
             for t, sv in zip(state, saved):
