@@ -876,6 +876,11 @@ int run_conv(ConvP p, hipStream_t st) {
     // batched launches with at most four K stages (the Winograd planes of the 64- and 128-channel layers): per-workgroup
     // set-up and epilogue dominate and the model underrates the smallest tile (measured 23.5 vs 27.4 us at 64 channels)
     if (p.nbatch > 1 && ksteps <= 4) { cfg = kNumTiles - 1; plan(cfg, splitk); }
+    // the long skinny GEMM of the relation head (fc6 forward: 128 rows, K = 50176): 128x64 tiles instead of the 128x128 the
+    // model picks -- twice the workgroups, each half as heavy.  Alone 436 vs 412 us, inside the two-stream step 4.88 vs
+    // 4.93 ms (the same effect as with the fused update's tile: lighter workgroups give the other stream its turn sooner)
+    static const int big_fc_tile = [] { const char* e = getenv("I2V_BIG_FC_TILE"); return e ? atoi(e) : 1; }();
+    if (big_fc_tile >= 0 && big_fc_tile < kNumTiles && p.M <= 256 && p.K >= 16384) { cfg = big_fc_tile; plan(cfg, splitk); }
     if (force >= 0 && force < kNumTiles) { cfg = force; plan(cfg, splitk); }
     p.splitk = splitk;
     p.k_per_split = i2v_cdiv(ksteps, splitk) * BKS;
