@@ -228,3 +228,16 @@ def tie_free_dets(seed, n, im_h=600, im_w=1000, clustered=False):
         b = boxes(seed + 3, n, im_h, im_w, 16, 400)
     s = np.sort(rng.permutation(4 * n + 16)[:n].astype(np.float32))[::-1] / np.float32(4 * n + 16)
     return np.concatenate([b.astype(np.float32), s[:, None].astype(np.float32)], 1)
+
+
+def context_inputs(B=2, H=320, W=480):
+    """Inputs of the ic/gc fixture (tools/gen_golden.py gen_context and tests/test_gpu_models.py): frames, gt, fixed proposals."""
+    im, info = frames(5, B, H, W)
+    gt, nb = gt_boxes(6, B, 6, 16, im_h=H, im_w=W)
+    rois = np.zeros((B, 600, 5), np.float32)
+    for b in range(B):
+        rois[b, :, 0] = b
+        rois[b, :, 1:] = boxes(430 + b, 600, im_h=H, im_w=W, min_side=16, max_side=220)
+        jit = np.random.default_rng(440 + b).normal(0, 6, (48, 4)).astype(np.float32)
+        rois[b, :48, 1:] = np.clip(gt[b, np.arange(48) % 6, :4] + jit, 0, [W - 1, H - 1, W - 1, H - 1])
+    return im, info, gt, nb, rois

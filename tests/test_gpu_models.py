@@ -61,6 +61,73 @@ def test_backbone_and_layer4_vs_reference_golden(cfg, gold):
     assert _rel_err(h2t.cpu().numpy(), g["head_to_tail_full"]) < REL
 
 
+@pytest.mark.parametrize("layers,blocks,nfr,seed", [(101, (3, 4, 23), 2, 1), (50, (3, 4, 6), 1, 0)])
+def test_backbone_full_frame_vs_reference_golden(cfg, gold, layers, blocks, nfr, seed):
+    """the C4 trunk on FULL 600x1000 frames (the 150x250 / 75x125 / 38x63 grids with their real
+    tile padding, Winograd F(4x4,3x3) on the frozen 3x3 layers) against the reference ResNet run on the same frames
+    (tools/gen_golden.py gen_full_frame): shape, sum, abs-sum and a strided sample of base_feat and of the style tap.
+    res101 on the two configs[1] frames; res50 on the configs[0] frame."""
+    from i2vsgg_amd.model.faster_rcnn.layers import C4Base
+    g = gold("backbone_full_frame")
+    p = syn.backbone_params(0, layers)
+    base = _load(C4Base(blocks), p, "RCNN_base.").to(DEV)
+    im, _ = syn.frames(seed, nfr, 600, 1000)
+    with torch.no_grad():
+        feat, feat1 = base(torch.from_numpy(im).to(DEV), tap=True)
+    for key, t in (("feat", feat), ("feat1", feat1)):
+        tag = "r%d_%s" % (layers, key)
+        v = t.contiguous().cpu().numpy()                         # logical NCHW order, as the reference stores it
+        assert tuple(v.shape) == tuple(g[tag + "_shape"]), tag
+        assert _rel_err(v.reshape(-1)[::251], g[tag + "_sample"]) < REL, tag
+        v64 = v.astype(np.float64)
+        assert abs(v64.sum() - float(g[tag + "_sum"])) < REL * float(g[tag + "_abs"]), tag
+        assert abs(np.abs(v64).sum() - float(g[tag + "_abs"])) < REL * float(g[tag + "_abs"]), tag
+
+
+def test_context_ic_gc_vs_reference_golden(cfg, gold):
+    """``_fasterRCNN`` with ic = gc = True (context vectors of both discriminators concatenated
+    in front of the layer4 feature) against the reference model run with the same parameters, the same fixed
+    proposals and the same np.random stream (tools/gen_golden.py gen_context)."""
+    from i2vsgg_amd.model.faster_rcnn.layers import load_reference_state
+    from i2vsgg_amd.model.faster_rcnn.resnet_instance_styleD_bilinear import resnet
+    g = gold("context_ic_gc")
+    n_cls = 16
+    cfg.TRAIN.BATCH_SIZE = 32
+    try:
+        net = resnet(tuple(range(n_cls)), 50, ic=True, gc=True)
+        net.create_architecture()
+        p = {}
+        p.update(syn.backbone_params(0, 50, top=True))
+        p.update(syn.det_head_params(11, n_cls, feat_d=2048 + 512 + 128))
+        p.update(syn.netd_params(12))
+        r = load_reference_state(net, p, strict=False)
+        assert not r.unexpected_keys, r.unexpected_keys
+        assert all(k.startswith("RCNN_rpn.") or "num_batches" in k for k in r.missing_keys), r.missing_keys
+        net.to(DEV).train()
+        im, info, gt, nb, rois = syn.context_inputs()
+        rois_d = torch.from_numpy(rois).to(DEV)
+
+        class FixedRPN(torch.nn.Module):
+            def forward(self, base_feat, im_info, gt_boxes, num_boxes, target=False):
+                z = torch.zeros(1, device=DEV)
+                return rois_d, z, z
+
+        net.RCNN_rpn = FixedRPN()
+        np.random.seed(3)
+        with torch.no_grad():
+            out = net(torch.from_numpy(im).to(DEV), torch.from_numpy(info).to(DEV), torch.from_numpy(gt).to(DEV),
+                      torch.from_numpy(nb).to(DEV), target=False, eta=0.1, eta_style=0.001)
+    finally:
+        cfg.TRAIN.BATCH_SIZE = 128
+    rr, cls_prob, bbox_pred, _, _, l_cls, l_box, label, d_inst, d_sty = out
+    assert np.array_equal(rr.cpu().numpy(), g["rois"]) and np.array_equal(label.cpu().numpy(), g["labels"])
+    assert _rel_err(cls_prob.cpu().numpy(), g["cls_prob"]) < REL
+    assert _rel_err(bbox_pred.cpu().numpy(), g["bbox_pred"]) < REL
+    assert _rel_err(l_cls.cpu().numpy(), g["loss_cls"]) < REL and _rel_err(l_box.cpu().numpy(), g["loss_box"]) < REL
+    assert _rel_err(d_inst.cpu().numpy(), g["d_instance"]) < REL
+    assert _rel_err(d_sty.cpu().numpy(), g["d_style"]) < REL
+
+
 def test_discriminators_vs_reference_golden(cfg, gold):
     from i2vsgg_amd.model.faster_rcnn.resnet_instance_styleD_bilinear import netD_pixel, netD_style
     g = gold("discriminators")

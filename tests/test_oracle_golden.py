@@ -160,6 +160,21 @@ def test_backbone_small(gold):
     np.testing.assert_allclose(h2t.numpy(), g["head_to_tail_full"], rtol=1e-4, atol=1e-5)
 
 
+def test_backbone_full_frame_res50(gold):
+    """The oracle trunk on one FULL 600x1000 frame (configs[0]: cfgs/res50.yml plumbing) against the reference ResNet-50
+    run on the same frame (tools/gen_golden.py gen_full_frame)."""
+    g = gold("backbone_full_frame")
+    p = syn.backbone_params(0, 50)
+    im, _ = syn.frames(0, 1, 600, 1000)
+    with torch.no_grad():
+        feat, feat1 = nets.extract_feature(torch.from_numpy(im), p, blocks=(3, 4, 6))
+    for key, t in (("feat", feat), ("feat1", feat1)):
+        v = t.numpy()
+        assert tuple(g["r50_%s_shape" % key]) == tuple(v.shape)
+        np.testing.assert_allclose(v.reshape(-1)[::251], g["r50_%s_sample" % key], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(np.abs(v.astype(np.float64)).sum(), float(g["r50_%s_abs" % key]), rtol=1e-5)
+
+
 def test_vrd_head(gold):
     g = gold("vrd_head")
     n_rel, n_cls = 62, 16

@@ -296,6 +296,85 @@ def gen_nets(cfg):
                             sigma=3, dim=[1, 2, 3]).numpy())
 
 
+def gen_full_frame(cfg):
+    """the reference ResNet on FULL 600x1000 frames, pinned by shape + sums + a strided sample
+    (the real 150x250 / 75x125 / 38x63 tile-padding paths of the implicit-GEMM and Winograd kernels).
+    res101 on the two bench frames (configs[1]); res50 on one frame (configs[0], cfgs/res50.yml plumbing)."""
+    import model.faster_rcnn.resnet_instance_styleD_bilinear as R
+    names = {"RCNN_base.0": "conv1", "RCNN_base.1": "bn1", "RCNN_base.4": "layer1", "RCNN_base.5": "layer2",
+             "RCNN_base.6": "layer3", "RCNN_top.0": "layer4"}
+    out = {}
+    for layers, ctor, nfr, seed in ((101, R.resnet101, 2, 1), (50, R.resnet50, 1, 0)):
+        bp = syn.backbone_params(0, layers)
+        net = ctor()
+        sd = {}
+        for k, v in bp.items():
+            for a, b in names.items():
+                if k.startswith(a + "."):
+                    sd[b + k[len(a):]] = v
+        miss = net.load_state_dict(sd, strict=False)
+        assert not miss.unexpected_keys
+        assert all(("fc." in k) or ("num_batches" in k) for k in miss.missing_keys), miss.missing_keys
+        net.eval()
+        im, _ = syn.frames(seed, nfr, 600, 1000)
+        with torch.no_grad():
+            x = net.maxpool(net.relu(net.bn1(net.conv1(torch.from_numpy(im)))))
+            f1 = net.layer2(net.layer1(x))          # base_feat1: the style tap (resnet_instance...:412-420)
+            f = net.layer3(f1)                      # base_feat
+        for key, v in (("feat1", f1.numpy()), ("feat", f.numpy())):
+            tag = "r%d_%s" % (layers, key)
+            out[tag + "_shape"] = np.array(v.shape)
+            out[tag + "_sum"] = np.array(v.astype(np.float64).sum())
+            out[tag + "_abs"] = np.array(np.abs(v.astype(np.float64)).sum())
+            out[tag + "_sample"] = v.reshape(-1)[::251].copy()
+        print("   res%d: feat %s |sum| %.4e" % (layers, tuple(f.shape), float(out["r%d_feat_abs" % layers])))
+    save("backbone_full_frame", "placeholders", **out)
+
+
+def gen_context(cfg):
+    """the reference ``_fasterRCNN`` (instance_styleD) with ic = gc = True run as shipped --
+    context vectors of both discriminators concatenated in front of the layer4 feature
+    (faster_rcnn_instance_styleD_bilinear.py:62-67,122-148) -- with the two pieces the reference cannot run here
+    supplied by the harness: the RPN (fixed proposals, so that no near-tied score decides the sample) and RoIAlignAvg
+    (legacy autograd.Function over an unbuildable extension -> oracle.cops).  Forward only, training mode."""
+    import model.faster_rcnn.resnet_instance_styleD_bilinear as R
+    n_cls = 16
+    cfg.TRAIN.BATCH_SIZE = 32
+    try:
+        net = R.resnet(tuple(range(n_cls)), 50, pretrained=False, class_agnostic=False, ic=True, gc=True)
+        net.create_architecture()
+        p = {}
+        p.update(syn.backbone_params(0, 50, top=True))
+        p.update(syn.det_head_params(11, n_cls, feat_d=2048 + 512 + 128))
+        p.update(syn.netd_params(12))
+        miss = net.load_state_dict(p, strict=False)
+        assert not miss.unexpected_keys, miss.unexpected_keys
+        assert all(k.startswith("RCNN_rpn.") or "num_batches" in k for k in miss.missing_keys), miss.missing_keys
+        im, info, gt, nb, rois = syn.context_inputs()
+
+        class FixedRPN(torch.nn.Module):
+            def forward(self, base_feat, im_info, gt_boxes, num_boxes, target=False):
+                return torch.from_numpy(rois), torch.zeros(1), torch.zeros(1)
+
+        class HarnessAlign(torch.nn.Module):
+            def forward(self, feat, r):
+                return torch.from_numpy(cops.roi_align_avg_fwd(feat.detach().numpy(), r.detach().numpy(), 7, 7, 1.0 / 16.0))
+
+        net.RCNN_rpn = FixedRPN()
+        net.RCNN_roi_align = HarnessAlign()
+        net.train()
+        np.random.seed(3)
+        with torch.no_grad():
+            out = net(torch.from_numpy(im), torch.from_numpy(info), torch.from_numpy(gt), torch.from_numpy(nb),
+                      target=False, eta=0.1, eta_style=0.001)
+        r, cls_prob, bbox_pred, _, _, l_cls, l_box, label, d_inst, d_sty = out
+        save("context_ic_gc", "placeholders", rois=r.numpy(), labels=label.numpy(), cls_prob=cls_prob.numpy(),
+             bbox_pred=bbox_pred.numpy(), loss_cls=l_cls.numpy(), loss_box=l_box.numpy(), d_instance=d_inst.numpy(),
+             d_style=d_sty.numpy())
+    finally:
+        cfg.TRAIN.BATCH_SIZE = 128
+
+
 def gen_vrd(cfg):
     """vrd.forward logits / BCE loss / grads with eval-mode dropout."""
     import pickle
@@ -368,17 +447,21 @@ def main():
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
-    todo = a.only.split(",") if a.only else ["direct", "rpn", "nets", "vrd"]
+    todo = a.only.split(",") if a.only else ["direct", "rpn", "nets", "full", "ctx", "vrd"]
     if "direct" in todo:
         print("[direct imports]")
         gen_direct()
-    if any(t in todo for t in ("rpn", "nets", "vrd")):
+    if any(t in todo for t in ("rpn", "nets", "full", "vrd", "ctx")):
         print("[imports with placeholders]")
         cfg = install_placeholders()
         if "rpn" in todo:
             gen_rpn_layers(cfg)
         if "nets" in todo:
             gen_nets(cfg)
+        if "full" in todo:
+            gen_full_frame(cfg)
+        if "ctx" in todo:
+            gen_context(cfg)
         if "vrd" in todo:
             gen_vrd(cfg)
 
