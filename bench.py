@@ -2,38 +2,99 @@
 """Headline benchmark: frames/sec at 600x1000, 32 ROI/frame (BASELINE.json).
 
 A "step" is one pass of the hot path over one batch of synthetic frames already resident in HBM.
-Workload at N=1 = BASELINE.json configs[1]: cfgs/res101.yml, batch = 2 frames, 32 boxes + 32
-relation pairs per frame, SGG_emb forward + backward + SGD update on one MI355X (ResNet-101 C4
-backbone forward under no_grad as the reference detaches it; relation head fwd+bwd; fp32).
-N>1: weak scaling, 2 frames per rank, one RCCL all-reduce of the vrd gradients per step.
 
-Prints ONE JSON line on rank 0 (see the contract in the task brief) with `roofline` for the
-dominant kernel (conv_igemm_f32, MFMA-bound) and `cpu_baseline` (the CPU oracle on the host cores).
+  --config sgg              (default, the headline) BASELINE.json configs[1]: cfgs/res101.yml, 2 frames/GPU, 32 boxes +
+                            32 relation pairs per frame, SGG_emb forward + backward + SGD (trainval_net_SGG_emb.py:189-255).
+                            With --gpus 8 this is configs[3] (16 frames over 8 GPUs, RCCL exchange of the vrd gradients).
+  --config instance_styled  configs[2]: instance_styleD D+G adversarial step, 4 source + 4 target frames/GPU, all of
+                            layer1-3 + heads trained (trainval_net_instance_styleD_bilinear.py:262-341).
+  --config joint            configs[4]: one instance_styleD step followed by one SGG_emb step on 4 frames/GPU.
+  --config res50            configs[0]: cfgs/res50.yml, ONE 600x1000 frame, Faster-RCNN forward + SGG_emb head forward
+                            (the reference's CPU-runnable plumbing case, here on the GPU and checked against the oracle).
+
+Prints ONE JSON line on rank 0 (the contract of the task brief).  The default run measures the headline and, single
+GPU only, adds the configs[2] measurement (own steps, own roofline block) under "also".
+
+--gpus N without a torchrun environment starts its own N ranks (one process per GPU, RCCL over xGMI, rendezvous on
+127.0.0.1) and exits non-zero if any rank fails to come up; under torchrun (RANK set) it is one of the ranks.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# before the HIP runtime initialises (i2vsgg_amd/__init__.py explains)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 
-import torch  # noqa: E402
-
-FRAMES_PER_RANK = 2
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0             # same guide, "HBM3E peak BW" (spec)
+SET_CFGS = ["ANCHOR_SCALES", "[8, 16, 32]", "ANCHOR_RATIOS", "[0.5,1,2]", "MAX_NUM_GT_BOXES", "30",
+            "TRAIN.BATCH_SIZE", "32", "TRAIN.RPN_POST_NMS_TOP_N_TARGET", "32"]
 
 
-def cpu_baseline(threads):
-    """The CPU oracle (a port: oracle/nets.py, torch-CPU fp32) on a bounded sample of the same
-    workload: ONE 600x1000 frame through the ResNet-101 C4 backbone + the relation head forward,
-    backward and SGD update for that frame's 32 boxes + 32 pairs."""
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="sgg", choices=["sgg", "instance_styled", "joint", "res50"])
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="headline only: skip the configs[2] measurement")
+    ap.add_argument("--layers", type=int, default=101)
+    ap.add_argument("--dump-launches", default="", help="write one line per GEMM launch of a profiled step")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous rehearsal on the CPU (gloo): no GPU work, prints the line with dry_run")
+    return ap.parse_args()
+
+
+# ----------------------------------------------------------------------------- launcher
+def launch_ranks(n):
+    """Start n copies of this script, one per GPU, and wait.  Runs BEFORE anything in this process touches the GPU."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), I2V_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            r = p.poll()
+            if r is None:
+                continue
+            alive.remove(p)
+            if r != 0 and rc == 0:
+                rc = r if r > 0 else 1
+                for q in alive:             # one rank down: the others would wait in a collective for ever
+                    q.terminate()
+        time.sleep(0.05)
+    if rc:
+        sys.stderr.write("bench.py: a rank exited with %d (%d ranks requested)\n" % (rc, n))
+    sys.exit(rc)
+
+
+# ----------------------------------------------------------------------------- CPU baseline
+def cpu_baseline(threads_list):
+    """The CPU oracle (a port: oracle/nets.py, torch-CPU fp32) on a bounded sample of the configs[1] workload: ONE
+    600x1000 frame through the ResNet-101 C4 backbone + the relation head forward, backward and SGD update for that
+    frame's 32 boxes + 32 pairs.  BASELINE.md section 3 protocol: 2 warm-up + 5 timed iterations, median, at every thread
+    count of ``threads_list``."""
     import numpy as np
+    import torch
     from i2vsgg_amd import synthetic as syn, train
     from i2vsgg_amd.model.faster_rcnn.faster_rcnn_SGG_emb import build_pair_tables
     from oracle import nets
-    torch.set_num_threads(threads)
     p = syn.backbone_params(0, 101, top=False)
     v = {k: t.requires_grad_() for k, t in syn.vrd_params(13).items()}
     im, info, annos = train.synthetic_sgg_batch(1, 1)
@@ -47,166 +108,336 @@ def cpu_baseline(threads):
             masks[i, j, y1:y2, x1:x2] = 1
     prd = syn.word_vectors(21, 62)
     opt = torch.optim.SGD(list(v.values()), lr=1e-4, momentum=0.9, weight_decay=5e-4)
-    times = []
-    for it in range(2):
-        t0 = time.perf_counter()
-        with torch.no_grad():
-            fmap, _ = nets.extract_feature(torch.from_numpy(im), p)
-        sc, _ = nets.vrd_head(fmap, boxes, relb, masks, ixs, ixo, prd, v, training=True)
-        loss = torch.nn.functional.binary_cross_entropy_with_logits(sc, torch.from_numpy(labels))
-        opt.zero_grad()
-        loss.backward()
-        opt.step()
-        times.append(time.perf_counter() - t0)
-    return 1.0 / min(times), min(times)
+    out = {}
+    for threads in threads_list:
+        torch.set_num_threads(threads)
+        times = []
+        for it in range(7):
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                fmap, _ = nets.extract_feature(torch.from_numpy(im), p)
+            sc, _ = nets.vrd_head(fmap, boxes, relb, masks, ixs, ixo, prd, v, training=True)
+            loss = torch.nn.functional.binary_cross_entropy_with_logits(sc, torch.from_numpy(labels))
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            if it >= 2:
+                times.append(time.perf_counter() - t0)
+        out[threads] = sorted(times)[len(times) // 2]
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--layers", type=int, default=101)
-    ap.add_argument("--dump-launches", default="", help="write one line per GEMM launch of a profiled step")
-    a = ap.parse_args()
+# ----------------------------------------------------------------------------- measurement helpers
+def timed_steps(step_fn, warmup, steps, dev):
+    import torch
+    from i2vsgg_amd import parallel
+    for _ in range(warmup):
+        step_fn()
+    parallel.barrier(dev)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    torch.cuda.synchronize(dev)
+    parallel.barrier(dev)
+    return parallel.max_over_ranks(time.perf_counter() - t0, dev)
 
-    from i2vsgg_amd import ops, parallel, train
-    from i2vsgg_amd.model.utils import config as c
-    rank, world, dev = parallel.init_from_env()
-    assert dev.type == "cuda", "bench.py needs a GPU (the product path has no CPU fallback)"
-    assert world == a.gpus or world == 1, "launch with torchrun --nproc-per-node %d" % a.gpus
-    c.cfg_from_file(c.default_cfg_file("res101"))
-    c.cfg_from_list(["ANCHOR_SCALES", "[8, 16, 32]", "ANCHOR_RATIOS", "[0.5,1,2]", "MAX_NUM_GT_BOXES", "30",
-                     "TRAIN.BATCH_SIZE", "32", "TRAIN.RPN_POST_NMS_TOP_N_TARGET", "32"])
 
-    # work on a stream of our own: HIP's legacy default stream does not keep back-to-back graph launches ordered once
-    # the host runs ahead, and every operation on it drags the other streams in (i2vsgg_amd/train.py, __call__)
-    torch.cuda.set_stream(torch.cuda.Stream(dev))
+def profile_eager(body, n_prof, dev):
+    """HIP events (on the launch stream) around every GEMM-shaped launch of ``n_prof`` eager steps of the same objects:
+    events cannot be read back from inside a graph replay."""
+    import torch
+    from i2vsgg_amd import ops
+    ops.PROFILE = []
+    for _ in range(n_prof):
+        body()
+    torch.cuda.synchronize(dev)
+    rec, ops.PROFILE = ops.PROFILE, None
+    return [dict(t=e0.elapsed_time(e1) * 1e-3, flops=fl, tag=tag, desc=d, bytes=by) for e0, e1, fl, tag, d, by in rec]
+
+
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ for this round
+    (rocprofv3 cannot run inside the timed process); None when there is no summary."""
+    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            try:
+                with open(path) as f:
+                    return json.load(f)[kernel_key]["hbm_bytes_per_launch_corrected"], "profiles/" + name
+            except Exception:
+                continue
+    return None, None
+
+
+def by_kind(rec, n_prof):
+    agg = {}
+    for r in rec:
+        d = agg.setdefault(r["tag"], [0.0, 0.0, 0])
+        d[0] += r["t"]; d[1] += r["flops"]; d[2] += 1
+    return {k: {"ms_per_step": 1e3 * v[0] / n_prof, "tflops": v[1] / max(v[0], 1e-12) / 1e12, "launches": v[2] // n_prof}
+            for k, v in agg.items()}
+
+
+# ----------------------------------------------------------------------------- configs[1] / configs[3]
+def run_sgg(a, rank, world, dev, frames_per_rank=2):
+    import torch
+    from i2vsgg_amd import train
     net = train.build_sgg_net(a.layers, device=dev)
-    step = train.SGGEmbStep(net, FRAMES_PER_RANK, seed=1 + rank, device=dev, use_graph=not a.no_graph)
+    step = train.SGGEmbStep(net, frames_per_rank, seed=1 + rank, device=dev, use_graph=not a.no_graph)
     graphed = step.capture(warmup=2)
-
-    def measure():
-        for _ in range(a.warmup):
-            step()
-        parallel.barrier(dev)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(a.steps):
-            step()
-        torch.cuda.synchronize(dev)
-        parallel.barrier(dev)
-        return parallel.max_over_ranks(time.perf_counter() - t0, dev)
-
-    elapsed = measure()
-    # The two-stream schedule has a slow mode on this stack (the same graphs at ~10 instead of ~5 ms per step, seen in
-    # about one run in ten; which stream priorities trigger it is what capture() measures).  If the timed loop came out
-    # far above what the stream tuning saw moments earlier, settle the streams again and measure again: W warm-up steps
-    # and exactly K timed steps once more, reported with "remeasured": true (single process only: with several ranks
-    # the high-priority side stream is the one that works and no slow run has been seen).
-    remeasured = False
-    tun = getattr(step, "bb_tuning_ms", None)
-    factor = float(os.environ.get("I2V_REMEASURE_FACTOR", "1.4"))
-    if world == 1 and graphed and tun and elapsed / a.steps * 1e3 > factor * min(tun.values()):
-        step._tune_for(torch.cuda.current_stream(dev))
-        elapsed = measure()
-        remeasured = True
+    elapsed = timed_steps(step, a.warmup, a.steps, dev)
     loss = float(step.loss)
 
-    # ---- roofline of the dominant kernel: HIP events around every implicit-GEMM launch of eager
-    #      steps (events cannot be read back from inside a graph replay), same process, same data
-    ops.PROFILE = []
+    # ---- roofline of the dominant kernel: conv_igemm_f32 (MFMA-bound)
     n_prof = 3
-    for _ in range(n_prof):
-        step._body()
-    torch.cuda.synchronize(dev)
-    rec = ops.PROFILE
-    ops.PROFILE = None
+    ov, step.overlap = step.overlap, False
+    rec = profile_eager(step._body, n_prof, dev)
+    step.overlap = ov
     # the calls that run on conv_igemm_f32: every forward and the convolution data gradients (linear-layer data
     # gradients run on the wgrad kernel with the roles swapped and are reported under by_kind only)
-    on_igemm = lambda tag, d: tag in ("fwd", "dgrad") and "(wgrad form)" not in d
-    fwd = [(e0.elapsed_time(e1) * 1e-3, fl) for e0, e1, fl, tag, d in rec if on_igemm(tag, d)]
-    t_conv = sum(t for t, _ in fwd)
-    f_conv = sum(f for _, f in fwd)
-    by_tag = {}
-    for e0, e1, fl, tag, _d in rec:
-        d = by_tag.setdefault(tag, [0.0, 0.0, 0])
-        d[0] += e0.elapsed_time(e1) * 1e-3; d[1] += fl; d[2] += 1
-    achieved = f_conv / t_conv / 1e12
-    # the same calls counted by the MACs the matrix cores actually execute (Winograd F(4x4,3x3): 9/36 of the direct count)
-    f_exec = sum((fl * (9.0 / 36.0 if "winograd F4" in d else 16.0 / 36.0 if "winograd" in d else 1.0))
-                 for e0, e1, fl, tag, d in rec if on_igemm(tag, d))
-    achieved_exec = f_exec / t_conv / 1e12
+    conv = [r for r in rec if r["tag"] in ("fwd", "dgrad") and "(wgrad form)" not in r["desc"]]
+    t_conv = sum(r["t"] for r in conv)
+    f_alg = sum(r["flops"] for r in conv)
+    # the MACs the matrix cores actually execute: Winograd F(4x4,3x3) runs 36/16 = 2.25 products per output where the direct
+    # form runs 9 (F(2x2): 16/4 = 4 against 9)
+    f_exec = sum(r["flops"] * (0.25 if "winograd F4" in r["desc"] else 4.0 / 9.0 if "winograd" in r["desc"] else 1.0) for r in conv)
+    b_alg = sum(r["bytes"] for r in conv)
+    n_launch = max(len(conv) // n_prof, 1)
     if a.dump_launches and rank == 0:
         per = len(rec) // n_prof
         with open(a.dump_launches, "w") as f:
-            for e0, e1, fl, tag, d in rec[-per:]:
-                t = e0.elapsed_time(e1) * 1e-3
-                f.write("%-6s %-40s %8.1f us %7.2f GF %6.1f TF\n" % (tag, d, t * 1e6, fl / 1e9, fl / t / 1e12))
-
-    # HBM traffic of the same kernel from the PMC passes committed under profiles/ (rocprofv3 cannot
-    # be run from inside the timed process); null when no summary for this round exists
-    traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-    if os.path.exists(pmc):
-        try:
-            with open(pmc) as f:
-                traffic = json.load(f)["conv_igemm_f32"]["hbm_bytes_per_launch_corrected"]
-            traffic_src = "profiles/r01_pmc_summary.json (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, bytes per launch)"
-        except Exception:
-            traffic = None
-    out = {
-        "metric": "frames/sec (600x1000, 32 ROI/frame)", "value": world * FRAMES_PER_RANK * a.steps / elapsed,
+            for r in rec[-per:]:
+                f.write("%-6s %-44s %8.1f us %7.2f GF %6.1f TF %8.2f MB\n" % (
+                    r["tag"], r["desc"], r["t"] * 1e6, r["flops"] / 1e9, r["flops"] / r["t"] / 1e12, r["bytes"] / 1e6))
+    traffic, traffic_src = pmc_traffic("conv_igemm_f32")
+    achieved = f_exec / t_conv / 1e12
+    tp = getattr(step, "tp", False)
+    line = {
+        "metric": "frames/sec (600x1000, 32 ROI/frame)", "value": world * frames_per_rank * a.steps / elapsed,
         "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE.json configs[1]: cfgs/res101.yml, SGG_emb fwd+bwd+SGD, %d frames/GPU "
-                               "600x1000, 32 boxes + 32 pairs/frame, ResNet-%d C4" % (FRAMES_PER_RANK, a.layers),
-                   "frames_per_gpu": FRAMES_PER_RANK, "global_frames": world * FRAMES_PER_RANK,
-                   "hip_graph": bool(graphed), "graph_error": getattr(step, "graph_error", None), "parallelism": ("dp%d (frames sharded) + vrd.fc6 cut by output columns across the ranks: RCCL all-reduce of the other "
-                                   "84 MB of gradients, 30 MB of activation gathers for fc6" % world) if getattr(step, "tp", False)
+        "config": {"workload": "BASELINE.json configs[%d]: cfgs/res101.yml, SGG_emb fwd+bwd+SGD, %d frames/GPU "
+                               "600x1000, 32 boxes + 32 pairs/frame, ResNet-%d C4" % (3 if world > 1 else 1, frames_per_rank, a.layers),
+                   "frames_per_gpu": frames_per_rank, "global_frames": world * frames_per_rank,
+                   "hip_graph": bool(graphed), "graph_error": step.graph_error,
+                   "parallelism": ("dp%d (frames sharded) + vrd.fc6 cut by output columns across the ranks: RCCL all-reduce of the "
+                                   "other 84 MB of gradients, 30 MB of activation gathers for fc6" % world) if tp
                    else "dp%d (frames sharded, RCCL all-reduce of vrd grads)" % world,
-                   "schedule": ("two streams: [head fwd+bwd (+ gradient exchange) + SGD] beside [backbone fwd of the next minibatch]; "
-                                "every step = 1 backbone pass + 1 head pass + 1 update, all inside the timed region"
-                                if getattr(step, "overlap", False) else
-                                "pipelined: head fwd+bwd -> [gradient exchange || backbone fwd of the next minibatch] -> SGD"
-                                if getattr(step, "pipelined", False) else "one graph: backbone fwd, head fwd+bwd, fused wgrad+SGD"),
-                   "backbone_stream_priority": getattr(step, "bb_priority", None),
-                   "backbone_stream_tuning_ms": getattr(step, "bb_tuning_ms", None), "remeasured": remeasured,
+                   "schedule": ("one graph per step, two branches: [head fwd+bwd (+ gradient exchange) + SGD of batch k] beside "
+                                "[backbone fwd of batch k+1]; every step = 1 backbone pass + 1 head pass + 1 update, all "
+                                "inside the timed region") if step.overlap
+                   else "one graph per step: backbone fwd, head fwd+bwd, fused wgrad+SGD" if graphed else "eager launches",
                    "loss": loss},
-        "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (every i2v_conv_fwd call and every convolution _dgrad call: kernel + its split-K helper kernels)", "achieved": achieved,
+        "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (every i2v_conv_fwd call and every convolution _dgrad call, "
+                                                "Winograd transform kernels included in the time)",
+                     "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                     "note": ("achieved = MACs the matrix cores EXECUTE x 2 / summed call durations (the 30 frozen 3x3 layers of "
+                              "layer1-3 run as Winograd F(4x4,3x3): 1/4 of the direct count); algorithmic_tflops counts the "
+                              "direct convolution's 2*M*N*K instead.  Durations: HIP events on the launch stream around "
+                              "every call of %d eager steps of the same objects") % n_prof,
+                     "algorithmic_tflops": f_alg / t_conv / 1e12,
+                     "algorithmic_frac": f_alg / t_conv / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                     "algorithmic_bytes_per_launch": b_alg / n_prof / n_launch,
+                     "launches_per_step": n_launch, "avg_launch_us": 1e6 * t_conv / max(len(conv), 1),
+                     "gflop_executed_per_step": f_exec / n_prof / 1e9, "gflop_algorithmic_per_step": f_alg / n_prof / 1e9,
+                     "by_kind": by_kind(rec, n_prof)},
+    }
+    return line, step, net
+
+
+# ----------------------------------------------------------------------------- configs[2]
+def run_instance_styled(a, rank, world, dev, steps, warmup, frames_per_rank=4):
+    import numpy as np
+    import torch
+    from i2vsgg_amd import train
+    from i2vsgg_amd.model.utils import config as c
+    np.random.seed(c.cfg.RNG_SEED + rank)
+    net = train.build_instance_styled_net(a.layers, device=dev)
+    step = train.InstanceStyleDStep(net, frames_per_rank, seed=3 + rank, device=dev)
+    graphed = step.capture(warmup=2) if (hasattr(step, "capture") and not a.no_graph) else False
+    if not graphed:
+        for _ in range(2):
+            step()
+    elapsed = timed_steps(step, warmup, steps, dev)
+    losses = {k: float(v) for k, v in step.losses.items()}
+    n_prof = 2
+    rec = profile_eager(step.eager_step if hasattr(step, "eager_step") else step, n_prof, dev)
+    wg = [r for r in rec if r["tag"] == "wgrad"]
+    t_wg, f_wg, b_wg = sum(r["t"] for r in wg), sum(r["flops"] for r in wg), sum(r["bytes"] for r in wg)
+    achieved = f_wg / max(t_wg, 1e-12) / 1e12
+    traffic, traffic_src = pmc_traffic("conv_wgrad2_f32")
+    line = {
+        "metric": "frames/sec (600x1000, 32 ROI/frame)", "value": world * 2 * frames_per_rank * steps / elapsed,
+        "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[2]: cfgs/res101.yml, instance_styleD D+G adversarial step, %d source + %d "
+                               "target frames/GPU 600x1000, 32 ROI/frame, ResNet-%d, layer1-3 + heads trained" % (
+                                   frames_per_rank, frames_per_rank, a.layers),
+                   "frames_per_gpu": 2 * frames_per_rank, "hip_graph": bool(graphed),
+                   "graph_error": getattr(step, "graph_error", None),
+                   "parallelism": "dp%d (frames sharded, RCCL all-reduce of 202 MB of gradients)" % world,
+                   "losses": losses, "max_mem_GB": torch.cuda.max_memory_allocated(dev) / 2 ** 30},
+        "roofline": {"bound": "mfma", "kernel": "conv_wgrad2_f32 (every filter gradient of the step)", "achieved": achieved,
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
                      "traffic": traffic, "traffic_source": traffic_src,
-                     "note": ("achieved = ALGORITHMIC FLOPs (2*M*N*K of the direct convolution / linear layer) of every i2v_conv_fwd, "
-                              "convolution _dgrad and Winograd call / their summed durations (linear-layer data gradients run on the "
-                              "wgrad kernel and are listed under by_kind only); the 30 frozen 3x3 layers of layer1-3 run as "
-                              "Winograd F(4x4,3x3) (transforms + one batched conv_igemm_f32 launch) and execute 4x fewer MACs "
-                              "than that count"),
-                     "executed_mfma_tflops": achieved_exec, "executed_mfma_frac": achieved_exec / MFMA_F32_PEAK_TFLOPS,
-                     "algorithmic_bytes_per_launch": 4.8e9 / max(len(fwd) // n_prof, 1),
-                     "launches_per_step": len(fwd) // n_prof,
-                     "avg_launch_us": 1e6 * t_conv / max(len(fwd), 1),
-                     "gflop_per_step": f_conv / n_prof / 1e9,
-                     "by_kind": {k: {"ms_per_step": 1e3 * v[0] / n_prof, "tflops": v[1] / max(v[0], 1e-12) / 1e12,
-                                     "launches": v[2] // n_prof} for k, v in by_tag.items()}},
+                     "algorithmic_bytes_per_launch": b_wg / max(len(wg), 1), "launches_per_step": len(wg) // n_prof,
+                     "avg_launch_us": 1e6 * t_wg / max(len(wg), 1), "by_kind": by_kind(rec, n_prof)},
     }
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        # the GPU box grants a CPU share (16 cores per GPU), not the whole host: never oversubscribe
-        threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
-        fps, sec = cpu_baseline(threads)
-        out["cpu_baseline"] = {"value": fps, "unit": "frames/s", "cores": threads, "kind": "port",
-                               "sample": "1 frame 600x1000: ResNet-101 C4 fwd + vrd head fwd/bwd/SGD for 32 boxes + "
-                                         "32 pairs, best of 2 (%.2f s)" % sec}
+    return line, step, net
+
+
+# ----------------------------------------------------------------------------- configs[4]
+def run_joint(a, rank, world, dev, frames_per_rank=4):
+    """One instance_styleD D+G step followed by one SGG_emb step on the same number of frames."""
+    import numpy as np
+    import torch
+    from i2vsgg_amd import train
+    from i2vsgg_amd.model.utils import config as c
+    np.random.seed(c.cfg.RNG_SEED + rank)
+    det = train.build_instance_styled_net(a.layers, device=dev)
+    dstep = train.InstanceStyleDStep(det, frames_per_rank, seed=3 + rank, device=dev)
+    dgraph = dstep.capture(warmup=2) if (hasattr(dstep, "capture") and not a.no_graph) else False
+    sgg = train.build_sgg_net(a.layers, device=dev)
+    sstep = train.SGGEmbStep(sgg, frames_per_rank, seed=1 + rank, device=dev, use_graph=not a.no_graph)
+    sgraph = sstep.capture(warmup=2)
+
+    def both():
+        dstep()
+        sstep()
+    elapsed = timed_steps(both, a.warmup, a.steps, dev)
+    line = {
+        "metric": "frames/sec (600x1000, 32 ROI/frame)", "value": world * frames_per_rank * a.steps / elapsed,
+        "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[4]: joint instance_styleD D+G step (%d source + %d target frames/GPU) + "
+                               "SGG_emb step on %d frames/GPU, 600x1000, 32 ROI/frame; a frame counts once" % (
+                                   frames_per_rank, frames_per_rank, frames_per_rank),
+                   "frames_per_gpu": frames_per_rank, "hip_graph": [bool(dgraph), bool(sgraph)],
+                   "parallelism": "dp%d (RCCL all-reduce of 202 MB + the vrd gradients)" % world,
+                   "loss_sgg": float(sstep.loss), "loss_det": float(dstep.losses["total"])},
+    }
+    return line, (dstep, sstep), (det, sgg)
+
+
+# ----------------------------------------------------------------------------- configs[0]
+def run_res50(a, rank, world, dev):
+    """cfgs/res50.yml, ONE 1x3x600x1000 frame: Faster-RCNN (instance_styleD detector, eval) forward + SGG_emb relation head
+    forward on the same frame -- the reference's CPU-runnable plumbing case; here timed on the GPU."""
+    import torch
+    from i2vsgg_amd import train, synthetic as syn
+    from i2vsgg_amd.model.utils import config as c
+    det = train.build_instance_styled_net(50, device=dev).eval()
+    sgg = train.build_sgg_net(50, device=dev).eval()
+    im, info = syn.frames(0, 1, 600, 1000)
+    gt, nb = syn.gt_boxes(0, 1, 8, det.n_classes, c.cfg.MAX_NUM_GT_BOXES, 600, 1000)
+    to = lambda x: torch.from_numpy(x).to(dev)
+    imd, infod, gtd, nbd = to(im), to(info), to(gt), to(nb)
+    sstep = train.SGGEmbStep(sgg, 1, seed=0, device=dev, n_boxes=8, n_pairs=8, use_graph=False)
+
+    def fwd():
+        with torch.no_grad():
+            out = det(imd, infod, gtd, nbd)
+            fmap = sgg.RCNN_base(sstep.im)
+            score, _ = sgg.vrd.forward_device(fmap, sstep.boxes, sstep.relb, sstep.masks, sstep.ixs, sstep.ixo)
+        return out, score
+    elapsed = timed_steps(fwd, a.warmup, a.steps, dev)
+    out, score = fwd()
+    line = {
+        "metric": "frames/sec (600x1000, 32 ROI/frame)", "value": world * a.steps / elapsed, "unit": "frames/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[0]: cfgs/res50.yml, 1x3x600x1000, Faster-RCNN forward (RPN_BATCHSIZE %d, %d "
+                               "test proposals) + SGG_emb head forward (8 boxes, 8 pairs), eager" % (
+                                   c.cfg.TRAIN.RPN_BATCHSIZE, out[0].shape[1]),
+                   "frames_per_gpu": 1, "hip_graph": False, "rois": list(out[0].shape), "rel_score": list(score.shape)},
+    }
+    return line, sstep, (det, sgg)
+
+
+# ----------------------------------------------------------------------------- main
+def dry_run(a):
+    """Launcher rehearsal without a GPU: rendezvous over gloo on 127.0.0.1, one collective, the JSON line."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("I2V_BENCH_FAIL_RANK") == str(rank):      # tests: a rank that never comes up
+        sys.exit(7)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)])
+    if world > 1:
+        dist.all_reduce(t)
+    if int(t.item()) != world * (world + 1) // 2:
+        sys.exit(3)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps({"metric": "frames/sec (600x1000, 32 ROI/frame)", "value": 0.0, "unit": "frames/s", "n_gpus": world,
+                          "steps": a.steps, "warmup": a.warmup, "dry_run": True, "config": {"workload": a.config}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main():
+    a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        launch_ranks(a.gpus)                 # does not return
+    if a.dry_run:
+        return dry_run(a)
+
+    import torch
+    from i2vsgg_amd import parallel
+    from i2vsgg_amd.model.utils import config as c
+    rank, world, dev = parallel.init_from_env()
+    assert dev.type == "cuda", "bench.py needs a GPU (the product path has no CPU fallback)"
+    if world != a.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the process group has %d ranks\n" % (a.gpus, world))
+        sys.exit(2)
+    c.cfg_from_file(c.default_cfg_file("res50" if a.config == "res50" else "res101"))
+    c.cfg_from_list(SET_CFGS)
+
+    keep = []
+    if a.config == "sgg":
+        line, step, net = run_sgg(a, rank, world, dev)
+        keep += [step, net]
+        if world == 1 and not a.no_also:
+            # configs[2] under the same driver clock: fewer steps (a step is ~15x longer), its own roofline block
+            torch.cuda.empty_cache()
+            also, s2, n2 = run_instance_styled(a, rank, world, dev, steps=max(4, a.steps // 4), warmup=2)
+            line["also"] = {"instance_styled": also}
+            keep += [s2, n2]
+    elif a.config == "instance_styled":
+        line, step, net = run_instance_styled(a, rank, world, dev, a.steps, a.warmup)
+        keep += [step, net]
+    elif a.config == "joint":
+        line, step, net = run_joint(a, rank, world, dev)
+        keep += [step, net]
+    else:
+        line, step, net = run_res50(a, rank, world, dev)
+        keep += [step, net]
+
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.config == "sgg":
+        # the GPU box grants a CPU share (16 cores per GPU), not the whole host: never oversubscribe
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        threads = min(16, cores)
+        sec = cpu_baseline(sorted({threads, min(8, threads)}, reverse=True))
+        line["cpu_baseline"] = {"value": 1.0 / sec[threads], "unit": "frames/s", "cores": threads, "kind": "port",
+                                "sample": "1 frame 600x1000: ResNet-101 C4 fwd + vrd head fwd/bwd/SGD for 32 boxes + 32 pairs; 2 "
+                                          "warm-up + 5 timed, median %.2f s" % sec[threads],
+                                "frames_per_s_by_threads": {str(k): 1.0 / v for k, v in sec.items()}}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         # the graphs that captured RCCL kernels go first: tearing the communicator down under them can abort
         import gc
         torch.cuda.synchronize(dev)
-        step.opt.unfuse()
-        del step, net
+        for obj in keep:
+            opt = getattr(obj, "opt", None)
+            if opt is not None:
+                opt.unfuse()
+        del keep, step, net
         gc.collect()
         torch.cuda.synchronize(dev)
         torch.distributed.destroy_process_group()

@@ -36,9 +36,12 @@ SIGNATURES = {
     "i2v_sort_desc_workspace_bytes": (_z, [_i, _i]),
     "i2v_sort_desc": (_i, [_p, _i, _i, _p, _p, _z, _p]),
     "i2v_bbox_overlaps": (_i, [_p, _i, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p]),
-    "i2v_conv_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
-    "i2v_conv_fwd_splits": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
-    "i2v_gemm_nt_batched": (_i, [_p, _p, _p, _i, _i, _i, _i, _l, _l, _l, _p]),
+    "i2v_conv_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "i2v_conv_fwd_splits": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _i, _z]),
+    "i2v_conv_split_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "i2v_set_tuning": (_i, [_i, _i]),
+    "i2v_get_tuning": (_i, [_i]),
+    "i2v_gemm_nt_batched": (_i, [_p, _p, _p, _i, _i, _i, _i, _l, _l, _l, _p, _z, _p]),
     "i2v_winograd_filter": (_i, [_p, _p, _i, _i, _p]),
     "i2v_conv3x3_winograd_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "i2v_conv3x3_winograd_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
@@ -46,11 +49,10 @@ SIGNATURES = {
     "i2v_winograd4_filter_dgrad": (_i, [_p, _p, _i, _i, _p]),
     "i2v_conv3x3_winograd4_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "i2v_conv3x3_winograd4_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
-    "i2v_conv_set_split_slot": (_i, [_i]),
     "i2v_conv_set_tile": (_i, [_i]),
     "i2v_conv_debug_clock": (_i, [_p]),
     "i2v_conv_dgrad_workspace_bytes": (_z, [_i, _i, _i, _i]),
-    "i2v_conv_dgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "i2v_conv_dgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p, _z, _p]),
     "i2v_conv_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "i2v_conv_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _z, _p]),
     "i2v_conv_wgrad_sgd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _p]),
@@ -96,6 +98,14 @@ def _load():
 
 
 lib = _load()
+
+# The library reads no environment variable; the documented I2V_* tuning switches are forwarded here, once, at import.
+TUNE = {"I2V_CONV_SPEC": 0, "I2V_SPLIT_TARGET": 1, "I2V_SPLIT_TARGET_SKINNY": 2, "I2V_SPLIT_BELOW": 3, "I2V_SPLIT_ATOMICS": 4,
+        "I2V_BIG_FC_TILE": 5, "I2V_WGRAD_V2": 6, "I2V_WGRAD_FUSED_TILE": 7, "I2V_WINO_ROWS": 8, "I2V_ROIPOOL_C128": 9}
+for _name, _key in TUNE.items():
+    if os.environ.get(_name) not in (None, ""):
+        if lib.i2v_set_tuning(_key, int(os.environ[_name])) != 0:
+            raise ImportError("i2vsgg_amd: bad value for %s" % _name)
 
 
 def check(rc, what):

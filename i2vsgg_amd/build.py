@@ -17,17 +17,40 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=o
 EXTRA = {"conv.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
-def _stale():
-    if not os.path.exists(OUT):
+STAMP = os.path.join(HERE, "build", "stamp.json")
+LAST = {"mode": None}       # "compiled" / "reused" after build(): what the last call did (the driver's build check reads it)
+
+
+def _digest():
+    """sha256 over every source, the header, the flags and this file: a shipped .so is reused only if it was built
+    from exactly these bytes (mtimes say nothing after a checkout or a copy to another box)."""
+    import hashlib
+    h = hashlib.sha256()
+    deps = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)) + [os.path.join(HERE, "..", "include", "i2vsgg_hip.h"),
+                                                                       os.path.abspath(__file__)]
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stale(digest):
+    if not os.path.exists(OUT) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(OUT)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "i2vsgg_hip.h"),
-                                                                os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    try:
+        import json
+        with open(STAMP) as f:
+            st = json.load(f)
+        return st.get("digest") != digest or st.get("so_size") != os.path.getsize(OUT)
+    except Exception:
+        return True
 
 
 def build(force=False, verbose=False):
-    if not force and not _stale():
+    digest = _digest()
+    if not force and not _stale(digest):
+        LAST["mode"] = "reused"
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
@@ -50,6 +73,10 @@ def build(force=False, verbose=False):
             sys.stderr.write(out.decode())
             raise RuntimeError("hipcc failed on %s" % src)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    import json
+    with open(STAMP, "w") as f:
+        json.dump({"digest": digest, "so_size": os.path.getsize(OUT)}, f)
+    LAST["mode"] = "compiled"
     return OUT
 
 

@@ -8,6 +8,7 @@
 #define I2V_WAVE 64
 
 void i2v_set_error(const char* fmt, ...);
+extern int g_i2v_tuning[];       // api.cpp; indexed by I2V_TUNE_*
 
 #define I2V_CHECK_ARG(cond, ...)                 \
     do {                                         \

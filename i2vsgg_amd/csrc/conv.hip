@@ -15,7 +15,6 @@
 // fragment is ONE b128 read; A and B use the same permutation, so the sum is unchanged.
 #include "common.h"
 #include <algorithm>
-#include <mutex>
 #include <type_traits>
 #include <stdlib.h>
 
@@ -720,70 +719,26 @@ constexpr int NUM_CU = 256;
 int g_force_tile = -1;           // i2v_conv_set_tile(): tuning hook (low byte: tile, bits 8-9: spec mode + 1)
 int g_ablate = 0;
 unsigned long long* g_clk = nullptr;   // i2v_conv_debug_clock()
-// -1 / 0: plain 4-wave kernel, 1: loader/MFMA specialised 8-wave kernel, 2: specialised when <= 3 workgroups per CU
-int g_spec_mode = [] { const char* e = getenv("I2V_CONV_SPEC"); return e ? atoi(e) : -1; }();
-int g_split_target_skinny = [] { const char* e = getenv("I2V_SPLIT_TARGET_SKINNY"); return e ? atoi(e) : -1; }();
-int g_split_target = [] { const char* e = getenv("I2V_SPLIT_TARGET"); return e ? atoi(e) : 2; }();
-// measured inside the step: target 3 for the skinny FC GEMMs (I2V_SPLIT_TARGET_SKINNY=3) makes the step 1 % faster (4.89 vs
-// 4.94 ms) although fc6 forward alone goes from 410 to 556 us and its time becomes unstable; 3 for everything the same, 4
-// slower (5.21).  The default stays at the setting that is best for the kernels on their own
-int g_split_below = [] { const char* e = getenv("I2V_SPLIT_BELOW"); return e ? atoi(e) : NUM_CU; }();
+// Tuning knobs live in g_i2v_tuning (i2v_set_tuning; the library itself reads no environment variable).
+// CONV_SPEC: -1 / 0 plain 4-wave kernel, 1 loader/MFMA specialised 8-wave kernel, 2 specialised when <= 3 workgroups per CU.
+// SPLIT_TARGET (workgroups per CU a split-K launch aims for), measured inside the step: 3 for the skinny FC GEMMs makes the
+// step 1 % faster (4.89 vs 4.94 ms) although fc6 forward alone goes from 410 to 556 us and its time becomes unstable; 3
+// for everything the same, 4 slower (5.21).  The default (2) is the setting that is best for the kernels on their own.
+#define g_spec_mode g_i2v_tuning[I2V_TUNE_CONV_SPEC]
+#define g_split_target g_i2v_tuning[I2V_TUNE_SPLIT_TARGET]
+#define g_split_target_skinny g_i2v_tuning[I2V_TUNE_SPLIT_TARGET_SKINNY]
+#define g_split_below g_i2v_tuning[I2V_TUNE_SPLIT_BELOW]
+#define g_split_atomics g_i2v_tuning[I2V_TUNE_SPLIT_ATOMICS]
+#define g_big_fc_tile g_i2v_tuning[I2V_TUNE_BIG_FC_TILE]
+#define g_wgrad_v2 g_i2v_tuning[I2V_TUNE_WGRAD_V2]
+#define g_wgrad_fused_tile g_i2v_tuning[I2V_TUNE_WGRAD_FUSED_TILE]
 
-// Split-K workspace: one slab + one counter array per stream (up to kSplitSlots streams; beyond that, or for
-// partials larger than a slab, the kernel falls back to fp32 atomics into y).  Allocated once, on the first
-// split-K call made outside a graph capture; handing a slot to a new stream is host bookkeeping only, so it is
-// legal while that stream is capturing.
-constexpr size_t kSplitSlabBytes = 48u << 20;
-constexpr int kSplitSlots = 6, kSplitCounters = 1024;
-int g_split_atomics = [] { const char* e = getenv("I2V_SPLIT_ATOMICS"); return e ? atoi(e) : 0; }();
-char* g_split_base = nullptr;
-int* g_split_cnt = nullptr;
-hipStream_t g_split_owner[kSplitSlots];
-int g_split_used = 0;
-int g_split_pin = -1;             // i2v_conv_set_split_slot(): >= 0 pins the slot (counted from the top) instead of keying by stream
-std::mutex g_split_mu;
-
-bool split_workspace(hipStream_t st, size_t need_bytes, long long tiles, float*& ws, int*& cnt) {
-    if (g_split_atomics || need_bytes > kSplitSlabBytes || tiles > kSplitCounters) return false;
-    std::lock_guard<std::mutex> lock(g_split_mu);
-    if (!g_split_base) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
-            (void)hipGetLastError();
-            return false;
-        }
-        char* base = nullptr;
-        int* c = nullptr;
-        if (hipMalloc((void**)&base, kSplitSlabBytes * kSplitSlots) != hipSuccess) { (void)hipGetLastError(); return false; }
-        if (hipMalloc((void**)&c, sizeof(int) * kSplitCounters * kSplitSlots) != hipSuccess) {
-            (void)hipGetLastError();
-            (void)hipFree(base);
-            return false;
-        }
-        (void)hipMemset(c, 0, sizeof(int) * kSplitCounters * kSplitSlots);
-        (void)hipDeviceSynchronize();
-        g_split_base = base;
-        g_split_cnt = c;
-    }
-    int slot = -1;
-    if (g_split_pin >= 0) {
-        // pinned by the caller: graphs that are captured on the same stream but replayed CONCURRENTLY on different
-        // streams (the overlapped backbone / head graphs) must not share a slab
-        slot = kSplitSlots - 1 - g_split_pin;
-        if (slot < g_split_used) return false;          // would collide with a stream-assigned slot
-    } else {
-        for (int i = 0; i < g_split_used; ++i)
-            if (g_split_owner[i] == st) slot = i;
-        if (slot < 0) {
-            if (g_split_used >= kSplitSlots - 2) return false;       // the top two slots are reserved for pins
-            slot = g_split_used++;
-            g_split_owner[slot] = st;
-        }
-    }
-    ws = reinterpret_cast<float*>(g_split_base + kSplitSlabBytes * slot);
-    cnt = g_split_cnt + kSplitCounters * slot;
-    return true;
-}
+// Split-K workspace, provided by the CALLER (i2v_conv_split_workspace_bytes): [kSplitCounters arrival counters | slab of
+// partial tiles].  The counters must be zero before the first launch that uses the workspace; every launch leaves them
+// zero again (the last workgroup to arrive at a tile resets its counter).  Launches that share a workspace must be
+// ordered on the device (same stream, or graph edges): two concurrently running launches need two workspaces.
+constexpr int kSplitCounters = 1024;
+constexpr size_t kSplitCounterBytes = sizeof(int) * kSplitCounters;
 
 template <class K>
 void set_max_lds(K kernel) {
@@ -822,7 +777,7 @@ constexpr TileCfg kTiles[] = {{128, 128, 1.00f}, {128, 64, 0.97f}, {96, 64, 0.95
                               {32, 64, 0.80f}};
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-int run_conv(ConvP p, hipStream_t st) {
+int run_conv(ConvP p, hipStream_t st, void* split_ws = nullptr, size_t split_ws_bytes = 0) {
     p.M = p.B * p.Ho * p.Wo;
     p.N = p.Cout;
     p.K = p.KH * p.KW * p.Cin;
@@ -879,8 +834,7 @@ int run_conv(ConvP p, hipStream_t st) {
     // the long skinny GEMM of the relation head (fc6 forward: 128 rows, K = 50176): 128x64 tiles instead of the 128x128 the
     // model picks -- twice the workgroups, each half as heavy.  Alone 436 vs 412 us, inside the two-stream step 4.88 vs
     // 4.93 ms (the same effect as with the fused update's tile: lighter workgroups give the other stream its turn sooner)
-    static const int big_fc_tile = [] { const char* e = getenv("I2V_BIG_FC_TILE"); return e ? atoi(e) : 1; }();
-    if (big_fc_tile >= 0 && big_fc_tile < kNumTiles && p.M <= 256 && p.K >= 16384) { cfg = big_fc_tile; plan(cfg, splitk); }
+    if (g_big_fc_tile >= 0 && g_big_fc_tile < kNumTiles && p.M <= 256 && p.K >= 16384) { cfg = g_big_fc_tile; plan(cfg, splitk); }
     if (force >= 0 && force < kNumTiles) { cfg = force; plan(cfg, splitk); }
     p.splitk = splitk;
     p.k_per_split = i2v_cdiv(ksteps, splitk) * BKS;
@@ -889,13 +843,19 @@ int run_conv(ConvP p, hipStream_t st) {
     p.ws = nullptr;
     p.cnt = nullptr;
     const size_t ws_need = (size_t)p.splitk * ntiles * kTiles[cfg].bm * kTiles[cfg].bn * sizeof(float);
-    // dry run: 0 = y needs no clear (no split, or the split is finished in-kernel), else the split factor
     // in-kernel finish pays where the output is large (atomics and the extra epilogue pass scale with it);
     // for the small FC outputs of the vrd head the atomics are cheap and a serial sum of many splits is not
-    const bool in_kernel = p.splitk > 1 && !g_split_atomics && p.splitk <= kSplitInKernelMax &&
-                           (long long)p.M * p.N >= (1 << 18) && ws_need <= kSplitSlabBytes && ntiles <= kSplitCounters;
+    const bool wants_ws = p.splitk > 1 && !g_split_atomics && p.splitk <= kSplitInKernelMax &&
+                          (long long)p.M * p.N >= (1 << 18) && ntiles <= kSplitCounters;
+    // dry == 2: the workspace this shape would use (0: none)
+    if (p.dry == 2) return wants_ws ? (int)std::min<size_t>(kSplitCounterBytes + ws_need, 0x7FFFFFFF) : 0;
+    const bool in_kernel = wants_ws && split_ws && kSplitCounterBytes + ws_need <= split_ws_bytes;
+    // dry == 1: 0 = y needs no clear (no split, or the split is finished in-kernel), else the split factor
     if (p.dry) return (p.splitk > 1 && !in_kernel) ? p.splitk : 0;
-    if (in_kernel) split_workspace(st, ws_need, ntiles, p.ws, p.cnt);
+    if (in_kernel) {
+        p.cnt = reinterpret_cast<int*>(split_ws);
+        p.ws = reinterpret_cast<float*>(static_cast<char*>(split_ws) + kSplitCounterBytes);
+    }
     const long long ytotal = (long long)p.M * p.N;
     if (p.splitk > 1 && !p.ws && !(p.flags & I2V_EPI_ZEROED)) hipMemsetAsync(p.y, 0, (size_t)ytotal * sizeof(float), st);
     // wave specialisation pays where few workgroups share a CU (nothing else hides the staging)
@@ -1499,7 +1459,6 @@ epilogue_bwd_scalar_kernel(const float* __restrict__ gy, const float* __restrict
 
 }  // namespace
 
-static int g_wgrad_v2 = [] { const char* e = getenv("I2V_WGRAD_V2"); return e ? atoi(e) : 1; }();
 
 // picks the kernel + pixel split for one wgrad problem; returns false when v2 cannot be used
 static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st) {
@@ -1510,8 +1469,7 @@ static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st) {
     // fused update: 128 filters x 64 taps -- the x tile is shared by twice the filters and half as many workgroups go
     // through the dispatcher.  Alone the kernel is slower than the 64x64 form (fc6: 792 vs 736 us), inside the step it is
     // faster (4.93 vs 5.00 ms, four alternating pairs): the rest of the step gets the chip back sooner
-    static const int fused_tile = [] { const char* e = getenv("I2V_WGRAD_FUSED_TILE"); return e ? atoi(e) : 128; }();
-    if (v2 && fused && fused_tile == 128 && p.N >= 128) tm = 128;
+    if (v2 && fused && g_wgrad_fused_tile == 128 && p.N >= 128) tm = 128;
     if (v2 && g_wgrad_v2 >= 2) {
         if (p.N >= 128) tm = 128;
         if (p.K >= 128 && tm == 128 && g_wgrad_v2 == 2) tk = 128;
@@ -1557,13 +1515,6 @@ extern "C" int32_t i2v_conv_debug_clock(void* buf) {
     return I2V_OK;
 }
 
-extern "C" int32_t i2v_conv_set_split_slot(int32_t pin) {
-    I2V_CHECK_ARG(pin >= -1 && pin <= 1, "conv_set_split_slot: pin must be -1 (by stream), 0 or 1");
-    std::lock_guard<std::mutex> lock(g_split_mu);
-    g_split_pin = pin;
-    return I2V_OK;
-}
-
 extern "C" int32_t i2v_conv_set_tile(int32_t cfg) {
     if (cfg < 0) { g_force_tile = -1; g_spec_mode = -1; g_ablate = 0; return I2V_OK; }
     g_force_tile = (cfg & 0xFF) == 0xFF ? -1 : (cfg & 0xFF);
@@ -1572,10 +1523,8 @@ extern "C" int32_t i2v_conv_set_tile(int32_t cfg) {
     return I2V_OK;
 }
 
-// 1 if i2v_conv_fwd will accumulate split-K partials with atomics for this shape (its output must then start at
-// zero: the call clears it itself unless the caller passes I2V_EPI_ZEROED), 0 otherwise, < 0 on error.
-extern "C" int32_t i2v_conv_fwd_splits(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH,
-                                       int32_t KW, int32_t stride, int32_t pad) {
+static int plan_conv(int dry, size_t ws_bytes, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH,
+                     int32_t KW, int32_t stride, int32_t pad) {
     int dummy = 0;
     int rc = check_conv("conv_fwd_splits", &dummy, &dummy, &dummy, B, H, W, Cin, Cout, KH, KW, stride, pad);
     if (rc) return rc;
@@ -1583,15 +1532,31 @@ extern "C" int32_t i2v_conv_fwd_splits(int32_t B, int32_t H, int32_t W, int32_t 
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad; p.pad_x = pad;
     p.Ho = (H + 2 * pad - KH) / stride + 1;
     p.Wo = (W + 2 * pad - KW) / stride + 1;
-    p.ostride = 1; p.force_tile = g_force_tile; p.dry = 1;
-    rc = run_conv(p, nullptr);
+    p.ostride = 1; p.force_tile = g_force_tile; p.dry = dry;
+    return run_conv(p, nullptr, ws_bytes ? &dummy : nullptr, ws_bytes);
+}
+
+// 1 if i2v_conv_fwd, given a split-K workspace of ws_bytes, will accumulate split-K partials with atomics for this
+// shape (its output must then start at zero: the call clears it itself unless the caller passes I2V_EPI_ZEROED),
+// 0 otherwise, < 0 on error.
+extern "C" int32_t i2v_conv_fwd_splits(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH,
+                                       int32_t KW, int32_t stride, int32_t pad, size_t ws_bytes) {
+    const int rc = plan_conv(1, ws_bytes, B, H, W, Cin, Cout, KH, KW, stride, pad);
     return rc < 0 ? rc : (rc > 1 ? 1 : 0);
+}
+
+// Bytes of split-K workspace i2v_conv_fwd would use for this shape (0: it does not split K, or it splits into so many
+// parts / so small an output that fp32 atomics are the better finish).
+extern "C" size_t i2v_conv_split_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH,
+                                                 int32_t KW, int32_t stride, int32_t pad) {
+    const int rc = plan_conv(2, 0, B, H, W, Cin, Cout, KH, KW, stride, pad);
+    return rc > 0 ? (size_t)rc : 0;
 }
 
 extern "C" int32_t i2v_conv_fwd(const float* x, const float* w, const float* scale, const float* shift,
                                 const float* res, float* y, int32_t B, int32_t H, int32_t W, int32_t Cin,
                                 int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad, int32_t flags,
-                                void* stream) {
+                                void* split_ws, size_t split_ws_bytes, void* stream) {
     int rc = check_conv("conv_fwd", x, w, y, B, H, W, Cin, Cout, KH, KW, stride, pad);
     if (rc) return rc;
     I2V_CHECK_ARG(!(flags & I2V_EPI_SCALE) || (scale && shift), "conv_fwd: EPI_SCALE needs scale and shift");
@@ -1604,7 +1569,7 @@ extern "C" int32_t i2v_conv_fwd(const float* x, const float* w, const float* sca
     p.Wo = (W + 2 * pad - KW) / stride + 1;
     p.flags = flags; p.ostride = 1; p.Hy = p.Ho; p.Wy = p.Wo;
     p.force_tile = g_force_tile;
-    rc = run_conv(p, (hipStream_t)stream);
+    rc = run_conv(p, (hipStream_t)stream, split_ws, split_ws_bytes);
     if (rc) return rc;
     I2V_CHECK_LAUNCH("conv_fwd");
     return I2V_OK;
@@ -1613,7 +1578,8 @@ extern "C" int32_t i2v_conv_fwd(const float* x, const float* w, const float* sca
 // nbatch independent GEMMs of one shape in ONE launch: C_z (M x N) = A_z (M x K) * B_z (N x K)^T, fp32, operand z at
 // base + z * stride (elements).  The 16 element-wise planes of a Winograd convolution are such a batch.
 extern "C" int32_t i2v_gemm_nt_batched(const float* a, const float* b, float* c, int32_t M, int32_t N, int32_t K,
-                                       int32_t nbatch, int64_t stride_a, int64_t stride_b, int64_t stride_c, void* stream) {
+                                       int32_t nbatch, int64_t stride_a, int64_t stride_b, int64_t stride_c,
+                                       void* split_ws, size_t split_ws_bytes, void* stream) {
     I2V_CHECK_ARG(a && b && c && M > 0 && N > 0 && K > 0 && nbatch > 0 && nbatch <= 65535, "gemm_nt_batched: bad argument");
     I2V_CHECK_ARG(K % 4 == 0, "gemm_nt_batched: K must be a multiple of 4");
     ConvP p = {};
@@ -1622,7 +1588,7 @@ extern "C" int32_t i2v_gemm_nt_batched(const float* a, const float* b, float* c,
     p.Ho = M; p.Wo = 1; p.flags = 0; p.ostride = 1; p.Hy = M; p.Wy = 1;
     p.force_tile = g_force_tile;
     p.nbatch = nbatch; p.bsx = stride_a; p.bsw = stride_b; p.bsy = stride_c;
-    int rc = run_conv(p, (hipStream_t)stream);
+    int rc = run_conv(p, (hipStream_t)stream, split_ws, split_ws_bytes);
     if (rc) return rc;
     I2V_CHECK_LAUNCH("gemm_nt_batched");
     return I2V_OK;
@@ -1647,7 +1613,7 @@ extern "C" size_t i2v_conv_dgrad_workspace_bytes(int32_t Cin, int32_t Cout, int3
 // to exactly the dense count (the zero-insertion form did s*s times that).
 extern "C" int32_t i2v_conv_dgrad(const float* gy, const float* w, float* gx, int32_t B, int32_t H, int32_t W,
                                      int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
-                                     void* ws, size_t ws_bytes, void* stream) {
+                                     void* ws, size_t ws_bytes, void* split_ws, size_t split_ws_bytes, void* stream) {
     int rc = check_conv("conv_dgrad", gy, w, gx, B, H, W, Cin, Cout, KH, KW, stride, pad);
     if (rc) return rc;
     I2V_CHECK_ARG(Cout % 4 == 0, "conv_dgrad: Cout must be a multiple of 4");
@@ -1677,7 +1643,7 @@ extern "C" int32_t i2v_conv_dgrad(const float* gy, const float* w, float* gx, in
             p.pad = 0; p.pad_x = 0; p.Ho = Ho; p.Wo = Wo; p.ostride = stride;
             hipMemsetAsync(gx, 0, (size_t)B * H * W * Cin * sizeof(float), st);
         }
-        rc = run_conv(p, st);
+        rc = run_conv(p, st, split_ws, split_ws_bytes);
         if (rc) return rc;
         I2V_CHECK_LAUNCH("conv_dgrad");
         return I2V_OK;
@@ -1709,7 +1675,7 @@ extern "C" int32_t i2v_conv_dgrad(const float* gy, const float* w, float* gx, in
             q.Wo = (W - rx + stride - 1) / stride;
             q.ostride = stride;
             q.y = gx + ((long long)ry * W + rx) * Cin;
-            rc = run_conv(q, st);
+            rc = run_conv(q, st, split_ws, split_ws_bytes);
             if (rc) return rc;
             wsub += wn;
         }

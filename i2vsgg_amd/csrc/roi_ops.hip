@@ -463,7 +463,7 @@ extern "C" int32_t i2v_roi_pool_fwd(const float* feat, int32_t feat_layout, int3
     I2V_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && R >= 0 && PH > 0 && PW > 0, "roi_pool_fwd: bad shape");
     I2V_CHECK_ARG(PH * PW <= 256, "roi_pool_fwd: pooled grid too large for the LDS stage");
     Strides fs = feat_strides(feat_layout, C, H, W), os = out_strides(out_layout, C, PH, PW);
-    static const int c128 = [] { const char* e = getenv("I2V_ROIPOOL_C128"); return e ? atoi(e) : 1; }();
+    const int c128 = g_i2v_tuning[I2V_TUNE_ROIPOOL_C128];
     if (c128 && feat_layout == I2V_LAYOUT_NHWC && C % 128 == 0 && (size_t)128 * PH * PW * 8 <= 64 * 1024) {
         roi_pool_fwd_c128_kernel<<<R * (C / 128), 256, (size_t)128 * PH * PW * 8, (hipStream_t)stream>>>(
             feat, rois, out, argmax, C, H, W, PH, PW, scale, out_layout == I2V_LAYOUT_NCHW);

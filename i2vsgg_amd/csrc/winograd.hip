@@ -13,7 +13,8 @@
 #include "common.h"
 
 extern "C" int32_t i2v_gemm_nt_batched(const float* a, const float* b, float* c, int32_t M, int32_t N, int32_t K,
-                                       int32_t nbatch, int64_t stride_a, int64_t stride_b, int64_t stride_c, void* stream);
+                                       int32_t nbatch, int64_t stride_a, int64_t stride_b, int64_t stride_c,
+                                       void* split_ws, size_t split_ws_bytes, void* stream);
 
 namespace {
 
@@ -408,7 +409,7 @@ extern "C" int32_t i2v_conv3x3_winograd_fwd(const float* x, const float* U, cons
     float* V = (float*)ws;
     float* Mx = (float*)((char*)ws + i2v_align(16 * (size_t)T * Cin * sizeof(float)));
     wino_input_kernel<<<(unsigned)i2v_cdiv(T * (Cin / 4), 256), 256, 0, st>>>(x, V, B, H, W, Cin, th, tw);
-    int rc = i2v_gemm_nt_batched(V, U, Mx, (int32_t)T, Cout, Cin, 16, T * Cin, (long long)Cout * Cin, T * Cout, stream);
+    int rc = i2v_gemm_nt_batched(V, U, Mx, (int32_t)T, Cout, Cin, 16, T * Cin, (long long)Cout * Cin, T * Cout, nullptr, 0, stream);
     if (rc) return rc;
     wino_output_kernel<<<(unsigned)i2v_cdiv(T * (Cout / 4), 256), 256, 0, st>>>(Mx, scale, shift, y, B, H, W, Cout, th, tw, relu);
     I2V_CHECK_LAUNCH("conv3x3_winograd_fwd");
@@ -454,11 +455,11 @@ extern "C" int32_t i2v_conv3x3_winograd4_fwd(const float* x, const float* U, con
     float* Mx = (float*)((char*)ws + i2v_align(36 * (size_t)T * Cin * sizeof(float)));
     // row-split transforms only where the one-thread-per-(tile, channel) launch cannot fill the chip (layer3: 34 vs
     // 37 us per layer); on layer1/2 their redundant loads cost more than the parallelism buys (79 vs 57 us)
-    static const int rows_env = [] { const char* e = getenv("I2V_WINO_ROWS"); return e ? atoi(e) : -1; }();   // bit 0: input, bit 1: output
+    const int rows_env = g_i2v_tuning[I2V_TUNE_WINO_ROWS];   // bit 0: input, bit 1: output; -1: by size
     const int rows = rows_env >= 0 ? rows_env : (T * (Cin > Cout ? Cin : Cout) <= 98304 ? 3 : 0);
     if (rows & 1) wino4_input_rows_kernel<<<dim3((unsigned)i2v_cdiv(T * Cin, 256), 6), 256, 0, st>>>(x, V, B, H, W, Cin, th, tw);
     else wino4_input_kernel<<<(unsigned)i2v_cdiv(T * Cin, 256), 256, 0, st>>>(x, V, B, H, W, Cin, th, tw);
-    int rc = i2v_gemm_nt_batched(V, U, Mx, (int32_t)T, Cout, Cin, 36, T * Cin, (long long)Cout * Cin, T * Cout, stream);
+    int rc = i2v_gemm_nt_batched(V, U, Mx, (int32_t)T, Cout, Cin, 36, T * Cin, (long long)Cout * Cin, T * Cout, nullptr, 0, stream);
     if (rc) return rc;
     if (rows & 2) wino4_output_rows_kernel<<<dim3((unsigned)i2v_cdiv(T * Cout, 256), 4), 256, 0, st>>>(Mx, scale, shift, y, B, H, W, Cout, th, tw, relu);
     else wino4_output_kernel<<<(unsigned)i2v_cdiv(T * Cout, 256), 256, 0, st>>>(Mx, scale, shift, y, B, H, W, Cout, th, tw, relu);

@@ -96,7 +96,7 @@ class Bottleneck(nn.Module):
 
     def _winograd_filter(self):
         w = self.conv2.weight
-        key = (w.data_ptr(), w._version, w.device)
+        key = ops.param_key(w)
         if getattr(self, "_wino_key", None) != key:
             with torch.no_grad():
                 self._wino_u, self._wino_key = ops.winograd_filter(w.detach(), WINOGRAD), key
@@ -153,11 +153,12 @@ class C4Base(nn.Sequential):
 
     def _stem_weight(self):
         w = self[0].weight
-        if self._w4 is None or self._w4.device != w.device or self._w4_ver != w._version:
+        key = ops.param_key(w)
+        if self._w4 is None or self._w4_key != key:
             with torch.no_grad():
                 w4 = torch.zeros((w.shape[0], 4, w.shape[2], w.shape[3]), device=w.device)
                 w4[:, :3] = w
-            self._w4, self._w4_ver = w4.contiguous(memory_format=_CL), w._version
+            self._w4, self._w4_key = w4.contiguous(memory_format=_CL), key
         return self._w4
 
     def stem(self, im):

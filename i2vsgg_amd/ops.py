@@ -42,15 +42,22 @@ def _is_nhwc(x):
 
 
 _ws_cache = {}
+SCRATCH = None      # dict of the active LaunchContext (below); None -> scratch per launch stream
 
 
 def workspace(nbytes, device, tag="default"):
-    """Grow-only scratch buffer per (device, tag)."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), tag)
-    buf = _ws_cache.get(key)
+    """Grow-only scratch buffer per (tag, owner).  The owner is the active ``LaunchContext`` when a step object has
+    installed one, else the launch stream: two pieces of work that may run concurrently on the device (two streams, two
+    HIP graphs replayed side by side) never share a scratch buffer -- every kernel that uses one assumes that the
+    launches before it on ITS stream are the only other users."""
+    cache = SCRATCH
+    if cache is None:
+        key = (device.index if device.index is not None else torch.cuda.current_device(), stream())
+        cache = _ws_cache.setdefault(key, {})
+    buf = cache.get(tag)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
-        _ws_cache[key] = buf
+        cache[tag] = buf
     return buf
 
 
@@ -266,16 +273,17 @@ def bbox_overlaps(boxes, gt, want_matrix=False):
 
 
 # ----------------------------------------------------------------------------- conv / linear
-PROFILE = None      # bench.py sets this to a list: (start_event, end_event, flops, tag) per GEMM launch
+PROFILE = None      # bench.py sets this to a list: (start_event, end_event, flops, tag, desc, algorithmic bytes) per GEMM launch
 
 
 class _Timed:
     """HIP events around one launch on the launch stream (torch's current stream) when profiling."""
 
-    def __init__(self, flops, tag, desc=""):
+    def __init__(self, flops, tag, desc="", nbytes=0):
         self.on = PROFILE is not None
         if self.on:
-            self.rec = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), flops, tag, desc)
+            self.rec = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), flops, tag, desc,
+                        float(nbytes))
 
     def __enter__(self):
         if self.on:
@@ -329,8 +337,74 @@ class ZeroArena:
         return t
 
 
+# Bumped whenever trained parameters change behind autograd's back (train.FusedSGD writes through raw device pointers and
+# never touches ``Tensor._version``): part of the key of every cache derived from a trained parameter.
+PARAM_EPOCH = 0
+
+
+def param_key(w):
+    return (w.data_ptr(), w._version, w.device, PARAM_EPOCH if getattr(w, "_i2v_trained", False) else 0)
+
+
 SMALL_GW_BYTES = 16 << 20
 ARENA = None        # set by a training step object (train.SGGEmbStep) around its forward/backward
+
+
+class SplitWorkspace:
+    """Caller-owned split-K scratch of the implicit-GEMM kernels (include/i2vsgg_hip.h, i2v_conv_fwd): arrival counters
+    (zero between launches) + a slab of partial tiles.  Launches that share one must be ordered on the device, so every
+    piece of work that may run CONCURRENTLY with another (two HIP graphs on two streams, two branches of one graph)
+    gets its own: a step object installs it in ``ops.SPLIT_WS`` around the code it captures.  Without one, calls use a
+    workspace per (device, launch stream)."""
+    BYTES = (48 << 20) + 4096
+
+    def __init__(self, device, nbytes=None):
+        self.buf = torch.zeros(int(nbytes or self.BYTES), dtype=torch.uint8, device=device)
+
+
+SPLIT_WS = None     # set like ARENA; None -> one workspace per launch stream
+_split_ws_by_stream = {}
+
+
+class LaunchContext:
+    """What one independently scheduled piece of captured work owns exclusively: the pre-zeroed arena of its
+    atomically accumulated outputs, its split-K workspace and its tagged scratch buffers.  ``with ctx:`` installs them
+    for the calls made inside (forward AND the autograd backward triggered inside the block)."""
+
+    def __init__(self, device, arena=True):
+        self.device = torch.device(device)
+        self.arena = ZeroArena(1024, self.device) if arena else None      # sized after the first eager step (fit())
+        self.split = SplitWorkspace(self.device)
+        self.scratch = {}
+
+    def fit(self):
+        """After an eager step: re-size the arena to what the step asked for."""
+        a = self.arena
+        if a is not None and a.wanted * 4 > a.buf.numel() * 4:
+            self.arena = ZeroArena(int(a.wanted * 4 * 1.05) + 4096, self.device)
+
+    def __enter__(self):
+        global ARENA, SPLIT_WS, SCRATCH
+        self._saved = (ARENA, SPLIT_WS, SCRATCH)
+        ARENA, SPLIT_WS, SCRATCH = self.arena, self.split, self.scratch
+        if self.arena is not None:
+            self.arena.reset()          # one clear for every atomically accumulated output of this piece of work
+        return self
+
+    def __exit__(self, *exc):
+        global ARENA, SPLIT_WS, SCRATCH
+        ARENA, SPLIT_WS, SCRATCH = self._saved
+        return False
+
+
+def _split_ws(device):
+    ws = SPLIT_WS
+    if ws is None:
+        key = (device.index if device.index is not None else torch.cuda.current_device(), stream())
+        ws = _split_ws_by_stream.get(key)
+        if ws is None:
+            ws = _split_ws_by_stream[key] = SplitWorkspace(device)
+    return ws.buf
 
 
 def _conv_fwd_raw(x, w, scale, shift, res, stride, pad, flags):
@@ -339,16 +413,18 @@ def _conv_fwd_raw(x, w, scale, shift, res, stride, pad, flags):
     Ho = (H + 2 * pad - KH) // stride + 1
     Wo = (W + 2 * pad - KW) // stride + 1
     y = None
-    if ARENA is not None and lib.i2v_conv_fwd_splits(B, H, W, Cin, Cout, KH, KW, stride, pad) == 1:
+    sws = _split_ws(x.device)
+    if ARENA is not None and lib.i2v_conv_fwd_splits(B, H, W, Cin, Cout, KH, KW, stride, pad, sws.numel()) == 1:
         y = ARENA.take(B, Cout, Ho, Wo)
         if y is not None:
             flags |= EPI_ZEROED
     if y is None:
         y = torch.empty((B, Cout, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=_CL)
     with _Timed(2.0 * B * Ho * Wo * Cout * KH * KW * Cin, "fwd",
-                "M%d N%d K%d (%dx%d s%d)" % (B * Ho * Wo, Cout, KH * KW * Cin, KH, KW, stride)):
+                "M%d N%d K%d (%dx%d s%d)" % (B * Ho * Wo, Cout, KH * KW * Cin, KH, KW, stride),
+                4 * (x.numel() + w.numel() + y.numel() + (res.numel() if res is not None else 0))):
         check(lib.i2v_conv_fwd(ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(res), ptr(y), B, H, W, Cin, Cout, KH, KW,
-                               stride, pad, flags, stream()), "conv_fwd")
+                               stride, pad, flags, ptr(sws), sws.numel(), stream()), "conv_fwd")
     return y
 
 
@@ -381,10 +457,11 @@ def _conv_dgrad_raw(g, w, in_shape, stride, pad):
         Cout += padc
     gx = torch.empty((B, Cin, H, W), device=dev, dtype=torch.float32, memory_format=_CL)
     ws = workspace(lib.i2v_conv_dgrad_workspace_bytes(Cin, Cout, KH, KW), dev, "dgrad")
+    sws = _split_ws(dev)
     with _Timed(2.0 * B * g.shape[2] * g.shape[3] * Cout * KH * KW * Cin, "dgrad",
-                "M%d N%d K%d" % (B * H * W, Cin, KH * KW * Cout)):
+                "M%d N%d K%d" % (B * H * W, Cin, KH * KW * Cout), 4 * (g.numel() + w.numel() + gx.numel())):
         check(lib.i2v_conv_dgrad(ptr(g), ptr(w), ptr(gx), B, H, W, Cin, Cout, KH, KW, stride, pad, ptr(ws), ws.numel(),
-                                 stream()), "conv_dgrad")
+                                 ptr(sws), sws.numel(), stream()), "conv_dgrad")
     return gx
 
 
@@ -404,7 +481,8 @@ def _conv_wgrad_raw(x, g, w_shape, stride, pad, tag="wgrad"):
     if gw is None:
         gw = torch.empty(w_shape, device=x.device, dtype=torch.float32, memory_format=_CL)
     with _Timed(2.0 * B * g.shape[2] * g.shape[3] * Cout * KH * KW * Cin, tag,
-                "N%d K%d M%d" % (Cout, KH * KW * Cin, B * g.shape[2] * g.shape[3]) + (" (wgrad form)" if tag != "wgrad" else "")):
+                "N%d K%d M%d" % (Cout, KH * KW * Cin, B * g.shape[2] * g.shape[3]) + (" (wgrad form)" if tag != "wgrad" else ""),
+                4 * (x.numel() + g.numel() + gw.numel())):
         check(lib.i2v_conv_wgrad(ptr(x), ptr(g), ptr(gw), B, H, W, Cin, Cout, KH, KW, stride, pad, beta, None, 0,
                                  stream()), "conv_wgrad")
     return gw
@@ -420,7 +498,8 @@ def _conv_wgrad_sgd_raw(x, g, w, cfg, stride, pad):
     B, Cin, H, W = x.shape
     Cout, _, KH, KW = w.shape
     with _Timed(2.0 * B * g.shape[2] * g.shape[3] * Cout * KH * KW * Cin, "wgrad",
-                "N%d K%d M%d +sgd" % (Cout, KH * KW * Cin, B * g.shape[2] * g.shape[3])):
+                "N%d K%d M%d +sgd" % (Cout, KH * KW * Cin, B * g.shape[2] * g.shape[3]),
+                4 * (x.numel() + g.numel() + 4 * w.numel())):        # filter and momentum each read and written once
         rc = lib.i2v_conv_wgrad_sgd(ptr(x), ptr(g), ptr(w), ptr(m), B, H, W, Cin, Cout, KH, KW, stride, pad, float(lr),
                                     float(mom), float(wd), stream())
     return rc
@@ -834,7 +913,8 @@ def conv3x3_winograd(x, U, scale=None, shift=None, relu=False, tag="fwd"):
     ws = workspace(wsb, x.device, "winograd")
     fn = lib.i2v_conv3x3_winograd4_fwd if four else lib.i2v_conv3x3_winograd_fwd
     with _Timed(2.0 * B * H * W * Cout * 9 * Cin, tag,
-                "M%d N%d K%d (3x3 winograd F%d)" % (B * H * W, Cout, 9 * Cin, 4 if four else 2)):
+                "M%d N%d K%d (3x3 winograd F%d)" % (B * H * W, Cout, 9 * Cin, 4 if four else 2),
+                4 * (x.numel() + 9 * Cout * Cin + y.numel())):
         check(fn(ptr(x), ptr(U), ptr(scale), ptr(shift), ptr(y), B, H, W, Cin, Cout, int(bool(relu)), ptr(ws), ws.numel(),
                  stream()), "conv3x3_winograd_fwd")
     return y

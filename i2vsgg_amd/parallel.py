@@ -65,7 +65,15 @@ def all_reduce_grads_start(params, group=None):
     on the current stream; work queued on the current stream AFTER this call overlaps them."""
     if not exchange_enabled():
         return None
-    grads = [p.grad for p in params if p.grad is not None and not is_local(p)]
+    # a FIXED list on every rank: a parameter that received no gradient here (an unused branch on this rank's batch)
+    # contributes zeros -- skipping it would give the ranks different collective sequences (a hang or mixed-up sums)
+    grads = []
+    for p in params:
+        if is_local(p):
+            continue
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        grads.append(p.grad)
     big = [g for g in grads if g.numel() * g.element_size() >= SMALL_BYTES]
     small = [g for g in grads if g.numel() * g.element_size() < SMALL_BYTES]
     # largest first: the 822 MB fc6 gradient dominates the exchange
@@ -138,6 +146,21 @@ class ColShardToOwnRows(torch.autograd.Function):
         allg = dh.new_empty((w, r, w * cs))
         dist.all_gather_into_tensor(allg.view(w * r, w * cs), dh.contiguous())
         return allg[:, :, rk * cs:(rk + 1) * cs].reshape(w * r, cs).contiguous()
+
+
+def assert_same_rows(n_rows, what="rows"):
+    """The column-parallel fc6 exchanges (gather_rows, ColShardToOwnRows) are fixed-size all-gathers: every rank must
+    bring the same number of rows.  Host-side check (one small all-gather of an int): call it where shapes are decided
+    -- when a step is captured, or per batch in eager mode -- never inside a captured region."""
+    if world_size() <= 1:
+        return
+    t = torch.tensor([int(n_rows)], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+    out = [torch.zeros_like(t) for _ in range(world_size())]
+    dist.all_gather(out, t)
+    counts = [int(o.item()) for o in out]
+    if len(set(counts)) != 1:
+        raise RuntimeError("column-parallel vrd.fc6 needs the same number of %s on every rank, got %s: pad the batch to "
+                           "a common size or set I2V_TP_FC6=0 (plain data parallelism)" % (what, counts))
 
 
 def mark_local(p):

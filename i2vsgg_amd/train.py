@@ -30,6 +30,7 @@ class FusedSGD:
             if not p.requires_grad:
                 continue
             is_bias = "bias" in name
+            p._i2v_trained = True        # updated through raw device pointers: caches keyed on p._version also key on ops.PARAM_EPOCH
             self.items.append(dict(
                 name=name, p=p, m=torch.zeros_like(p),
                 lr=lr * ((T.DOUBLE_BIAS + 1) if is_bias else 1),
@@ -63,6 +64,39 @@ class FusedSGD:
     def params(self):
         return [it["p"] for it in self.items]
 
+    @staticmethod
+    def bump():
+        """The parameters changed (an eager ``step()``, a fused wgrad+SGD epilogue or a graph replay that contains
+        them): whatever is derived from trained parameters and cached (Winograd-domain filters) is stale."""
+        ops.PARAM_EPOCH += 1
+
+    def state_dict(self):
+        """torch.optim.SGD's layout (param_groups + state[i]['momentum_buffer']) in named_parameters order, so that a
+        checkpoint written here resumes under torch.optim.SGD and vice versa."""
+        return {"state": {i: {"momentum_buffer": it["m"].detach().clone()} for i, it in enumerate(self.items)},
+                "param_groups": [{"lr": it["lr"], "momentum": self.momentum, "weight_decay": it["wd"], "params": [i],
+                                  "name": it["name"]} for i, it in enumerate(self.items)]}
+
+    def load_state_dict(self, sd):
+        groups = sd["param_groups"]
+        flat = [pi for g in groups for pi in g["params"]]
+        if len(flat) != len(self.items):
+            raise ValueError("optimizer state holds %d parameters, this optimizer %d" % (len(flat), len(self.items)))
+        by_param = {pi: g for g in groups for pi in g["params"]}
+        for i, it in enumerate(self.items):
+            g = by_param[flat[i]]
+            it["lr"], it["wd"] = float(g["lr"]), float(g.get("weight_decay", it["wd"]))
+            self.momentum = float(g.get("momentum", self.momentum))
+            st = sd["state"].get(flat[i], sd["state"].get(str(flat[i])))
+            if st is not None and st.get("momentum_buffer") is not None:
+                it["m"].copy_(st["momentum_buffer"].reshape(it["m"].shape))
+            else:
+                it["m"].zero_()
+        for k in list(self._fused_keys):       # fused entries hold (momentum, lr, ...) by value
+            for it in self.items:
+                if it["p"].data_ptr() == k:
+                    ops.FUSED_SGD[k] = (it["m"], it["lr"], self.momentum, it["wd"])
+
     def zero_grad(self):
         for it in self.items:
             it["p"].grad = None
@@ -70,6 +104,9 @@ class FusedSGD:
     def scale_lr(self, k):
         for it in self.items:
             it["lr"] *= k
+            ent = ops.FUSED_SGD.get(it["p"].data_ptr())
+            if ent is not None:                 # fused entries hold the rate by value (a captured graph holds it too:
+                ops.FUSED_SGD[it["p"].data_ptr()] = (ent[0], it["lr"], ent[2], ent[3])   # re-capture after a decay)
 
     MULTI_BELOW = 1 << 20       # tensors under 1 Mi elements share one launch
 
@@ -89,6 +126,7 @@ class FusedSGD:
         if small:
             ops.sgd_momentum_multi_([p for p, _, _ in small], [g for _, g, _ in small], [it["m"] for _, _, it in small],
                                     [it["lr"] for _, _, it in small], [it["wd"] for _, _, it in small], self.momentum)
+        self.bump()
 
 
 def synthetic_sgg_batch(seed, n_frames, n_boxes=32, n_pairs=32, n_rel=62, n_cls=16, h=600, w=1000):
@@ -99,16 +137,55 @@ def synthetic_sgg_batch(seed, n_frames, n_boxes=32, n_pairs=32, n_rel=62, n_cls=
     return im, info, annos
 
 
+class _Slot:
+    """One minibatch worth of head inputs packed into ONE device buffer (256-B aligned fields), so that moving a
+    batch between pipeline stages is a single copy whatever the number of fields."""
+
+    def __init__(self, fields, device):
+        self.spec, off = [], 0
+        for name, t in fields.items():
+            nbytes = t.numel() * t.element_size()
+            self.spec.append((name, off, nbytes, t.dtype, tuple(t.shape)))
+            off += (nbytes + 255) // 256 * 256
+        self.buf = torch.zeros(max(off, 256), dtype=torch.uint8, device=device)
+        self.views = {name: self.buf[o:o + n].view(dt).view(shape) for name, o, n, dt, shape in self.spec}
+
+    def same_layout(self, fields):
+        return [(n, dt, sh) for n, _, _, dt, sh in self.spec] == [(n, t.dtype, tuple(t.shape)) for n, t in fields.items()]
+
+    def write(self, fields):
+        for name, t in fields.items():
+            self.views[name].copy_(t)
+
+
 class SGGEmbStep:
+    """One step of trainval_net_SGG_emb.py:189-255 (pre_det) as a replayable object.
+
+    A step = one backbone pass (no grad: the reference detaches the feature map, faster_rcnn_SGG_emb.py:148), one
+    relation-head forward + backward, one gradient exchange (world > 1), one SGD(momentum) update of ``vrd.*``.
+
+    Schedule (``overlap``, the default with HIP graphs): the backbone is frozen in this loop, so the backbone pass of
+    the NEXT minibatch does not depend on this step's update.  The whole step is ONE captured graph with two branches
+    between a fork and a join: [head fwd + bwd (+ exchange) + SGD of batch k] beside [backbone of batch k+1].  The
+    branches own disjoint device state (``ops.LaunchContext``: zero arena, split-K workspace, scratch) and meet only at
+    graph edges: the feature-map hand-off (one 20 MB copy before the fork) and the join.  There is one graph launch
+    per step on the caller's stream, no side stream, no event and no priority for a caller to get wrong.
+
+    Minibatches move through a three-slot pipeline so that ``stage()`` may be called at any time between steps:
+    ``stage(b)`` writes the frames of b (read by the NEXT call's backbone branch) and its head inputs into the ``in``
+    slot; each call starts with cur <- nxt, nxt <- in (two small copies inside the graph) and then runs head(cur) beside
+    backbone(frames).  A batch staged before call k is therefore consumed by the backbone in call k and by the head in
+    call k+1 -- features and boxes / labels of one batch always meet.  ``overlap=False`` (and eager mode): backbone and
+    head of the staged batch in the same call."""
+
     def __init__(self, net, n_frames, vrd_lr=1e-4, seed=1, device="cuda:0", h=600, w=1000, n_boxes=32, n_pairs=32,
-                 use_graph=True, fuse_sgd=True, zero_arena=True):
+                 use_graph=True, fuse_sgd=True, zero_arena=True, overlap=None):
+        import os
         self.net, self.dev, self.n_frames = net, torch.device(device), n_frames
         self.world = parallel.world_size()
         self.geom = (h, w, n_boxes, n_pairs)
-        self.reseed(seed)
         # data parallelism for everything except vrd.fc6, which is cut by output columns (parallel.py): its 822 MB
         # gradient -- 91 % of the exchange -- stays local and its SGD update stays fused into the wgrad epilogue
-        import os
         self.tp = parallel.exchange_enabled() and os.environ.get("I2V_TP_FC6", "1") != "0" and \
             net.vrd.fc6.fc.weight.shape[0] % max(self.world, 1) == 0
         if self.tp and net.vrd.tp is None:
@@ -117,18 +194,22 @@ class SGGEmbStep:
         self.fused = self.opt.fuse_wgrad() if fuse_sgd else []
         self.loss = torch.zeros((), device=self.dev)
         self.graph = None
+        self.graph_error = None
         self.use_graph = use_graph
-        self.arena = ops.ZeroArena(1024, self.dev) if zero_arena else None    # sized after the first step
-        self.arena_bb = ops.ZeroArena(1024, self.dev) if zero_arena else None
-        self.fmap = None
-        self.fmap_head = None
-        self.pipelined = False
-        import os as _os
-        self.overlap = _os.environ.get("I2V_OVERLAP", "1") != "0" and use_graph
+        if overlap is None:
+            overlap = os.environ.get("I2V_OVERLAP", "1") != "0"
+        self.overlap = bool(overlap) and use_graph
+        self.ctx_bb = ops.LaunchContext(self.dev, arena=zero_arena)        # backbone branch
+        self.ctx_head = ops.LaunchContext(self.dev, arena=zero_arena)      # head branch
+        self.im = self.fmap = self.fmap_head = None
+        self.cur = self.nxt = self.inp = None
+        self.primed = False
+        self.reseed(seed)
 
-    def reseed(self, seed):
-        """(Re)generate the synthetic minibatch: frames, pair tables, masks, labels -> static device inputs (the
-        data layer's job; resident before the timed region).  Shapes do not depend on the seed."""
+    # ------------------------------------------------------------------ data side
+    def _synthetic(self, seed):
+        """SURVEY.md 8d config 2 as device tensors: frames in the layout the device front-end emits (ops.image_prep:
+        NHWC with the stem's zero fourth channel) + the head inputs of faster_rcnn_SGG_emb.py:170-245."""
         from .model.faster_rcnn.faster_rcnn_SGG_emb import build_pair_tables, rasterize_masks
         h, w, n_boxes, n_pairs = self.geom
         head = self.net.vrd
@@ -144,275 +225,183 @@ class SGGEmbStep:
             boxes.append(b5); relb.append(r5); bounds.append(bnd); labels.append(lab)
             ixs.append(s + off); ixo.append(o + off); counts.append(lab.shape[0]); off += gt.shape[0]
         t = lambda a, dt=torch.float32: torch.from_numpy(np.concatenate(a)).to(self.dev, dt)
-        # frames in the layout the device front-end emits (ops.image_prep): NHWC with the stem's zero fourth channel
         im4 = torch.zeros((im.shape[0], 4) + tuple(im.shape[2:]), device=self.dev).contiguous(memory_format=torch.channels_last)
         im4[:, :3] = torch.from_numpy(im).to(self.dev)
-        new = dict(im=im4, info=torch.from_numpy(info).to(self.dev), boxes=t(boxes),
-                   relb=t(relb), labels=t(labels), ixs=t(ixs, torch.long), ixo=t(ixo, torch.long),
-                   masks=torch.nn.functional.pad(rasterize_masks(np.concatenate(bounds), self.dev), (0, 0, 0, 0, 0, 2)),  # 2 zero channels: the float4 pad of conv_lo.0, done once by the data side
-                   wrow=torch.cat([torch.full((c,), 1.0 / (c * len(counts))) for c in counts]).to(self.dev))
-        for k, v in new.items():
-            cur = getattr(self, k, None)
-            if cur is not None and cur.shape == v.shape:
-                cur.copy_(v)                 # keep addresses: a captured graph stays valid
-            else:
-                setattr(self, k, v)
-        self.n_rows = int(self.boxes.shape[0] + self.relb.shape[0])
+        fields = dict(boxes=t(boxes), relb=t(relb), labels=t(labels), ixs=t(ixs, torch.long), ixo=t(ixo, torch.long),
+                      # 2 zero channels: the float4 pad of conv_lo.0, done once by the data side
+                      masks=torch.nn.functional.pad(rasterize_masks(np.concatenate(bounds), self.dev), (0, 0, 0, 0, 0, 2)),
+                      wrow=torch.cat([torch.full((c,), 1.0 / (c * len(counts))) for c in counts]).to(self.dev))
+        return im4, torch.from_numpy(info).to(self.dev), fields
 
-    # The step in two halves.  The backbone is frozen in this loop (the reference detaches it), so its
-    # forward does not depend on the head's weights: with data parallelism the backbone pass of the NEXT
-    # minibatch runs while the gradients of this one are exchanged (see __call__).
+    def stage(self, im4, info, fields):
+        """Hand the NEXT minibatch to the step: frames (N,4,H,W) channels_last + head inputs.  Ordered on the caller's
+        stream like everything else: it may be called right after ``__call__`` returns, the copies queue behind the
+        step that is still running.  Shapes must match the first staged batch once a graph has been captured."""
+        if self.inp is None or (self.graph is None and not self.inp.same_layout(fields)):
+            self.cur, self.nxt, self.inp = (_Slot(fields, self.dev) for _ in range(3))
+            for k, v in self.cur.views.items():
+                setattr(self, k, v)                      # the head reads the ``cur`` slot
+            self.im, self.info = im4.clone(memory_format=torch.preserve_format), info.clone()
+            self.n_rows = int(fields["boxes"].shape[0] + fields["relb"].shape[0])
+            for slot in (self.cur, self.nxt, self.inp):
+                slot.write(fields)
+            self.primed = False
+            return
+        if not self.inp.same_layout(fields) or im4.shape != self.im.shape:
+            raise ValueError("SGGEmbStep.stage: the captured graph is bound to the shapes of the first staged batch")
+        if self.tp and self.graph is None:
+            parallel.assert_same_rows(fields["boxes"].shape[0] + fields["relb"].shape[0], "boxes + pairs")
+        self.im.copy_(im4)
+        self.info.copy_(info)
+        self.inp.write(fields)
+
+    def reseed(self, seed):
+        """Stage the synthetic minibatch of ``seed`` (the data layer's job; resident before the timed region)."""
+        self.stage(*self._synthetic(seed))
+
+    # ------------------------------------------------------------------ the two halves of a step
+    def _rotate(self):
+        if self.overlap:
+            self.cur.buf.copy_(self.nxt.buf)
+            self.nxt.buf.copy_(self.inp.buf)
+        else:
+            self.cur.buf.copy_(self.inp.buf)
+
     def _backbone(self):
-        ops.ARENA = self.arena_bb
-        try:
-            if self.arena_bb is not None:
-                self.arena_bb.reset()
+        with self.ctx_bb:
             with torch.no_grad():
                 fmap = self.net.RCNN_base(self.im)
             if self.fmap is None:
                 self.fmap = torch.empty_like(fmap)
-            self.fmap.copy_(fmap)           # static address for the head's graph; 20 MB, ~8 us
-        finally:
-            ops.ARENA = None
+            self.fmap.copy_(fmap)           # static address across replays; 20 MB, ~8 us
 
     def _head(self):
-        ops.ARENA = self.arena
-        try:
-            if self.arena is not None:
-                self.arena.reset()          # one clear for every atomically accumulated output of this half
+        with self.ctx_head:
             fmap = self.fmap_head if self.overlap else self.fmap
             score, _ = self.net.vrd.forward_device(fmap, self.boxes, self.relb, self.masks, self.ixs, self.ixo)
             loss = ops.bce_rows(score, self.labels, self.wrow)     # sum_r wrow[r] * mean_c BCE: one kernel each way
             self.opt.zero_grad()
             (loss / self.world).backward()
             self.loss.copy_(loss.detach())
-        finally:
-            ops.ARENA = None
+            parallel.all_reduce_grads(self.opt.params())           # world > 1: RCCL, captured with the rest of the branch
+            self.opt.step()
 
     def _body(self):
+        """Eager form, and what the sequential graph captures: backbone, then head, of the staged batch."""
+        self._rotate()
         self._backbone()
-        if self.overlap:
+        self._head()
+
+    def _body_overlapped(self):
+        """What the overlapped graph captures.  Fork / join through the capturing stream: everything the side stream
+        does lies between ``side.wait_stream(main)`` and ``main.wait_stream(side)``, i.e. inside the graph."""
+        main = torch.cuda.current_stream(self.dev)
+        self._rotate()
+        self.fmap_head.copy_(self.fmap)     # hand-off: features of the batch now in ``cur`` (computed by the previous call)
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            self._backbone()                # batch k+1
+        self._head()                        # batch k
+        main.wait_stream(self._side)
+
+    def prime(self):
+        """Overlapped schedule only: backbone pass of the batch staged first, so that the first call's head finds its
+        features (``nxt`` <- ``in`` as a call would have done)."""
+        if self.overlap and not self.primed:
+            self.nxt.buf.copy_(self.inp.buf)
+            self._backbone()
             if self.fmap_head is None:
                 self.fmap_head = torch.empty_like(self.fmap)
-            self.fmap_head.copy_(self.fmap)
-        self._head()
-        parallel.all_reduce_grads(self.opt.params())
-        self.opt.step()
+        self.primed = True
 
-    def _size_arenas(self):
-        for name in ("arena", "arena_bb"):
-            a = getattr(self, name)
-            if a is not None and a.wanted * 4 > a.buf.numel() * 4:
-                setattr(self, name, ops.ZeroArena(int(a.wanted * 4 * 1.05) + 4096, self.dev))
+    def capture(self, warmup=2, restore=False):
+        """Warm up eagerly (sizes the arenas, fills the allocator), then capture the step into ONE HIP graph.
+        Returns False (and keeps the eager form, ``graph_error`` says why) when graphs are off or capture fails.
+        ``restore``: the warm-up steps are real training steps on the staged batch; put parameters, momentum and the RNG
+        state back afterwards (a training loop that must not see them).  ``warmup=0`` re-captures (after a learning-rate
+        change: rates live in the captured kernel arguments)."""
+        saved = None
+        if restore and warmup:
+            state = [it["p"].data for it in self.opt.items] + [it["m"] for it in self.opt.items]
+            saved = (state, [t.clone() for t in state], torch.cuda.get_rng_state(self.dev))
+        try:
+            return self._capture(warmup)
+        finally:
+            if saved is not None:
+                torch.cuda.synchronize(self.dev)
+                with torch.no_grad():
+                    for t, sv in zip(saved[0], saved[1]):
+                        t.copy_(sv)
+                torch.cuda.set_rng_state(saved[2], self.dev)
+                self.opt.bump()
 
-    def capture(self, warmup=2):
-        """Warm up eagerly on a side stream, then capture the step into HIP graphs.
-
-        world == 1: one graph for the whole step.  world > 1 (or I2V_SPLIT_GRAPH=1): three graphs --
-        backbone forward / head forward+backward / SGD update -- with the RCCL all-reduce of the
-        (graph-static) gradient tensors launched eagerly between them: the collective stays outside
-        capture, the ~330 compute launches do not go through Python."""
-        import os
+    def _capture(self, warmup):
+        if self.tp:
+            parallel.assert_same_rows(self.n_rows, "boxes + pairs")
+        ov, self.overlap = self.overlap, False          # the warm-up steps are sequential eager steps
         s = torch.cuda.Stream(self.dev)
         s.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(s):
             for i in range(warmup):
                 self._body()
                 if i == 0:
-                    self._size_arenas()
+                    self.ctx_bb.fit()
+                    self.ctx_head.fit()
         torch.cuda.current_stream(self.dev).wait_stream(s)
         torch.cuda.synchronize(self.dev)
+        self.overlap = ov
         if not self.use_graph:
             return False
-        self.s_main = torch.cuda.Stream(self.dev)       # every replay runs here (see __call__)
-        self.pipelined = parallel.exchange_enabled() or os.environ.get("I2V_SPLIT_GRAPH") == "1"
+        self.graph = None
         try:
+            g = torch.cuda.CUDAGraph()
             if self.overlap:
-                self._capture_overlapped()
-                self._tune_for(torch.cuda.current_stream(self.dev))
-            elif not self.pipelined:
-                g = torch.cuda.CUDAGraph()
+                self.prime()
+                torch.cuda.synchronize(self.dev)
+                self._side = torch.cuda.Stream(self.dev)
+                with torch.cuda.graph(g):
+                    self._body_overlapped()
+            else:
                 with torch.cuda.graph(g):
                     self._body()
-                self.graph = (g,)
-            else:
-                gbb, gh, gs = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                # The backbone graph gets its OWN memory pool: it is replayed between the head graph and
-                # the SGD graph, and graphs that share a pool may reuse each other's freed blocks -- its
-                # activations would land on the gradients the update is about to read.
-                with torch.cuda.graph(gbb):
-                    self._backbone()
-                with torch.cuda.graph(gh):
-                    self._head()
-                self._grads = [p.grad for p in self.opt.params()]      # static tensors owned by the head graph's pool
-                with torch.cuda.graph(gs, pool=gh.pool()):
-                    self.opt.step()
-                self.graph = (gbb, gh, gs)
-                self.s_main.wait_stream(torch.cuda.current_stream(self.dev))
-                with torch.cuda.stream(self.s_main):
-                    gbb.replay()            # feature map of the first timed step
+            self.graph = g
             return True
         except Exception as e:      # report, fall back to eager launches
             self.graph = None
-            self.pipelined = self.overlap = False
+            self.overlap = False
             self.graph_error = repr(e)
             torch.cuda.synchronize(self.dev)
             return False
 
-    def _capture_overlapped(self):
-        """Two streams.  The backbone is frozen, so the backbone pass of the NEXT minibatch does not depend on this
-        step's update: it runs on its own stream BESIDE this step's head (whose long kernels -- the fused fc6
-        wgrad+SGD, ROI pooling -- are HBM- or latency-bound, and whose ~100 small kernels leave most CUs idle) and
-        beside the gradient exchange, instead of after them.  The feature map is handed over through a copy at the
-        top of each step.  The graphs pin different split-K workspace slabs (they are captured on one stream but
-        replayed concurrently).  Single GPU: head graph = head fwd+bwd + SGD.  Multi-GPU: head graph (with the
-        column-parallel fc6 collectives captured), eager all-reduce of the remaining gradients, SGD graph."""
-        from ._lib import lib
-        self.s_bb = torch.cuda.Stream(self.dev)          # capture() -> _tune_side_stream() settles its priority
-        self.ev_bb, self.ev_copy = torch.cuda.Event(), torch.cuda.Event()
-        gbb, gh = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        gs = torch.cuda.CUDAGraph() if self.pipelined else None
-        try:
-            lib.i2v_conv_set_split_slot(1)
-            with torch.cuda.graph(gbb):
-                self._backbone()
-            lib.i2v_conv_set_split_slot(0)
-            with torch.cuda.graph(gh):
-                self._head()
-                if not self.pipelined:
-                    self.opt.step()
-            if self.pipelined:
-                self._grads = [p.grad for p in self.opt.params()]      # static tensors owned by the head graph's pool
-                with torch.cuda.graph(gs, pool=gh.pool()):
-                    self.opt.step()
-        finally:
-            lib.i2v_conv_set_split_slot(-1)
-        self.graph = (gbb, gh, gs) if self.pipelined else (gbb, gh)
-
-    def _host_stream(self, caller):
-        """The stream that carries the head graph for this caller: the caller's own, unless that is HIP's legacy
-        default stream (see __call__)."""
-        return self.s_main if caller == torch.cuda.default_stream(self.dev) else caller
-
-    def _tune_for(self, caller):
-        """Settle the side stream for the stream the replays will run on: which priority interleaves depends on the
-        PAIR of streams (measured: the same high-priority side stream gives 5.1 ms beside one stream and 10.3 beside
-        another), so the measurement runs on the hosting stream itself and is repeated when a later call arrives on a
-        different one.  Snapshot, steps and restore all run there -- never on the default stream."""
-        host = self._host_stream(caller)
-        self._tuned_for = host                      # the tuning steps below go through __call__
-        if host != caller:
-            torch.cuda.synchronize(self.dev)
-            host.wait_stream(caller)
-        with torch.cuda.stream(host):
-            self._tune_side_stream()
-        if host != caller:
-            caller.wait_stream(host)
-            torch.cuda.synchronize(self.dev)
-
-    def _prime(self, stream):
-        """Backbone pass of the first step on ``stream`` (the feature map the first head replay consumes)."""
-        self.s_bb = stream
-        torch.cuda.synchronize(self.dev)
-        with torch.cuda.stream(stream):
-            self.graph[0].replay()
-            self.ev_bb.record(stream)
-
-    def _tune_side_stream(self):
-        """Which stream carries the backbone graph is settled by measurement.  How HIP maps streams to hardware queues
-        decides whether the two graphs interleave at all, and it depends on things this object does not control.
-        Measured on MI355X / ROCm 7.2 (ms per step): without a process group a normal-priority side stream gives 5.1
-        and a high-priority one 10.3; with an RCCL process group alive it is 6.1 (the side stream shares an in-order
-        queue: no interleaving) against 5.1.  So: run three steps with each, keep the faster, and put parameters,
-        momentum and the RNG state back exactly as they were -- the tuning steps leave no trace in the trajectory.
-        I2V_BB_PRIORITY=0/-1 pins the choice."""
-        import os
-        import time
-        pin = os.environ.get("I2V_BB_PRIORITY")
-        if pin is not None:
-            self.bb_priority = int(pin)
-            self._prime(torch.cuda.Stream(self.dev, priority=self.bb_priority))
-            return
-        state = [it["p"].data for it in self.opt.items] + [it["m"] for it in self.opt.items]
-        saved = [t.clone() for t in state]
-        rng = torch.cuda.get_rng_state(self.dev)
-        timing = {}
-        for prio in (0, -1):
-            stream = torch.cuda.Stream(self.dev, priority=prio)
-            self._prime(stream)
-            self()                                    # settle
-            torch.cuda.synchronize(self.dev)
-            t0 = time.perf_counter()
-            for _ in range(3):
-                self()
-            torch.cuda.synchronize(self.dev)
-            timing[prio] = (time.perf_counter() - t0, stream)
-        # normal priority unless the high-priority stream is clearly faster (it is by ~17 % when an RCCL process group is
-        # alive): when the two measure alike, the high-priority stream has been seen to fall into the 10 ms mode later
-        self.bb_priority = -1 if timing[-1][0] < 0.92 * timing[0][0] else 0
-        self.bb_tuning_ms = {k: v[0] / 3 * 1e3 for k, v in timing.items()}
-        with torch.no_grad():
-            for t, sv in zip(state, saved):
-                t.copy_(sv)
-        torch.cuda.set_rng_state(rng, self.dev)
-        self._prime(timing[self.bb_priority][1])
-
-    def _call_overlapped(self):
-        gbb, gh = self.graph[0], self.graph[1]
-        cur = torch.cuda.current_stream(self.dev)
-        cur.wait_event(self.ev_bb)          # backbone(i) done
-        self.fmap_head.copy_(self.fmap)     # hand-off: 20 MB
-        self.ev_copy.record(cur)
-        with torch.cuda.stream(self.s_bb):
-            self.s_bb.wait_event(self.ev_copy)
-            gbb.replay()                    # backbone(i+1), beside ...
-            self.ev_bb.record(self.s_bb)
-        gh.replay()                         # ... head(i) fwd + bwd (+ SGD on one GPU)
-        if self.pipelined:
-            parallel.all_reduce_grads(self.opt.params())      # the exchange also runs beside the backbone stream
-            self.graph[2].replay()
-        return self.loss
-
     def __call__(self):
-        """One step = one backbone pass, one head pass, one exchange (world > 1), one update.  Default: the backbone
-        pass is the NEXT minibatch's, on its own stream beside this step's head (``_capture_overlapped``; the frames
-        are static here, in a training loop that is where the next batch goes).  I2V_OVERLAP=0: everything on one
-        stream -- one graph on one GPU; head -> [exchange || backbone] -> SGD with world > 1."""
+        """One step on the caller's current stream (any stream, the legacy default stream included: see
+        ``_graph_launch_guard``).  Returns the device scalar holding the loss of the batch the head just processed."""
         if self.graph is None:
             self._body()
-            return self.loss
-        # Graph replays never go to HIP's legacy default stream.  Measured (tools/loss_trace.py, bench.py): with the
-        # two-stream step replayed back to back on the default stream, about half of the 23-step runs end with a
-        # different, an all-zero-logit or a NaN loss; a host-side synchronize of that stream before every step removes
-        # it, and so does replaying on an ordinary stream -- there every run reproduces the one-graph / eager
-        # trajectory to the last bit or two (tests/test_gpu_models.py::test_sgg_step_back_to_back_replays_are_ordered).
-        # A caller that is on the default stream gets the replays on a stream of this object, ordered against its own
-        # stream on both sides and with a device synchronize before each step (event waits alone were not enough once
-        # the side stream had a priority): correct, but it costs the overlap across steps (6.0 instead of 5.1 ms per
-        # step), so bench.py and the training script set an ordinary current stream.
-        caller = torch.cuda.current_stream(self.dev)
-        host = self._host_stream(caller)
-        detour = host != caller
-        if self.overlap and getattr(self, "_tuned_for", None) != host:
-            self._tune_for(caller)                  # first call from this stream
-        if detour:
-            torch.cuda.synchronize(self.dev)        # nothing of the previous step in flight: the conservative form
-            self.s_main.wait_stream(caller)
-        with torch.cuda.stream(host):
-            if self.overlap:
-                self._call_overlapped()
-            elif len(self.graph) == 1:
-                self.graph[0].replay()
-            else:
-                gbb, gh, gs = self.graph
-                gh.replay()
-                token = parallel.all_reduce_grads_start(self.opt.params())
-                gbb.replay()
-                parallel.all_reduce_grads_finish(token)
-                gs.replay()
-        if detour:
-            caller.wait_stream(self.s_main)
+        else:
+            _graph_launch_guard()
+            self.graph.replay()
+        self.opt.bump()
         return self.loss
+
+    def flush(self):
+        """Overlapped schedule: run the head of the batch staged last (its backbone pass ran in the previous call)."""
+        return self()
+
+
+def _graph_launch_guard():
+    """ROCm 7.2's HIP runtime replays a graph through pre-built AQL packet batches (``DEBUG_CLR_GRAPH_PACKET_CAPTURE``,
+    on by default).  On the LEGACY DEFAULT stream that path loses the order between a graph's nodes and the stream's
+    other work while a second stream is busy (losses off by 2e-2 from the second step on, NaN
+    weights; same graphs correct on any created stream, and correct on the default stream with the packet path off).
+    i2vsgg_amd/__init__.py switches the path off before the runtime initialises; if the process had already initialised
+    HIP with it on, replaying on the default stream is refused rather than risked."""
+    import os
+    if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1") != "0" and \
+            torch.cuda.current_stream() == torch.cuda.default_stream():
+        raise RuntimeError("HIP graph replay on the legacy default stream with DEBUG_CLR_GRAPH_PACKET_CAPTURE on: set "
+                           "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before the first HIP call (importing i2vsgg_amd before "
+                           "torch.cuda is initialised does it) or run the step on a stream made with torch.cuda.Stream()")
 
 
 class InstanceStyleDStep:

@@ -191,19 +191,37 @@ int32_t i2v_bbox_overlaps(const float* boxes, int32_t box_stride, int32_t box_of
  * wgrad: gw (Cout,KH,KW,Cin) (+)= gy^T * im2col(x); beta=0 overwrites, beta=1 accumulates. */
 int32_t i2v_conv_fwd(const float* x, const float* w, const float* scale, const float* shift, const float* res,
                      float* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
-                     int32_t KH, int32_t KW, int32_t stride, int32_t pad, int32_t flags, void* stream);
-/* Small-M shapes split K over several workgroups per tile.  The partial tiles normally go through a per-stream
- * workspace owned by the library and the last workgroup of a tile sums them in split order and applies the
- * epilogue (deterministic, y needs no clear).  Returns 1 only when this shape would instead fall back to fp32
- * atomics into y (partials larger than the 48 MiB slab, or I2V_SPLIT_ATOMICS=1): y must then start at zero --
- * the call clears it unless I2V_EPI_ZEROED is passed, which lets a caller batch many clears into one.  0
- * otherwise, < 0 on error. */
+                     int32_t KH, int32_t KW, int32_t stride, int32_t pad, int32_t flags,
+                     void* split_workspace, size_t split_workspace_bytes, void* stream);
+/* Small-M shapes split K over several workgroups per tile.  With a CALLER-PROVIDED split-K workspace
+ * (i2v_conv_split_workspace_bytes for the shape; NULL / 0 = none) the partial tiles go through it and the last
+ * workgroup of a tile sums them in split order and applies the epilogue: deterministic, y needs no clear.
+ * Workspace contract: device memory, 256-B aligned; its first 4096 bytes (the arrival counters) must be zero before
+ * the first launch that uses it and every launch leaves them zero again; launches that share a workspace must be
+ * ordered on the device (one stream, or graph edges) -- two launches that may run concurrently need two workspaces.
+ * The library owns no device memory and keeps no per-stream state.
+ * i2v_conv_fwd_splits returns 1 when this shape, given a workspace of ws_bytes, would instead accumulate with fp32
+ * atomics into y (no / too small a workspace, more than 4 splits, or a small output): y must then start at zero --
+ * the call clears it unless I2V_EPI_ZEROED is passed, which lets a caller batch many clears into one.  0 otherwise,
+ * < 0 on error. */
 int32_t i2v_conv_fwd_splits(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW,
-                            int32_t stride, int32_t pad);
-/* The split-K workspace is one slab per stream.  Work that is captured on one stream but REPLAYED concurrently on
- * several (two HIP graphs overlapped on two streams) must not share a slab: pin = 0 / 1 selects one of two reserved
- * slabs for every following call of this process until pin = -1 restores keying by stream. */
-int32_t i2v_conv_set_split_slot(int32_t pin);
+                            int32_t stride, int32_t pad, size_t ws_bytes);
+size_t  i2v_conv_split_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH,
+                                       int32_t KW, int32_t stride, int32_t pad);
+/* Tuning knobs (process-wide, host side only; the library reads no environment variable).  key = I2V_TUNE_*. */
+#define I2V_TUNE_CONV_SPEC            0   /* -1/0 plain 4-wave conv kernel, 1 loader+MFMA specialised, 2 specialised at <= 3 workgroups/CU */
+#define I2V_TUNE_SPLIT_TARGET         1   /* workgroups per CU a split-K launch aims for (default 2) */
+#define I2V_TUNE_SPLIT_TARGET_SKINNY  2   /* the same for GEMMs of <= 256 rows (-1: as SPLIT_TARGET) */
+#define I2V_TUNE_SPLIT_BELOW          3   /* split K only when the unsplit grid has fewer tiles than this (default 256) */
+#define I2V_TUNE_SPLIT_ATOMICS        4   /* 1: always finish split-K with atomics */
+#define I2V_TUNE_BIG_FC_TILE          5   /* tile index for the long skinny GEMMs (rows <= 256, K >= 16384); -1: cost model */
+#define I2V_TUNE_WGRAD_V2             6   /* 0: first-generation wgrad kernel, 1: default, 2/3: larger tiles */
+#define I2V_TUNE_WGRAD_FUSED_TILE     7   /* 128 (default) or 64: filters per workgroup of the fused wgrad+SGD kernel */
+#define I2V_TUNE_WINO_ROWS            8   /* -1 by size; bit 0 / 1: row-split Winograd input / output transform */
+#define I2V_TUNE_ROIPOOL_C128         9   /* 1 (default): 128-channel ROIPool forward kernel for NHWC maps */
+#define I2V_TUNE_COUNT               10
+int32_t i2v_set_tuning(int32_t key, int32_t value);
+int32_t i2v_get_tuning(int32_t key);
 /* tuning hook: cfg < 0 = cost model; else low byte = tile shape 0..5 (0xFF = cost model),
  * bits 8-9 = 0 auto / 1 plain 4-wave kernel / 2 loader+MFMA specialised 8-wave kernel */
 int32_t i2v_conv_set_tile(int32_t cfg);
@@ -214,7 +232,8 @@ int32_t i2v_conv_debug_clock(void* buf);
 size_t  i2v_conv_dgrad_workspace_bytes(int32_t Cin, int32_t Cout, int32_t KH, int32_t KW);
 int32_t i2v_conv_dgrad(const float* gy, const float* w, float* gx, int32_t B, int32_t H, int32_t W,
                        int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
-                       void* workspace, size_t workspace_bytes, void* stream);
+                       void* workspace, size_t workspace_bytes, void* split_workspace, size_t split_workspace_bytes,
+                       void* stream);
 size_t  i2v_conv_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                                        int32_t KH, int32_t KW, int32_t stride, int32_t pad);
 int32_t i2v_conv_wgrad(const float* x, const float* gy, float* gw, int32_t B, int32_t H, int32_t W,
@@ -224,7 +243,8 @@ int32_t i2v_conv_wgrad(const float* x, const float* gy, float* gw, int32_t B, in
 /* nbatch independent GEMMs of one shape in one launch: C_z (M x N) = A_z (M x K) * B_z (N x K)^T (fp32; operand z at
  * base + z * stride elements; K % 4 == 0). */
 int32_t i2v_gemm_nt_batched(const float* a, const float* b, float* c, int32_t M, int32_t N, int32_t K, int32_t nbatch,
-                            int64_t stride_a, int64_t stride_b, int64_t stride_c, void* stream);
+                            int64_t stride_a, int64_t stride_b, int64_t stride_c,
+                            void* split_workspace, size_t split_workspace_bytes, void* stream);
 
 /* Winograd F(2x2,3x3) forward for stride-1 / pad-1 3x3 convolutions whose filter is FROZEN (the SGG_emb backbone:
  * resnet_instance_styleD_bilinear.py:197-217 under the detach of faster_rcnn_SGG_emb.py:148): 2.25x fewer MACs than

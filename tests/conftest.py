@@ -1,6 +1,10 @@
 import os
 import sys
 
+# before anything initialises the HIP runtime (i2vsgg_amd/__init__.py explains; the package sets it too, this line makes
+# the order independent of which test module imports what first)
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 import numpy as np
 import pytest
 

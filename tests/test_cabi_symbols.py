@@ -40,6 +40,14 @@ def test_argument_errors_are_status_codes_not_crashes():
     assert rc == -1
     assert b"null" in _lib.lib.i2v_last_error()
     rc = _lib.lib.i2v_conv_fwd(ctypes.c_void_p(16), ctypes.c_void_p(16), None, None, None, ctypes.c_void_p(16),
-                               1, 8, 8, 3, 8, 1, 1, 1, 0, 0, None)
+                               1, 8, 8, 3, 8, 1, 1, 1, 0, 0, None, 0, None)
     assert rc == -1 and b"multiple of 4" in _lib.lib.i2v_last_error()
+    # split-K scratch is the caller's (no library-owned device memory): the per-shape query, and the dry plan that tells
+    # a caller whether the output must start at zero, depend only on shapes and on the size the caller offers
+    need = _lib.lib.i2v_conv_split_workspace_bytes(2, 38, 63, 1024, 256, 1, 1, 1, 0)        # layer3 1x1, two frames
+    assert 4096 < need <= (48 << 20) + 4096
+    assert _lib.lib.i2v_conv_fwd_splits(2, 38, 63, 1024, 256, 1, 1, 1, 0, 0) == 1          # no workspace: atomics
+    assert _lib.lib.i2v_conv_fwd_splits(2, 38, 63, 1024, 256, 1, 1, 1, 0, need) == 0       # finished in the kernel
+    assert _lib.lib.i2v_conv_split_workspace_bytes(2, 150, 250, 64, 64, 1, 1, 1, 0) == 0   # large grid: no split
+    assert _lib.lib.i2v_set_tuning(99, 1) == -1 and _lib.lib.i2v_get_tuning(1) == 2
     assert _lib.lib.i2v_nms_workspace_bytes(2, 12000) == 2 * 12000 * 188 * 8

@@ -344,27 +344,25 @@ def test_fused_wgrad_sgd_equals_separate_update(cfg):
     assert not np.array_equal(res[0][0], w0)
 
 
-def test_sgg_step_schedules_match_single_graph(cfg, monkeypatch):
-    """Every schedule of the step computes the losses and weights of the plain one-graph step:
-    overlap (default, one GPU): backbone graph of the next minibatch on its own stream beside the head+SGD graph;
-    split: the multi-GPU graph cut (backbone / head / SGD graphs, exchange launched eagerly between them), sequential
-    (I2V_OVERLAP=0: head -> [exchange || backbone] -> SGD) and overlapped (two streams)."""
+def test_sgg_step_schedules_match_single_graph(cfg):
+    """Every schedule of the step computes the losses and weights of the eager sequential step: the sequential graph
+    (overlap=False) and the overlapped graph (fork / join: head of batch k beside the backbone of batch k+1), each with
+    the fused wgrad+SGD update and with the separate update kernels."""
     from i2vsgg_amd import train
     res = {}
-    for overlap, split in (("0", "0"), ("1", "0"), ("0", "1"), ("1", "1")):
-        monkeypatch.setenv("I2V_OVERLAP", overlap)
-        monkeypatch.setenv("I2V_SPLIT_GRAPH", split)
+    for key in (("eager", True), ("seq", True), ("overlap", True), ("seq", False), ("overlap", False)):
+        mode, fuse = key
         net = train.build_sgg_net(layers=50, seed=5, device=DEV)
         net.vrd.dropout = False
-        step = train.SGGEmbStep(net, 2, seed=3, device=DEV, h=200, w=320, n_boxes=6, n_pairs=5, fuse_sgd=(split == "0"))
-        assert step.capture(warmup=1), getattr(step, "graph_error", None)
-        assert step.pipelined == (split == "1") and step.overlap == (overlap == "1")
-        assert len(step.graph) == {("0", "0"): 1, ("1", "0"): 2, ("0", "1"): 3, ("1", "1"): 3}[(overlap, split)]
+        step = train.SGGEmbStep(net, 2, seed=3, device=DEV, h=200, w=320, n_boxes=6, n_pairs=5, fuse_sgd=fuse,
+                                use_graph=mode != "eager", overlap=mode == "overlap")
+        assert step.capture(warmup=1) == (mode != "eager"), step.graph_error
+        assert step.overlap == (mode == "overlap")
         losses = [float(step().item()) for _ in range(4)]
         torch.cuda.synchronize()
-        res[(overlap, split)] = (losses, net.vrd.fc7.fc.weight.detach().cpu().numpy().copy())
+        res[key] = (losses, net.vrd.fc7.fc.weight.detach().cpu().numpy().copy())
         step.opt.unfuse()
-    l0, w0 = res[("0", "0")]
+    l0, w0 = res[("eager", True)]
     assert l0[0] != l0[3]                                                     # the weights do move
     for key, (l1, w1) in res.items():
         for a, b in zip(l0, l1):
@@ -373,13 +371,14 @@ def test_sgg_step_schedules_match_single_graph(cfg, monkeypatch):
 
 
 def test_sgg_step_back_to_back_replays_are_ordered(cfg):
-    """The two-stream step replayed back to back WITHOUT a host synchronisation between steps (the bench loop: the
-    host runs several steps ahead of the device) follows the same loss trajectory as the same step synchronised after
-    every replay -- from the default stream (replays detour through the step's own stream) and from an ordinary
-    stream (replays go to the caller's stream).  Full configs[1] shapes: the ordering failure this guards against
-    (train.SGGEmbStep.__call__) only shows when a step is long enough for the host to run ahead."""
+    """The overlapped step replayed back to back WITHOUT a host synchronisation between steps (the bench loop: the host
+    runs several steps ahead of the device) follows the loss trajectory of the same step synchronised after every replay
+    -- from an ordinary stream and from HIP's legacy default stream, with nothing but the graph launch on the caller's
+    stream.  Full configs[1] shapes: the ordering failure this guards against (the runtime's
+    packet-capture replay path on the default stream) only shows when a step is long enough for the host to run ahead."""
     from i2vsgg_amd import train
     n = 20
+    assert os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"      # tests/conftest.py, before HIP initialises
 
     def run(own_stream, sync):
         net = train.build_sgg_net(101, device=DEV)
@@ -390,7 +389,7 @@ def test_sgg_step_back_to_back_replays_are_ordered(cfg):
             s.wait_stream(prev)
             torch.cuda.set_stream(s)
         try:
-            assert step.capture(warmup=2) and step.overlap, getattr(step, "graph_error", None)
+            assert step.capture(warmup=2) and step.overlap, step.graph_error
             for i in range(3):
                 step()
             torch.cuda.synchronize()            # bench.py's shape: warm-up, synchronise, timed steps back to back
@@ -411,27 +410,94 @@ def test_sgg_step_back_to_back_replays_are_ordered(cfg):
             assert abs(got[0] - want[0]) < 1e-5 and abs(got[1] - want[1]) < 1e-6 * want[1], (own, got, want)
 
 
-def test_captured_backbone_graph_is_idempotent_after_one_warmup(cfg, monkeypatch):
-    """A graph captured right after ONE warm-up step (the arena of atomically accumulated outputs has just been
-    re-sized and has recorded no use yet) still carries its clear: replaying the backbone graph again and again gives
-    the eager feature map every time.  (Without the clear each replay accumulates into the previous one's outputs.)"""
+def test_sgg_step_staged_batches_meet_their_features(cfg):
+    """A NEW minibatch staged between replays of the captured, overlapped step (what a training loop does; round-1
+    advice: reseed() used to race the backbone pass already queued on the side stream): the loss sequence equals the
+    eager sequential loop over the same batches -- batch k's boxes / labels always meet batch k's feature map -- with the
+    one-call lag of the pipeline (a batch staged before call k is the head's batch in call k+1)."""
     from i2vsgg_amd import train
-    monkeypatch.setenv("I2V_BB_PRIORITY", "0")
+    seeds = [3, 11, 12, 13, 14]
+
+    def run_eager():
+        net = train.build_sgg_net(layers=50, seed=5, device=DEV)
+        net.vrd.dropout = False
+        step = train.SGGEmbStep(net, 2, seed=seeds[0], device=DEV, h=200, w=320, n_boxes=6, n_pairs=5, use_graph=False)
+        assert not step.capture(warmup=1)
+        losses = []
+        for k, sd in enumerate(seeds):
+            if k:
+                step.reseed(sd)
+            losses.append(float(step()))
+        w = net.vrd.fc7.fc.weight.detach().cpu().numpy().copy()
+        step.opt.unfuse()
+        return losses, w
+
+    # the graph run reads each loss right after its call (the device scalar is overwritten by the next replay)
+    def run_graph():
+        net = train.build_sgg_net(layers=50, seed=5, device=DEV)
+        net.vrd.dropout = False
+        step = train.SGGEmbStep(net, 2, seed=seeds[0], device=DEV, h=200, w=320, n_boxes=6, n_pairs=5)
+        assert step.capture(warmup=1) and step.overlap, step.graph_error
+        keep = torch.zeros(len(seeds), device=DEV)
+        for k, sd in enumerate(seeds[1:]):
+            step.reseed(sd)
+            keep[k].copy_(step())
+        keep[len(seeds) - 1].copy_(step.flush())
+        torch.cuda.synchronize()
+        w = net.vrd.fc7.fc.weight.detach().cpu().numpy().copy()
+        step.opt.unfuse()
+        return keep.tolist(), w
+
+    l0, w0 = run_eager()
+    l1, w1 = run_graph()
+    assert len(set(round(x, 5) for x in l0)) == len(l0)                     # the batches differ
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 1e-5 * abs(a), (l0, l1)
+    assert _rel_err(w1, w0) < 1e-5
+
+
+def test_captured_step_is_idempotent_after_one_warmup(cfg):
+    """A graph captured right after ONE warm-up step (the arena of atomically accumulated outputs has just been
+    re-sized and has recorded no use yet) still carries its clear: the backbone branch of every replay writes the eager
+    feature map.  (Without the clear each replay accumulates into the previous one's outputs.)"""
+    from i2vsgg_amd import train
     net = train.build_sgg_net(layers=50, seed=5, device=DEV)
     step = train.SGGEmbStep(net, 2, seed=3, device=DEV, h=200, w=320, n_boxes=6, n_pairs=5)
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        assert step.capture(warmup=1) and step.overlap, getattr(step, "graph_error", None)
+    assert step.capture(warmup=1) and step.overlap, step.graph_error
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        want = net.RCNN_base(step.im).clone()
+    for _ in range(3):
+        step()
         torch.cuda.synchronize()
-        with torch.no_grad():
-            want = net.RCNN_base(step.im).clone()
-        for _ in range(3):
-            step.graph[0].replay()
-            torch.cuda.synchronize()
-            assert _rel_err(step.fmap.cpu().numpy(), want.cpu().numpy()) < 1e-5
-    torch.cuda.current_stream().wait_stream(s)
+        assert _rel_err(step.fmap.cpu().numpy(), want.cpu().numpy()) < 1e-5
     step.opt.unfuse()
+
+
+def test_winograd_filter_cache_follows_the_fused_optimizer(cfg):
+    """Round-1 advice: FusedSGD writes parameters through raw device pointers (no Tensor._version bump), so a
+    Winograd-domain filter cached by an eval forward must be invalidated by the optimizer: eval -> train steps -> eval
+    equals the direct (cache-free) kernel on the updated weights."""
+    from i2vsgg_amd import ops, train
+    from i2vsgg_amd.model.faster_rcnn.layers import Bottleneck
+    torch.manual_seed(0)
+    blk = Bottleneck(256, 64).to(DEV)
+    x = torch.randn(2, 256, 24, 40, device=DEV).contiguous(memory_format=torch.channels_last)
+    opt = train.FusedSGD([("conv2.weight", blk.conv2.weight)], lr=0.5, momentum=0.0, weight_decay=0.0)
+    with torch.no_grad():
+        y0 = blk(x).clone()                               # caches the transformed filter
+    for _ in range(2):
+        opt.zero_grad()
+        blk(x).square().mean().backward()
+        opt.step()
+    with torch.no_grad():
+        y1 = blk(x)                                       # Winograd with the (re-)transformed filter
+        s2, b2 = blk.bn2.folded()
+        h = ops.conv2d(x, blk.conv1.weight, *blk.bn1.folded(), None, 1, 0, relu=True)
+        h = ops.conv2d(h, blk.conv2.weight, s2, b2, None, 1, 1, relu=True)           # direct kernel, no cache
+        want = ops.conv2d(h, blk.conv3.weight, *blk.bn3.folded(), x, 1, 0, relu=True)
+    assert _rel_err(y1.cpu().numpy(), y0.cpu().numpy()) > 1e-3           # the weights did move
+    assert _rel_err(y1.cpu().numpy(), want.cpu().numpy()) < 1e-4
 
 
 def test_detect_frame_eval_loop_matches_oracle_postprocess(cfg):
@@ -566,8 +632,8 @@ def test_consistency_terms_match_reference_formula(cfg):
 
 def test_sgg_step_tensor_parallel_fc6_rehearsal_matches_single_graph(cfg, monkeypatch):
     """The multi-GPU form of the step on ONE rank (1-rank RCCL group, I2V_FORCE_EXCHANGE=1): column-parallel fc6 with
-    its three collectives captured in the head graph, fused fc6 update, pipelined backbone -- same losses and weights
-    as the plain one-graph step.  (The 2-rank numerics of the column cut are checked on CPU under gloo.)"""
+    its three collectives and the all-reduce of the remaining gradients captured in the head branch of the step graph, fused
+    fc6 update -- same losses and weights as the single-GPU step.  (The 2-rank numerics of the column cut are checked on CPU under gloo.)"""
     import torch.distributed as dist
     from i2vsgg_amd import parallel, train
     res = []
@@ -583,8 +649,7 @@ def test_sgg_step_tensor_parallel_fc6_rehearsal_matches_single_graph(cfg, monkey
             step = train.SGGEmbStep(net, 1, seed=3, device=DEV, h=200, w=320, n_boxes=6, n_pairs=5)
             assert step.tp == forced and (net.vrd.tp is not None) == forced
             assert "vrd.fc6.fc.weight" in step.fused           # the fc6 update stays fused in both forms
-            assert step.capture(warmup=1), getattr(step, "graph_error", None)
-            assert step.pipelined == forced
+            assert step.capture(warmup=1) and step.overlap, step.graph_error
             losses = [float(step().item()) for _ in range(3)]
             torch.cuda.synchronize()
             w6, _ = net.vrd.gather_fc6()

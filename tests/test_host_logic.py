@@ -199,3 +199,32 @@ def test_column_parallel_fc6_equals_data_parallel_world_size_2_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert "rank %d ok" % r in o
+
+
+def _run_bench(args, env=None, timeout=180):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, **(env or {}))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        e.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, env=e,
+                         timeout=timeout)
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    return out.returncode, [json.loads(l) for l in lines], out.stderr
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` without torchrun starts N ranks itself (the role of nn.DataParallel behind --mGPUs,
+    trainval_net_SGG_emb.py:175-176): rehearsed on the CPU with gloo -- rendezvous on 127.0.0.1, one collective over
+    both ranks, ONE JSON line from rank 0 carrying the world size."""
+    rc, lines, err = _run_bench(["--gpus", "2", "--dry-run", "--config", "sgg"])
+    assert rc == 0, err
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2 and lines[0]["dry_run"] is True
+
+
+def test_bench_fails_when_a_rank_does_not_come_up():
+    rc, lines, err = _run_bench(["--gpus", "2", "--dry-run"], env={"I2V_BENCH_FAIL_RANK": "1"})
+    assert rc != 0 and not lines
+    assert "rank exited" in err

@@ -18,6 +18,9 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
+if os.environ.get("RACE_LATE_ENV"):      # does the runtime still honour the flag when it is set after `import torch`?
+    os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = "0"
+
 from i2vsgg_amd import train  # noqa: E402
 from i2vsgg_amd.model.utils import config as c  # noqa: E402
 
@@ -36,6 +39,32 @@ def run(mode, sync=False):
     if nodrop:
         net.vrd.dropout = False
     step = train.SGGEmbStep(net, 2, seed=1, device=DEV)
+    if os.environ.get("RACE_WS_UNIQUE"):
+        # every workspace request of the given tag gets a buffer of its own, kept alive for the life of the process:
+        # no two launches share scratch (tests whether the shared grow-only scratch is the hazard)
+        from i2vsgg_amd import ops
+        keep = globals().setdefault("_KEEP", [])
+        tags = os.environ["RACE_WS_UNIQUE"].split(",")
+        ws0 = globals().setdefault("_WS0", ops.workspace)
+
+        def ws_unique(nbytes, device, tag="default"):
+            if tag in tags:
+                b = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+                keep.append(b)
+                return b
+            return ws0(nbytes, device, tag)
+        ops.workspace = ws_unique
+    dot = os.environ.get("RACE_DOT")
+    if dot and not globals().get("_DOT_DONE"):
+        G0 = torch.cuda.CUDAGraph
+        made = []
+
+        class G(G0):
+            def __init__(self, *a, **k):
+                super().__init__(*a, **k)
+                self.enable_debug_mode()
+                made.append(self)
+        torch.cuda.CUDAGraph = G
     start = torch.zeros(1, dtype=torch.long, device=DEV)
     end = torch.zeros(1, dtype=torch.long, device=DEV)
     log = torch.full((64,), -7.0, device=DEV)
@@ -59,6 +88,18 @@ def run(mode, sync=False):
     try:
         assert step.capture(warmup=2) and step.overlap, getattr(step, "graph_error", None)
         gbb, gh = step.graph[0], step.graph[1]
+        if dot and not globals().get("_DOT_DONE"):
+            globals()["_DOT_DONE"] = True
+            torch.cuda.CUDAGraph = G0
+            for i, g in enumerate(made[:2]):
+                try:
+                    g.debug_dump("%s.%d.dot" % (dot, i))
+                    txt = open("%s.%d.dot" % (dot, i)).read()
+                    import re
+                    kinds = {k: len(re.findall(k, txt)) for k in ("MEMSET", "MEMCPY", "KERNEL", "->")}
+                    print("DOT graph %d: %s, %d bytes" % (i, kinds, len(txt)), flush=True)
+                except Exception as e:
+                    print("DOT dump failed:", repr(e), flush=True)
         cur = torch.cuda.current_stream(DEV)
         torch.cuda.synchronize()
         start.zero_(); end.zero_(); log.fill_(-7.0)

@@ -47,10 +47,10 @@ def t(fn, n=20):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-tg = t(lambda: lib.i2v_gemm_nt_batched(ptr(V), ptr(U), ptr(M), T, c, c, 16, T * c, c * c, T * c, stream()))
+tg = t(lambda: lib.i2v_gemm_nt_batched(ptr(V), ptr(U), ptr(M), T, c, c, 16, T * c, c * c, T * c, None, 0, stream()))
 print("batched GEMM 16 x (%d x %d x %d): %.1f us = %.1f TF" % (T, c, c, tg, 16 * 2.0 * T * c * c / tg / 1e6))
 for tile in range(6):
     lib.i2v_conv_set_tile(tile)
-    tg = t(lambda: lib.i2v_gemm_nt_batched(ptr(V), ptr(U), ptr(M), T, c, c, 16, T * c, c * c, T * c, stream()))
+    tg = t(lambda: lib.i2v_gemm_nt_batched(ptr(V), ptr(U), ptr(M), T, c, c, 16, T * c, c * c, T * c, None, 0, stream()))
     print("   tile %d: %.1f us" % (tile, tg))
 lib.i2v_conv_set_tile(-1)
