@@ -672,6 +672,231 @@ conv_igemm_f32(const ConvP p_in) {
     }
 }
 
+// ---------------------------------------------------------------- pointwise / plain-GEMM specialisation
+// y[m][n] = epi(sum_k A[m][k] * Wt[n][k]) where row m of A IS row m of x (1x1 filter, stride 1, same grid; linear layers;
+// the element-wise planes of a Winograd convolution).  The layer3 bottleneck GEMMs are short (K = 256: 8 stages of MFMA
+// work, ~12k cycles), so what a workgroup does OUTSIDE the K loop decides: this kernel has no tap table, no row masks, no
+// integer division per row, prefetches the epilogue's operands (residual tile, BN scale / shift) before the K loop, and
+// its epilogue never touches LDS: the MFMA operands are swapped (weights as the row operand), so a lane's four
+// accumulator registers are four CONSECUTIVE output channels of one pixel -- scale/shift/residual/ReLU in registers, one
+// 16-B store per fragment, no LDS round trip, no barrier.  Staging, swizzled LDS image and the K loop are conv_igemm_f32's.
+// Split-K (<= kSplitInKernelMax): partial tiles go to the caller's workspace in REGISTER order (fragment, wave, lane), the
+// last workgroup to arrive sums them in split order -- same protocol as conv_igemm_f32, whole-wave 1-KB rows.
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ void __launch_bounds__(THREADS)
+conv_gemm_f32(const ConvP p_in) {
+    ConvP p = p_in;
+    if (p.nbatch > 1) {
+        p.x += (long long)blockIdx.z * p.bsx;
+        p.w += (long long)blockIdx.z * p.bsw;
+        p.y += (long long)blockIdx.z * p.bsy;
+    }
+    constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
+    constexpr int A_LD = (BM * 8 + THREADS - 1) / THREADS, B_LD = (BN * 8 + THREADS - 1) / THREADS;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float (*As)[BM * BKS] = reinterpret_cast<float (*)[BM * BKS]>(smem);
+    float (*Bs)[BN * BKS] = reinterpret_cast<float (*)[BN * BKS]>(smem + 2 * BM * BKS);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    int tile;
+    {       // XCD-aware tile order (conv_igemm_f32)
+        const int nt = gridDim.x, q = nt >> 3, r = nt & 7, x = blockIdx.x & 7, i = blockIdx.x >> 3;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int kbeg = blockIdx.y * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int kc = tid & 7, kg = kc * 4;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    constexpr unsigned INV = 0x80000000u;
+    unsigned a_vk[A_LD], b_vk[B_LD];
+#pragma unroll
+    for (int q = 0; q < A_LD; ++q) {
+        const int row = (tid >> 3) + q * (THREADS / 8);
+        const int m = m0 + row;
+        a_vk[q] = (row < BM && m < p.M) ? ((unsigned)(m * p.K) + (unsigned)kg) * 4u : INV;
+    }
+#pragma unroll
+    for (int q = 0; q < B_LD; ++q) {
+        const int row = (tid >> 3) + q * (THREADS / 8);
+        const int n = n0 + row;
+        b_vk[q] = (row < BN && n < p.N) ? ((unsigned)(n * p.K) + (unsigned)kg) * 4u : INV;
+    }
+    float4 ra[A_LD], rb[B_LD];
+    // the k offset of a stage is uniform: it rides in the scalar offset of the buffer load; a lane beyond kend (the last,
+    // partial stage of a K that is not a multiple of 32) gets the 2 GiB bit OR-ed in and reads zeros
+    auto gload = [&](int k0) {
+        const unsigned so = (unsigned)k0 * 4u;
+        const unsigned kinv = ~(unsigned)((k0 + kg - kend) >> 31) & INV;
+#pragma unroll
+        for (int q = 0; q < A_LD; ++q)
+            ra[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, a_vk[q] | kinv, so, 0));
+#pragma unroll
+        for (int q = 0; q < B_LD; ++q)
+            rb[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, b_vk[q] | kinv, so, 0));
+    };
+    auto sstore = [&](int S) {
+#pragma unroll
+        for (int q = 0; q < A_LD; ++q) {
+            const int row = (tid >> 3) + q * (THREADS / 8);
+            if (row < BM) *(float4*)&As[S][row * BKS + ((kc ^ ((row >> 1) & 7)) << 2)] = ra[q];
+        }
+#pragma unroll
+        for (int q = 0; q < B_LD; ++q) {
+            const int row = (tid >> 3) + q * (THREADS / 8);
+            if (row < BN) *(float4*)&Bs[S][row * BKS + ((kc ^ ((row >> 1) & 7)) << 2)] = rb[q];
+        }
+    };
+    gload(kbeg);                          // first: everything below hides behind this round trip
+
+    // operands of the epilogue, fetched now.  A lane owns channels n .. n+3 of pixel m for every fragment (i, j):
+    //   m = m0 + (wm*TM + i)*16 + (lane & 15),   n = n0 + (wn*TN + j)*16 + 4*(lane >> 4)
+    const bool split = p.splitk > 1;
+    constexpr bool PREFETCH_RES = TM * TN <= 8;
+    float4 sc[TN], sh[TN], rres[PREFETCH_RES ? TM : 1][PREFETCH_RES ? TN : 1];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 16 + 4 * fg;
+        const bool ok = n < p.N;
+        sc[j] = (ok && (p.flags & I2V_EPI_SCALE)) ? *(const float4*)(p.scale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+        sh[j] = (ok && (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS))) ? *(const float4*)(p.shift + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (PREFETCH_RES && !split && (p.flags & I2V_EPI_RESIDUAL)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int m = m0 + (wm * TM + i) * 16 + fr, n = n0 + (wn * TN + j) * 16 + 4 * fg;
+                rres[PREFETCH_RES ? i : 0][PREFETCH_RES ? j : 0] = (m < p.M && n < p.N)
+                    ? __builtin_bit_cast(float4, __builtin_nontemporal_load((const f32x4*)(p.res + (long long)m * p.N + n)))
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+    }
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float4 av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = (wm * TM + i) * 16 + fr;
+                av[i] = *(const float4*)&As[buf][row * BKS + (((h * 4 + fg) ^ ((row >> 1) & 7)) << 2)];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = (wn * TN + j) * 16 + fr;
+                bv[j] = *(const float4*)&Bs[buf][row * BKS + (((h * 4 + fg) ^ ((row >> 1) & 7)) << 2)];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float a = t == 0 ? av[i].x : t == 1 ? av[i].y : t == 2 ? av[i].z : av[i].w;
+                        const float b = t == 0 ? bv[j].x : t == 1 ? bv[j].y : t == 2 ? bv[j].z : bv[j].w;
+                        // weights are the ROW operand: D[row = channel][col = pixel], a lane holds 4 consecutive channels
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, acc[i][j], 0, 0, 0);
+                    }
+        }
+    };
+    sstore(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BKS) {
+        const bool more = k0 + BKS < kend;
+        if (more) gload(k0 + BKS);
+        compute(buf);
+        if (more) sstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    auto finish = [&](int i, int j, f32x4 v, float4 rr) {
+        const int m = m0 + (wm * TM + i) * 16 + fr, n = n0 + (wn * TN + j) * 16 + 4 * fg;
+        if (m >= p.M || n >= p.N) return;
+        float4 o = make_float4(v[0] * sc[j].x + sh[j].x, v[1] * sc[j].y + sh[j].y, v[2] * sc[j].z + sh[j].z,
+                               v[3] * sc[j].w + sh[j].w);
+        if (p.flags & I2V_EPI_RESIDUAL) { o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
+        if (p.flags & I2V_EPI_RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        *(float4*)(p.y + (long long)m * p.N + n) = o;
+    };
+    auto res_at = [&](int i, int j) -> float4 {
+        const int m = m0 + (wm * TM + i) * 16 + fr, n = n0 + (wn * TN + j) * 16 + 4 * fg;
+        return (m < p.M && n < p.N) ? __builtin_bit_cast(float4, __builtin_nontemporal_load((const f32x4*)(p.res + (long long)m * p.N + n)))
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    if (!split) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.flags & I2V_EPI_RESIDUAL) rr = PREFETCH_RES ? rres[PREFETCH_RES ? i : 0][PREFETCH_RES ? j : 0] : res_at(i, j);
+                finish(i, j, acc[i][j], rr);
+            }
+        return;
+    }
+    // ---- split-K: partials in register order through the caller's workspace (sc1 stores / loads: coherent across the
+    // XCDs without fences; conv_igemm_f32 has the protocol's rationale)
+    constexpr int SC01 = 16;
+    const size_t split_stride = (size_t)gridDim.x * (BM * BN);
+    const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.ws + (size_t)tile * (BM * BN)), 0, 0x7FFFFFF0, 0x00020000);
+    const unsigned mine = (unsigned)(blockIdx.y * split_stride * sizeof(float));
+    auto slot = [&](int i, int j) { return (unsigned)((((i * TN + j) * 4 + wave) * 64 + lane) * 16); };
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), wsr, mine + slot(i, j), 0, SC01);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    __shared__ int last_flag;
+    if (tid == 0) {
+        const int arrived = __hip_atomic_fetch_add(p.cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = arrived == (int)gridDim.y - 1;
+        if (last) __hip_atomic_store(p.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = last;
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    const int nsplit = gridDim.y, my = blockIdx.y;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        float4 u[TN][kSplitInKernelMax], rr[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int sp = 0; sp < kSplitInKernelMax; ++sp)
+                u[j][sp] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                    wsr, (sp < nsplit && sp != my) ? slot(i, j) + (unsigned)(sp * split_stride * sizeof(float)) : 0xFFFFFFF0u, 0, SC01));
+            rr[j] = (p.flags & I2V_EPI_RESIDUAL) ? res_at(i, j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float4 m4 = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            float4 v = my == 0 ? m4 : u[j][0];
+#pragma unroll
+            for (int sp = 1; sp < kSplitInKernelMax; ++sp) {      // slots >= nsplit were read out of range: zeros
+                const float4 t = sp == my ? m4 : u[j][sp];
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            finish(i, j, (f32x4){v.x, v.y, v.z, v.w}, rr[j]);
+        }
+    }
+}
+
 // epilogue of the split-K path (partials were accumulated with fp32 atomics)
 __global__ void conv_epilogue_kernel(float* __restrict__ y, const float* __restrict__ scale,
                                      const float* __restrict__ shift, const float* __restrict__ res, long long total4,
@@ -767,6 +992,15 @@ void launch_tile(const ConvP& p, bool spec, hipStream_t st) {
         if ((p.ablate & 12) == 12) { conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false, 12><<<dim3(tiles, p.splitk, p.nbatch > 1 ? p.nbatch : 1), THREADS, lds, st>>>(p); return; }
     }
     const dim3 grid(tiles, p.splitk, p.nbatch > 1 ? p.nbatch : 1);
+    // pointwise layers / plain GEMMs whose split-K (if any) is finished in the kernel: the lean specialisation
+    const bool pointwise = p.KH == 1 && p.KW == 1 && p.pad == 0 && p.pad_x == 0 && p.stride == 1 && p.ostride == 1 &&
+                           p.Ho == p.H && p.Wo == p.W && (p.N & 3) == 0 && (p.K & 3) == 0 && (p.splitk <= 1 || p.ws);
+    if (pointwise && !spec && g_i2v_tuning[I2V_TUNE_CONV_GEMM] && !p.clk && !p.ablate) {
+        static bool once_g = [] { set_max_lds(conv_gemm_f32<WAVES_M, WAVES_N, TM, TN>); return true; }();
+        (void)once_g;
+        conv_gemm_f32<WAVES_M, WAVES_N, TM, TN><<<grid, THREADS, (size_t)(2 * (BM + BN) * BKS) * sizeof(float), st>>>(p);
+        return;
+    }
     if (spec) conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, true><<<grid, 2 * THREADS, lds, st>>>(p);
     else conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false><<<grid, THREADS, lds, st>>>(p);
 }

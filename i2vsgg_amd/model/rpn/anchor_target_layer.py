@@ -3,7 +3,9 @@
 IoU of the inside anchors against the ground truth runs in a HIP kernel and the labelling is
 device arithmetic; only the fg/bg SUBSAMPLING is done on the host, because the reference draws it
 from the global ``np.random`` stream in a fixed call order (:131, :143) and that order is part of
-the contract (cfg.RNG_SEED).  Quirks kept for parity: the inside test uses ``im_info[0]`` for every
+the contract (cfg.RNG_SEED).  ``device_sampling = True`` (set by a step object that captures the step into a HIP graph)
+draws the same subsample sizes from torch's device generator instead: no host round trip, a different (equally uniform)
+random stream.  Quirks kept for parity: the inside test uses ``im_info[0]`` for every
 image (:85-86) and the loss weights use the example count of the LAST image (:156-160)."""
 import numpy as np
 import torch
@@ -23,6 +25,8 @@ class _AnchorTargetLayer(nn.Module):
         self._num_anchors = self._base.shape[0]
         self._allowed_border = 0
         self._cache = {}
+        self.device_sampling = False     # True: subsample on the device (capturable), torch's generator
+        self.image_size = None           # (h, w) of im_info[0] known on the host: skips the .tolist() synchronisation
 
     def _anchors_for(self, H, W, imh, imw, device):
         key = (H, W, imh, imw, str(device))
@@ -39,34 +43,39 @@ class _AnchorTargetLayer(nn.Module):
         """labels (B,HWA), targets (B,HWA,4), inside-w, outside-w (B,HWA) in (y,x,a) order."""
         B = gt_boxes.size(0)
         dev = gt_boxes.device
-        info0 = im_info[0].tolist()
+        info0 = self.image_size if self.image_size is not None else im_info[0].tolist()
         anc, inside, total = self._anchors_for(H, W, int(info0[0]), int(info0[1]), dev)
         ov, max_ov, argmax = ops.bbox_overlaps(anc, gt_boxes, want_matrix=True)
-        labels = torch.full_like(max_ov, -1.0)
         T = cfg.TRAIN
-        if not T.RPN_CLOBBER_POSITIVES:
-            labels[max_ov < T.RPN_NEGATIVE_OVERLAP] = 0
+        neg, one, zero = torch.full_like(max_ov, -1.0), torch.ones_like(max_ov), torch.zeros_like(max_ov)
+        labels = neg                                                         # torch.where throughout: no index_put
+        if not T.RPN_CLOBBER_POSITIVES:                                      # with a boolean mask (it synchronises)
+            labels = torch.where(max_ov < T.RPN_NEGATIVE_OVERLAP, zero, labels)
         gt_max = ov.max(1)[0]
         gt_max = torch.where(gt_max == 0, torch.full_like(gt_max, 1e-5), gt_max)
-        labels[(ov == gt_max.unsqueeze(1)).sum(2) > 0] = 1
-        labels[max_ov >= T.RPN_POSITIVE_OVERLAP] = 1
+        labels = torch.where((ov == gt_max.unsqueeze(1)).sum(2) > 0, one, labels)
+        labels = torch.where(max_ov >= T.RPN_POSITIVE_OVERLAP, one, labels)
         if T.RPN_CLOBBER_POSITIVES:
-            labels[max_ov < T.RPN_NEGATIVE_OVERLAP] = 0
-        # --- subsampling on the host with the reference's np.random call order
-        lab = labels.cpu().numpy()
+            labels = torch.where(max_ov < T.RPN_NEGATIVE_OVERLAP, zero, labels)
         num_fg = int(T.RPN_FG_FRACTION * T.RPN_BATCHSIZE)
-        sum_fg, sum_bg = (lab == 1).sum(1), (lab == 0).sum(1)
-        for i in range(B):
-            if sum_fg[i] > num_fg:
-                fg = np.nonzero(lab[i] == 1)[0]
-                lab[i, fg[np.random.permutation(fg.size)[:fg.size - num_fg]]] = -1
-            num_bg = T.RPN_BATCHSIZE - int((lab[i] == 1).sum())
-            if sum_bg[i] > num_bg:
-                bg = np.nonzero(lab[i] == 0)[0]
-                lab[i, bg[np.random.permutation(bg.size)[:bg.size - num_bg]]] = -1
         assert T.RPN_POSITIVE_WEIGHT < 0, "only the uniform weighting of the reference recipes is supported"
-        w = 1.0 / float((lab[B - 1] >= 0).sum())
-        labels = torch.from_numpy(lab).to(dev)
+        if self.device_sampling:
+            labels = self._subsample_device(labels, num_fg, int(T.RPN_BATCHSIZE))
+            w = 1.0 / (labels[B - 1] >= 0).sum().float()
+        else:
+            # --- subsampling on the host with the reference's np.random call order
+            lab = labels.cpu().numpy()
+            sum_fg, sum_bg = (lab == 1).sum(1), (lab == 0).sum(1)
+            for i in range(B):
+                if sum_fg[i] > num_fg:
+                    fg = np.nonzero(lab[i] == 1)[0]
+                    lab[i, fg[np.random.permutation(fg.size)[:fg.size - num_fg]]] = -1
+                num_bg = T.RPN_BATCHSIZE - int((lab[i] == 1).sum())
+                if sum_bg[i] > num_bg:
+                    bg = np.nonzero(lab[i] == 0)[0]
+                    lab[i, bg[np.random.permutation(bg.size)[:bg.size - num_bg]]] = -1
+            w = 1.0 / float((lab[B - 1] >= 0).sum())
+            labels = torch.from_numpy(lab).to(dev)
         gt_sel = torch.gather(gt_boxes[:, :, :4], 1, argmax.long().unsqueeze(2).expand(-1, -1, 4))
         tg = bbox_transform_batch(anc, gt_sel)
         inw = (labels == 1).float() * T.RPN_BBOX_INSIDE_WEIGHTS[0]
@@ -78,6 +87,25 @@ class _AnchorTargetLayer(nn.Module):
             return full
 
         return unmap(labels, -1), unmap(tg, 0), unmap(inw, 0), unmap(outw, 0)
+
+    @staticmethod
+    def _subsample_device(labels, num_fg, batchsize):
+        """anchor_target_layer.py:123-143 without leaving the device: keep at most ``num_fg`` foreground anchors and
+        ``batchsize - #fg`` background anchors per image, chosen uniformly (rank of an i.i.d. uniform key among the
+        candidates), the rest -> -1.  Fixed shapes, no host value: capturable."""
+        B, N = labels.shape
+        ar = torch.arange(N, device=labels.device).expand(B, N)
+
+        def rank_among(mask):
+            key = torch.where(mask, torch.rand_like(labels), torch.full_like(labels, 2.0))
+            order = key.argsort(1)
+            return torch.empty_like(order).scatter_(1, order, ar)
+
+        fg = labels == 1
+        labels = torch.where(fg & (rank_among(fg) >= num_fg), torch.full_like(labels, -1.0), labels)
+        n_bg = batchsize - (labels == 1).sum(1, keepdim=True)
+        bg = labels == 0
+        return torch.where(bg & (rank_among(bg) >= n_bg), torch.full_like(labels, -1.0), labels)
 
     def forward(self, input):
         """Reference API: input = (rpn_cls_score, gt_boxes, im_info, num_boxes) ->

@@ -56,9 +56,9 @@ class _RPN(nn.Module):
             # (y,x,a)-ordered views of the NHWC maps: no permute copies
             c = cls.permute(0, 2, 3, 1)                                        # (B,H,W,2A), contiguous view
             pair = torch.stack((c[..., :A], c[..., A:]), -1).reshape(-1, 2)     # (B*HWA, 2) = (bg, fg)
-            lab = labels.reshape(-1)
-            keep = lab.ne(-1).nonzero().view(-1)
-            self.rpn_loss_cls = F.cross_entropy(pair.index_select(0, keep), lab.index_select(0, keep).long())
+            # rpn.py:89-96 selects the anchors with label != -1 and averages their cross entropy; ignore_index does the
+            # same sum over the same anchors without a data-dependent shape (nonzero() synchronises with the host)
+            self.rpn_loss_cls = F.cross_entropy(pair, labels.reshape(-1).long(), ignore_index=-1)
             pred = box.permute(0, 2, 3, 1).reshape(B, -1, 4)
             self.rpn_loss_box = _smooth_l1_loss(pred, tg, inw.unsqueeze(2), outw.unsqueeze(2), sigma=3, dim=[1, 2])
         return rois, self.rpn_loss_cls, self.rpn_loss_box

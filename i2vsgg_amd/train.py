@@ -408,8 +408,12 @@ class InstanceStyleDStep:
     """One D+G adversarial step (trainval_net_instance_styleD_bilinear.py:262-341): source forward with
     detection + RPN losses and 0.5*mean(d^2) for both discriminators, target forward with
     0.5*mean((1-d)^2), style terms weighted by style_lambda, ONE backward through the gradient-reversal
-    layers, one SGD step over every trainable parameter.  Eager (the target layers sample on the host
-    with the reference's np.random stream, which needs two small D2H copies per step)."""
+    layers, one SGD step over every trainable parameter.
+
+    Eager by default with the target layers sampling on the host from the reference's np.random stream (bit parity with
+    the reference's RNG contract; two small D2H copies per step).  ``capture()`` switches the target layers to
+    device-side sampling (same subsample sizes, torch's generator) and records the whole step -- both forwards, the
+    backward, the gradient exchange and the update -- into ONE HIP graph."""
 
     def __init__(self, net, n_frames, lr=5e-4, eta=0.1, eta_style=0.001, style_lambda=1.0, seed=3, device="cuda:0",
                  h=600, w=1000, n_gt=8, cr=False):
@@ -417,6 +421,7 @@ class InstanceStyleDStep:
         self.cr = cr                  # --cr: consistency regularisation between instance- and image-level D (:299-312)
         self.world = parallel.world_size()
         self.eta, self.eta_style, self.style_lambda = eta, eta_style, style_lambda
+        self.geom = (h, w)
         ims, info = syn.frames(seed, n_frames, h, w)
         imt, _ = syn.frames(seed + 100, n_frames, h, w)
         gt, nb = syn.gt_boxes(seed, n_frames, n_gt, net.n_classes, cfg.MAX_NUM_GT_BOXES, h, w)
@@ -425,31 +430,80 @@ class InstanceStyleDStep:
         self.gt_t = torch.zeros((n_frames, 1, 5), device=self.dev)
         self.nb_t = torch.zeros((n_frames,), device=self.dev)
         self.opt = FusedSGD(list(net.named_parameters()), lr)
-        self.losses = {}
+        self.ctx = ops.LaunchContext(self.dev)
+        self.names = ["total", "det", "dloss_s", "dloss_t", "dloss_s_style", "dloss_t_style"] + \
+            (["source_adv_cst", "target_adv_cst"] if cr else [])
+        self.losses = {k: torch.zeros((), device=self.dev) for k in self.names}     # static addresses: a captured step writes here
+        self.graph = None
+        self.graph_error = None
+
+    def _body(self):
+        net = self.net
+        with self.ctx:
+            out = net(self.im_s, self.info, self.gt, self.nb, target=False, eta=self.eta, eta_style=self.eta_style)
+            _, _, _, l_rpn_cls, l_rpn_box, l_cls, l_box, _, d_inst, d_style = out
+            loss = l_rpn_cls.mean() + l_rpn_box.mean() + l_cls.mean() + l_box.mean()
+            dloss_s = 0.5 * torch.mean(d_inst ** 2)
+            dloss_s_style = 0.5 * torch.mean(d_style ** 2)
+            d_inst_t, d_style_t = net(self.im_t, self.info, self.gt_t, self.nb_t, target=True, eta=self.eta,
+                                      eta_style=self.eta_style)
+            dloss_t = 0.5 * torch.mean((1 - d_inst_t) ** 2)
+            dloss_t_style = 0.5 * torch.mean((1 - d_style_t) ** 2)
+            total = loss + dloss_s + dloss_t + self.style_lambda * (dloss_s_style + dloss_t_style)
+            vals = dict(det=loss, dloss_s=dloss_s, dloss_t=dloss_t, dloss_s_style=dloss_s_style, dloss_t_style=dloss_t_style)
+            if self.cr:
+                cst = consistency_terms(d_inst, d_style, d_inst_t, d_style_t)
+                total = total + cst["source_adv_cst"] + cst["target_adv_cst"]
+                vals.update(cst)
+            vals["total"] = total
+            self.opt.zero_grad()
+            (total / self.world).backward()
+            parallel.all_reduce_grads(self.opt.params())
+            self.opt.step()
+            for k in self.names:
+                self.losses[k].copy_(vals[k].detach())
+
+    eager_step = _body
+
+    def _device_sampling(self, on):
+        h, w = self.geom
+        atl = self.net.RCNN_rpn.RPN_anchor_target
+        atl.device_sampling = on
+        atl.image_size = (h, w) if on else None
+        self.net.RCNN_proposal_target.device_sampling = on
+
+    def capture(self, warmup=2):
+        """Device-side target sampling, eager warm-up, then the whole step as ONE HIP graph.  False (eager form kept,
+        ``graph_error`` says why) when capture fails."""
+        self._device_sampling(True)
+        s = torch.cuda.Stream(self.dev)
+        s.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(s):
+            for i in range(warmup):
+                self._body()
+                if i == 0:
+                    self.ctx.fit()
+        torch.cuda.current_stream(self.dev).wait_stream(s)
+        torch.cuda.synchronize(self.dev)
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._body()
+            self.graph = g
+            return True
+        except Exception as e:
+            self.graph = None
+            self.graph_error = repr(e)
+            torch.cuda.synchronize(self.dev)
+            return False
 
     def __call__(self):
-        net = self.net
-        out = net(self.im_s, self.info, self.gt, self.nb, target=False, eta=self.eta, eta_style=self.eta_style)
-        _, _, _, l_rpn_cls, l_rpn_box, l_cls, l_box, _, d_inst, d_style = out
-        loss = l_rpn_cls.mean() + l_rpn_box.mean() + l_cls.mean() + l_box.mean()
-        dloss_s = 0.5 * torch.mean(d_inst ** 2)
-        dloss_s_style = 0.5 * torch.mean(d_style ** 2)
-        d_inst_t, d_style_t = net(self.im_t, self.info, self.gt_t, self.nb_t, target=True, eta=self.eta,
-                                  eta_style=self.eta_style)
-        dloss_t = 0.5 * torch.mean((1 - d_inst_t) ** 2)
-        dloss_t_style = 0.5 * torch.mean((1 - d_style_t) ** 2)
-        total = loss + dloss_s + dloss_t + self.style_lambda * (dloss_s_style + dloss_t_style)
-        cst = {}
-        if self.cr:
-            cst = consistency_terms(d_inst, d_style, d_inst_t, d_style_t)
-            total = total + cst["source_adv_cst"] + cst["target_adv_cst"]
-        self.opt.zero_grad()
-        (total / self.world).backward()
-        parallel.all_reduce_grads(self.opt.params())
-        self.opt.step()
-        self.losses = dict(total=total.detach(), det=loss.detach(), dloss_s=dloss_s.detach(), dloss_t=dloss_t.detach(),
-                           dloss_s_style=dloss_s_style.detach(), dloss_t_style=dloss_t_style.detach(),
-                           **{k: v.detach() for k, v in cst.items()})
+        if self.graph is None:
+            self._body()
+        else:
+            _graph_launch_guard()
+            self.graph.replay()
+            self.opt.bump()
         return self.losses["total"]
 
 

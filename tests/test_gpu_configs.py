@@ -1,0 +1,179 @@
+"""The BASELINE.json configs at FULL size on the GPU (600x1000 frames), through size-independent properties and, where a
+CPU restatement finishes in seconds, against the oracle.
+
+configs[2]  cfgs/res101.yml, instance_styleD D+G adversarial step, 4 source + 4 target frames
+            (trainval_net_instance_styleD_bilinear.py:262-341)
+configs[0]  cfgs/res50.yml, one 1x3x600x1000 frame, Faster-RCNN forward + SGG_emb head (cfgs/res50.yml:1-17)
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from i2vsgg_amd import synthetic as syn  # noqa: E402
+
+DEV = "cuda:0"
+SET = ["ANCHOR_SCALES", "[8, 16, 32]", "ANCHOR_RATIOS", "[0.5,1,2]", "MAX_NUM_GT_BOXES", "30"]
+
+
+@pytest.fixture()
+def fresh_cfg():
+    """A test here loads its own yml; the global cfg singleton is put back afterwards (other modules load res101)."""
+    from i2vsgg_amd.model.utils import config as c
+    saved = copy.deepcopy(dict(c.cfg))
+
+    def load(net, extra=()):
+        c.cfg_from_file(c.default_cfg_file(net))
+        c.cfg_from_list(SET + list(extra))
+        return c.cfg
+    yield load
+    c._merge_a_into_b(c.AttrDict(saved), c.cfg)
+
+
+def _finite(d):
+    return all(np.isfinite(float(v)) for v in d.values())
+
+
+def test_instance_styled_step_full_size(fresh_cfg):
+    """configs[2] at full size, B = 4 + 4 frames of 600x1000, ResNet-101, 32 ROI / frame:
+      * every loss of the step is finite and the trained parameters of every group move (layer1-3, layer4, RPN, both
+        discriminators, the detection heads);
+      * the step on the fused kernels (one-kernel netD_pixel, Winograd forward / data gradient for the trained 3x3 layers,
+        multi-tensor fused SGD) reproduces the losses of the same step on the plain forms (layer-by-layer netD_pixel,
+        direct 3x3 kernels, torch.optim.SGD with the reference's parameter groups) for two consecutive steps -- the second
+        one sees the first one's update -- within 1e-3 relative, same np.random stream;
+      * the captured form (device-side target sampling, ONE HIP graph) replays to finite losses close to the host-sampled
+        ones and keeps training."""
+    cfg = fresh_cfg("res101", ["TRAIN.BATCH_SIZE", "32", "TRAIN.RPN_POST_NMS_TOP_N_TARGET", "32"])
+    from i2vsgg_amd import ops, train
+    names = ["RCNN_base.4.0.conv1.weight", "RCNN_base.6.22.conv2.weight", "RCNN_top.0.2.conv3.weight",
+             "RCNN_rpn.RPN_Conv.weight", "netD_pixel.conv1.weight", "netD_style.fc_1.weight", "RCNN_cls_score.weight",
+             "RCNN_bbox_pred.bias"]
+
+    def run(plain):
+        torch.manual_seed(0)
+        np.random.seed(cfg.RNG_SEED)
+        net = train.build_instance_styled_net(101, device=DEV)
+        before = {k: v.detach().clone() for k, v in net.named_parameters() if k in names}
+        step = train.InstanceStyleDStep(net, 4, seed=3, device=DEV)
+        saved = (ops.WINOGRAD_TRAIN, net.netD_pixel.forward)
+        if plain:
+            ops.WINOGRAD_TRAIN = False
+            net.netD_pixel.forward = net.netD_pixel._forward_layers
+            T = cfg.TRAIN
+            groups = [{"params": [p], "lr": 5e-4 * ((T.DOUBLE_BIAS + 1) if "bias" in n else 1),
+                       "weight_decay": (T.WEIGHT_DECAY if T.BIAS_DECAY else 0.0) if "bias" in n else T.WEIGHT_DECAY}
+                      for n, p in net.named_parameters() if p.requires_grad]        # trainval_net_instance...:134-148
+            sgd = torch.optim.SGD(groups, momentum=T.MOMENTUM)
+
+            class Plain:
+                params = staticmethod(lambda: [g["params"][0] for g in groups])
+                zero_grad = staticmethod(lambda: sgd.zero_grad(set_to_none=True))
+                step = staticmethod(sgd.step)
+                bump = staticmethod(lambda: None)
+            step.opt = Plain
+        try:
+            out = []
+            for _ in range(2):
+                step()
+                out.append({k: float(v) for k, v in step.losses.items()})
+            moved = {k: float((dict(net.named_parameters())[k].detach() - before[k]).abs().max()) for k in names}
+        finally:
+            ops.WINOGRAD_TRAIN, net.netD_pixel.forward = saved
+        return out, moved, net, step
+
+    fused, moved, net, step = run(False)
+    assert all(_finite(d) for d in fused), fused
+    assert all(v > 0 for v in moved.values()), moved
+    plain, _, net2, step2 = run(True)
+    del net2, step2
+    for a, b in zip(fused, plain):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 1e-3 * max(abs(b[k]), 1e-6), (k, fused, plain)
+    # ---- captured form: device-side sampling, one graph
+    assert step.capture(warmup=1), step.graph_error
+    w0 = net.RCNN_base[6][22].conv2.weight.detach().clone()
+    got = []
+    for _ in range(3):
+        step()
+        got.append({k: float(v) for k, v in step.losses.items()})
+    assert all(_finite(d) for d in got), got
+    assert not torch.equal(w0, net.RCNN_base[6][22].conv2.weight.detach())
+    # a different random subsample of the same anchors / proposals: the losses stay in the neighbourhood of the host-sampled run
+    assert abs(got[0]["det"] - fused[1]["det"]) < 0.25 * fused[1]["det"], (got, fused)
+    assert abs(got[0]["dloss_s"] - fused[1]["dloss_s"]) < 0.05 * fused[1]["dloss_s"]
+
+
+def test_device_sampling_statistics(fresh_cfg):
+    """The device-side samplers draw what the reference's host code draws (anchor_target_layer.py:123-143,
+    proposal_target_layer_cascade.py:140-182): subsample sizes, class of every kept index, replacement rules."""
+    cfg = fresh_cfg("res101", ["TRAIN.BATCH_SIZE", "32"])
+    from i2vsgg_amd.model.rpn.anchor_target_layer import _AnchorTargetLayer
+    from i2vsgg_amd.model.rpn.proposal_target_layer_cascade import _ProposalTargetLayer
+    torch.manual_seed(1)
+    B, N = 3, 5000
+    lab = torch.full((B, N), -1.0, device=DEV)
+    lab[0, :300] = 1; lab[0, 300:4000] = 0             # more fg than 128, more bg than the rest
+    lab[1, :40] = 1; lab[1, 40:4000] = 0               # few fg: bg fills up to 256 - 40
+    lab[2, :10] = 1; lab[2, 10:60] = 0                 # fewer candidates than the batch: everything kept
+    perm = torch.stack([torch.randperm(N, device=DEV) for _ in range(B)])
+    lab = torch.gather(lab, 1, perm)
+    out = _AnchorTargetLayer._subsample_device(lab, 128, 256)
+    fg, bg = (out == 1).sum(1).tolist(), (out == 0).sum(1).tolist()
+    assert fg == [128, 40, 10] and bg == [128, 216, 50]
+    assert bool(((out == 1) <= (lab == 1)).all()) and bool(((out == 0) <= (lab == 0)).all())      # kept only from its class
+    out2 = _AnchorTargetLayer._subsample_device(lab, 128, 256)
+    assert not torch.equal(out, out2)                                                               # random, not a prefix
+    # proposals: image 0 both classes, image 1 only fg, image 2 only bg
+    mo = torch.zeros(3, 400, device=DEV)
+    mo[0, :50] = 0.8; mo[0, 50:] = 0.2
+    mo[1, :] = 0.9
+    mo[2, :] = 0.1
+    keep, nfg = _ProposalTargetLayer._sample_device(mo, 32, 8)
+    assert nfg.view(-1).tolist() == [8, 32, 0]
+    k0 = keep[0].tolist()
+    assert all(i < 50 for i in k0[:8]) and len(set(k0[:8])) == 8 and all(i >= 50 for i in k0[8:])
+    assert all(0 <= i < 400 for i in keep[1].tolist() + keep[2].tolist())
+    assert len(set(keep[2].tolist())) > 16                                                           # spread over the candidates
+
+
+def test_res50_yml_full_frame_plumbing(fresh_cfg):
+    """configs[0]: cfgs/res50.yml (RPN_BATCHSIZE 128, BATCH_SIZE 128, DOUBLE_BIAS False) on ONE 1x3x600x1000 frame:
+    detector forward in eval mode (TEST proposal settings: 6000 -> 300) and the SGG_emb relation head forward on the same
+    frame's feature map; the head's scores equal the CPU oracle's on the same feature map within 1e-3."""
+    cfg = fresh_cfg("res50")
+    assert cfg.TRAIN.RPN_BATCHSIZE == 128 and cfg.TRAIN.BATCH_SIZE == 128 and cfg.TRAIN.DOUBLE_BIAS is False
+    from i2vsgg_amd import train
+    from oracle import nets
+    det = train.build_instance_styled_net(50, device=DEV).eval()
+    im, info = syn.frames(0, 1, 600, 1000)
+    gt, nb = syn.gt_boxes(0, 1, 8, det.n_classes, cfg.MAX_NUM_GT_BOXES, 600, 1000)
+    to = lambda x: torch.from_numpy(x).to(DEV)
+    with torch.no_grad():
+        rois, cls_prob, bbox_pred, *_rest, d_inst, d_style = det(to(im), to(info), to(gt), to(nb))
+    P = cfg.TEST.RPN_POST_NMS_TOP_N
+    assert tuple(rois.shape) == (1, P, 5) and tuple(cls_prob.shape) == (1, P, det.n_classes)
+    assert tuple(bbox_pred.shape) == (1, P, 4 * det.n_classes)
+    assert bool(torch.isfinite(cls_prob).all()) and bool(torch.isfinite(bbox_pred).all())
+    np.testing.assert_allclose(cls_prob.sum(2).cpu().numpy(), 1.0, rtol=1e-5)
+    r = rois[0].cpu().numpy()
+    assert (r[:, 1] >= 0).all() and (r[:, 3] <= 999).all() and (r[:, 2] >= 0).all() and (r[:, 4] <= 599).all()
+    assert (r[:, 3] >= r[:, 1]).all() and (r[:, 4] >= r[:, 2]).all()
+    # relation head on the same frame: 8 boxes, 8 pairs
+    sgg = train.build_sgg_net(50, device=DEV).eval()
+    step = train.SGGEmbStep(sgg, 1, seed=0, device=DEV, n_boxes=8, n_pairs=8, use_graph=False)
+    with torch.no_grad():
+        fmap = sgg.RCNN_base(step.im)
+        score, feat = sgg.vrd.forward_device(fmap, step.boxes, step.relb, step.masks, step.ixs, step.ixo)
+    assert tuple(fmap.shape) == (1, 1024, 38, 63) and tuple(score.shape) == (8, 62)
+    np.testing.assert_allclose(score.sum(1).cpu().numpy(), 1.0, rtol=1e-5)           # eval: softmax over predicates
+    p = {k: v.detach().cpu() for k, v in sgg.state_dict().items()}
+    with torch.no_grad():
+        ref, _ = nets.vrd_head(fmap.contiguous().cpu(), step.boxes.cpu().numpy(), step.relb.cpu().numpy(),
+                               step.masks[:, :2].cpu().numpy(), step.ixs.cpu().numpy(), step.ixo.cpu().numpy(),
+                               sgg.vrd.prd_vecs, p, training=False)
+    np.testing.assert_allclose(score.cpu().numpy(), ref.numpy(), rtol=1e-3, atol=1e-6)
+    step.opt.unfuse()

@@ -728,3 +728,59 @@ def test_winograd_3x3_vs_torch_fp32(ops, B, C, N, H, W):
     assert U4.shape == (36, N, C)
     y4 = ops.conv3x3_winograd(xd, U4, torch.from_numpy(sc).to(DEV), torch.from_numpy(sh).to(DEV), relu=True)
     assert np.abs(y4.cpu().numpy() - r2.numpy()).max() <= 1e-4 * max(np.abs(r2.numpy()).max(), 1.0)
+
+
+@pytest.mark.parametrize("M,K,N,res", [(4788, 1024, 256, False),     # layer3 conv1, two frames: split-K finished in the kernel
+                                       (4788, 256, 1024, True),      # layer3 conv3 + residual + ReLU
+                                       (18750, 128, 512, True),      # layer2 conv3: 4 stages
+                                       (9000, 64, 256, True),        # layer1 conv3 shape class: 2 stages
+                                       (2394, 512, 256, False),      # one frame
+                                       (62, 300, 1024, False),       # K and M not multiples of the tile / stage
+                                       (9000, 300, 36, False)])      # N % 16 != 0, K % 32 != 0, two splits finished in the kernel
+def test_pointwise_gemm_kernel_equals_generic_kernel(ops, M, K, N, res):
+    """conv_gemm_f32 (lean pointwise / plain-GEMM specialisation: swapped MFMA operands, register epilogue) computes
+    bit for bit what conv_igemm_f32 computes -- same K order per accumulator, same split order -- and both match torch
+    within fp32 rounding."""
+    from i2vsgg_amd._lib import lib
+    rng = np.random.default_rng(M + K + N)
+    x = torch.from_numpy(rng.standard_normal((M, K), dtype=np.float32)).to(DEV)
+    w = torch.from_numpy((rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)).to(DEV)
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, N).astype(np.float32)).to(DEV)
+    sh = torch.from_numpy(rng.uniform(-0.5, 0.5, N).astype(np.float32)).to(DEV)
+    r = torch.from_numpy(rng.standard_normal((M, N), dtype=np.float32)).to(DEV) if res else None
+    x4, w4 = x.view(M, K, 1, 1), w.view(N, K, 1, 1)
+    r4 = r.view(M, N, 1, 1) if res else None
+    out = {}
+    try:
+        for mode in (1, 0):
+            assert lib.i2v_set_tuning(10, mode) == 0
+            out[mode] = ops.conv2d(x4, w4, sc, sh, r4, 1, 0, relu=True).view(M, N).clone()
+    finally:
+        lib.i2v_set_tuning(10, 1)
+    assert torch.equal(out[1], out[0])
+    ref = x.double() @ w.double().t() * sc.double() + sh.double()
+    if res:
+        ref = ref + r.double()
+    ref = torch.relu(ref)
+    np.testing.assert_allclose(out[1].cpu().numpy(), ref.float().cpu().numpy(), rtol=2e-5, atol=2e-5)
+
+
+def test_pointwise_gemm_kernel_batched_planes(ops):
+    """The 36 element-wise planes of a Winograd F(4x4,3x3) layer3 convolution as one batched launch on conv_gemm_f32."""
+    from i2vsgg_amd._lib import lib, ptr, stream
+    rng = np.random.default_rng(11)
+    nb, M, K, N = 36, 320, 256, 256
+    a = torch.from_numpy(rng.standard_normal((nb, M, K), dtype=np.float32)).to(DEV)
+    b = torch.from_numpy((rng.standard_normal((nb, N, K), dtype=np.float32) / 16).astype(np.float32)).to(DEV)
+    out = {}
+    try:
+        for mode in (1, 0):
+            lib.i2v_set_tuning(10, mode)
+            c = torch.empty((nb, M, N), device=DEV)
+            assert lib.i2v_gemm_nt_batched(ptr(a), ptr(b), ptr(c), M, N, K, nb, M * K, N * K, M * N, None, 0, stream()) == 0
+            out[mode] = c
+    finally:
+        lib.i2v_set_tuning(10, 1)
+    assert torch.equal(out[1], out[0])
+    ref = torch.bmm(a.double(), b.double().transpose(1, 2)).float()
+    np.testing.assert_allclose(out[1].cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-5)

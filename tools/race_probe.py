@@ -34,6 +34,7 @@ def run(mode, sync=False):
     nobb = "nobb" in mode
     nodrop = "nodrop" in mode
     gap = "gap" in mode
+    noev = "noev" in mode           # the backbone graph replays on its stream with NO event tying it to the head's stream
     os.environ["I2V_BB_PRIORITY"] = str(prio)
     net = train.build_sgg_net(101, device=DEV)
     if nodrop:
@@ -102,19 +103,28 @@ def run(mode, sync=False):
                     print("DOT dump failed:", repr(e), flush=True)
         cur = torch.cuda.current_stream(DEV)
         torch.cuda.synchronize()
+        if os.environ.get("RACE_WARM_NULL") and not own:
+            # one EAGER head pass on the stream the replays will use (the legacy default stream): every kernel of the head
+            # has then been dispatched once through the runtime's ordinary path on this stream's hardware queue
+            head0()
+            torch.cuda.synchronize()
         start.zero_(); end.zero_(); log.fill_(-7.0)
         trace = torch.zeros(N, device=DEV)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(N):
-            cur.wait_event(step.ev_bb)
+            if not noev:
+                cur.wait_event(step.ev_bb)
             step.fmap_head.copy_(step.fmap)
-            step.ev_copy.record(cur)
+            if not noev:
+                step.ev_copy.record(cur)
             if not nobb:
                 with torch.cuda.stream(step.s_bb):
-                    step.s_bb.wait_event(step.ev_copy)
+                    if not noev:
+                        step.s_bb.wait_event(step.ev_copy)
                     gbb.replay()
-                    step.ev_bb.record(step.s_bb)
+                    if not noev:
+                        step.ev_bb.record(step.s_bb)
             gh.replay()
             trace[i].copy_(step.loss.detach().reshape(()))
             if sync:
