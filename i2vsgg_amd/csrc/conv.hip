@@ -50,6 +50,7 @@ struct ConvP {
     unsigned long long* clk;     // diagnostic only (i2v_conv_debug_clock): per-workgroup {shader cycles, 100 MHz ticks}
     float* ws;                   // split-K partial tiles [split][tile][BM*BN] (nullptr: fp32 atomics into y)
     int* cnt;                    // split-K arrival counters, one per tile, zero between launches
+    int knob;                    // experiment knob of conv_gemm_f32 (I2V_TUNE_STAGGER): 0 = off
     int nbatch;                  // > 1: blockIdx.z selects one of nbatch independent GEMMs (Winograd planes)
     long long bsx, bsw, bsy;     // element strides between the batches of x, w and y
 };
@@ -682,10 +683,14 @@ conv_igemm_f32(const ConvP p_in) {
 // 16-B store per fragment, no LDS round trip, no barrier.  Staging, swizzled LDS image and the K loop are conv_igemm_f32's.
 // Split-K (<= kSplitInKernelMax): partial tiles go to the caller's workspace in REGISTER order (fragment, wave, lane), the
 // last workgroup to arrive sums them in split order -- same protocol as conv_igemm_f32, whole-wave 1-KB rows.
-template <int WAVES_M, int WAVES_N, int TM, int TN>
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool CLK = false>
 __global__ void __launch_bounds__(THREADS)
 conv_gemm_f32(const ConvP p_in) {
     ConvP p = p_in;
+    // CLK: diagnostic instantiation (i2v_conv_debug_clock): per workgroup {start, end in 100 MHz ticks, prologue / K-loop /
+    // epilogue shader cycles, HW_ID, XCC_ID} into a buffer of their own; the product instantiation has no stamp
+    unsigned long long c_rt0 = 0, c_t0 = 0, c_t1 = 0, c_t2 = 0;
+    if constexpr (CLK) { c_rt0 = __builtin_amdgcn_s_memrealtime(); c_t0 = __builtin_amdgcn_s_memtime(); }
     if (p.nbatch > 1) {
         p.x += (long long)blockIdx.z * p.bsx;
         p.w += (long long)blockIdx.z * p.bsw;
@@ -752,31 +757,51 @@ conv_gemm_f32(const ConvP p_in) {
             if (row < BN) *(float4*)&Bs[S][row * BKS + ((kc ^ ((row >> 1) & 7)) << 2)] = rb[q];
         }
     };
+    if (p.knob > 0) {                     // experiment (I2V_TUNE_STAGGER): co-resident workgroups start ~knob kcycles apart
+        const int r = (blockIdx.x >> 8) & 3;
+        for (int i = 0; i < r * p.knob; ++i) __builtin_amdgcn_s_sleep(16);
+    }
     gload(kbeg);                          // first: everything below hides behind this round trip
 
-    // operands of the epilogue, fetched now.  A lane owns channels n .. n+3 of pixel m for every fragment (i, j):
+    // Operands of the epilogue.  A lane owns channels n .. n+3 of pixel m for every fragment (i, j):
     //   m = m0 + (wm*TM + i)*16 + (lane & 15),   n = n0 + (wn*TN + j)*16 + 4*(lane >> 4)
+    // They are fetched by buffer loads that are ALWAYS issued (an absent operand or an out-of-range lane gets the 2 GiB
+    // offset and reads zeros without traffic): a load under a condition makes the number of loads in flight unknowable
+    // to the compiler, which then drains everything (s_waitcnt vmcnt(0)) in front of the first LDS store -- with the
+    // 19.6 MB residual of a layer3 conv3 in flight that cost 4.5k of 8.1k prologue cycles (tools/gemm_phase.py).
+    // The residual tile is requested one stage before the last, behind that stage's operand loads (returns are in
+    // order): its latency lies under the last stage's MFMAs, and no operand load ever waits for it.
     const bool split = p.splitk > 1;
     constexpr bool PREFETCH_RES = TM * TN <= 8;
+    const unsigned n_bytes = (unsigned)p.N * 4u;
+    const __amdgpu_buffer_rsrc_t scr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.scale ? p.scale : p.shift ? p.shift : (const float*)p.x), 0, n_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t shr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.shift ? p.shift : (const float*)p.x), 0, n_bytes, 0x00020000);
+    const unsigned long long y_bytes = (unsigned long long)p.M * p.N * 4ull;
+    const __amdgpu_buffer_rsrc_t resr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.res ? p.res : (const float*)p.x), 0, (unsigned)(y_bytes < 0x7FFFFFF0ull ? y_bytes : 0x7FFFFFF0ull), 0x00020000);
+    const unsigned sc_inv = (p.flags & I2V_EPI_SCALE) ? 0u : INV;
+    const unsigned sh_inv = (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) ? 0u : INV;
+    const unsigned res_inv = ((p.flags & I2V_EPI_RESIDUAL) && !split) ? 0u : INV;
     float4 sc[TN], sh[TN], rres[PREFETCH_RES ? TM : 1][PREFETCH_RES ? TN : 1];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + (wn * TN + j) * 16 + 4 * fg;
-        const bool ok = n < p.N;
-        sc[j] = (ok && (p.flags & I2V_EPI_SCALE)) ? *(const float4*)(p.scale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
-        sh[j] = (ok && (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS))) ? *(const float4*)(p.shift + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const unsigned off = n < p.N ? (unsigned)n * 4u : INV;
+        sc[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(scr, off | sc_inv, 0, 0));
+        sh[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(shr, off | sh_inv, 0, 0));
     }
-    if (PREFETCH_RES && !split && (p.flags & I2V_EPI_RESIDUAL)) {
+    auto issue_res = [&]() {
+        if constexpr (PREFETCH_RES) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int m = m0 + (wm * TM + i) * 16 + fr, n = n0 + (wn * TN + j) * 16 + 4 * fg;
-                rres[PREFETCH_RES ? i : 0][PREFETCH_RES ? j : 0] = (m < p.M && n < p.N)
-                    ? __builtin_bit_cast(float4, __builtin_nontemporal_load((const f32x4*)(p.res + (long long)m * p.N + n)))
-                    : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-    }
+                for (int j = 0; j < TN; ++j) {
+                    const int m = m0 + (wm * TM + i) * 16 + fr, n = n0 + (wn * TN + j) * 16 + 4 * fg;
+                    const unsigned off = (m < p.M && n < p.N) ? (unsigned)(m * p.N + n) * 4u : INV;
+                    rres[i][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(resr, off | res_inv, 0, 2));   // nt: last use of the block input
+                }
+        }
+    };
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -812,39 +837,65 @@ conv_gemm_f32(const ConvP p_in) {
     };
     sstore(0);
     __syncthreads();
-    int buf = 0;
-    for (int k0 = kbeg; k0 < kend; k0 += BKS) {
-        const bool more = k0 + BKS < kend;
-        if (more) gload(k0 + BKS);
+    if constexpr (CLK) c_t1 = __builtin_amdgcn_s_memtime();
+    int buf = 0, k0 = kbeg;
+    for (; k0 + 2 * BKS < kend; k0 += BKS) {          // every stage but the last two
+        gload(k0 + BKS);
         compute(buf);
-        if (more) sstore(buf ^ 1);
+        sstore(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
+    if (k0 + BKS < kend) {                            // two stages left: operands of the last one, then the residual tile
+        gload(k0 + BKS);
+        issue_res();
+        compute(buf);
+        sstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    } else {
+        issue_res();
+    }
+    compute(buf);                                     // last stage (no barrier: nothing is staged after it)
+    if constexpr (CLK) c_t2 = __builtin_amdgcn_s_memtime();
+    auto stamp = [&]() {
+        if constexpr (CLK) {
+            __builtin_amdgcn_s_waitcnt(0);
+            if (tid == 0) {
+                unsigned long long* o = p.clk + 8 * ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+                o[0] = c_rt0; o[1] = __builtin_amdgcn_s_memrealtime();
+                o[2] = c_t1 - c_t0; o[3] = c_t2 - c_t1; o[4] = __builtin_amdgcn_s_memtime() - c_t2;
+                o[5] = __builtin_amdgcn_s_getreg(63492); o[6] = __builtin_amdgcn_s_getreg(63508); o[7] = 1;
+            }
+        }
+    };
 
     auto finish = [&](int i, int j, f32x4 v, float4 rr) {
         const int m = m0 + (wm * TM + i) * 16 + fr, n = n0 + (wn * TN + j) * 16 + 4 * fg;
         if (m >= p.M || n >= p.N) return;
-        float4 o = make_float4(v[0] * sc[j].x + sh[j].x, v[1] * sc[j].y + sh[j].y, v[2] * sc[j].z + sh[j].z,
-                               v[3] * sc[j].w + sh[j].w);
+        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (p.flags & I2V_EPI_SCALE) { o.x *= sc[j].x; o.y *= sc[j].y; o.z *= sc[j].z; o.w *= sc[j].w; }   // an absent operand was read as zeros
+        if (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) { o.x += sh[j].x; o.y += sh[j].y; o.z += sh[j].z; o.w += sh[j].w; }
         if (p.flags & I2V_EPI_RESIDUAL) { o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
         if (p.flags & I2V_EPI_RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
         *(float4*)(p.y + (long long)m * p.N + n) = o;
     };
     auto res_at = [&](int i, int j) -> float4 {
         const int m = m0 + (wm * TM + i) * 16 + fr, n = n0 + (wn * TN + j) * 16 + 4 * fg;
-        return (m < p.M && n < p.N) ? __builtin_bit_cast(float4, __builtin_nontemporal_load((const f32x4*)(p.res + (long long)m * p.N + n)))
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+        const unsigned off = (m < p.M && n < p.N && (p.flags & I2V_EPI_RESIDUAL)) ? (unsigned)(m * p.N + n) * 4u : INV;
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(resr, off, 0, 2));
     };
     if (!split) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                float4 rr = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.flags & I2V_EPI_RESIDUAL) rr = PREFETCH_RES ? rres[PREFETCH_RES ? i : 0][PREFETCH_RES ? j : 0] : res_at(i, j);
+                float4 rr;
+                if constexpr (PREFETCH_RES) rr = rres[PREFETCH_RES ? i : 0][PREFETCH_RES ? j : 0];
+                else rr = res_at(i, j);
                 finish(i, j, acc[i][j], rr);
             }
+        stamp();
         return;
     }
     // ---- split-K: partials in register order through the caller's workspace (sc1 stores / loads: coherent across the
@@ -870,7 +921,7 @@ conv_gemm_f32(const ConvP p_in) {
         last_flag = last;
     }
     __syncthreads();
-    if (!last_flag) return;
+    if (!last_flag) { stamp(); return; }
     const int nsplit = gridDim.y, my = blockIdx.y;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -881,7 +932,7 @@ conv_gemm_f32(const ConvP p_in) {
             for (int sp = 0; sp < kSplitInKernelMax; ++sp)
                 u[j][sp] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
                     wsr, (sp < nsplit && sp != my) ? slot(i, j) + (unsigned)(sp * split_stride * sizeof(float)) : 0xFFFFFFF0u, 0, SC01));
-            rr[j] = (p.flags & I2V_EPI_RESIDUAL) ? res_at(i, j) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rr[j] = res_at(i, j);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -895,6 +946,7 @@ conv_gemm_f32(const ConvP p_in) {
             finish(i, j, (f32x4){v.x, v.y, v.z, v.w}, rr[j]);
         }
     }
+    stamp();
 }
 
 // epilogue of the split-K path (partials were accumulated with fp32 atomics)
@@ -995,10 +1047,16 @@ void launch_tile(const ConvP& p, bool spec, hipStream_t st) {
     // pointwise layers / plain GEMMs whose split-K (if any) is finished in the kernel: the lean specialisation
     const bool pointwise = p.KH == 1 && p.KW == 1 && p.pad == 0 && p.pad_x == 0 && p.stride == 1 && p.ostride == 1 &&
                            p.Ho == p.H && p.Wo == p.W && (p.N & 3) == 0 && (p.K & 3) == 0 && (p.splitk <= 1 || p.ws);
-    if (pointwise && !spec && g_i2v_tuning[I2V_TUNE_CONV_GEMM] && !p.clk && !p.ablate) {
-        static bool once_g = [] { set_max_lds(conv_gemm_f32<WAVES_M, WAVES_N, TM, TN>); return true; }();
+    if (pointwise && !spec && g_i2v_tuning[I2V_TUNE_CONV_GEMM] && !p.ablate) {
+        static bool once_g = [] {
+            set_max_lds(conv_gemm_f32<WAVES_M, WAVES_N, TM, TN>);
+            set_max_lds(conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, true>);
+            return true;
+        }();
         (void)once_g;
-        conv_gemm_f32<WAVES_M, WAVES_N, TM, TN><<<grid, THREADS, (size_t)(2 * (BM + BN) * BKS) * sizeof(float), st>>>(p);
+        const size_t lds_g = (size_t)(2 * (BM + BN) * BKS) * sizeof(float);
+        if (p.clk) conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, true><<<grid, THREADS, lds_g, st>>>(p);
+        else conv_gemm_f32<WAVES_M, WAVES_N, TM, TN><<<grid, THREADS, lds_g, st>>>(p);
         return;
     }
     if (spec) conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, true><<<grid, 2 * THREADS, lds, st>>>(p);
@@ -1033,6 +1091,7 @@ int run_conv(ConvP p, hipStream_t st, void* split_ws = nullptr, size_t split_ws_
     p.w_bytes = (unsigned)wb;
     p.clk = g_clk;
     p.ablate = g_ablate;
+    p.knob = g_i2v_tuning[I2V_TUNE_STAGGER];
     const int force = p.force_tile;
     const int ksteps = i2v_cdiv(p.K, BKS);
     // tile + split-K choice: minimise (rounds over the 256 CUs) x (MACs per workgroup) / efficiency.
