@@ -98,6 +98,89 @@ roi_align_fwd_nhwc(const float* __restrict__ feat, const float* __restrict__ roi
     }
 }
 
+// ---------------------------------------------------------------- forward, NHWC, column-pair blocks
+// The row kernel above walks the AW sample columns of its output row one after the other: 8 dependent HBM round trips
+// per workgroup and only R*PH workgroups (224 at 32 ROIs: fewer than the chip has CUs) -- 18.7 us for 16 MB, 0.11 of
+// the HBM roofline (profiles/r01_roi_nms_bench.txt).  Here a workgroup owns TWO output columns of one output row: its
+// (2 x 3) samples x 4 taps = 24 16-byte loads per lane are all issued before the first one is used (ONE round trip),
+// and the grid is R*PH*ceil(PW/2) workgroups (896 at 32 ROIs).  Out-of-map samples load tap (0,0) and are zeroed by a
+// select, so no load sits under a condition.  Same arithmetic, same order: bit-equal to the row kernel and the oracle.
+template <int AVG>
+__global__ void __launch_bounds__(256)
+roi_align_fwd_nhwc_cols(const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
+                        int R, int C, int H, int W, int PH, int PW, float scale, Strides os) {
+    const int groups = (PW + 1) >> 1;
+    // XCD-aware placement: workgroups b and b+8 share an XCD (and its L2), so ALL workgroups of one ROI get the same
+    // b % 8 -- the ROI's window of the map then crosses the fabric once instead of once per XCD (PMC, 4 frames x 32 ROIs:
+    // 173 MB of HBM traffic for 65 MB of algorithmic bytes with the plain order).  Placement only; R is padded to a
+    // multiple of 8 by the launcher and the surplus workgroups exit.
+    const int per_roi = PH * groups;
+    const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
+    const int r = x + 8 * (i / per_roi), inner = i % per_roi;
+    if (r >= R) return;
+    const int g = inner % groups, ph = inner / groups, pw0 = 2 * g;
+    const float* roi = rois + 5 * (long long)r;
+    const int b = (int)roi[0];
+    const int AH = PH + AVG, AW = PW + AVG;
+    const float* fb = feat + (long long)b * H * W * C;
+    constexpr int NR = 1 + AVG, NC = 2 + AVG;          // sample rows / columns this workgroup needs
+    Sample sm[NR][NC];
+#pragma unroll
+    for (int k = 0; k < NR; ++k)
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            sm[k][j] = ra_sample(roi, scale, H, W, AH, AW, ph + k, min(pw0 + j, AW - 1));
+            if (pw0 + j >= AW) sm[k][j].ok = 0;
+            if (!sm[k][j].ok) { sm[k][j].hs = 0; sm[k][j].ws = 0; }
+        }
+    for (int c = threadIdx.x * 4; c < C; c += blockDim.x * 4) {
+        float4 t[NR][NC][4];
+#pragma unroll
+        for (int k = 0; k < NR; ++k)
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const float* p = fb + ((long long)sm[k][j].hs * W + sm[k][j].ws) * C + c;
+                t[k][j][0] = *(const float4*)p;
+                t[k][j][1] = *(const float4*)(p + C);
+                t[k][j][2] = *(const float4*)(p + (long long)W * C);
+                t[k][j][3] = *(const float4*)(p + (long long)W * C + C);
+            }
+        float4 v[NR][NC];
+#pragma unroll
+        for (int k = 0; k < NR; ++k)
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                const Sample s = sm[k][j];
+                float4 q;
+                q.x = bilinear(t[k][j][0].x, t[k][j][1].x, t[k][j][2].x, t[k][j][3].x, s.hr, s.wr);
+                q.y = bilinear(t[k][j][0].y, t[k][j][1].y, t[k][j][2].y, t[k][j][3].y, s.hr, s.wr);
+                q.z = bilinear(t[k][j][0].z, t[k][j][1].z, t[k][j][2].z, t[k][j][3].z, s.hr, s.wr);
+                q.w = bilinear(t[k][j][0].w, t[k][j][1].w, t[k][j][2].w, t[k][j][3].w, s.hr, s.wr);
+                v[k][j] = s.ok ? q : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pw = pw0 + j;
+            if (pw >= PW) break;
+            float4 o;
+            if (AVG) {      // avg_pool2d(2, stride 1): fp32 running sum in window raster order, then /4
+                o.x = (((v[0][j].x + v[0][j + AVG].x) + v[AVG][j].x) + v[AVG][j + AVG].x) / 4.f;
+                o.y = (((v[0][j].y + v[0][j + AVG].y) + v[AVG][j].y) + v[AVG][j + AVG].y) / 4.f;
+                o.z = (((v[0][j].z + v[0][j + AVG].z) + v[AVG][j].z) + v[AVG][j + AVG].z) / 4.f;
+                o.w = (((v[0][j].w + v[0][j + AVG].w) + v[AVG][j].w) + v[AVG][j + AVG].w) / 4.f;
+            } else {
+                o = v[0][j];
+            }
+            float* q = out + r * os.b + ph * os.h + pw * os.w + c * os.c;
+            if (os.c == 1) {
+                *(float4*)q = o;
+            } else {
+                q[0] = o.x; q[os.c] = o.y; q[2 * os.c] = o.z; q[3 * os.c] = o.w;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- forward, any layout
 // one thread per output element; the reference's own decomposition
 // (roi_align_kernel.cu:15-70).  Used for NCHW features (inner-boundary drop-in).
@@ -426,8 +509,15 @@ extern "C" int32_t i2v_roi_align_fwd(const float* feat, int32_t feat_layout, int
     hipStream_t st = (hipStream_t)stream;
     Strides os = out_strides(out_layout, C, PH, PW);
     if (feat_layout == I2V_LAYOUT_NHWC && (C % 4) == 0) {
-        if (avg) roi_align_fwd_nhwc<1><<<R * PH, 256, 0, st>>>(feat, rois, out, C, H, W, PH, PW, scale, os);
-        else roi_align_fwd_nhwc<0><<<R * PH, 256, 0, st>>>(feat, rois, out, C, H, W, PH, PW, scale, os);
+        const int groups = (PW + 1) / 2;
+        if (!g_i2v_tuning[I2V_TUNE_ROIALIGN_COLS]) {
+            if (avg) roi_align_fwd_nhwc<1><<<R * PH, 256, 0, st>>>(feat, rois, out, C, H, W, PH, PW, scale, os);
+            else roi_align_fwd_nhwc<0><<<R * PH, 256, 0, st>>>(feat, rois, out, C, H, W, PH, PW, scale, os);
+        } else if (avg) {
+            roi_align_fwd_nhwc_cols<1><<<(R + 7) / 8 * 8 * PH * groups, 256, 0, st>>>(feat, rois, out, R, C, H, W, PH, PW, scale, os);
+        } else {
+            roi_align_fwd_nhwc_cols<0><<<(R + 7) / 8 * 8 * PH * groups, 256, 0, st>>>(feat, rois, out, R, C, H, W, PH, PW, scale, os);
+        }
     } else {
         Strides fs = feat_strides(feat_layout, C, H, W);
         long long total = (long long)R * C * PH * PW;

@@ -200,6 +200,9 @@ class SGGEmbStep:
             overlap = os.environ.get("I2V_OVERLAP", "1") != "0"
         self.overlap = bool(overlap) and use_graph
         self.ctx_bb = ops.LaunchContext(self.dev, arena=zero_arena)        # backbone branch
+        self.bb_split = os.environ.get("I2V_BB_SPLIT", "1") == "1" and use_graph and n_frames > 1
+        self.ctx_frames = [ops.LaunchContext(self.dev, arena=zero_arena) for _ in range(n_frames)] if self.bb_split else []
+        self._frame_streams = [torch.cuda.Stream(self.dev) for _ in range(n_frames)] if self.bb_split else []
         self.ctx_head = ops.LaunchContext(self.dev, arena=zero_arena)      # head branch
         self.im = self.fmap = self.fmap_head = None
         self.cur = self.nxt = self.inp = None
@@ -275,6 +278,25 @@ class SGGEmbStep:
                 self.fmap = torch.empty_like(fmap)
             self.fmap.copy_(fmap)           # static address across replays; 20 MB, ~8 us
 
+    def _backbone_per_frame(self, join=True):
+        """Captured form with ``bb_split``: the frames of the minibatch are independent chains of ~100 short kernels each
+        (a layer3 GEMM of one frame runs ~15 us, a quarter of it set-up, first-load latency and the store tail with the
+        matrix pipe idle).  One graph branch per frame: the kernels of the two chains are co-resident on every CU, the
+        fixed phases of one lie under the K loops of the other."""
+        main = torch.cuda.current_stream(self.dev)
+        n = self.im.shape[0]
+        for f in range(n):
+            st = self._frame_streams[f]
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                with self.ctx_frames[f]:
+                    with torch.no_grad():
+                        fm = self.net.RCNN_base(self.im[f:f + 1])
+                    self.fmap[f:f + 1].copy_(fm)
+        if join:
+            for f in range(n):
+                main.wait_stream(self._frame_streams[f])
+
     def _head(self):
         with self.ctx_head:
             fmap = self.fmap_head if self.overlap else self.fmap
@@ -298,6 +320,12 @@ class SGGEmbStep:
         main = torch.cuda.current_stream(self.dev)
         self._rotate()
         self.fmap_head.copy_(self.fmap)     # hand-off: features of the batch now in ``cur`` (computed by the previous call)
+        if self.bb_split:                   # one branch per frame, forked from the capturing stream itself (a fork inside a
+            self._backbone_per_frame(join=False)      # forked branch crashes hipStreamEndCapture on ROCm 7.2)
+            self._head()
+            for st in self._frame_streams:
+                main.wait_stream(st)
+            return
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
             self._backbone()                # batch k+1
@@ -352,6 +380,14 @@ class SGGEmbStep:
         self.overlap = ov
         if not self.use_graph:
             return False
+        if self.bb_split:                               # size the per-frame arenas: two eager per-frame passes
+            for _rep in range(2):
+                for f, ctx in enumerate(self.ctx_frames):
+                    with ctx:
+                        with torch.no_grad():
+                            self.net.RCNN_base(self.im[f:f + 1])
+                    ctx.fit()
+            torch.cuda.synchronize(self.dev)
         self.graph = None
         try:
             g = torch.cuda.CUDAGraph()
