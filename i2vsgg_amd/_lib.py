@@ -62,6 +62,8 @@ SIGNATURES = {
     "i2v_sgd_momentum_multi": (_i, [_p, _p, _p, _p, _p, _p, _i, _f, _p]),
     "i2v_dstyle_pool_fwd": (_i, [_p, _p, _p, _l, _i, _i, _i, _p]),
     "i2v_dstyle_pool_bwd": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _i, _p]),
+    "i2v_dstyle_fused_workspace_bytes": (_z, [_l, _i, _i, _i]),
+    "i2v_dstyle_fused_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _i, _p, _z, _p]),
     "i2v_relation_topk_workspace_bytes": (_z, [_i, _i]),
     "i2v_relation_topk": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _z, _p]),
     "i2v_image_prep_size": (_i, [_i, _i, _i, _p, _p, _p]),

@@ -1,6 +1,7 @@
 """instance_styleD detector pieces (faster_rcnn/resnet_instance_styleD_bilinear.py): the two
 discriminators and the ``resnet`` wrapper (C4 base, layer4 as ROI head, frozen BN)."""
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -14,6 +15,7 @@ from .layers import C4Base, ConvParams, load_reference_state, make_layer
 from .utils import Linear, _LinearParams
 
 RESNET_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
+FUSED_STYLE = os.environ.get("I2V_FUSED_STYLE", "1") != "0"      # 0: two GEMM launches + a pooling pass (the round-1 form)
 
 
 class netD_pixel(nn.Module):
@@ -70,9 +72,15 @@ class netD_style(nn.Module):
         x = GradReverse.apply(x, lamb)
         b, c, h, w = x.shape
         rows = ops.as_nhwc(x).permute(0, 2, 3, 1).reshape(b * h * w, c)            # (positions, 512), a view
-        x1 = ops.linear(rows, self.fc_1.weight, self.fc_1.bias)
-        x2 = ops.linear(rows, self.fc_2.weight, self.fc_2.bias)
-        z = ops.dstyle_pool(x1.view(b, h * w, -1), x2.view(b, h * w, -1), self.dim, self.rank)
+        if FUSED_STYLE:
+            # both projections, their product, the rank sum and the spatial sum in ONE kernel: the 2 x (9375 x 2560)
+            # intermediates of :122-131 never go to HBM on a forward-only call (a training call writes them once,
+            # for the backward; the separate pooling pass over them is gone either way)
+            z = ops.dstyle_fused(rows, self.fc_1.weight, self.fc_1.bias, self.fc_2.weight, self.fc_2.bias, b, self.dim, self.rank)
+        else:
+            x1 = ops.linear(rows, self.fc_1.weight, self.fc_1.bias)
+            x2 = ops.linear(rows, self.fc_2.weight, self.fc_2.bias)
+            z = ops.dstyle_pool(x1.view(b, h * w, -1), x2.view(b, h * w, -1), self.dim, self.rank)
         z = torch.sqrt(F.relu(z)) - torch.sqrt(F.relu(-z))
         z = F.normalize(z, p=2, dim=1)
         d = torch.sigmoid(ops.linear(z, self.fc1.weight, self.fc1.bias))

@@ -701,6 +701,69 @@ class _DStylePoolFn(torch.autograd.Function):
         return g1, g2, None, None
 
 
+class _DStyleFusedFn(torch.autograd.Function):
+    """netD_style's two projections + bilinear pooling as one kernel (i2v_dstyle_fused_fwd).  Forward-only calls keep
+    nothing but z; when a gradient will be asked for, the projections are written as well and the backward is the
+    existing chain on them: g1 = gz*x2, g2 = gz*x1 (one pass), then for each projection the bias column sums, the data
+    gradient and the filter gradient of a linear layer."""
+
+    @staticmethod
+    def forward(ctx, rows, w1, b1, w2, b2, n_img, dim, rank):
+        _need_cuda(rows, w1, b1, w2, b2)
+        rows, w1, w2 = rows.contiguous(), w1.contiguous(), w2.contiguous()
+        M, K = rows.shape
+        P = M // n_img
+        N = dim * rank
+        dev = rows.device
+        keep = any(ctx.needs_input_grad[:5])
+        z = torch.empty((n_img, dim), device=dev, dtype=torch.float32)
+        x1 = torch.empty((M, N), device=dev, dtype=torch.float32) if keep else None
+        x2 = torch.empty((M, N), device=dev, dtype=torch.float32) if keep else None
+        ws = workspace(lib.i2v_dstyle_fused_workspace_bytes(P, n_img, dim, rank), dev, "dstyle")
+        with _Timed(2.0 * 2 * M * N * K, "fwd", "dstyle fused M%d N2x%d K%d" % (M, N, K),
+                    4 * (rows.numel() + 2 * w1.numel() + (2 * M * N if keep else 0))):
+            check(lib.i2v_dstyle_fused_fwd(ptr(rows), ptr(w1), ptr(b1.contiguous()), ptr(w2), ptr(b2.contiguous()), ptr(z),
+                                           ptr(x1), ptr(x2), P, n_img, K, dim, rank, ptr(ws), ws.numel(), stream()),
+                  "dstyle_fused_fwd")
+        ctx.save_for_backward(rows, w1, w2, x1, x2)
+        ctx.cfg = (n_img, dim, rank)
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        rows, w1, w2, x1, x2 = ctx.saved_tensors
+        n_img, dim, rank = ctx.cfg
+        M, K = rows.shape
+        N = dim * rank
+        g1, g2 = torch.empty_like(x1), torch.empty_like(x2)
+        check(lib.i2v_dstyle_pool_bwd(ptr(gz.contiguous()), ptr(x1), ptr(x2), ptr(g1), ptr(g2), M // n_img, n_img, dim, rank,
+                                      stream()), "dstyle_pool_bwd")
+        rows4 = rows.view(M, K, 1, 1)
+        grows = gw1 = gb1 = gw2 = gb2 = None
+        outs = []
+        for g, w, need_w, need_b in ((g1, w1, ctx.needs_input_grad[1], ctx.needs_input_grad[2]),
+                                    (g2, w2, ctx.needs_input_grad[3], ctx.needs_input_grad[4])):
+            g4 = g.view(M, N, 1, 1)
+            gb = None
+            if need_b:
+                gb = ARENA.take_flat(N) if ARENA is not None else None
+                if gb is None:
+                    gb = torch.zeros((N,), device=g.device, dtype=torch.float32)
+                check(lib.i2v_epilogue_bwd(ptr(g), None, None, None, None, ptr(gb), M, N, 0, None, stream()), "epilogue_bwd")
+            gw = _conv_wgrad_raw(rows4, g4, (N, K, 1, 1), 1, 0).view(N, K) if need_w else None
+            gx = _conv_dgrad_raw(g4, w.view(N, K, 1, 1), (M, K, 1, 1), 1, 0).view(M, K) if ctx.needs_input_grad[0] else None
+            outs.append((gx, gw, gb))
+        if ctx.needs_input_grad[0]:
+            grows = outs[0][0].add_(outs[1][0])
+        return grows, outs[0][1], outs[0][2], outs[1][1], outs[1][2], None, None, None
+
+
+def dstyle_fused(rows, w1, b1, w2, b2, n_img, dim, rank):
+    """z (n_img, dim) of netD_style from the (n_img * positions, 512) rows of the style tap: both 512 -> dim*rank
+    projections and the product / rank / spatial reduction in one kernel."""
+    return _DStyleFusedFn.apply(rows, w1, b1, w2, b2, int(n_img), int(dim), int(rank))
+
+
 def dstyle_pool(x1, x2, dim, rank):
     """z[b,d] = sum_pos sum_r x1[b,pos,d*rank+r]*x2[b,pos,d*rank+r] (x1,x2: (B,rows,dim*rank))."""
     return _DStylePoolFn.apply(x1, x2, int(dim), int(rank))

@@ -301,6 +301,15 @@ int32_t i2v_dstyle_pool_fwd(const float* x1, const float* x2, float* z, int64_t 
                             int32_t dim, int32_t rank, void* stream);
 int32_t i2v_dstyle_pool_bwd(const float* gz, const float* x1, const float* x2, float* g1, float* g2,
                             int64_t rows, int32_t n_img, int32_t dim, int32_t rank, void* stream);
+/* netD_style's bilinear pooling fused into the projection GEMMs (resnet_instance_styleD_bilinear.py:122-136): one kernel
+ * computes x1 = x*W1^T + b1 and x2 = x*W2^T + b2 tile by tile (x (n_img*rows, k); W (dim*rank, k) each) and reduces
+ * x1*x2 over the tile's positions in its epilogue; a second small kernel sums the per-tile partial rows (fixed order:
+ * reproducible) and the rank groups into z (n_img, dim).  x1 / x2 (n_img*rows, dim*rank) are written only when both
+ * pointers are given (a training step keeps them for i2v_dstyle_pool_bwd); NULL, NULL = nothing but z leaves the kernel. */
+size_t  i2v_dstyle_fused_workspace_bytes(int64_t rows, int32_t n_img, int32_t dim, int32_t rank);
+int32_t i2v_dstyle_fused_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                             float* z, float* x1, float* x2, int64_t rows, int32_t n_img, int32_t k, int32_t dim,
+                             int32_t rank, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- small fused pieces of the relation head's tail ---------------------------------------------
  * rows here are 64 x 300, so each aten op of the reference expression is one launch-bound kernel.

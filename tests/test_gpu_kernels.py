@@ -784,3 +784,35 @@ def test_pointwise_gemm_kernel_batched_planes(ops):
     assert torch.equal(out[1], out[0])
     ref = torch.bmm(a.double(), b.double().transpose(1, 2)).float()
     np.testing.assert_allclose(out[1].cpu().numpy(), ref.cpu().numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("n_img,P", [(2, 75), (1, 608), (2, 9375)])
+def test_dstyle_fused_equals_projections_plus_pooling(ops, n_img, P):
+    """netD_style's fused kernel (two projections + product + rank / spatial sums, resnet_instance_styleD_bilinear.py:
+    122-131) against the two-GEMM + pooling-pass form it replaces: z within fp32 summation-order noise, every gradient
+    (input rows, both filters, both biases) likewise; a forward-only call gives the same z without writing projections."""
+    rng = np.random.default_rng(n_img * 1000 + P)
+    dim, rank, K = 512, 5, 512
+    M, N = n_img * P, dim * rank
+    mk = lambda shape, s: torch.from_numpy((rng.standard_normal(shape, dtype=np.float32) * s).astype(np.float32)).to(DEV)
+    rows0, w1, b1, w2, b2 = mk((M, K), 1.0), mk((N, K), 0.03), mk((N,), 0.02), mk((N, K), 0.03), mk((N,), 0.02)
+    gz = mk((n_img, dim), 1.0)
+    out = {}
+    for fused in (True, False):
+        t = [a.clone().requires_grad_() for a in (rows0, w1, b1, w2, b2)]
+        if fused:
+            z = ops.dstyle_fused(t[0], t[1], t[2], t[3], t[4], n_img, dim, rank)
+        else:
+            x1, x2 = ops.linear(t[0], t[1], t[2]), ops.linear(t[0], t[3], t[4])
+            z = ops.dstyle_pool(x1.view(n_img, P, N), x2.view(n_img, P, N), dim, rank)
+        z.backward(gz)
+        out[fused] = [z.detach()] + [a.grad for a in t]
+    for a, b in zip(out[True], out[False]):
+        scale = float(b.abs().max())
+        assert float((a - b).abs().max()) <= 2e-5 * scale + 1e-6, (float((a - b).abs().max()), scale)
+    with torch.no_grad():
+        z0 = ops.dstyle_fused(rows0, w1, b1, w2, b2, n_img, dim, rank)
+    assert torch.equal(z0, out[True][0])
+    ref = (((rows0.double() @ w1.double().t() + b1.double()) * (rows0.double() @ w2.double().t() + b2.double()))
+           .view(n_img, P, dim, rank).sum((1, 3)))
+    assert float((z0.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
