@@ -194,24 +194,35 @@ def run_sgg(a, rank, world, dev, frames_per_rank=2):
     ov, step.overlap = step.overlap, False
     rec = profile_eager(step._body, n_prof, dev)
     step.overlap = ov
-    # the calls that run on conv_igemm_f32: every forward and the convolution data gradients (linear-layer data
-    # gradients run on the wgrad kernel with the roles swapped and are reported under by_kind only)
+    # The dominant kernel of the step is conv_gemm_f32 (the pointwise layers of the bottlenecks: 60 of the ~110 GEMM launches
+    # and most of the conv time): every call tagged [gemm] is exactly one launch of it, so flops / HIP-event time of those
+    # calls is the kernel's own rate.  `all_conv` keeps the whole-backbone view (every i2v_conv_fwd / convolution _dgrad
+    # call, Winograd transform kernels included in the time): executed MACs (Winograd F(4x4,3x3) runs 1/4 of the direct
+    # count, F(2x2) 4/9) and the direct convolution's algorithmic count.
+    gemm = [r for r in rec if r["tag"] == "fwd" and "[gemm]" in r["desc"]]
+    t_gemm = sum(r["t"] for r in gemm)
+    f_gemm = sum(r["flops"] for r in gemm)
+    b_gemm = sum(r["bytes"] for r in gemm)
+    n_gemm = max(len(gemm) // n_prof, 1)
     conv = [r for r in rec if r["tag"] in ("fwd", "dgrad") and "(wgrad form)" not in r["desc"]]
     t_conv = sum(r["t"] for r in conv)
     f_alg = sum(r["flops"] for r in conv)
-    # the MACs the matrix cores actually execute: Winograd F(4x4,3x3) runs 36/16 = 2.25 products per output where the direct
-    # form runs 9 (F(2x2): 16/4 = 4 against 9)
     f_exec = sum(r["flops"] * (0.25 if "winograd F4" in r["desc"] else 4.0 / 9.0 if "winograd" in r["desc"] else 1.0) for r in conv)
-    b_alg = sum(r["bytes"] for r in conv)
-    n_launch = max(len(conv) // n_prof, 1)
     if a.dump_launches and rank == 0:
         per = len(rec) // n_prof
         with open(a.dump_launches, "w") as f:
             for r in rec[-per:]:
-                f.write("%-6s %-44s %8.1f us %7.2f GF %6.1f TF %8.2f MB\n" % (
+                f.write("%-6s %-52s %8.1f us %7.2f GF %6.1f TF %8.2f MB\n" % (
                     r["tag"], r["desc"], r["t"] * 1e6, r["flops"] / 1e9, r["flops"] / r["t"] / 1e12, r["bytes"] / 1e6))
-    traffic, traffic_src = pmc_traffic("conv_igemm_f32")
-    achieved = f_exec / t_conv / 1e12
+    traffic, traffic_src = pmc_traffic("conv_gemm_f32")
+    achieved = f_gemm / max(t_gemm, 1e-12) / 1e12
+    # algorithmic bytes of EVERY conv_gemm_f32 launch of a step, for the comparison with the PMC traffic (which averages over
+    # all launches of the kernel): the pointwise calls + the batched plane GEMM inside every Winograd call
+    import re
+    wino = [r for r in rec if "winograd" in r["desc"] and "gemmMB=" in r["desc"]]
+    b_wino = sum(float(re.search(r"gemmMB=([0-9.]+)", r["desc"]).group(1)) * 1e6 for r in wino)
+    n_all = max((len(gemm) + len(wino)) // n_prof, 1)
+    b_all = (b_gemm + b_wino) / n_prof / n_all
     tp = getattr(step, "tp", False)
     line = {
         "metric": "frames/sec (600x1000, 32 ROI/frame)", "value": world * frames_per_rank * a.steps / elapsed,
@@ -230,19 +241,26 @@ def run_sgg(a, rank, world, dev, frames_per_rank=2):
                                 "inside the timed region") if step.overlap
                    else "one graph per step: backbone fwd, head fwd+bwd, fused wgrad+SGD" if graphed else "eager launches",
                    "loss": loss},
-        "roofline": {"bound": "mfma", "kernel": "conv_igemm_f32 (every i2v_conv_fwd call and every convolution _dgrad call, "
-                                                "Winograd transform kernels included in the time)",
+        "roofline": {"bound": "mfma", "kernel": "conv_gemm_f32 (pointwise bottleneck layers and the other plain GEMMs it serves; one "
+                                                "launch per call)",
                      "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                     "note": ("achieved = MACs the matrix cores EXECUTE x 2 / summed call durations (the 30 frozen 3x3 layers of "
-                              "layer1-3 run as Winograd F(4x4,3x3): 1/4 of the direct count); algorithmic_tflops counts the "
-                              "direct convolution's 2*M*N*K instead.  Durations: HIP events on the launch stream around "
-                              "every call of %d eager steps of the same objects") % n_prof,
-                     "algorithmic_tflops": f_alg / t_conv / 1e12,
-                     "algorithmic_frac": f_alg / t_conv / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                     "algorithmic_bytes_per_launch": b_alg / n_prof / n_launch,
-                     "launches_per_step": n_launch, "avg_launch_us": 1e6 * t_conv / max(len(conv), 1),
-                     "gflop_executed_per_step": f_exec / n_prof / 1e9, "gflop_algorithmic_per_step": f_alg / n_prof / 1e9,
+                     "note": ("achieved = 2*M*N*K of every conv_gemm_f32 launch of a step / the summed launch durations (HIP events "
+                              "on the launch stream around every call of %d eager steps of the same objects); all MACs are "
+                              "executed MACs.  all_conv = every convolution forward / data-gradient call of the step "
+                              "(Winograd layers included with their transform kernels)") % n_prof,
+                     "launches_per_step": n_gemm, "avg_launch_us": 1e6 * t_gemm / max(len(gemm), 1),
+                     "algorithmic_bytes_per_launch": b_all, "launches_per_step_incl_winograd_planes": n_all,
+                     "traffic_over_algorithmic": (traffic / b_all) if traffic else None,
+                     "algorithmic_bytes_per_pointwise_launch": b_gemm / n_prof / n_gemm,
+                     "gflop_per_step": f_gemm / n_prof / 1e9,
+                     "all_conv": {"ms_per_step": 1e3 * t_conv / n_prof, "launches_per_step": len(conv) // n_prof,
+                                  "executed_tflops": f_exec / t_conv / 1e12,
+                                  "executed_frac": f_exec / t_conv / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                  "algorithmic_tflops": f_alg / t_conv / 1e12,
+                                  "algorithmic_frac": f_alg / t_conv / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                  "gflop_executed_per_step": f_exec / n_prof / 1e9,
+                                  "gflop_algorithmic_per_step": f_alg / n_prof / 1e9},
                      "by_kind": by_kind(rec, n_prof)},
     }
     return line, step, net

@@ -420,8 +420,15 @@ def _conv_fwd_raw(x, w, scale, shift, res, stride, pad, flags):
             flags |= EPI_ZEROED
     if y is None:
         y = torch.empty((B, Cout, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=_CL)
+    # which kernel serves the call (profiling only): pointwise layers whose split-K, if any, finishes in the kernel run on
+    # conv_gemm_f32, everything else on conv_igemm_f32 (csrc/conv.hip, launch_tile)
+    kern = ""
+    if PROFILE is not None:
+        pointwise = (KH, KW, stride, pad) == (1, 1, 1, 0) and Cout % 4 == 0 and Cin % 4 == 0
+        kern = " [gemm]" if pointwise and lib.i2v_get_tuning(10) and \
+            lib.i2v_conv_fwd_splits(B, H, W, Cin, Cout, KH, KW, stride, pad, sws.numel()) == 0 else " [igemm]"
     with _Timed(2.0 * B * Ho * Wo * Cout * KH * KW * Cin, "fwd",
-                "M%d N%d K%d (%dx%d s%d)" % (B * Ho * Wo, Cout, KH * KW * Cin, KH, KW, stride),
+                "M%d N%d K%d (%dx%d s%d)%s" % (B * Ho * Wo, Cout, KH * KW * Cin, KH, KW, stride, kern),
                 4 * (x.numel() + w.numel() + y.numel() + (res.numel() if res is not None else 0))):
         check(lib.i2v_conv_fwd(ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(res), ptr(y), B, H, W, Cin, Cout, KH, KW,
                                stride, pad, flags, ptr(sws), sws.numel(), stream()), "conv_fwd")
@@ -975,8 +982,12 @@ def conv3x3_winograd(x, U, scale=None, shift=None, relu=False, tag="fwd"):
     wsb = (lib.i2v_conv3x3_winograd4_workspace_bytes if four else lib.i2v_conv3x3_winograd_workspace_bytes)(B, H, W, Cin, Cout)
     ws = workspace(wsb, x.device, "winograd")
     fn = lib.i2v_conv3x3_winograd4_fwd if four else lib.i2v_conv3x3_winograd_fwd
+    # the batched GEMM of the call is one conv_gemm_f32 launch over the planes: its operand bytes, for the traffic roofline
+    planes, tl = (36, 4) if four else (16, 2)
+    T = B * ((H + tl - 1) // tl) * ((W + tl - 1) // tl)
+    gemm_mb = 4e-6 * planes * (T * Cin + Cout * Cin + T * Cout)
     with _Timed(2.0 * B * H * W * Cout * 9 * Cin, tag,
-                "M%d N%d K%d (3x3 winograd F%d)" % (B * H * W, Cout, 9 * Cin, 4 if four else 2),
+                "M%d N%d K%d (3x3 winograd F%d) gemmMB=%.2f" % (B * H * W, Cout, 9 * Cin, 4 if four else 2, gemm_mb),
                 4 * (x.numel() + 9 * Cout * Cin + y.numel())):
         check(fn(ptr(x), ptr(U), ptr(scale), ptr(shift), ptr(y), B, H, W, Cin, Cout, int(bool(relu)), ptr(ws), ws.numel(),
                  stream()), "conv3x3_winograd_fwd")

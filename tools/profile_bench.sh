@@ -1,13 +1,13 @@
 #!/bin/bash
 # The rocprofv3 evidence behind bench.py's roofline block; run on the GPU box from the repo root.
-#   tools/profile_bench.sh [steps] [warmup]   -> gpurun_out/prof_bench/{trace,fetch,write} + profiles/r01_*
+#   tools/profile_bench.sh [steps] [warmup]   -> gpurun_out/prof_bench/{trace,fetch,write} + gpurun_out/r02_* (copy to profiles/)
 set -e
 steps=${1:-6}; warm=${2:-2}
 export TMPDIR=/tmp
 out=gpurun_out/prof_bench
 rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- python3 bench.py --steps $steps --warmup $warm --no-cpu-baseline --no-graph > $out/trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o bench -- python3 bench.py --steps $steps --warmup $warm --no-cpu-baseline --no-graph > $out/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o bench -- python3 bench.py --steps $steps --warmup $warm --no-cpu-baseline --no-graph > $out/write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- python3 bench.py --steps $steps --warmup $warm --no-cpu-baseline --no-also --no-graph > $out/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o bench -- python3 bench.py --steps $steps --warmup $warm --no-cpu-baseline --no-also --no-graph > $out/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o bench -- python3 bench.py --steps $steps --warmup $warm --no-cpu-baseline --no-also --no-graph > $out/write.log 2>&1
 # every eager step of the run: capture warm-up (2) + W + K + the 3 event-timed steps of the roofline block, see bench.py
-python3 tools/pmc_summary.py $out $((steps + warm + 2 + 3)) gpurun_out/r01
+python3 tools/pmc_summary.py $out $((steps + warm + 2 + 3)) gpurun_out/r02
