@@ -34,9 +34,15 @@ class _fasterRCNN(nn.Module):
         self.RCNN_roi_align = RoIAlignAvg(cfg.POOLING_SIZE, cfg.POOLING_SIZE, 1.0 / 16.0)
 
     def forward(self, im_data, im_info, gt_boxes, num_boxes, target=False, eta=1.0, eta_style=1.0):
-        batch_size = im_data.size(0)
-        im_info, gt_boxes, num_boxes = im_info.data, gt_boxes.data, num_boxes.data
         base_feat, base_feat1 = self.extract_feature(im_data)
+        return self.forward_features(base_feat, base_feat1, im_info, gt_boxes, num_boxes, target, eta, eta_style)
+
+    def forward_features(self, base_feat, base_feat1, im_info, gt_boxes, num_boxes, target=False, eta=1.0, eta_style=1.0):
+        """Everything of ``forward`` behind ``extract_feature`` (:62-182).  A training step that runs the backbone ONCE
+        over the source and target frames of a D+G step (frozen BN: no cross-frame statistics, so one 8-frame pass equals
+        two 4-frame passes) calls this twice, on the two halves of the feature maps (train.InstanceStyleDStep)."""
+        batch_size = base_feat.size(0)
+        im_info, gt_boxes, num_boxes = im_info.data, gt_boxes.data, num_boxes.data
         if self.gc:
             d_style, _ = self.netD_style(base_feat1, eta_style)
             if not target:

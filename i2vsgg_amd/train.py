@@ -440,6 +440,28 @@ def _graph_launch_guard():
                            "torch.cuda is initialised does it) or run the step on a stream made with torch.cuda.Stream()")
 
 
+class _SplitBatch(torch.autograd.Function):
+    """(x[:n], x[n:]) along the batch axis as views; the backward writes the two gradients into ONE buffer (autograd's own
+    slice backward zero-fills a full-size tensor per slice and adds them)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n, ctx.shape = n, tuple(x.shape)
+        ctx.fmt = torch.channels_last if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) else torch.contiguous_format
+        return x[:n], x[n:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        ref = ga if ga is not None else gb
+        out = torch.empty(ctx.shape, device=ref.device, dtype=ref.dtype, memory_format=ctx.fmt)
+        for dst, g in ((out[:ctx.n], ga), (out[ctx.n:], gb)):
+            if g is None:
+                dst.zero_()
+            else:
+                dst.copy_(g)
+        return out, None
+
+
 class InstanceStyleDStep:
     """One D+G adversarial step (trainval_net_instance_styleD_bilinear.py:262-341): source forward with
     detection + RPN losses and 0.5*mean(d^2) for both discriminators, target forward with
@@ -463,6 +485,9 @@ class InstanceStyleDStep:
         gt, nb = syn.gt_boxes(seed, n_frames, n_gt, net.n_classes, cfg.MAX_NUM_GT_BOXES, h, w)
         to = lambda a: torch.from_numpy(a).to(self.dev)
         self.im_s, self.im_t, self.info, self.gt, self.nb = to(ims), to(imt), to(info), to(gt), to(nb)
+        import os
+        self.batched = os.environ.get("I2V_ISD_BATCHED", "1") != "0"
+        self.im_st = torch.cat((self.im_s, self.im_t), 0) if self.batched else None
         self.gt_t = torch.zeros((n_frames, 1, 5), device=self.dev)
         self.nb_t = torch.zeros((n_frames,), device=self.dev)
         self.opt = FusedSGD(list(net.named_parameters()), lr)
@@ -472,17 +497,32 @@ class InstanceStyleDStep:
         self.losses = {k: torch.zeros((), device=self.dev) for k in self.names}     # static addresses: a captured step writes here
         self.graph = None
         self.graph_error = None
+        self._fitted = False
 
     def _body(self):
         net = self.net
         with self.ctx:
-            out = net(self.im_s, self.info, self.gt, self.nb, target=False, eta=self.eta, eta_style=self.eta_style)
+            if self.batched:
+                # ONE backbone pass over the source and the target frames (the reference makes two, :271 and :293; with
+                # frozen BN they are the same arithmetic): half the launches of the trunk's forward, data-gradient and
+                # filter-gradient kernels, each over twice the pixels, and no accumulation adds between two backward
+                # passes through the same filters
+                feat, feat1 = net.extract_feature(self.im_st)
+                n = self.im_s.shape[0]
+                (fs, ft), (f1s, f1t) = _SplitBatch.apply(feat, n), _SplitBatch.apply(feat1, n)
+                out = net.forward_features(fs, f1s, self.info, self.gt, self.nb, False, self.eta, self.eta_style)
+            else:
+                out = net(self.im_s, self.info, self.gt, self.nb, target=False, eta=self.eta, eta_style=self.eta_style)
             _, _, _, l_rpn_cls, l_rpn_box, l_cls, l_box, _, d_inst, d_style = out
             loss = l_rpn_cls.mean() + l_rpn_box.mean() + l_cls.mean() + l_box.mean()
             dloss_s = 0.5 * torch.mean(d_inst ** 2)
             dloss_s_style = 0.5 * torch.mean(d_style ** 2)
-            d_inst_t, d_style_t = net(self.im_t, self.info, self.gt_t, self.nb_t, target=True, eta=self.eta,
-                                      eta_style=self.eta_style)
+            if self.batched:
+                d_inst_t, d_style_t = net.forward_features(ft, f1t, self.info, self.gt_t, self.nb_t, True, self.eta,
+                                                           self.eta_style)
+            else:
+                d_inst_t, d_style_t = net(self.im_t, self.info, self.gt_t, self.nb_t, target=True, eta=self.eta,
+                                          eta_style=self.eta_style)
             dloss_t = 0.5 * torch.mean((1 - d_inst_t) ** 2)
             dloss_t_style = 0.5 * torch.mean((1 - d_style_t) ** 2)
             total = loss + dloss_s + dloss_t + self.style_lambda * (dloss_s_style + dloss_t_style)
@@ -536,6 +576,9 @@ class InstanceStyleDStep:
     def __call__(self):
         if self.graph is None:
             self._body()
+            if not self._fitted:            # eager use: size the arena of atomically accumulated outputs after the first step
+                self.ctx.fit()
+                self._fitted = True
         else:
             _graph_launch_guard()
             self.graph.replay()
