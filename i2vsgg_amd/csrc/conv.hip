@@ -1218,6 +1218,7 @@ struct WgP {
     float* sgd_m; float lr, mom, wd;       // sgd_m != NULL: gw is the PARAMETER, updated in place (fused SGD)
     unsigned x_bytes, gy_bytes;            // buffer descriptor sizes (v2 kernel)
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, M, N, K, m_per_split, lgCin;
+    unsigned long long* clk;               // diagnostic (i2v_conv_debug_clock): per-workgroup stamps, CLK instantiation only
 };
 
 template <int BM, int BN>   // BM over n (Cout), BN over k; 4 waves as 2x2, 64x64 tiles: BM=BN=64 -> wave 32x32
@@ -1340,9 +1341,11 @@ conv_wgrad_f32(const WgP p) {
 // an in-register transpose, four ds_write_b128 -- no scalar LDS traffic, no bank-conflicted transposes.
 // FUSED_SGD: the instantiation that runs the SGD update in its epilogue (prefetches the filter / momentum tiles:
 // +34 VGPRs, four waves per SIMD instead of five -- which the plain gradient kernel should not pay)
-template <int TM, int TN, bool FUSED_SGD = false>       // tile = (2*TM*16) filters x (2*TN*16) taps, 4 waves as 2x2
+template <int TM, int TN, bool FUSED_SGD = false, bool CLK = false>       // tile = (2*TM*16) filters x (2*TN*16) taps, 4 waves as 2x2
 __global__ void __launch_bounds__(THREADS)
 conv_wgrad2_f32(const WgP p) {
+    unsigned long long c_rt0 = 0, c_t0 = 0, c_t1 = 0, c_t2 = 0;
+    if constexpr (CLK) { c_rt0 = __builtin_amdgcn_s_memrealtime(); c_t0 = __builtin_amdgcn_s_memtime(); }
     constexpr int BMW = 2 * TM * 16, BNW = 2 * TN * 16;
     constexpr int A_BLK = BMW * 2, B_BLK = BNW * 2;             // (cols/4) * 8 row-groups
     constexpr int NBLK = (A_BLK + B_BLK + THREADS - 1) / THREADS;
@@ -1391,7 +1394,22 @@ conv_wgrad2_f32(const WgP p) {
         }
     }
     float4 r[NBLK][4];
-    const bool lin = p.H == 1 && p.W == 1 && p.KH == 1 && p.KW == 1 && p.pad == 0 && p.stride == 1;     // uniform
+    // pointwise layers on the same grid (and linear layers): input pixel index == output pixel index, no pixel arithmetic
+    const bool lin = p.KH == 1 && p.KW == 1 && p.pad == 0 && p.stride == 1;     // uniform
+    // other filters: the (ox, oy, b) of a block's first pixel is divided out ONCE and then carried from stage to stage
+    // (stages advance by 32 pixels; one conditional wrap suffices while a row holds at least 32 pixels) -- the three
+    // integer divisions per stage and block were ~100 of the ~250 vector instructions a stage issues beside its 32 MFMAs
+    // (tools/wgrad_phase.py: 6.2k cycles per stage against 4.1k of MFMA time at 4 workgroups per CU)
+    const bool carry = p.Wo >= BKS;
+    int sx[NBLK], sy[NBLK], sb[NBLK];
+#pragma unroll
+    for (int q = 0; q < NBLK; ++q) {
+        const int m0 = mbeg + 4 * m4[q];
+        sx[q] = m0 % p.Wo;
+        const int tt = m0 / p.Wo;
+        sy[q] = tt % p.Ho;
+        sb[q] = tt / p.Ho;
+    }
     // No divergent control flow around the loads: the A/B role of a block is uniform per wave (A_BLK is a multiple of
     // 128), so the descriptor is picked with a scalar select, and a masked element gets the 2 GiB bit OR-ed into its
     // offset (the buffer returns 0) -- written as `cond ? off : OOB` the compiler wraps every load in its own branch.
@@ -1401,13 +1419,27 @@ conv_wgrad2_f32(const WgP p) {
             const bool a_u = __builtin_amdgcn_readfirstlane((int)is_a[q]) != 0;
             const __amdgpu_buffer_rsrc_t rs = a_u ? gr : xr;
             const int m0 = ms + 4 * m4[q];
-            int ox = 0, oy = 0, b = 0;
-            if (!a_u && !lin) {             // one division pair per 4 consecutive pixels, the rest by carry
-                ox = m0 % p.Wo;
-                const int tt = m0 / p.Wo;
-                oy = tt % p.Ho;
-                b = tt / p.Ho;
+            int ox = sx[q], oy = sy[q], b = sb[q];
+            if (!a_u && !lin) {
+                if (carry) {                // next stage: 32 pixels on
+                    int nx = ox + BKS, ny = oy, nb = b;
+                    if (nx >= p.Wo) { nx -= p.Wo; ++ny; if (ny == p.Ho) { ny = 0; ++nb; } }
+                    sx[q] = nx; sy[q] = ny; sb[q] = nb;
+                } else {                    // short rows (the 7x7 / 4x4 maps of the ROI head): divide
+                    ox = m0 % p.Wo;
+                    const int tt = m0 / p.Wo;
+                    oy = tt % p.Ho;
+                    b = tt / p.Ho;
+                }
             }
+            // the block's 4 consecutive pixels: offsets from the first one's by increments (a pixel past the end of the row
+            // moves to the next row -- or the next image -- by one precomputed delta: rows hold >= 4 pixels)
+            const int iy0 = oy * p.stride - p.pad + ky[q], ix0 = ox * p.stride - p.pad + kx[q];
+            const int base = ((b * p.H + iy0) * p.W + ix0) * p.Cin + coff[q];
+            const bool last_row = oy + 1 == p.Ho;
+            const int iy1 = last_row ? ky[q] - p.pad : iy0 + p.stride;                     // row of the pixels after a wrap
+            const int wrap_delta = ((last_row ? p.H - (p.Ho - 1) * p.stride : p.stride) * p.W - p.Wo * p.stride) * p.Cin;
+            const bool y0_in = iy0 >= 0 && iy0 < p.H, y1_in = iy1 >= 0 && iy1 < p.H;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int m = m0 + t;
@@ -1415,8 +1447,14 @@ conv_wgrad2_f32(const WgP p) {
                 if (a_u) {
                     off = (unsigned)(m * p.N + coff[q]) * 4u;
                 } else if (lin) {
-                    off = (unsigned)(m * p.Cin + coff[q]) * 4u;         // linear layer: row m of x, no pixel arithmetic
-                } else {
+                    off = (unsigned)(m * p.Cin + coff[q]) * 4u;         // pointwise / linear layer: row m of x
+                } else if (p.Wo >= 4) {
+                    const bool w = ox + t >= p.Wo;
+                    const int ix = ix0 + t * p.stride - (w ? p.Wo * p.stride : 0);
+                    const bool inside = (w ? y1_in : y0_in) && ix >= 0 && ix < p.W;
+                    off = (unsigned)(base + t * p.stride * p.Cin + (w ? wrap_delta : 0)) * 4u;
+                    off |= inside ? 0u : 0x80000000u;
+                } else {                    // rows shorter than a block: pixel by pixel
                     const int iy = oy * p.stride - p.pad + ky[q], ix = ox * p.stride - p.pad + kx[q];
                     const bool inside = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
                     off = (unsigned)(((b * p.H + iy) * p.W + ix) * p.Cin + coff[q]) * 4u;
@@ -1506,6 +1544,7 @@ conv_wgrad2_f32(const WgP p) {
     gload(mbeg);
     sstore(0);
     __syncthreads();
+    if constexpr (CLK) c_t1 = __builtin_amdgcn_s_memtime();
     int buf = 0;
     for (int ms = mbeg; ms < mend; ms += BKS) {
         const bool more = ms + BKS < mend;
@@ -1515,6 +1554,7 @@ conv_wgrad2_f32(const WgP p) {
         __syncthreads();
         buf ^= 1;
     }
+    if constexpr (CLK) c_t2 = __builtin_amdgcn_s_memtime();
 
     // epilogue through LDS: rows = filters n, columns = taps k (contiguous in gw)
 #pragma unroll
@@ -1564,6 +1604,15 @@ conv_wgrad2_f32(const WgP p) {
             const int row = e / BNW, col = e % BNW;
             const int n = n0 + row, k = k0 + col;
             if (n < p.N && k < p.K) atomicAdd(p.gw + (long long)n * p.K + k, smem[row * CROW + col]);
+        }
+    }
+    if constexpr (CLK) {
+        __builtin_amdgcn_s_waitcnt(0);
+        if (tid == 0 && p.clk) {
+            unsigned long long* o = p.clk + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
+            o[0] = c_rt0; o[1] = __builtin_amdgcn_s_memrealtime();
+            o[2] = c_t1 - c_t0; o[3] = c_t2 - c_t1; o[4] = __builtin_amdgcn_s_memtime() - c_t2;
+            o[5] = __builtin_amdgcn_s_getreg(63492); o[6] = __builtin_amdgcn_s_getreg(63508); o[7] = 1;
         }
     }
 }
@@ -1772,7 +1821,9 @@ static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st) {
     int splits = 1;
     const int msteps = i2v_cdiv(p.M, rs);
     if (!fused) {
-        splits = (int)((4 * NUM_CU + tiles - 1) / tiles);
+        // one round of workgroups: floor, not ceil (144 tiles x 8 splits = 1152 workgroups on 1024 slots ran 1.5 rounds)
+        const int per_cu = g_i2v_tuning[I2V_TUNE_WGRAD_PER_CU];
+        splits = (int)((long long)per_cu * NUM_CU / tiles);
         if (splits > msteps / 4) splits = msteps / 4;
         if (splits < 1) splits = 1;
     }
@@ -1788,6 +1839,7 @@ static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st) {
     else if (tm == 128 && tk == 128) conv_wgrad2_f32<4, 4><<<grid, THREADS, 0, st>>>(p);
     else if (tm == 128) conv_wgrad2_f32<4, 2><<<grid, THREADS, 0, st>>>(p);
     else if (fused) conv_wgrad2_f32<2, 2, true><<<grid, THREADS, 0, st>>>(p);
+    else if (g_clk) { p.clk = g_clk; conv_wgrad2_f32<2, 2, false, true><<<grid, THREADS, 0, st>>>(p); }
     else conv_wgrad2_f32<2, 2><<<grid, THREADS, 0, st>>>(p);
     return true;
 }
