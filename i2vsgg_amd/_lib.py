@@ -51,6 +51,7 @@ SIGNATURES = {
     "i2v_conv3x3_winograd4_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "i2v_conv_set_tile": (_i, [_i]),
     "i2v_conv_debug_clock": (_i, [_p]),
+    "i2v_debug_clock_stamp": (_i, [_p, _p]),
     "i2v_conv_dgrad_workspace_bytes": (_z, [_i, _i, _i, _i]),
     "i2v_conv_dgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p, _z, _p]),
     "i2v_conv_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),

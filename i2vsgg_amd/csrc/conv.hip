@@ -1860,6 +1860,18 @@ extern "C" int32_t i2v_conv_debug_clock(void* buf) {
     return I2V_OK;
 }
 
+namespace {
+__global__ void clock_stamp_kernel(unsigned long long* out) {
+    if (threadIdx.x == 0) { out[0] = __builtin_amdgcn_s_memtime(); out[1] = __builtin_amdgcn_s_memrealtime(); }
+}
+}  // namespace
+
+extern "C" int32_t i2v_debug_clock_stamp(void* out2, void* stream) {
+    clock_stamp_kernel<<<1, 64, 0, (hipStream_t)stream>>>((unsigned long long*)out2);
+    I2V_CHECK_LAUNCH("i2v_debug_clock_stamp");
+    return I2V_OK;
+}
+
 extern "C" int32_t i2v_conv_set_tile(int32_t cfg) {
     if (cfg < 0) { g_force_tile = -1; g_spec_mode = -1; g_ablate = 0; return I2V_OK; }
     g_force_tile = (cfg & 0xFF) == 0xFF ? -1 : (cfg & 0xFF);

@@ -233,6 +233,9 @@ int32_t i2v_conv_set_tile(int32_t cfg);
  * ticks since kernel start, setup cycles, total cycles, then (specialised kernel only) loader LDS-store / load-issue /
  * barrier cycles and MFMA-wave compute cycles}; the in-kernel clock is total cycles / ticks * 100 MHz */
 int32_t i2v_conv_debug_clock(void* buf);
+/* diagnostic: one-lane kernel writing {shader-clock counter, 100 MHz counter} to out2[0..1] on `stream`; two stamps around
+ * a stretch of work give the shader clock the chip held over it (tools/step_clock.py) */
+int32_t i2v_debug_clock_stamp(void* out2, void* stream);
 size_t  i2v_conv_dgrad_workspace_bytes(int32_t Cin, int32_t Cout, int32_t KH, int32_t KW);
 int32_t i2v_conv_dgrad(const float* gy, const float* w, float* gx, int32_t B, int32_t H, int32_t W,
                        int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
