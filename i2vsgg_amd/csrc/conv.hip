@@ -34,6 +34,7 @@ constexpr int kSplitInKernelMax = 4;   // most splits the in-kernel split-K fini
 
 struct ConvP {
     const float* x; const float* w; const float* scale; const float* shift; const float* res; float* y;
+    const float* mask;           // I2V_EPI_MASK: y = mask > 0 ? y : 0, same shape as y (the ReLU of the tensor a data gradient flows into)
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;    // pad = top padding; may be negative (a crop)
     int pad_x;                   // left padding (run_conv callers set both; the sub-filters of a strided dgrad differ)
     int M, N, K;                 // GEMM sizes
@@ -591,7 +592,7 @@ conv_igemm_f32(const ConvP p_in) {
                         const float4 sc = *(const float4*)(p.scale + n);
                         vv[0] *= sc.x; vv[1] *= sc.y; vv[2] *= sc.z; vv[3] *= sc.w;
                     }
-                    if (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) {
+                    if ((p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) && p.shift) {
                         const float4 sh = *(const float4*)(p.shift + n);
                         vv[0] += sh.x; vv[1] += sh.y; vv[2] += sh.z; vv[3] += sh.w;
                     }
@@ -602,6 +603,11 @@ conv_igemm_f32(const ConvP p_in) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) vv[q] = fmaxf(vv[q], 0.f);
                     }
+                    if (p.flags & I2V_EPI_MASK) {
+                        const float4 mk = *(const float4*)(p.mask + o);
+                        vv[0] = mk.x > 0.f ? vv[0] : 0.f; vv[1] = mk.y > 0.f ? vv[1] : 0.f;
+                        vv[2] = mk.z > 0.f ? vv[2] : 0.f; vv[3] = mk.w > 0.f ? vv[3] : 0.f;
+                    }
                     *(float4*)(p.y + o) = make_float4(vv[0], vv[1], vv[2], vv[3]);
                 } else {
 #pragma unroll
@@ -609,9 +615,10 @@ conv_igemm_f32(const ConvP p_in) {
                         if (n + q >= p.N) break;
                         float t = vv[q];
                         if (p.flags & I2V_EPI_SCALE) t *= p.scale[n + q];
-                        if (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) t += p.shift[n + q];
+                        if ((p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) && p.shift) t += p.shift[n + q];
                         if (p.flags & I2V_EPI_RESIDUAL) t += p.res[o + q];
                         if (p.flags & I2V_EPI_RELU) t = fmaxf(t, 0.f);
+                        if ((p.flags & I2V_EPI_MASK) && !(p.mask[o + q] > 0.f)) t = 0.f;
                         p.y[o + q] = t;
                     }
                 }
@@ -636,7 +643,7 @@ conv_igemm_f32(const ConvP p_in) {
                 const float4 sc = *(const float4*)(p.scale + n);
                 v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
             }
-            if (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) {
+            if ((p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) && p.shift) {
                 const float4 sh = *(const float4*)(p.shift + n);
                 v.x += sh.x; v.y += sh.y; v.z += sh.z; v.w += sh.w;
             }
@@ -649,6 +656,10 @@ conv_igemm_f32(const ConvP p_in) {
             if (p.flags & I2V_EPI_RELU) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
+            if (p.flags & I2V_EPI_MASK) {
+                const float4 mk = *(const float4*)(p.mask + o);
+                v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+            }
             *(float4*)(p.y + o) = v;
         }
     } else {
@@ -658,10 +669,11 @@ conv_igemm_f32(const ConvP p_in) {
             if (m >= p.M || n >= p.N) continue;
             float v = smem[row * CROW + col];
             if (p.flags & I2V_EPI_SCALE) v *= p.scale[n];
-            if (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) v += p.shift[n];
+            if ((p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) && p.shift) v += p.shift[n];
             const long long o = out_index(m) + n;
             if (p.flags & I2V_EPI_RESIDUAL) v += p.res[o];
             if (p.flags & I2V_EPI_RELU) v = fmaxf(v, 0.f);
+            if ((p.flags & I2V_EPI_MASK) && !(p.mask[o] > 0.f)) v = 0.f;
             p.y[o] = v;
         }
     }
@@ -780,8 +792,10 @@ conv_gemm_f32(const ConvP p_in) {
     const __amdgpu_buffer_rsrc_t resr = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.res ? p.res : (const float*)p.x), 0, (unsigned)(y_bytes < 0x7FFFFFF0ull ? y_bytes : 0x7FFFFFF0ull), 0x00020000);
     const unsigned sc_inv = (p.flags & I2V_EPI_SCALE) ? 0u : INV;
-    const unsigned sh_inv = (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) ? 0u : INV;
+    const unsigned sh_inv = ((p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) && p.shift) ? 0u : INV;     // scale without shift: the data-gradient epilogue
     const unsigned res_inv = ((p.flags & I2V_EPI_RESIDUAL) && !split) ? 0u : INV;
+    const __amdgpu_buffer_rsrc_t mskr = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.mask ? p.mask : (const float*)p.x), 0, (unsigned)(y_bytes < 0x7FFFFFF0ull ? y_bytes : 0x7FFFFFF0ull), 0x00020000);
     float4 sc[TN], sh[TN], rres[PREFETCH_RES ? TM : 1][PREFETCH_RES ? TN : 1];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -870,14 +884,15 @@ conv_gemm_f32(const ConvP p_in) {
         }
     };
 
-    auto finish = [&](int i, int j, f32x4 v, float4 rr) {
+    auto finish = [&](int i, int j, f32x4 v, float4 rr, float4 mk) {
         const int m = m0 + (wm * TM + i) * 16 + fr, n = n0 + (wn * TN + j) * 16 + 4 * fg;
         if (m >= p.M || n >= p.N) return;
         float4 o = make_float4(v[0], v[1], v[2], v[3]);
         if (p.flags & I2V_EPI_SCALE) { o.x *= sc[j].x; o.y *= sc[j].y; o.z *= sc[j].z; o.w *= sc[j].w; }   // an absent operand was read as zeros
-        if (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) { o.x += sh[j].x; o.y += sh[j].y; o.z += sh[j].z; o.w += sh[j].w; }
+        if ((p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) && p.shift) { o.x += sh[j].x; o.y += sh[j].y; o.z += sh[j].z; o.w += sh[j].w; }
         if (p.flags & I2V_EPI_RESIDUAL) { o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
         if (p.flags & I2V_EPI_RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        if (p.flags & I2V_EPI_MASK) { o.x = mk.x > 0.f ? o.x : 0.f; o.y = mk.y > 0.f ? o.y : 0.f; o.z = mk.z > 0.f ? o.z : 0.f; o.w = mk.w > 0.f ? o.w : 0.f; }
         *(float4*)(p.y + (long long)m * p.N + n) = o;
     };
     auto res_at = [&](int i, int j) -> float4 {
@@ -885,7 +900,25 @@ conv_gemm_f32(const ConvP p_in) {
         const unsigned off = (m < p.M && n < p.N && (p.flags & I2V_EPI_RESIDUAL)) ? (unsigned)(m * p.N + n) * 4u : INV;
         return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(resr, off, 0, 2));
     };
+    auto mask_at = [&](int i, int j) -> float4 {
+        const int m = m0 + (wm * TM + i) * 16 + fr, n = n0 + (wn * TN + j) * 16 + 4 * fg;
+        const unsigned off = (m < p.M && n < p.N && (p.flags & I2V_EPI_MASK)) ? (unsigned)(m * p.N + n) * 4u : INV;
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(mskr, off, 0, 0));
+    };
     if (!split) {
+        // the mask tile (data gradients only) is fetched here, all fragments at once, into registers the K loop no longer
+        // needs: prefetched beside the residual it would cost the forward layers 4 x TM x TN registers they never use
+        float4 mk[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) mk[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.flags & I2V_EPI_MASK) {           // uniform; behind the K loop a conditional load disturbs no wait count
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) mk[i][j] = mask_at(i, j);
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -893,7 +926,7 @@ conv_gemm_f32(const ConvP p_in) {
                 float4 rr;
                 if constexpr (PREFETCH_RES) rr = rres[PREFETCH_RES ? i : 0][PREFETCH_RES ? j : 0];
                 else rr = res_at(i, j);
-                finish(i, j, acc[i][j], rr);
+                finish(i, j, acc[i][j], rr, mk[i][j]);
             }
         stamp();
         return;
@@ -925,7 +958,7 @@ conv_gemm_f32(const ConvP p_in) {
     const int nsplit = gridDim.y, my = blockIdx.y;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        float4 u[TN][kSplitInKernelMax], rr[TN];
+        float4 u[TN][kSplitInKernelMax], rr[TN], mk[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -933,6 +966,7 @@ conv_gemm_f32(const ConvP p_in) {
                 u[j][sp] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
                     wsr, (sp < nsplit && sp != my) ? slot(i, j) + (unsigned)(sp * split_stride * sizeof(float)) : 0xFFFFFFF0u, 0, SC01));
             rr[j] = res_at(i, j);
+            mk[j] = (p.flags & I2V_EPI_MASK) ? mask_at(i, j) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -943,7 +977,7 @@ conv_gemm_f32(const ConvP p_in) {
                 const float4 t = sp == my ? m4 : u[j][sp];
                 v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
             }
-            finish(i, j, (f32x4){v.x, v.y, v.z, v.w}, rr[j]);
+            finish(i, j, (f32x4){v.x, v.y, v.z, v.w}, rr[j], mk[j]);
         }
     }
     stamp();
@@ -951,36 +985,41 @@ conv_gemm_f32(const ConvP p_in) {
 
 // epilogue of the split-K path (partials were accumulated with fp32 atomics)
 __global__ void conv_epilogue_kernel(float* __restrict__ y, const float* __restrict__ scale,
-                                     const float* __restrict__ shift, const float* __restrict__ res, long long total4,
-                                     int N, int flags) {
+                                     const float* __restrict__ shift, const float* __restrict__ res,
+                                     const float* __restrict__ mask, long long total4, int N, int flags) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total4;
          i += (long long)gridDim.x * blockDim.x) {
         float4 v = ((float4*)y)[i];
         const int n = (int)((i * 4) % N);
         float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
         if (flags & I2V_EPI_SCALE) sc = *(const float4*)(scale + n);
-        if (flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) sh = *(const float4*)(shift + n);
+        if ((flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) && shift) sh = *(const float4*)(shift + n);
         v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
         if (flags & I2V_EPI_RESIDUAL) {
             float4 r = ((const float4*)res)[i];
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
         }
         if (flags & I2V_EPI_RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (flags & I2V_EPI_MASK) {
+            const float4 mk = ((const float4*)mask)[i];
+            v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+        }
         ((float4*)y)[i] = v;
     }
 }
 
 __global__ void conv_epilogue_scalar_kernel(float* __restrict__ y, const float* __restrict__ scale,
                                             const float* __restrict__ shift, const float* __restrict__ res,
-                                            long long total, int N, int flags) {
+                                            const float* __restrict__ mask, long long total, int N, int flags) {
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
         const int n = (int)(i % N);
         float v = y[i];
         if (flags & I2V_EPI_SCALE) v *= scale[n];
-        if (flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) v += shift[n];
+        if ((flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) && shift) v += shift[n];
         if (flags & I2V_EPI_RESIDUAL) v += res[i];
         if (flags & I2V_EPI_RELU) v = fmaxf(v, 0.f);
+        if ((flags & I2V_EPI_MASK) && !(mask[i] > 0.f)) v = 0.f;
         y[i] = v;
     }
 }
@@ -1163,13 +1202,13 @@ int run_conv(ConvP p, hipStream_t st, void* split_ws = nullptr, size_t split_ws_
         case 4: launch_tile<2, 2, 2, 2>(p, spec, st); break;
         default: launch_tile<2, 2, 1, 2>(p, spec, st); break;
     }
-    if (p.splitk > 1 && !p.ws && (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS | I2V_EPI_RESIDUAL | I2V_EPI_RELU))) {
+    if (p.splitk > 1 && !p.ws && (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS | I2V_EPI_RESIDUAL | I2V_EPI_RELU | I2V_EPI_MASK))) {
         if (p.N % 4 == 0)
             conv_epilogue_kernel<<<(int)fmin((double)i2v_cdiv(ytotal / 4, 256), 4096.0), 256, 0, st>>>(
-                p.y, p.scale, p.shift, p.res, ytotal / 4, p.N, p.flags);
+                p.y, p.scale, p.shift, p.res, p.mask, ytotal / 4, p.N, p.flags);
         else
             conv_epilogue_scalar_kernel<<<(int)fmin((double)i2v_cdiv(ytotal, 256), 4096.0), 256, 0, st>>>(
-                p.y, p.scale, p.shift, p.res, ytotal, p.N, p.flags);
+                p.y, p.scale, p.shift, p.res, p.mask, ytotal, p.N, p.flags);
     }
     return I2V_OK;
 }
@@ -1177,7 +1216,7 @@ int run_conv(ConvP p, hipStream_t st, void* split_ws = nullptr, size_t split_ws_
 // ---------------------------------------------------------------- dgrad helper
 // wt[c][KH-1-ky][KW-1-kx][n] = w[n][ky][kx][c]: the filter of the transposed conv.
 __global__ void weight_dgrad_layout(const float* __restrict__ w, float* __restrict__ wt, int Cout, int KH, int KW,
-                                    int Cin) {
+                                    int Cin, const float* __restrict__ nscale = nullptr) {
     const long long total = (long long)Cout * KH * KW * Cin;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
          i += (long long)gridDim.x * blockDim.x) {
@@ -1187,7 +1226,10 @@ __global__ void weight_dgrad_layout(const float* __restrict__ w, float* __restri
         int kx = t % KW; t /= KW;
         int ky = t % KH;
         int c = t / KH;
-        wt[i] = w[(((long long)n * KH + (KH - 1 - ky)) * KW + (KW - 1 - kx)) * Cin + c];
+        // nscale: a per-filter factor on gy (the frozen-BN scale between the conv and the tensor gy belongs to) folded into
+        // the transposed filter: dgrad(gy * s, w) == dgrad(gy, diag(s) w)
+        const float v = w[(((long long)n * KH + (KH - 1 - ky)) * KW + (KW - 1 - kx)) * Cin + c];
+        wt[i] = nscale ? v * nscale[n] : v;
     }
 }
 
@@ -1215,6 +1257,7 @@ __global__ void weight_dgrad_sub_layout(const float* __restrict__ w, float* __re
 // the MFMA fragments want; split over m across blockIdx.y with fp32 atomics.
 struct WgP {
     const float* x; const float* gy; float* gw; int direct;
+    const float* row_scale;                // gw[n][:] = row_scale[n] * sum (a frozen-BN scale on gy applied where the sum ends), or NULL
     float* sgd_m; float lr, mom, wd;       // sgd_m != NULL: gw is the PARAMETER, updated in place (fused SGD)
     unsigned x_bytes, gy_bytes;            // buffer descriptor sizes (v2 kernel)
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, M, N, K, m_per_split, lgCin;
@@ -1560,10 +1603,13 @@ conv_wgrad2_f32(const WgP p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int rr = 0; rr < 4; ++rr) {
+            const int row = (wm * TM + i) * 16 + 4 * fg + rr;
+            const float rsc = (p.row_scale && n0 + row < p.N) ? p.row_scale[n0 + row] : 1.f;
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
-                smem[((wm * TM + i) * 16 + 4 * fg + rr) * CROW + (wn * TN + j) * 16 + fr] = acc[i][j][rr];
+            for (int j = 0; j < TN; ++j)
+                smem[row * CROW + (wn * TN + j) * 16 + fr] = p.row_scale ? acc[i][j][rr] * rsc : acc[i][j][rr];
+        }
     __syncthreads();
     if (PREFETCH_W && p.sgd_m) {
 #pragma unroll
@@ -1806,6 +1852,7 @@ epilogue_bwd_scalar_kernel(const float* __restrict__ gy, const float* __restrict
 static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st) {
     const long long xb = (long long)p.B * p.H * p.W * p.Cin * 4, gb = (long long)p.M * p.N * 4;
     const bool v2 = (p.N % 4 == 0) && xb < (1ll << 31) && gb < (1ll << 31) && g_wgrad_v2;
+    if (p.row_scale && !v2) { i2v_set_error("conv_wgrad_scaled: shape outside the v2 kernel (Cout % 4, 2 GiB operands)"); return false; }
     // bigger tiles raise the FLOP per staged byte (the reduction dim is streamed): 128x128 = 32 FLOP/B vs 16
     int tm = 64, tk = 64;
     // fused update: 128 filters x 64 taps -- the x tile is shared by twice the filters and half as many workgroups go
@@ -1968,11 +2015,17 @@ extern "C" size_t i2v_conv_dgrad_workspace_bytes(int32_t Cin, int32_t Cout, int3
 // output rows a + c0 - t with c0 = (r + pad - ky0) / s.  So every parity class (ry, rx) is its own stride-1
 // correlation of gy with a flipped sub-filter, written to every s-th pixel of gx: s*s launches whose MACs add up
 // to exactly the dense count (the zero-insertion form did s*s times that).
-extern "C" int32_t i2v_conv_dgrad(const float* gy, const float* w, float* gx, int32_t B, int32_t H, int32_t W,
-                                     int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
-                                     void* ws, size_t ws_bytes, void* split_ws, size_t split_ws_bytes, void* stream) {
+static int conv_dgrad_impl(const float* gy, const float* w, const float* gy_scale, const float* out_scale,
+                           const float* res, const float* mask, float* gx, int32_t B, int32_t H, int32_t W,
+                           int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
+                           void* ws, size_t ws_bytes, void* split_ws, size_t split_ws_bytes, void* stream) {
     int rc = check_conv("conv_dgrad", gy, w, gx, B, H, W, Cin, Cout, KH, KW, stride, pad);
     if (rc) return rc;
+    const bool fused = gy_scale || out_scale || res || mask;
+    if (fused && stride != 1) {
+        i2v_set_error("conv_dgrad_fused: stride 1 only (a strided layer takes i2v_conv_dgrad and separate passes)");
+        return I2V_ERR_UNSUPPORTED;
+    }
     I2V_CHECK_ARG(Cout % 4 == 0, "conv_dgrad: Cout must be a multiple of 4");
     if (!ws || ws_bytes < (size_t)Cout * KH * KW * Cin * sizeof(float)) {
         i2v_set_error("conv_dgrad: workspace too small");
@@ -1984,12 +2037,15 @@ extern "C" int32_t i2v_conv_dgrad(const float* gy, const float* w, float* gx, in
     p.x = gy; p.y = gx;
     p.B = B; p.H = Ho; p.W = Wo; p.Cin = Cout; p.Cout = Cin; p.stride = 1;
     p.flags = 0;
+    if (out_scale) { p.scale = out_scale; p.shift = nullptr; p.flags |= I2V_EPI_SCALE; }
+    if (res) { p.res = res; p.flags |= I2V_EPI_RESIDUAL; }
+    if (mask) { p.mask = mask; p.flags |= I2V_EPI_MASK; }
     p.force_tile = g_force_tile;
     p.Hy = H; p.Wy = W;
     const bool pointwise = KH == 1 && KW == 1 && pad == 0;
     if (stride == 1 || pointwise) {
         const long long wn = (long long)Cout * KH * KW * Cin;
-        weight_dgrad_layout<<<(int)fmin((double)i2v_cdiv(wn, 256), 4096.0), 256, 0, st>>>(w, (float*)ws, Cout, KH, KW, Cin);
+        weight_dgrad_layout<<<(int)fmin((double)i2v_cdiv(wn, 256), 4096.0), 256, 0, st>>>(w, (float*)ws, Cout, KH, KW, Cin, gy_scale);
         p.w = (const float*)ws;
         p.KH = KH; p.KW = KW;
         if (stride == 1) {
@@ -2041,24 +2097,51 @@ extern "C" int32_t i2v_conv_dgrad(const float* gy, const float* w, float* gx, in
     return I2V_OK;
 }
 
-extern "C" int32_t i2v_conv_wgrad(const float* x, const float* gy, float* gw, int32_t B, int32_t H, int32_t W,
+extern "C" int32_t i2v_conv_dgrad(const float* gy, const float* w, float* gx, int32_t B, int32_t H, int32_t W,
                                   int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
-                                  float beta, void* ws, size_t ws_bytes, void* stream) {
-    (void)ws; (void)ws_bytes;
+                                  void* ws, size_t ws_bytes, void* split_ws, size_t split_ws_bytes, void* stream) {
+    return conv_dgrad_impl(gy, w, nullptr, nullptr, nullptr, nullptr, gx, B, H, W, Cin, Cout, KH, KW, stride, pad, ws, ws_bytes,
+                           split_ws, split_ws_bytes, stream);
+}
+
+extern "C" int32_t i2v_conv_dgrad_fused(const float* gy, const float* w, const float* gy_scale, const float* out_scale,
+                                        const float* res, const float* mask, float* gx, int32_t B, int32_t H, int32_t W,
+                                        int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
+                                        void* ws, size_t ws_bytes, void* split_ws, size_t split_ws_bytes, void* stream) {
+    return conv_dgrad_impl(gy, w, gy_scale, out_scale, res, mask, gx, B, H, W, Cin, Cout, KH, KW, stride, pad, ws, ws_bytes,
+                           split_ws, split_ws_bytes, stream);
+}
+
+static int conv_wgrad_impl(const float* x, const float* gy, float* gw, const float* row_scale, int32_t B, int32_t H,
+                           int32_t W, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
+                           float beta, void* stream) {
     int rc = check_conv("conv_wgrad", x, gy, gw, B, H, W, Cin, Cout, KH, KW, stride, pad);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     WgP p = {};
-    p.x = x; p.gy = gy; p.gw = gw;
+    p.x = x; p.gy = gy; p.gw = gw; p.row_scale = row_scale;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
     p.Ho = (H + 2 * pad - KH) / stride + 1;
     p.Wo = (W + 2 * pad - KW) / stride + 1;
     p.M = B * p.Ho * p.Wo; p.N = Cout; p.K = KH * KW * Cin;
     p.lgCin = ilog2_exact(Cin);
     I2V_CHECK_ARG(beta == 0.f || beta == 1.f, "conv_wgrad: beta must be 0 or 1");
-    launch_wgrad(p, beta, false, st);
+    if (!launch_wgrad(p, beta, false, st)) return I2V_ERR_UNSUPPORTED;
     I2V_CHECK_LAUNCH("conv_wgrad");
     return I2V_OK;
+}
+
+extern "C" int32_t i2v_conv_wgrad(const float* x, const float* gy, float* gw, int32_t B, int32_t H, int32_t W,
+                                  int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
+                                  float beta, void* ws, size_t ws_bytes, void* stream) {
+    (void)ws; (void)ws_bytes;
+    return conv_wgrad_impl(x, gy, gw, nullptr, B, H, W, Cin, Cout, KH, KW, stride, pad, beta, stream);
+}
+
+extern "C" int32_t i2v_conv_wgrad_scaled(const float* x, const float* gy, const float* row_scale, float* gw, int32_t B,
+                                         int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW,
+                                         int32_t stride, int32_t pad, float beta, void* stream) {
+    return conv_wgrad_impl(x, gy, gw, row_scale, B, H, W, Cin, Cout, KH, KW, stride, pad, beta, stream);
 }
 
 // wgrad with the SGD(momentum) update of that filter fused into the accumulator epilogue: the gradient

@@ -228,7 +228,8 @@ wino4_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, in
 
 __global__ void __launch_bounds__(256)
 wino4_output_kernel(const float* __restrict__ Mx, const float* __restrict__ scale, const float* __restrict__ shift,
-                    float* __restrict__ y, int B, int H, int W, int N, int th, int tw, int relu) {
+                    float* __restrict__ y, int B, int H, int W, int N, int th, int tw, int relu,
+                    const float* __restrict__ mask = nullptr) {
     const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     const long long T = (long long)B * th * tw;
     if (idx >= T * N) return;
@@ -260,7 +261,9 @@ wino4_output_kernel(const float* __restrict__ Mx, const float* __restrict__ scal
             if (ox >= W) continue;
             float v = o[q] * sc + sh;
             if (relu) v = fmaxf(v, 0.f);
-            y[(((long long)b * H + oy) * W + ox) * N + n] = v;
+            const long long at = (((long long)b * H + oy) * W + ox) * N + n;
+            if (mask && !(mask[at] > 0.f)) v = 0.f;       // data gradient: the ReLU of the tensor it flows into
+            y[at] = v;
         }
     }
 }
@@ -347,7 +350,8 @@ __device__ inline void wino4_output_row(const float* __restrict__ src, long long
 
 __global__ void __launch_bounds__(256)
 wino4_output_rows_kernel(const float* __restrict__ Mx, const float* __restrict__ scale, const float* __restrict__ shift,
-                         float* __restrict__ y, int B, int H, int W, int N, int th, int tw, int relu) {
+                         float* __restrict__ y, int B, int H, int W, int N, int th, int tw, int relu,
+                         const float* __restrict__ mask = nullptr) {
     const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     const long long T = (long long)B * th * tw;
     if (idx >= T * N) return;
@@ -374,7 +378,9 @@ wino4_output_rows_kernel(const float* __restrict__ Mx, const float* __restrict__
         if (ox >= W) continue;
         float v = o[q] * sc + sh;
         if (relu) v = fmaxf(v, 0.f);
-        y[(((long long)b * H + oy) * W + ox) * N + n] = v;
+        const long long at = (((long long)b * H + oy) * W + ox) * N + n;
+        if (mask && !(mask[at] > 0.f)) v = 0.f;
+        y[at] = v;
     }
 }
 
@@ -439,9 +445,9 @@ extern "C" size_t i2v_conv3x3_winograd4_workspace_bytes(int32_t B, int32_t H, in
     return i2v_align(36 * T * Cin * sizeof(float)) + i2v_align(36 * T * Cout * sizeof(float));
 }
 
-extern "C" int32_t i2v_conv3x3_winograd4_fwd(const float* x, const float* U, const float* scale, const float* shift,
-                                             float* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
-                                             int32_t relu, void* ws, size_t ws_bytes, void* stream) {
+static int winograd4_impl(const float* x, const float* U, const float* scale, const float* shift, const float* mask,
+                          float* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                          int32_t relu, void* ws, size_t ws_bytes, void* stream) {
     I2V_CHECK_ARG(x && U && y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_winograd4_fwd: bad argument");
     I2V_CHECK_ARG(Cin % 4 == 0, "conv3x3_winograd4_fwd: Cin must be a multiple of 4");
     if (!ws || ws_bytes < i2v_conv3x3_winograd4_workspace_bytes(B, H, W, Cin, Cout)) {
@@ -461,8 +467,22 @@ extern "C" int32_t i2v_conv3x3_winograd4_fwd(const float* x, const float* U, con
     else wino4_input_kernel<<<(unsigned)i2v_cdiv(T * Cin, 256), 256, 0, st>>>(x, V, B, H, W, Cin, th, tw);
     int rc = i2v_gemm_nt_batched(V, U, Mx, (int32_t)T, Cout, Cin, 36, T * Cin, (long long)Cout * Cin, T * Cout, nullptr, 0, stream);
     if (rc) return rc;
-    if (rows & 2) wino4_output_rows_kernel<<<dim3((unsigned)i2v_cdiv(T * Cout, 256), 4), 256, 0, st>>>(Mx, scale, shift, y, B, H, W, Cout, th, tw, relu);
-    else wino4_output_kernel<<<(unsigned)i2v_cdiv(T * Cout, 256), 256, 0, st>>>(Mx, scale, shift, y, B, H, W, Cout, th, tw, relu);
+    if (rows & 2) wino4_output_rows_kernel<<<dim3((unsigned)i2v_cdiv(T * Cout, 256), 4), 256, 0, st>>>(Mx, scale, shift, y, B, H, W, Cout, th, tw, relu, mask);
+    else wino4_output_kernel<<<(unsigned)i2v_cdiv(T * Cout, 256), 256, 0, st>>>(Mx, scale, shift, y, B, H, W, Cout, th, tw, relu, mask);
     I2V_CHECK_LAUNCH("conv3x3_winograd4_fwd");
     return I2V_OK;
+}
+
+extern "C" int32_t i2v_conv3x3_winograd4_fwd(const float* x, const float* U, const float* scale, const float* shift,
+                                             float* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                                             int32_t relu, void* ws, size_t ws_bytes, void* stream) {
+    return winograd4_impl(x, U, scale, shift, nullptr, y, B, H, W, Cin, Cout, relu, ws, ws_bytes, stream);
+}
+
+extern "C" int32_t i2v_conv3x3_winograd4_dgrad(const float* gy, const float* U, const float* out_scale, const float* mask,
+                                               float* gx, int32_t B, int32_t H, int32_t W, int32_t Cout, int32_t Cin,
+                                               void* ws, size_t ws_bytes, void* stream) {
+    // the data gradient of a stride-1 / pad-1 3x3 layer is the same convolution with U = i2v_winograd4_filter_dgrad(w):
+    // gy has Cout channels, gx has Cin
+    return winograd4_impl(gy, U, out_scale, nullptr, mask, gx, B, H, W, Cout, Cin, 0, ws, ws_bytes, stream);
 }

@@ -93,6 +93,18 @@ class Bottleneck(nn.Module):
         self.bn3 = FrozenBN(planes * 4)
         self.downsample = downsample
         self.stride = stride
+        # the backward protocol of ops._BottleneckFn: my input is the previous block's ReLU output / the next block (the
+        # only consumer of my output) masks the gradient it hands me.  Set by make_layer.
+        self.in_relu = False
+        self._next = []
+
+    def _fused(self):
+        """The whole block as one autograd node: stride 1 (a stride-1 projection on the skip branch included), gradients
+        being recorded, every filter training, no per-filter fused SGD registered for them."""
+        if not (ops.BLOCK_FUSED and self.stride == 1 and torch.is_grad_enabled()):
+            return False
+        ws = [self.conv1.weight, self.conv2.weight, self.conv3.weight] + ([self.downsample[0].weight] if self.downsample is not None else [])
+        return all(w.requires_grad and w.data_ptr() not in ops.FUSED_SGD for w in ws) and self.conv1.cin % 4 == 0
 
     def _winograd_filter(self):
         w = self.conv2.weight
@@ -106,6 +118,13 @@ class Bottleneck(nn.Module):
         s1, b1 = self.bn1.folded()
         s2, b2 = self.bn2.folded()
         s3, b3 = self.bn3.folded()
+        if self._fused() and x.is_cuda:
+            down = None
+            if self.downsample is not None:
+                down = (self.downsample[0].weight,) + tuple(self.downsample[1].folded())
+            nxt = self._next[0] if self._next else None
+            return ops.bottleneck(x, self.conv1.weight, self.conv2.weight, self.conv3.weight, (s1, b1), (s2, b2), (s3, b3), down,
+                                  in_relu=self.in_relu, out_premasked=nxt is not None and nxt._fused())
         out = ops.conv2d(x, self.conv1.weight, s1, b1, None, self.stride, 0, relu=True)
         if WINOGRAD and not torch.is_grad_enabled() and self.conv2.cin >= WINOGRAD_MIN_CIN:
             # no gradient is being recorded (the detached SGG_emb backbone, eval): the 3x3 runs as Winograd F(2x2,3x3)
@@ -126,6 +145,9 @@ def make_layer(inplanes, planes, blocks, stride):
         down = nn.Sequential(ConvParams(inplanes, planes * 4, 1, stride), FrozenBN(planes * 4))
     layers = [Bottleneck(inplanes, planes, stride, down)]
     layers += [Bottleneck(planes * 4, planes) for _ in range(1, blocks)]
+    for prev, blk in zip(layers[:-1], layers[1:]):      # inside a layer a block's output has exactly one consumer: the next block
+        blk.in_relu = True
+        prev._next = [blk]                              # (a list: not a registered submodule)
     return nn.Sequential(*layers), planes * 4
 
 

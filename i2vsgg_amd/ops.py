@@ -604,6 +604,139 @@ class _ConvFn(torch.autograd.Function):
         return gx, gw, None, gbias, gres, None, None, None, None
 
 
+# ---------------------------------------------------------------- a trained bottleneck as ONE autograd node
+# I2V_BLOCK_FUSED=0: every conv of a trained bottleneck is its own autograd node again (one streaming pass over the
+# activation gradient per conv for the BN scale / ReLU mask, the skip connection's gradient added by autograd)
+BLOCK_FUSED = os.environ.get("I2V_BLOCK_FUSED", "1") != "0"
+
+
+def _dgrad_fused(g, w, in_shape, pad, gy_scale=None, out_scale=None, res=None, mask=None):
+    """gx = mask > 0 ? (dgrad(g * gy_scale, w) * out_scale + res) : 0 of a stride-1 layer (i2v_conv_dgrad_fused)."""
+    B, Cin, H, W = in_shape
+    Cout, _, KH, KW = w.shape
+    gx = torch.empty((B, Cin, H, W), device=g.device, dtype=torch.float32, memory_format=_CL)
+    ws = workspace(lib.i2v_conv_dgrad_workspace_bytes(Cin, Cout, KH, KW), g.device, "dgrad")
+    sws = _split_ws(g.device)
+    extra = (res.numel() if res is not None else 0) + (mask.numel() if mask is not None else 0)
+    with _Timed(2.0 * B * H * W * Cout * KH * KW * Cin, "dgrad", "M%d N%d K%d +epi" % (B * H * W, Cin, KH * KW * Cout),
+                4 * (g.numel() + w.numel() + gx.numel() + extra)):
+        check(lib.i2v_conv_dgrad_fused(ptr(g), ptr(w), ptr(gy_scale), ptr(out_scale), ptr(res), ptr(mask), ptr(gx), B, H, W,
+                                       Cin, Cout, KH, KW, 1, pad, ptr(ws), ws.numel(), ptr(sws), sws.numel(), stream()),
+              "conv_dgrad_fused")
+    return gx
+
+
+def _wgrad_scaled(x, g, w_shape, pad, row_scale):
+    """gw[n] = row_scale[n] * wgrad(x, g)[n] of a stride-1 layer; output placement as in _conv_wgrad_raw."""
+    B, Cin, H, W = x.shape
+    Cout, _, KH, KW = w_shape
+    gw, beta = None, 0.0
+    n = Cout * Cin * KH * KW
+    if ARENA is not None and n * 4 <= SMALL_GW_BYTES and B * g.shape[2] * g.shape[3] > 224:
+        flat = ARENA.take_flat(n)
+        if flat is not None:
+            gw, beta = flat.view(Cout, KH, KW, Cin).permute(0, 3, 1, 2), 1.0
+    if gw is None:
+        gw = torch.empty(w_shape, device=x.device, dtype=torch.float32, memory_format=_CL)
+    with _Timed(2.0 * B * g.shape[2] * g.shape[3] * Cout * KH * KW * Cin, "wgrad",
+                "N%d K%d M%d *s" % (Cout, KH * KW * Cin, B * g.shape[2] * g.shape[3]), 4 * (x.numel() + g.numel() + gw.numel())):
+        check(lib.i2v_conv_wgrad_scaled(ptr(x), ptr(g), ptr(row_scale), ptr(gw), B, H, W, Cin, Cout, KH, KW, 1, pad, beta,
+                                        stream()), "conv_wgrad_scaled")
+    return gw
+
+
+def _winograd_dgrad_fused(g, U, out_scale, mask):
+    """gx = mask > 0 ? (F(4x4,3x3) data gradient of a stride-1 / pad-1 3x3 layer * out_scale) : 0; U = winograd_filter_dgrad(w)."""
+    B, Cout, H, W = g.shape
+    Cin = U.shape[1]
+    gx = torch.empty((B, Cin, H, W), device=g.device, dtype=torch.float32, memory_format=_CL)
+    ws = workspace(lib.i2v_conv3x3_winograd4_workspace_bytes(B, H, W, Cout, Cin), g.device, "winograd")
+    T = B * ((H + 3) // 4) * ((W + 3) // 4)
+    with _Timed(2.0 * B * H * W * Cout * 9 * Cin, "dgrad",
+                "M%d N%d K%d (3x3 winograd F4) gemmMB=%.2f +epi" % (B * H * W, Cin, 9 * Cout, 4e-6 * 36 * (T * Cout + Cout * Cin + T * Cin)),
+                4 * (g.numel() + 9 * Cout * Cin + 2 * gx.numel())):
+        check(lib.i2v_conv3x3_winograd4_dgrad(ptr(g), ptr(U), ptr(out_scale), ptr(mask), ptr(gx), B, H, W, Cout, Cin, ptr(ws),
+                                              ws.numel(), stream()), "conv3x3_winograd4_dgrad")
+    return gx
+
+
+class _BottleneckFn(torch.autograd.Function):
+    """out = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + skip(x)) of a STRIDE-1 bottleneck with frozen BNs
+    (resnet_instance_styleD_bilinear.py:181-217) as one autograd node.  The forward is the four fused-epilogue convs of the
+    layer-by-layer form.  The backward never makes a pass of its own over an activation gradient:
+
+      * the BN scale and the ReLU mask between two convs ride in the epilogue of the data-gradient kernel that produces the
+        gradient (out_scale, mask = the consumer conv's own input, which IS the ReLU output), or -- the scale in front of
+        conv3 and the skip conv, where no ReLU sits -- in the transposed filter (dgrad) and in the per-filter-row factor of
+        the filter gradient;
+      * the skip connection's gradient is the residual operand of conv1's data gradient (autograd adds nothing);
+      * ``in_relu``: x is the ReLU output of the previous block; the returned gx is then already multiplied by (x > 0), and
+        ``out_premasked`` tells this block that ITS consumer did the same for it (only set when the next block is the only
+        consumer of ``out``; model.faster_rcnn.layers.make_layer).
+    Per block and step: 3 passes over inner activations + 4 over the block output + autograd's add (3) become 2 extra
+    epilogue reads."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, w3, wd, s1, b1, s2, b2, s3, b3, sd, bd, in_relu, out_premasked, wino):
+        _need_cuda(x, w1, w2, w3)
+        x = as_nhwc(x)
+        w1, w2, w3 = as_nhwc(w1), as_nhwc(w2), as_nhwc(w3)
+        a1 = _conv_fwd_raw(x, w1, s1, b1, None, 1, 0, EPI_SCALE | EPI_RELU)
+        if wino:
+            a2 = conv3x3_winograd(a1, winograd_filter(w2.detach(), 4), s2, b2, True)
+        else:
+            a2 = _conv_fwd_raw(a1, w2, s2, b2, None, 1, 1, EPI_SCALE | EPI_RELU)
+        if wd is not None:
+            wd = as_nhwc(wd)
+            res = _conv_fwd_raw(x, wd, sd, bd, None, 1, 0, EPI_SCALE)
+        else:
+            res = x
+        out = _conv_fwd_raw(a2, w3, s3, b3, res, 1, 0, EPI_SCALE | EPI_RESIDUAL | EPI_RELU)
+        ctx.flags = (bool(in_relu), bool(out_premasked), bool(wino), wd is not None)
+        ctx.save_for_backward(x, a1, a2, out, w1, w2, w3, wd, s1, s2, s3, sd)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, a1, a2, out, w1, w2, w3, wd, s1, s2, s3, sd = ctx.saved_tensors
+        in_relu, premasked, wino, has_ds = ctx.flags
+        need = ctx.needs_input_grad
+        g = as_nhwc(g)
+        if premasked:
+            gpre = g
+        else:       # the consumers of ``out`` know nothing of its ReLU: one masking pass
+            gpre = torch.empty_like(g)
+            M, N = g.shape[0] * g.shape[2] * g.shape[3], g.shape[1]
+            check(lib.i2v_epilogue_bwd(ptr(g), ptr(out), None, ptr(gpre), None, None, M, N, 1, None, stream()), "epilogue_bwd")
+        # conv3: gy = gpre * s3
+        gw3 = _wgrad_scaled(a2, gpre, w3.shape, 0, s3) if need[3] else None
+        g2 = _dgrad_fused(gpre, w3, a2.shape, 0, gy_scale=s3, out_scale=s2, mask=a2)         # gradient at conv2's raw output
+        # conv2
+        gw2 = _conv_wgrad_raw(a1, g2, w2.shape, 1, 1) if need[2] else None
+        if wino:
+            g1 = _winograd_dgrad_fused(g2, winograd_filter_dgrad(w2), s1, a1)
+        else:
+            g1 = _dgrad_fused(g2, w2, a1.shape, 1, out_scale=s1, mask=a1)
+        # conv1 (+ the skip branch)
+        gw1 = _conv_wgrad_raw(x, g1, w1.shape, 1, 0) if need[1] else None
+        gwd = gx = None
+        if has_ds and need[4]:
+            gwd = _wgrad_scaled(x, gpre, wd.shape, 0, sd)
+        if need[0]:
+            skip = _dgrad_fused(gpre, wd, x.shape, 0, gy_scale=sd) if has_ds else gpre
+            gx = _dgrad_fused(g1, w1, x.shape, 0, res=skip, mask=x if in_relu else None)
+        return (gx, gw1, gw2, gw3, gwd) + (None,) * 11
+
+
+def bottleneck(x, w1, w2, w3, bn1, bn2, bn3, down=None, in_relu=False, out_premasked=False):
+    """A stride-1 bottleneck with frozen BNs whose filters train, as one autograd node (``_BottleneckFn``).  bn* = (scale,
+    shift) of the folded BN; ``down`` = (filter, scale, shift) of a stride-1 projection on the skip branch or None."""
+    wino = (WINOGRAD_TRAIN and w2.shape[1] >= WINOGRAD_TRAIN_MIN_C and w2.shape[0] >= WINOGRAD_TRAIN_MIN_C and w2.shape[1] % 4 == 0)
+    wd, sd, bd = down if down is not None else (None, None, None)
+    return _BottleneckFn.apply(x, w1, w2, w3, wd, bn1[0], bn1[1], bn2[0], bn2[1], bn3[0], bn3[1], sd, bd, bool(in_relu),
+                               bool(out_premasked), bool(wino))
+
+
 def conv2d(x, w, scale=None, shift=None, res=None, stride=1, pad=0, relu=False, winograd=False):
     """Implicit-GEMM conv with fused epilogue.  x (B,Cin,H,W), w (Cout,Cin,KH,KW); Cin % 4 == 0."""
     B, Cin, H, W = x.shape

@@ -43,6 +43,7 @@ extern "C" {
 #define I2V_EPI_SCALE     4      /* y = acc*scale[n] + shift[n]  (frozen BN)       */
 #define I2V_EPI_BIAS      8      /* y = acc + shift[n]                             */
 #define I2V_EPI_ZEROED   16      /* caller guarantees y is all zeros (skips the split-K clear) */
+#define I2V_EPI_MASK     32      /* last: y = mask > 0 ? y : 0 (i2v_conv_dgrad_fused: the ReLU a data gradient flows back into) */
 
 int32_t     i2v_version(void);
 const char* i2v_last_error(void);
@@ -236,6 +237,28 @@ int32_t i2v_conv_debug_clock(void* buf);
 /* diagnostic: one-lane kernel writing {shader-clock counter, 100 MHz counter} to out2[0..1] on `stream`; two stamps around
  * a stretch of work give the shader clock the chip held over it (tools/step_clock.py) */
 int32_t i2v_debug_clock_stamp(void* out2, void* stream);
+/* Backward-protocol forms of the data / filter gradient (the instance_styleD training step, where layer1-3 and layer4
+ * train behind frozen BatchNorms: trainval_net_instance_styleD_bilinear.py:262-341, resnet_instance_styleD_bilinear.py:181-217).
+ * Between two convolutions of a bottleneck sit a frozen-BN scale and a ReLU; instead of one streaming pass per layer over
+ * the activation gradient (g = gy * (y > 0) * scale) the factors ride in the kernels that touch the data anyway:
+ *   i2v_conv_dgrad_fused   gx = mask > 0 ? (dgrad(gy * gy_scale[cout], w) * out_scale[cin] + res) : 0
+ *                          gy_scale: folded into the transposed filter; out_scale / res / mask: epilogue operands, each
+ *                          may be NULL; res and mask have the shape of gx.  Stride 1 only (I2V_ERR_UNSUPPORTED otherwise).
+ *   i2v_conv_wgrad_scaled  gw[n] = row_scale[n] * wgrad(x, gy)[n]   (the BN scale that belongs on gy, applied once per
+ *                          filter row where the reduction over the pixels ends); beta as in i2v_conv_wgrad.
+ *   i2v_conv3x3_winograd4_dgrad  gx = mask > 0 ? (winograd F(4x4,3x3) data gradient * out_scale[cin]) : 0,
+ *                          U = i2v_winograd4_filter_dgrad(w); workspace i2v_conv3x3_winograd4_workspace_bytes(B,H,W,Cout,Cin). */
+int32_t i2v_conv_dgrad_fused(const float* gy, const float* w, const float* gy_scale, const float* out_scale,
+                             const float* res, const float* mask, float* gx, int32_t B, int32_t H, int32_t W,
+                             int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
+                             void* workspace, size_t workspace_bytes, void* split_workspace, size_t split_workspace_bytes,
+                             void* stream);
+int32_t i2v_conv_wgrad_scaled(const float* x, const float* gy, const float* row_scale, float* gw, int32_t B,
+                              int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW,
+                              int32_t stride, int32_t pad, float beta, void* stream);
+int32_t i2v_conv3x3_winograd4_dgrad(const float* gy, const float* U, const float* out_scale, const float* mask,
+                                    float* gx, int32_t B, int32_t H, int32_t W, int32_t Cout, int32_t Cin,
+                                    void* workspace, size_t workspace_bytes, void* stream);
 size_t  i2v_conv_dgrad_workspace_bytes(int32_t Cin, int32_t Cout, int32_t KH, int32_t KW);
 int32_t i2v_conv_dgrad(const float* gy, const float* w, float* gx, int32_t B, int32_t H, int32_t W,
                        int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,

@@ -42,7 +42,8 @@ def test_instance_styled_step_full_size(fresh_cfg):
       * every loss of the step is finite and the trained parameters of every group move (layer1-3, layer4, RPN, both
         discriminators, the detection heads);
       * the step on the fused kernels (one-kernel netD_pixel, Winograd forward / data gradient for the trained 3x3 layers,
-        multi-tensor fused SGD) reproduces the losses of the same step on the plain forms (layer-by-layer netD_pixel,
+        stride-1 bottlenecks as single autograd nodes with the BN-scale / ReLU-mask / skip-gradient passes folded into the
+        gradient kernels, multi-tensor fused SGD) reproduces the losses of the same step on the plain forms (layer-by-layer netD_pixel,
         direct 3x3 kernels, torch.optim.SGD with the reference's parameter groups) for two consecutive steps -- the second
         one sees the first one's update -- within 1e-3 relative, same np.random stream;
       * the captured form (device-side target sampling, ONE HIP graph) replays to finite losses close to the host-sampled
@@ -59,9 +60,10 @@ def test_instance_styled_step_full_size(fresh_cfg):
         net = train.build_instance_styled_net(101, device=DEV)
         before = {k: v.detach().clone() for k, v in net.named_parameters() if k in names}
         step = train.InstanceStyleDStep(net, 4, seed=3, device=DEV)
-        saved = (ops.WINOGRAD_TRAIN, net.netD_pixel.forward)
+        saved = (ops.WINOGRAD_TRAIN, net.netD_pixel.forward, ops.BLOCK_FUSED)
         if plain:
             ops.WINOGRAD_TRAIN = False
+            ops.BLOCK_FUSED = False          # every conv its own autograd node, separate scale / mask passes
             net.netD_pixel.forward = net.netD_pixel._forward_layers
             T = cfg.TRAIN
             groups = [{"params": [p], "lr": 5e-4 * ((T.DOUBLE_BIAS + 1) if "bias" in n else 1),
@@ -82,7 +84,7 @@ def test_instance_styled_step_full_size(fresh_cfg):
                 out.append({k: float(v) for k, v in step.losses.items()})
             moved = {k: float((dict(net.named_parameters())[k].detach() - before[k]).abs().max()) for k in names}
         finally:
-            ops.WINOGRAD_TRAIN, net.netD_pixel.forward = saved
+            ops.WINOGRAD_TRAIN, net.netD_pixel.forward, ops.BLOCK_FUSED = saved
         return out, moved, net, step
 
     fused, moved, net, step = run(False)

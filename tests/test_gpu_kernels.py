@@ -816,3 +816,84 @@ def test_dstyle_fused_equals_projections_plus_pooling(ops, n_img, P):
     ref = (((rows0.double() @ w1.double().t() + b1.double()) * (rows0.double() @ w2.double().t() + b2.double()))
            .view(n_img, P, dim, rank).sum((1, 3)))
     assert float((z0.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+def _layer_reference(layer, x):
+    """Plain torch fp32 of a make_layer() stack (frozen BN as scale / shift)."""
+    for blk in layer:
+        def cbr(h, conv, bn, relu, stride=1, pad=0):
+            s, b = bn.folded()
+            h = F.conv2d(h, conv.weight, None, stride, pad) * s.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+            return F.relu(h) if relu else h
+        h = cbr(x, blk.conv1, blk.bn1, True, blk.stride)
+        h = cbr(h, blk.conv2, blk.bn2, True, 1, 1)
+        h = cbr(h, blk.conv3, blk.bn3, False)
+        skip = x if blk.downsample is None else cbr(x, blk.downsample[0], blk.downsample[1], False, blk.stride)
+        x = F.relu(h + skip)
+    return x
+
+
+@pytest.mark.parametrize("cin,planes,hw", [(64, 64, (30, 44)), (256, 64, (22, 36)), (512, 128, (14, 20))])
+def test_trained_bottleneck_stack_as_fused_autograd_nodes(cin, planes, hw):
+    """ops._BottleneckFn (BN scale / ReLU mask / skip gradient folded into the data- and filter-gradient kernels, block-to-
+    block hand-over of pre-masked gradients) against (a) plain torch fp32 autograd and (b) the layer-by-layer form
+    (I2V_BLOCK_FUSED=0) on a 3-block layer: output, input gradient and every filter gradient."""
+    from i2vsgg_amd import ops
+    from i2vsgg_amd.model.faster_rcnn.layers import make_layer
+    torch.manual_seed(3)
+    layer, _ = make_layer(cin, planes, 3, 1)
+    layer = layer.to(DEV)
+    for m in layer.modules():
+        if hasattr(m, "running_var"):
+            m.running_var.uniform_(0.5, 2.0); m.running_mean.normal_(0, 0.2)
+            m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.2)
+            m.invalidate()
+    x0 = torch.relu(torch.randn(2, cin, *hw, device=DEV)).contiguous(memory_format=torch.channels_last)
+    gout = torch.randn(2, planes * 4, *hw, device=DEV).contiguous(memory_format=torch.channels_last)
+    params = [p for p in layer.parameters() if p.requires_grad]
+
+    def run(fn):
+        x = x0.clone().requires_grad_(True)
+        for p in params:
+            p.grad = None
+        y = fn(x)
+        (y * gout).sum().backward()
+        return [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in params]
+
+    assert ops.BLOCK_FUSED and all(b._fused() for b in layer)
+    assert layer[0]._next[0] is layer[1] and layer[1].in_relu and not layer[0].in_relu
+    fused = run(layer)
+    ops.BLOCK_FUSED = False
+    try:
+        plain = run(layer)
+    finally:
+        ops.BLOCK_FUSED = True
+    ref = run(lambda x: _layer_reference(layer, x))
+    names = ["out", "gx"] + [n for n, p in layer.named_parameters() if p.requires_grad]
+    for n, a, b, c in zip(names, fused, plain, ref):
+        scale = float(c.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-4 * scale, ("fused vs layer-by-layer", n, float((a - b).abs().max()), scale)
+        assert float((a - c).abs().max()) <= 1e-3 * scale, ("fused vs torch", n, float((a - c).abs().max()), scale)
+
+
+def test_conv_dgrad_fused_and_wgrad_scaled_vs_torch():
+    """The C-ABI pieces alone: gx = mask>0 ? (dgrad(gy*gs, w)*os + res) : 0 and gw = rs * wgrad(x, gy), 1x1 and 3x3."""
+    from i2vsgg_amd import ops
+    torch.manual_seed(5)
+    for (cin, cout, k, pad, hw) in [(64, 256, 1, 0, (25, 31)), (256, 64, 1, 0, (25, 31)), (64, 64, 3, 1, (17, 23)), (1024, 256, 1, 0, (38, 63))]:
+        B = 2
+        cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+        x = cl(torch.randn(B, cin, *hw, device=DEV))
+        w = cl(torch.randn(cout, cin, k, k, device=DEV) * 0.05)
+        gy = cl(torch.randn(B, cout, *hw, device=DEV))
+        gs, osc = torch.rand(cout, device=DEV) + 0.5, torch.rand(cin, device=DEV) + 0.5
+        res, mask = cl(torch.randn(B, cin, *hw, device=DEV)), cl(torch.randn(B, cin, *hw, device=DEV))
+        got = ops._dgrad_fused(gy, w, x.shape, pad, gs, osc, res, mask)
+        want = F.conv_transpose2d(gy * gs.view(1, -1, 1, 1), w, None, 1, pad) * osc.view(1, -1, 1, 1) + res
+        want = torch.where(mask > 0, want, torch.zeros_like(want))
+        assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max()), (cin, cout, k)
+        plain = ops._dgrad_fused(gy, w, x.shape, pad)
+        assert float((plain - F.conv_transpose2d(gy, w, None, 1, pad)).abs().max()) <= 1e-4 * float(plain.abs().max())
+        gw = ops._wgrad_scaled(x, gy, w.shape, pad, gs)
+        wref = torch.nn.grad.conv2d_weight(x, w.shape, gy, 1, pad) * gs.view(-1, 1, 1, 1)
+        assert float((gw - wref).abs().max()) <= 1e-4 * float(wref.abs().max()), (cin, cout, k)
