@@ -695,7 +695,7 @@ conv_igemm_f32(const ConvP p_in) {
 // 16-B store per fragment, no LDS round trip, no barrier.  Staging, swizzled LDS image and the K loop are conv_igemm_f32's.
 // Split-K (<= kSplitInKernelMax): partial tiles go to the caller's workspace in REGISTER order (fragment, wave, lane), the
 // last workgroup to arrive sums them in split order -- same protocol as conv_igemm_f32, whole-wave 1-KB rows.
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool CLK = false>
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool CLK = false, bool MASK = false>
 __global__ void __launch_bounds__(THREADS)
 conv_gemm_f32(const ConvP p_in) {
     ConvP p = p_in;
@@ -892,7 +892,7 @@ conv_gemm_f32(const ConvP p_in) {
         if ((p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) && p.shift) { o.x += sh[j].x; o.y += sh[j].y; o.z += sh[j].z; o.w += sh[j].w; }
         if (p.flags & I2V_EPI_RESIDUAL) { o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
         if (p.flags & I2V_EPI_RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-        if (p.flags & I2V_EPI_MASK) { o.x = mk.x > 0.f ? o.x : 0.f; o.y = mk.y > 0.f ? o.y : 0.f; o.z = mk.z > 0.f ? o.z : 0.f; o.w = mk.w > 0.f ? o.w : 0.f; }
+        if constexpr (MASK) { o.x = mk.x > 0.f ? o.x : 0.f; o.y = mk.y > 0.f ? o.y : 0.f; o.z = mk.z > 0.f ? o.z : 0.f; o.w = mk.w > 0.f ? o.w : 0.f; }
         *(float4*)(p.y + (long long)m * p.N + n) = o;
     };
     auto res_at = [&](int i, int j) -> float4 {
@@ -913,7 +913,7 @@ conv_gemm_f32(const ConvP p_in) {
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) mk[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.flags & I2V_EPI_MASK) {           // uniform; behind the K loop a conditional load disturbs no wait count
+        if constexpr (MASK) {                   // the MASK instantiation serves data gradients only (launch_tile)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -966,7 +966,8 @@ conv_gemm_f32(const ConvP p_in) {
                 u[j][sp] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
                     wsr, (sp < nsplit && sp != my) ? slot(i, j) + (unsigned)(sp * split_stride * sizeof(float)) : 0xFFFFFFF0u, 0, SC01));
             rr[j] = res_at(i, j);
-            mk[j] = (p.flags & I2V_EPI_MASK) ? mask_at(i, j) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (MASK) mk[j] = mask_at(i, j);
+            else mk[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -1090,11 +1091,13 @@ void launch_tile(const ConvP& p, bool spec, hipStream_t st) {
         static bool once_g = [] {
             set_max_lds(conv_gemm_f32<WAVES_M, WAVES_N, TM, TN>);
             set_max_lds(conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, true>);
+            set_max_lds(conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true>);
             return true;
         }();
         (void)once_g;
         const size_t lds_g = (size_t)(2 * (BM + BN) * BKS) * sizeof(float);
-        if (p.clk) conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, true><<<grid, THREADS, lds_g, st>>>(p);
+        if (p.flags & I2V_EPI_MASK) conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true><<<grid, THREADS, lds_g, st>>>(p);
+        else if (p.clk) conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, true><<<grid, THREADS, lds_g, st>>>(p);
         else conv_gemm_f32<WAVES_M, WAVES_N, TM, TN><<<grid, THREADS, lds_g, st>>>(p);
         return;
     }
@@ -1447,6 +1450,8 @@ conv_wgrad2_f32(const WgP p) {
     int sx[NBLK], sy[NBLK], sb[NBLK];
 #pragma unroll
     for (int q = 0; q < NBLK; ++q) {
+        sx[q] = sy[q] = sb[q] = 0;
+        if (lin) continue;                   // uniform: the skinny GEMMs of the relation head live ~4 stages, set-up counts
         const int m0 = mbeg + 4 * m4[q];
         sx[q] = m0 % p.Wo;
         const int tt = m0 / p.Wo;
@@ -1475,40 +1480,46 @@ conv_wgrad2_f32(const WgP p) {
                     b = tt / p.Ho;
                 }
             }
-            // the block's 4 consecutive pixels: offsets from the first one's by increments (a pixel past the end of the row
-            // moves to the next row -- or the next image -- by one precomputed delta: rows hold >= 4 pixels)
-            const int iy0 = oy * p.stride - p.pad + ky[q], ix0 = ox * p.stride - p.pad + kx[q];
-            const int base = ((b * p.H + iy0) * p.W + ix0) * p.Cin + coff[q];
-            const bool last_row = oy + 1 == p.Ho;
-            const int iy1 = last_row ? ky[q] - p.pad : iy0 + p.stride;                     // row of the pixels after a wrap
-            const int wrap_delta = ((last_row ? p.H - (p.Ho - 1) * p.stride : p.stride) * p.W - p.Wo * p.stride) * p.Cin;
-            const bool y0_in = iy0 >= 0 && iy0 < p.H, y1_in = iy1 >= 0 && iy1 < p.H;
+            // The offsets are computed under uniform branches, the LOADS are not: a load inside a branch makes the number of
+            // loads in flight unknowable to the compiler, which then drains everything (vmcnt(0)) before the first LDS
+            // store -- the fused-SGD form would wait for its prefetched filter / momentum tiles there (fc6: +17 %).
+            unsigned offs[4];
+            if (a_u || lin) {               // row m of gy / of x: no pixel arithmetic
+                const int rowlen = a_u ? p.N : p.Cin;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int m = m0 + t;
-                unsigned off;
-                if (a_u) {
-                    off = (unsigned)(m * p.N + coff[q]) * 4u;
-                } else if (lin) {
-                    off = (unsigned)(m * p.Cin + coff[q]) * 4u;         // pointwise / linear layer: row m of x
-                } else if (p.Wo >= 4) {
+                for (int t = 0; t < 4; ++t) offs[t] = (unsigned)((m0 + t) * rowlen + coff[q]) * 4u;
+            } else if (p.Wo >= 4) {
+                // the block's 4 consecutive pixels: offsets from the first one's by increments (a pixel past the end of the
+                // row moves to the next row -- or the next image -- by one precomputed delta: rows hold >= 4 pixels)
+                const int iy0 = oy * p.stride - p.pad + ky[q], ix0 = ox * p.stride - p.pad + kx[q];
+                const int base = ((b * p.H + iy0) * p.W + ix0) * p.Cin + coff[q];
+                const bool last_row = oy + 1 == p.Ho;
+                const int iy1 = last_row ? ky[q] - p.pad : iy0 + p.stride;                     // row of the pixels after a wrap
+                const int wrap_delta = ((last_row ? p.H - (p.Ho - 1) * p.stride : p.stride) * p.W - p.Wo * p.stride) * p.Cin;
+                const bool y0_in = iy0 >= 0 && iy0 < p.H, y1_in = iy1 >= 0 && iy1 < p.H;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
                     const bool w = ox + t >= p.Wo;
                     const int ix = ix0 + t * p.stride - (w ? p.Wo * p.stride : 0);
                     const bool inside = (w ? y1_in : y0_in) && ix >= 0 && ix < p.W;
-                    off = (unsigned)(base + t * p.stride * p.Cin + (w ? wrap_delta : 0)) * 4u;
-                    off |= inside ? 0u : 0x80000000u;
-                } else {                    // rows shorter than a block: pixel by pixel
+                    offs[t] = ((unsigned)(base + t * p.stride * p.Cin + (w ? wrap_delta : 0)) * 4u) | (inside ? 0u : 0x80000000u);
+                }
+            } else {                        // rows shorter than a block: pixel by pixel
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
                     const int iy = oy * p.stride - p.pad + ky[q], ix = ox * p.stride - p.pad + kx[q];
                     const bool inside = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-                    off = (unsigned)(((b * p.H + iy) * p.W + ix) * p.Cin + coff[q]) * 4u;
-                    off |= inside ? 0u : 0x80000000u;
+                    offs[t] = ((unsigned)(((b * p.H + iy) * p.W + ix) * p.Cin + coff[q]) * 4u) | (inside ? 0u : 0x80000000u);
                     const bool wx = ox + 1 == p.Wo;
                     const bool wy = wx && oy + 1 == p.Ho;
                     ox = wx ? 0 : ox + 1;
                     oy = wy ? 0 : (wx ? oy + 1 : oy);
                     b += wy ? 1 : 0;
                 }
-                off |= (live[q] && m < mend) ? 0u : 0x80000000u;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const unsigned off = offs[t] | ((live[q] && m0 + t < mend) ? 0u : 0x80000000u);
                 r[q][t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
             }
         }
@@ -1605,7 +1616,8 @@ conv_wgrad2_f32(const WgP p) {
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
             const int row = (wm * TM + i) * 16 + 4 * fg + rr;
-            const float rsc = (p.row_scale && n0 + row < p.N) ? p.row_scale[n0 + row] : 1.f;
+            float rsc = 1.f;
+            if (p.row_scale) rsc = n0 + row < p.N ? p.row_scale[n0 + row] : 0.f;      // uniform branch
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 smem[row * CROW + (wn * TN + j) * 16 + fr] = p.row_scale ? acc[i][j][rr] * rsc : acc[i][j][rr];
@@ -1871,6 +1883,7 @@ static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st) {
         // one round of workgroups: floor, not ceil (144 tiles x 8 splits = 1152 workgroups on 1024 slots ran 1.5 rounds)
         const int per_cu = g_i2v_tuning[I2V_TUNE_WGRAD_PER_CU];
         splits = (int)((long long)per_cu * NUM_CU / tiles);
+        if (splits < 2) splits = (int)(((long long)per_cu * NUM_CU + tiles - 1) / tiles);   // more than half a round of tiles: as before
         if (splits > msteps / 4) splits = msteps / 4;
         if (splits < 1) splits = 1;
     }
