@@ -1261,6 +1261,8 @@ __global__ void weight_dgrad_sub_layout(const float* __restrict__ w, float* __re
 struct WgP {
     const float* x; const float* gy; float* gw; int direct;
     const float* row_scale;                // gw[n][:] = row_scale[n] * sum (a frozen-BN scale on gy applied where the sum ends), or NULL
+    int nbatch;                            // > 1: blockIdx.z selects one of nbatch independent GEMMs (the planes of a Winograd filter gradient)
+    long long bsx, bsg, bsw;               // element strides between the batches of x, gy and gw
     float* sgd_m; float lr, mom, wd;       // sgd_m != NULL: gw is the PARAMETER, updated in place (fused SGD)
     unsigned x_bytes, gy_bytes;            // buffer descriptor sizes (v2 kernel)
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, M, N, K, m_per_split, lgCin;
@@ -1389,9 +1391,15 @@ conv_wgrad_f32(const WgP p) {
 // +34 VGPRs, four waves per SIMD instead of five -- which the plain gradient kernel should not pay)
 template <int TM, int TN, bool FUSED_SGD = false, bool CLK = false>       // tile = (2*TM*16) filters x (2*TN*16) taps, 4 waves as 2x2
 __global__ void __launch_bounds__(THREADS)
-conv_wgrad2_f32(const WgP p) {
+conv_wgrad2_f32(const WgP p_in) {
+    WgP p = p_in;
     unsigned long long c_rt0 = 0, c_t0 = 0, c_t1 = 0, c_t2 = 0;
     if constexpr (CLK) { c_rt0 = __builtin_amdgcn_s_memrealtime(); c_t0 = __builtin_amdgcn_s_memtime(); }
+    if (p.nbatch > 1) {
+        p.x += (long long)blockIdx.z * p.bsx;
+        p.gy += (long long)blockIdx.z * p.bsg;
+        p.gw += (long long)blockIdx.z * p.bsw;
+    }
     constexpr int BMW = 2 * TM * 16, BNW = 2 * TN * 16;
     constexpr int A_BLK = BMW * 2, B_BLK = BNW * 2;             // (cols/4) * 8 row-groups
     constexpr int NBLK = (A_BLK + B_BLK + THREADS - 1) / THREADS;
@@ -1882,18 +1890,20 @@ static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st) {
     if (!fused) {
         // one round of workgroups: floor, not ceil (144 tiles x 8 splits = 1152 workgroups on 1024 slots ran 1.5 rounds)
         const int per_cu = g_i2v_tuning[I2V_TUNE_WGRAD_PER_CU];
-        splits = (int)((long long)per_cu * NUM_CU / tiles);
-        if (splits < 2) splits = (int)(((long long)per_cu * NUM_CU + tiles - 1) / tiles);   // more than half a round of tiles: as before
+        const long long all_tiles = tiles * (p.nbatch > 1 ? p.nbatch : 1);
+        splits = (int)((long long)per_cu * NUM_CU / all_tiles);
+        if (splits < 2) splits = (int)(((long long)per_cu * NUM_CU + all_tiles - 1) / all_tiles);   // more than half a round of tiles: as before
         if (splits > msteps / 4) splits = msteps / 4;
         if (splits < 1) splits = 1;
     }
     p.m_per_split = i2v_cdiv(msteps, splits) * rs;
     splits = i2v_cdiv(p.M, p.m_per_split);
     p.direct = (splits == 1 && beta == 0.f) || fused;
-    if (beta == 0.f && !p.direct) hipMemsetAsync(p.gw, 0, (size_t)p.N * p.K * sizeof(float), st);
+    if (beta == 0.f && !p.direct)
+        hipMemsetAsync(p.gw, 0, (p.nbatch > 1 ? (size_t)(p.nbatch - 1) * p.bsw : 0) * sizeof(float) + (size_t)p.N * p.K * sizeof(float), st);
     p.x_bytes = (unsigned)xb;
     p.gy_bytes = (unsigned)gb;
-    const dim3 grid((unsigned)tiles, splits);
+    const dim3 grid((unsigned)tiles, splits, p.nbatch > 1 ? p.nbatch : 1);
     if (!v2) conv_wgrad_f32<64, 64><<<grid, THREADS, 0, st>>>(p);
     else if (fused && tm == 128 && tk == 64) conv_wgrad2_f32<4, 2, true><<<grid, THREADS, 0, st>>>(p);
     else if (tm == 128 && tk == 128) conv_wgrad2_f32<4, 4><<<grid, THREADS, 0, st>>>(p);
@@ -2141,6 +2151,30 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, const flo
     I2V_CHECK_ARG(beta == 0.f || beta == 1.f, "conv_wgrad: beta must be 0 or 1");
     if (!launch_wgrad(p, beta, false, st)) return I2V_ERR_UNSUPPORTED;
     I2V_CHECK_LAUNCH("conv_wgrad");
+    return I2V_OK;
+}
+
+// gw[z] (N x K) = gy[z]^T (M x N) . x[z] (M x K) for z < nbatch: the element-wise planes of a Winograd filter gradient
+// (csrc/winograd.hip).  gw is overwritten; the batches of gw must be contiguous when the reduction is split (one clear).
+extern "C" int32_t i2v_gemm_tn_batched(const float* x, const float* gy, float* gw, int32_t M, int32_t N, int32_t K,
+                                       int32_t nbatch, long long stride_x, long long stride_gy, long long stride_gw,
+                                       void* stream) {
+    I2V_CHECK_ARG(x && gy && gw && M > 0 && N > 0 && K > 0 && nbatch > 0, "gemm_tn_batched: bad argument");
+    I2V_CHECK_ARG(N % 4 == 0 && K % 4 == 0, "gemm_tn_batched: N and K must be multiples of 4");
+    I2V_CHECK_ARG(nbatch == 1 || stride_gw == (long long)N * K, "gemm_tn_batched: gw batches must be contiguous");
+    WgP p = {};
+    p.x = x; p.gy = gy; p.gw = gw;
+    p.B = 1; p.H = 1; p.W = M; p.Cin = K; p.Cout = N; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
+    p.Ho = 1; p.Wo = M;
+    p.M = M; p.N = N; p.K = K;
+    p.lgCin = ilog2_exact(K);
+    p.nbatch = nbatch; p.bsx = stride_x; p.bsg = stride_gy; p.bsw = stride_gw;
+    if (!g_wgrad_v2 || (long long)M * K * 4 >= (1ll << 31) || (long long)M * N * 4 >= (1ll << 31)) {
+        i2v_set_error("gemm_tn_batched: operand larger than 2 GiB per batch");
+        return I2V_ERR_UNSUPPORTED;
+    }
+    launch_wgrad(p, 0.f, false, (hipStream_t)stream);
+    I2V_CHECK_LAUNCH("gemm_tn_batched");
     return I2V_OK;
 }
 

@@ -12,6 +12,9 @@
 // streaming kernels that overlap with MFMA work of the other stream.
 #include "common.h"
 
+extern "C" int32_t i2v_gemm_tn_batched(const float* x, const float* gy, float* gw, int32_t M, int32_t N, int32_t K,
+                                       int32_t nbatch, long long stride_x, long long stride_gy, long long stride_gw,
+                                       void* stream);
 extern "C" int32_t i2v_gemm_nt_batched(const float* a, const float* b, float* c, int32_t M, int32_t N, int32_t K,
                                        int32_t nbatch, int64_t stride_a, int64_t stride_b, int64_t stride_c,
                                        void* split_ws, size_t split_ws_bytes, void* stream);
@@ -384,6 +387,88 @@ wino4_output_rows_kernel(const float* __restrict__ Mx, const float* __restrict__
     }
 }
 
+// ---- filter gradient in the F(4x4,3x3) domain.  With U = G g G^T the forward is y = A^T [U (.) B^T d B] A per tile, so
+//   dL/dg = G^T [ sum over tiles (A gy A^T) (.) (B^T d B) ] G
+// 36 plane GEMMs  X[p] (Cout x Cin) = Ygy[p]^T (T x Cout) . V[p] (T x Cin)  with a quarter of the direct form's MACs (the
+// reduction runs over tiles, not pixels x taps), one transform of gy (A gy A^T: 4x4 -> 6x6, zero beyond the image), the
+// input transform of the forward, and a 36 -> 9 transform per (filter, channel) at the end.
+__device__ inline void a6(const float v[4], float o[6]) {            // A v  (A = (A^T)^T, 6 x 4)
+    o[0] = v[0];
+    o[1] = v[0] + v[1] + v[2] + v[3];
+    o[2] = v[0] - v[1] + v[2] - v[3];
+    o[3] = v[0] + 2.f * v[1] + 4.f * v[2] + 8.f * v[3];
+    o[4] = v[0] - 2.f * v[1] + 4.f * v[2] - 8.f * v[3];
+    o[5] = v[3];
+}
+__device__ inline void gt6(const float x[6], float o[3]) {           // G^T x
+    o[0] = 0.25f * x[0] + (-1.f / 6.f) * (x[1] + x[2]) + (1.f / 24.f) * (x[3] + x[4]);
+    o[1] = (-1.f / 6.f) * (x[1] - x[2]) + (1.f / 12.f) * (x[3] - x[4]);
+    o[2] = (-1.f / 6.f) * (x[1] + x[2]) + (1.f / 6.f) * (x[3] + x[4]) + x[5];
+}
+
+__global__ void __launch_bounds__(256)
+wino4_gy_kernel(const float* __restrict__ gy, float* __restrict__ Y, int B, int H, int W, int N, int th, int tw) {
+    const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    const long long T = (long long)B * th * tw;
+    if (idx >= T * N) return;
+    const int n = (int)(idx % N);
+    const long long t = idx / N;
+    const int tx = (int)(t % tw), ty = (int)((t / tw) % th), b = (int)(t / ((long long)tw * th));
+    float m[6][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {               // column q of the 4x4 tile through A (rows)
+        const int ox = 4 * tx + q;
+        float d[4], o[6];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oy = 4 * ty + r;
+            d[r] = (oy < H && ox < W) ? gy[(((long long)b * H + oy) * W + ox) * N + n] : 0.f;
+        }
+        a6(d, o);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) m[r][q] = o[r];
+    }
+    const long long plane = T * N;
+    float* o = Y + t * N + n;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        float v[6];
+        a6(m[r], v);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) o[(long long)(6 * r + q) * plane] = v[q];
+    }
+}
+
+// gw[n][ky][kx][c] = beta * gw + row_scale[n] * (G^T X G)[ky][kx],  X[6r+q][n][c]
+__global__ void wino4_wgrad_final_kernel(const float* __restrict__ X, float* __restrict__ gw, const float* __restrict__ row_scale,
+                                         int Cout, int Cin, float beta) {
+    const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (idx >= (long long)Cout * Cin) return;
+    const int c = (int)(idx % Cin), n = (int)(idx / Cin);
+    const long long plane = (long long)Cout * Cin;
+    float t[3][6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        float x[6], o[3];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) x[r] = X[(long long)(6 * r + q) * plane + idx];
+        gt6(x, o);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t[k][q] = o[k];
+    }
+    const float rs = row_scale ? row_scale[n] : 1.f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        float o[3];
+        gt6(t[ky], o);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            float* dst = gw + (((long long)n * 3 + ky) * 3 + kx) * Cin + c;
+            *dst = (beta != 0.f ? beta * *dst : 0.f) + rs * o[kx];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int32_t i2v_winograd_filter(const float* w, float* U, int32_t Cout, int32_t Cin, void* stream) {
@@ -485,4 +570,41 @@ extern "C" int32_t i2v_conv3x3_winograd4_dgrad(const float* gy, const float* U, 
     // the data gradient of a stride-1 / pad-1 3x3 layer is the same convolution with U = i2v_winograd4_filter_dgrad(w):
     // gy has Cout channels, gx has Cin
     return winograd4_impl(gy, U, out_scale, nullptr, mask, gx, B, H, W, Cout, Cin, 0, ws, ws_bytes, stream);
+}
+
+extern "C" size_t i2v_conv3x3_winograd4_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 256;
+    const size_t T = (size_t)B * ((H + 3) / 4) * ((W + 3) / 4);
+    return i2v_align(36 * T * Cin * sizeof(float)) + i2v_align(36 * T * Cout * sizeof(float)) +
+           i2v_align(36 * (size_t)Cout * Cin * sizeof(float));
+}
+
+// Filter gradient of a stride-1 / pad-1 3x3 layer in the F(4x4,3x3) domain: gw (Cout,3,3,Cin) = beta * gw +
+// row_scale[n] * wgrad(x, gy).  x (B,H,W,Cin), gy (B,H,W,Cout) NHWC; Cin % 4 == 0 and Cout % 4 == 0.
+extern "C" int32_t i2v_conv3x3_winograd4_wgrad(const float* x, const float* gy, const float* row_scale, float* gw,
+                                               int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, float beta,
+                                               void* ws, size_t ws_bytes, void* stream) {
+    I2V_CHECK_ARG(x && gy && gw && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_winograd4_wgrad: bad argument");
+    I2V_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0, "conv3x3_winograd4_wgrad: Cin and Cout must be multiples of 4");
+    I2V_CHECK_ARG(beta == 0.f || beta == 1.f, "conv3x3_winograd4_wgrad: beta must be 0 or 1");
+    if (!ws || ws_bytes < i2v_conv3x3_winograd4_wgrad_workspace_bytes(B, H, W, Cin, Cout)) {
+        i2v_set_error("conv3x3_winograd4_wgrad: workspace too small");
+        return I2V_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int th = (H + 3) / 4, tw = (W + 3) / 4;
+    const long long T = (long long)B * th * tw;
+    float* V = (float*)ws;
+    float* Y = (float*)((char*)ws + i2v_align(36 * (size_t)T * Cin * sizeof(float)));
+    float* X = (float*)((char*)Y + i2v_align(36 * (size_t)T * Cout * sizeof(float)));
+    const int rows_env = g_i2v_tuning[I2V_TUNE_WINO_ROWS];
+    const int rows = rows_env >= 0 ? rows_env : (T * Cin <= 98304 ? 1 : 0);
+    if (rows & 1) wino4_input_rows_kernel<<<dim3((unsigned)i2v_cdiv(T * Cin, 256), 6), 256, 0, st>>>(x, V, B, H, W, Cin, th, tw);
+    else wino4_input_kernel<<<(unsigned)i2v_cdiv(T * Cin, 256), 256, 0, st>>>(x, V, B, H, W, Cin, th, tw);
+    wino4_gy_kernel<<<(unsigned)i2v_cdiv(T * Cout, 256), 256, 0, st>>>(gy, Y, B, H, W, Cout, th, tw);
+    int rc = i2v_gemm_tn_batched(V, Y, X, (int32_t)T, Cout, Cin, 36, T * Cin, T * Cout, (long long)Cout * Cin, stream);
+    if (rc) return rc;
+    wino4_wgrad_final_kernel<<<(unsigned)i2v_cdiv((long long)Cout * Cin, 256), 256, 0, st>>>(X, gw, row_scale, Cout, Cin, beta);
+    I2V_CHECK_LAUNCH("conv3x3_winograd4_wgrad");
+    return I2V_OK;
 }

@@ -472,7 +472,18 @@ def _conv_dgrad_raw(g, w, in_shape, stride, pad):
     return gx
 
 
-def _conv_wgrad_raw(x, g, w_shape, stride, pad, tag="wgrad"):
+# I2V_WINOGRAD_WGRAD=0: the filter gradient of a trained 3x3 layer stays on the direct kernel (its forward and data gradient
+# are Winograd F(4x4,3x3) with WINOGRAD_TRAIN)
+WINOGRAD_WGRAD = os.environ.get("I2V_WINOGRAD_WGRAD", "1") != "0"
+
+
+def _winograd_wgrad_ok(x, w_shape, stride, pad):
+    Cout, Cin, KH, KW = w_shape
+    return (WINOGRAD_WGRAD and WINOGRAD_TRAIN and (KH, KW, stride, pad) == (3, 3, 1, 1) and Cin % 4 == 0 and Cout % 4 == 0
+            and Cin >= WINOGRAD_TRAIN_MIN_C and Cout >= WINOGRAD_TRAIN_MIN_C)
+
+
+def _conv_wgrad_raw(x, g, w_shape, stride, pad, tag="wgrad", row_scale=None, winograd=False):
     B, Cin, H, W = x.shape
     Cout, _, KH, KW = w_shape
     # small filters: the pixel reduction is split over workgroups and accumulated with atomics, which needs a
@@ -487,11 +498,24 @@ def _conv_wgrad_raw(x, g, w_shape, stride, pad, tag="wgrad"):
             gw, beta = flat.view(Cout, KH, KW, Cin).permute(0, 3, 1, 2), 1.0
     if gw is None:
         gw = torch.empty(w_shape, device=x.device, dtype=torch.float32, memory_format=_CL)
+    if winograd and _winograd_wgrad_ok(x, w_shape, stride, pad):
+        # stride-1 / pad-1 3x3 layer of a trained bottleneck: 36 plane GEMMs over the 4x4 tiles, a quarter of the MACs
+        ws = workspace(lib.i2v_conv3x3_winograd4_wgrad_workspace_bytes(B, H, W, Cin, Cout), x.device, "winograd")
+        T = B * ((H + 3) // 4) * ((W + 3) // 4)
+        with _Timed(2.0 * B * H * W * Cout * 9 * Cin, tag, "N%d K%d M%d (3x3 winograd F4)" % (Cout, 9 * Cin, B * H * W),
+                    4 * (x.numel() + g.numel() + gw.numel())):
+            check(lib.i2v_conv3x3_winograd4_wgrad(ptr(x), ptr(g), ptr(row_scale), ptr(gw), B, H, W, Cin, Cout, beta, ptr(ws),
+                                                  ws.numel(), stream()), "conv3x3_winograd4_wgrad")
+        return gw
     with _Timed(2.0 * B * g.shape[2] * g.shape[3] * Cout * KH * KW * Cin, tag,
                 "N%d K%d M%d" % (Cout, KH * KW * Cin, B * g.shape[2] * g.shape[3]) + (" (wgrad form)" if tag != "wgrad" else ""),
                 4 * (x.numel() + g.numel() + gw.numel())):
-        check(lib.i2v_conv_wgrad(ptr(x), ptr(g), ptr(gw), B, H, W, Cin, Cout, KH, KW, stride, pad, beta, None, 0,
-                                 stream()), "conv_wgrad")
+        if row_scale is not None:
+            check(lib.i2v_conv_wgrad_scaled(ptr(x), ptr(g), ptr(row_scale), ptr(gw), B, H, W, Cin, Cout, KH, KW, stride, pad,
+                                            beta, stream()), "conv_wgrad_scaled")
+        else:
+            check(lib.i2v_conv_wgrad(ptr(x), ptr(g), ptr(gw), B, H, W, Cin, Cout, KH, KW, stride, pad, beta, None, 0,
+                                     stream()), "conv_wgrad")
     return gw
 
 
@@ -600,7 +624,9 @@ class _ConvFn(torch.autograd.Function):
             fused = FUSED_SGD.get(w.data_ptr())
             # the filter is read by dgrad above before it is updated here
             if fused is None or _conv_wgrad_sgd_raw(x, g, w, fused, stride, pad) != 0:
-                gw = _conv_wgrad_raw(x, g, w.shape, stride, pad)
+                # Winograd filter gradient for every eligible 3x3 (the RPN's too: its FORWARD stays direct for the proposal
+                # ranking's sake, the filter gradient only feeds the next step's weights)
+                gw = _conv_wgrad_raw(x, g, w.shape, stride, pad, winograd=True)
         return gx, gw, None, gbias, gres, None, None, None, None
 
 
@@ -628,21 +654,7 @@ def _dgrad_fused(g, w, in_shape, pad, gy_scale=None, out_scale=None, res=None, m
 
 def _wgrad_scaled(x, g, w_shape, pad, row_scale):
     """gw[n] = row_scale[n] * wgrad(x, g)[n] of a stride-1 layer; output placement as in _conv_wgrad_raw."""
-    B, Cin, H, W = x.shape
-    Cout, _, KH, KW = w_shape
-    gw, beta = None, 0.0
-    n = Cout * Cin * KH * KW
-    if ARENA is not None and n * 4 <= SMALL_GW_BYTES and B * g.shape[2] * g.shape[3] > 224:
-        flat = ARENA.take_flat(n)
-        if flat is not None:
-            gw, beta = flat.view(Cout, KH, KW, Cin).permute(0, 3, 1, 2), 1.0
-    if gw is None:
-        gw = torch.empty(w_shape, device=x.device, dtype=torch.float32, memory_format=_CL)
-    with _Timed(2.0 * B * g.shape[2] * g.shape[3] * Cout * KH * KW * Cin, "wgrad",
-                "N%d K%d M%d *s" % (Cout, KH * KW * Cin, B * g.shape[2] * g.shape[3]), 4 * (x.numel() + g.numel() + gw.numel())):
-        check(lib.i2v_conv_wgrad_scaled(ptr(x), ptr(g), ptr(row_scale), ptr(gw), B, H, W, Cin, Cout, KH, KW, 1, pad, beta,
-                                        stream()), "conv_wgrad_scaled")
-    return gw
+    return _conv_wgrad_raw(x, g, w_shape, 1, pad, row_scale=row_scale)
 
 
 def _winograd_dgrad_fused(g, U, out_scale, mask):
@@ -712,7 +724,7 @@ class _BottleneckFn(torch.autograd.Function):
         gw3 = _wgrad_scaled(a2, gpre, w3.shape, 0, s3) if need[3] else None
         g2 = _dgrad_fused(gpre, w3, a2.shape, 0, gy_scale=s3, out_scale=s2, mask=a2)         # gradient at conv2's raw output
         # conv2
-        gw2 = _conv_wgrad_raw(a1, g2, w2.shape, 1, 1) if need[2] else None
+        gw2 = _conv_wgrad_raw(a1, g2, w2.shape, 1, 1, winograd=wino) if need[2] else None
         if wino:
             g1 = _winograd_dgrad_fused(g2, winograd_filter_dgrad(w2), s1, a1)
         else:

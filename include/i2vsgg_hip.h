@@ -259,6 +259,16 @@ int32_t i2v_conv_wgrad_scaled(const float* x, const float* gy, const float* row_
 int32_t i2v_conv3x3_winograd4_dgrad(const float* gy, const float* U, const float* out_scale, const float* mask,
                                     float* gx, int32_t B, int32_t H, int32_t W, int32_t Cout, int32_t Cin,
                                     void* workspace, size_t workspace_bytes, void* stream);
+/* Filter gradient of a stride-1 / pad-1 3x3 layer in the Winograd F(4x4,3x3) domain (a quarter of the direct form's MACs:
+ * 36 plane GEMMs reduced over the 4x4 tiles):  gw (Cout,3,3,Cin) = beta * gw + row_scale[cout] * wgrad(x, gy), beta 0 or 1,
+ * row_scale may be NULL.  The caller's workspace holds both transformed operands and the 36 partial planes. */
+size_t  i2v_conv3x3_winograd4_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
+int32_t i2v_conv3x3_winograd4_wgrad(const float* x, const float* gy, const float* row_scale, float* gw,
+                                    int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, float beta,
+                                    void* workspace, size_t workspace_bytes, void* stream);
+/* gw[z] (N x K) = gy[z]^T (M x N) . x[z] (M x K), z < nbatch (the plane GEMMs above); N % 4 == K % 4 == 0 */
+int32_t i2v_gemm_tn_batched(const float* x, const float* gy, float* gw, int32_t M, int32_t N, int32_t K,
+                            int32_t nbatch, long long stride_x, long long stride_gy, long long stride_gw, void* stream);
 size_t  i2v_conv_dgrad_workspace_bytes(int32_t Cin, int32_t Cout, int32_t KH, int32_t KW);
 int32_t i2v_conv_dgrad(const float* gy, const float* w, float* gx, int32_t B, int32_t H, int32_t W,
                        int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,

@@ -60,7 +60,7 @@ def test_instance_styled_step_full_size(fresh_cfg):
         net = train.build_instance_styled_net(101, device=DEV)
         before = {k: v.detach().clone() for k, v in net.named_parameters() if k in names}
         step = train.InstanceStyleDStep(net, 4, seed=3, device=DEV)
-        saved = (ops.WINOGRAD_TRAIN, net.netD_pixel.forward, ops.BLOCK_FUSED)
+        saved = (ops.WINOGRAD_TRAIN, net.netD_pixel.forward, ops.BLOCK_FUSED)      # WINOGRAD_TRAIN off: direct wgrad too
         if plain:
             ops.WINOGRAD_TRAIN = False
             ops.BLOCK_FUSED = False          # every conv its own autograd node, separate scale / mask passes

@@ -919,3 +919,22 @@ def test_conv_dgrad_fused_and_wgrad_scaled_vs_torch():
         gw = ops._wgrad_scaled(x, gy, w.shape, pad, gs)
         wref = torch.nn.grad.conv2d_weight(x, w.shape, gy, 1, pad) * gs.view(-1, 1, 1, 1)
         assert float((gw - wref).abs().max()) <= 1e-4 * float(wref.abs().max()), (cin, cout, k)
+
+
+@pytest.mark.parametrize("B,C,N,H,W", [(2, 64, 64, 30, 44), (1, 128, 64, 13, 21), (2, 256, 256, 38, 63), (4, 64, 128, 75, 125)])
+def test_winograd_filter_gradient_vs_torch(B, C, N, H, W):
+    """i2v_conv3x3_winograd4_wgrad (36 plane GEMMs over the 4x4 tiles + the two operand transforms + the 36 -> 9 transform)
+    against float64 torch and against the direct filter-gradient kernel; beta = 1 accumulates; row_scale scales rows."""
+    from i2vsgg_amd import ops
+    torch.manual_seed(B + C)
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    x, g = cl(torch.randn(B, C, H, W, device=DEV)), cl(torch.randn(B, N, H, W, device=DEV))
+    rs = torch.rand(N, device=DEV) + 0.5
+    want = torch.nn.grad.conv2d_weight(x.double(), (N, C, 3, 3), g.double(), 1, 1)
+    scale = float(want.abs().max())
+    got = ops._conv_wgrad_raw(x, g, (N, C, 3, 3), 1, 1, winograd=True)
+    direct = ops._conv_wgrad_raw(x, g, (N, C, 3, 3), 1, 1)
+    assert float((direct.double() - want).abs().max()) <= 1e-4 * scale
+    assert float((got.double() - want).abs().max()) <= 2e-4 * scale, float((got.double() - want).abs().max()) / scale
+    got = ops._conv_wgrad_raw(x, g, (N, C, 3, 3), 1, 1, winograd=True, row_scale=rs)
+    assert float((got.double() - want * rs.double().view(-1, 1, 1, 1)).abs().max()) <= 2e-4 * 1.5 * scale
