@@ -334,7 +334,10 @@ def test_conv_bwd_vs_torch_autograd(ops, case):
     y.backward(gy.to(DEV))
     tol = dict(rtol=3e-4, atol=3e-4)
     np.testing.assert_allclose(xd.grad.cpu().numpy(), xt.grad.numpy(), **tol)
-    np.testing.assert_allclose(wd.grad.cpu().numpy(), wt.grad.numpy(), **tol)
+    # eligible 3x3 layers take the Winograd F(4x4,3x3) filter gradient: fp32 error ~2e-5 of the tensor's range (the
+    # transform constants reach 8 and 1/24), where the direct kernel has ~1e-6
+    wtol = dict(rtol=3e-4, atol=max(3e-4, 5e-5 * float(wt.grad.abs().max())))
+    np.testing.assert_allclose(wd.grad.cpu().numpy(), wt.grad.numpy(), **wtol)
     np.testing.assert_allclose(bd.grad.cpu().numpy(), bt.grad.numpy(), **tol)
 
 
