@@ -572,6 +572,10 @@ class _ConvFn(torch.autograd.Function):
         else:
             y = _conv_fwd_raw(x, w, scale, shift, res, stride, pad, flags)
         ctx.wino = wino
+        # the data gradient of an eligible 3x3 layer takes the Winograd form even where the forward may not (the RPN conv)
+        ctx.wino_dgrad = wino or (WINOGRAD_TRAIN and WINOGRAD_WGRAD and stride == 1 and pad == 1 and tuple(w.shape[2:]) == (3, 3)
+                                  and w.shape[1] >= WINOGRAD_TRAIN_MIN_C and w.shape[0] >= WINOGRAD_TRAIN_MIN_C
+                                  and w.shape[1] % 4 == 0 and w.shape[0] % 4 == 0)
         ctx.cfg = (stride, pad, relu, scale is not None, shift is not None, res is not None)
         ctx.save_for_backward(x, w, scale, y if relu else None)
         return y
@@ -600,7 +604,7 @@ class _ConvFn(torch.autograd.Function):
             gpre = torch.empty_like(gy) if (want_pre and has_scale) else None
             # a linear layer whose data gradient will run on the wgrad kernel wants g column-major as well: written by
             # this pass instead of a transpose kernel of its own
-            if ctx.needs_input_grad[0] and not ctx.wino and _linear_dgrad_as_wgrad(x.shape, w.shape, stride, pad):
+            if ctx.needs_input_grad[0] and not ctx.wino_dgrad and _linear_dgrad_as_wgrad(x.shape, w.shape, stride, pad):
                 g_t = torch.empty((N, M, 1, 1), device=gy.device, dtype=torch.float32)
             check(lib.i2v_epilogue_bwd(ptr(gy), ptr(y), ptr(scale) if has_scale else None, ptr(g), ptr(gpre), ptr(gbias),
                                        M, N, int(relu), ptr(g_t), stream()), "epilogue_bwd")
@@ -613,7 +617,7 @@ class _ConvFn(torch.autograd.Function):
             gres = gy if need_res else None
         gx = None
         if ctx.needs_input_grad[0]:
-            if ctx.wino:
+            if ctx.wino_dgrad:
                 gx = conv3x3_winograd(g, winograd_filter_dgrad(w), tag="dgrad")
             elif g_t is not None:
                 gx = _conv_wgrad_raw(w, g_t, (x.shape[0], x.shape[1], 1, 1), 1, 0, tag="dgrad")
