@@ -1261,6 +1261,7 @@ __global__ void weight_dgrad_sub_layout(const float* __restrict__ w, float* __re
 struct WgP {
     const float* x; const float* gy; float* gw; int direct;
     const float* row_scale;                // gw[n][:] = row_scale[n] * sum (a frozen-BN scale on gy applied where the sum ends), or NULL
+    int xcd_remap;                         // (tile, split) from the dispatch index so that a split's tiles share an XCD (launch_wgrad)
     int nbatch;                            // > 1: blockIdx.z selects one of nbatch independent GEMMs (the planes of a Winograd filter gradient)
     long long bsx, bsg, bsw;               // element strides between the batches of x, gy and gw
     float* sgd_m; float lr, mom, wd;       // sgd_m != NULL: gw is the PARAMETER, updated in place (fused SGD)
@@ -1413,8 +1414,18 @@ conv_wgrad2_f32(const WgP p_in) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_k = (p.K + BNW - 1) / BNW;
-    const int n0 = (blockIdx.x / tiles_k) * BMW, k0 = (blockIdx.x % tiles_k) * BNW;
-    const int mbeg = blockIdx.y * p.m_per_split, mend = min(p.M, mbeg + p.m_per_split);
+    // XCD-aware order (p.xcd_remap: the split count is a multiple of 8): workgroups are dealt to the 8 XCDs round robin in
+    // dispatch order, and every XCD has its own L2.  All tiles of one pixel range (one split) read the same rows of gy and
+    // x; dealt in (tile, split) order they land on all 8 XCDs and every L2 fetches those rows again (PMC: 3.6x the
+    // algorithmic bytes on the layer3 shapes).  Remapped, split s lives on XCD s % 8 with all of its tiles.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.xcd_remap) {
+        const int L = by * gridDim.x + bx, g = L & 7, r = L >> 3;
+        by = g + 8 * (r / (int)gridDim.x);
+        bx = r % (int)gridDim.x;
+    }
+    const int n0 = (bx / tiles_k) * BMW, k0 = (bx % tiles_k) * BNW;
+    const int mbeg = by * p.m_per_split, mend = min(p.M, mbeg + p.m_per_split);
     const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)p.gy, 0, p.gy_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
     constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -1904,6 +1915,7 @@ static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st) {
     p.x_bytes = (unsigned)xb;
     p.gy_bytes = (unsigned)gb;
     const dim3 grid((unsigned)tiles, splits, p.nbatch > 1 ? p.nbatch : 1);
+    p.xcd_remap = (splits % 8 == 0 && p.nbatch <= 1 && g_i2v_tuning[I2V_TUNE_WGRAD_XCD]) ? 1 : 0;
     if (!v2) conv_wgrad_f32<64, 64><<<grid, THREADS, 0, st>>>(p);
     else if (fused && tm == 128 && tk == 64) conv_wgrad2_f32<4, 2, true><<<grid, THREADS, 0, st>>>(p);
     else if (tm == 128 && tk == 128) conv_wgrad2_f32<4, 4><<<grid, THREADS, 0, st>>>(p);

@@ -224,7 +224,8 @@ size_t  i2v_conv_split_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t 
 #define I2V_TUNE_STAGGER             11   /* experiment: co-resident conv_gemm_f32 workgroups start this many kcycles apart (0 = off) */
 #define I2V_TUNE_ROIALIGN_COLS       12   /* 1 (default): ROIAlign forward on column-pair workgroups (one memory round trip) */
 #define I2V_TUNE_WGRAD_PER_CU        13   /* workgroups per CU a split-over-pixels wgrad launch aims for (default 4) */
-#define I2V_TUNE_COUNT               14
+#define I2V_TUNE_WGRAD_XCD           14   /* 1 (default): a filter-gradient split's tiles share an XCD when the split count is a multiple of 8 */
+#define I2V_TUNE_COUNT               15
 int32_t i2v_set_tuning(int32_t key, int32_t value);
 int32_t i2v_get_tuning(int32_t key);
 /* tuning hook: cfg < 0 = cost model; else low byte = tile shape 0..5 (0xFF = cost model),

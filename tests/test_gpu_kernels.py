@@ -884,7 +884,7 @@ def test_trained_bottleneck_stack_as_fused_autograd_nodes(cin, planes, hw):
         """A pre-activation within rounding of zero takes the other side of its ReLU in one of the two computations (the
         filter gradients are summed with atomics: even the same path does not repeat bit for bit); the gradient behind that
         pixel then differs by O(1) and the difference spreads, attenuated, through the 3x3 and 1x1 layers below it.  So:
-        small in the L2 sense (a missing mask / scale / skip term is O(1) there), and no more than 0.1 % of the elements
+        small in the L2 sense (1 in 8 runs reaches 1e-2 on the 14x20 case; a missing mask / scale / skip term is >= 0.3 there), and no more than 0.1 % of the elements
         off by 5 % of the tensor's range."""
         scale = float(b.abs().max()) + 1e-12
         err = (a - b).abs()
@@ -893,9 +893,9 @@ def test_trained_bottleneck_stack_as_fused_autograd_nodes(cin, planes, hw):
         return frac <= 1e-3 and l2 <= tol, (frac, l2)
 
     for n, a, b, c in zip(names, fused, plain, ref):
-        ok, why = close(a, b, 1e-2)
+        ok, why = close(a, b, 5e-2)
         assert ok, ("fused vs layer-by-layer", n, why)
-        ok, why = close(a, c, 1e-2)
+        ok, why = close(a, c, 5e-2)
         assert ok, ("fused vs torch float64", n, why)
     # the forward has no knife edge that matters at this tolerance
     assert float((fused[0] - ref[0]).abs().max()) <= 1e-3 * float(ref[0].abs().max())
