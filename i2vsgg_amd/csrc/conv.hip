@@ -1396,10 +1396,22 @@ conv_wgrad2_f32(const WgP p_in) {
     WgP p = p_in;
     unsigned long long c_rt0 = 0, c_t0 = 0, c_t1 = 0, c_t2 = 0;
     if constexpr (CLK) { c_rt0 = __builtin_amdgcn_s_memrealtime(); c_t0 = __builtin_amdgcn_s_memtime(); }
+    // XCD-aware order (p.xcd_remap: splits x planes is a multiple of 8): workgroups are dealt to the 8 XCDs round robin in
+    // dispatch order, and every XCD has its own L2.  All tiles of one pixel range (one split of one plane) read the same rows
+    // of gy and x; dealt in (tile, split) order they land on all 8 XCDs and every L2 fetches those rows again (PMC: 3.6x the
+    // algorithmic bytes on the layer3 shapes).  Remapped, group s = (split, plane) lives on XCD s % 8 with all of its tiles.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_remap) {
+        const int L = (bz * (int)gridDim.y + by) * (int)gridDim.x + bx, g = L & 7, r = L >> 3;
+        const int grp = g + 8 * (r / (int)gridDim.x);
+        bx = r % (int)gridDim.x;
+        by = grp % (int)gridDim.y;
+        bz = grp / (int)gridDim.y;
+    }
     if (p.nbatch > 1) {
-        p.x += (long long)blockIdx.z * p.bsx;
-        p.gy += (long long)blockIdx.z * p.bsg;
-        p.gw += (long long)blockIdx.z * p.bsw;
+        p.x += (long long)bz * p.bsx;
+        p.gy += (long long)bz * p.bsg;
+        p.gw += (long long)bz * p.bsw;
     }
     constexpr int BMW = 2 * TM * 16, BNW = 2 * TN * 16;
     constexpr int A_BLK = BMW * 2, B_BLK = BNW * 2;             // (cols/4) * 8 row-groups
@@ -1414,16 +1426,6 @@ conv_wgrad2_f32(const WgP p_in) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_k = (p.K + BNW - 1) / BNW;
-    // XCD-aware order (p.xcd_remap: the split count is a multiple of 8): workgroups are dealt to the 8 XCDs round robin in
-    // dispatch order, and every XCD has its own L2.  All tiles of one pixel range (one split) read the same rows of gy and
-    // x; dealt in (tile, split) order they land on all 8 XCDs and every L2 fetches those rows again (PMC: 3.6x the
-    // algorithmic bytes on the layer3 shapes).  Remapped, split s lives on XCD s % 8 with all of its tiles.
-    int bx = blockIdx.x, by = blockIdx.y;
-    if (p.xcd_remap) {
-        const int L = by * gridDim.x + bx, g = L & 7, r = L >> 3;
-        by = g + 8 * (r / (int)gridDim.x);
-        bx = r % (int)gridDim.x;
-    }
     const int n0 = (bx / tiles_k) * BMW, k0 = (bx % tiles_k) * BNW;
     const int mbeg = by * p.m_per_split, mend = min(p.M, mbeg + p.m_per_split);
     const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc((void*)p.gy, 0, p.gy_bytes, 0x00020000);
@@ -1915,7 +1917,7 @@ static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st) {
     p.x_bytes = (unsigned)xb;
     p.gy_bytes = (unsigned)gb;
     const dim3 grid((unsigned)tiles, splits, p.nbatch > 1 ? p.nbatch : 1);
-    p.xcd_remap = (splits % 8 == 0 && p.nbatch <= 1 && g_i2v_tuning[I2V_TUNE_WGRAD_XCD]) ? 1 : 0;
+    p.xcd_remap = ((splits * (p.nbatch > 1 ? p.nbatch : 1)) % 8 == 0 && g_i2v_tuning[I2V_TUNE_WGRAD_XCD]) ? 1 : 0;
     if (!v2) conv_wgrad_f32<64, 64><<<grid, THREADS, 0, st>>>(p);
     else if (fused && tm == 128 && tk == 64) conv_wgrad2_f32<4, 2, true><<<grid, THREADS, 0, st>>>(p);
     else if (tm == 128 && tk == 128) conv_wgrad2_f32<4, 4><<<grid, THREADS, 0, st>>>(p);
