@@ -62,6 +62,9 @@ SIGNATURES = {
     "i2v_conv3x3_winograd4_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "i2v_conv3x3_winograd4_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _z, _p]),
     "i2v_gemm_tn_batched": (_i, [_p, _p, _p, _i, _i, _i, _i, _l, _l, _l, _p]),
+    "i2v_conv3x3_winograd4_v_bytes": (_z, [_i, _i, _i, _i]),
+    "i2v_conv3x3_winograd4_fwd_keep": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
+    "i2v_conv3x3_winograd4_wgrad_v": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _z, _p]),
     "i2v_conv_wgrad_sgd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _p]),
     "i2v_epilogue_bwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _p]),
     "i2v_maxpool3x3s2_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),

@@ -532,7 +532,7 @@ extern "C" size_t i2v_conv3x3_winograd4_workspace_bytes(int32_t B, int32_t H, in
 
 static int winograd4_impl(const float* x, const float* U, const float* scale, const float* shift, const float* mask,
                           float* y, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
-                          int32_t relu, void* ws, size_t ws_bytes, void* stream) {
+                          int32_t relu, void* ws, size_t ws_bytes, void* stream, float* v_keep = nullptr) {
     I2V_CHECK_ARG(x && U && y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_winograd4_fwd: bad argument");
     I2V_CHECK_ARG(Cin % 4 == 0, "conv3x3_winograd4_fwd: Cin must be a multiple of 4");
     if (!ws || ws_bytes < i2v_conv3x3_winograd4_workspace_bytes(B, H, W, Cin, Cout)) {
@@ -542,7 +542,7 @@ static int winograd4_impl(const float* x, const float* U, const float* scale, co
     hipStream_t st = (hipStream_t)stream;
     const int th = (H + 3) / 4, tw = (W + 3) / 4;
     const long long T = (long long)B * th * tw;
-    float* V = (float*)ws;
+    float* V = v_keep ? v_keep : (float*)ws;        // v_keep: the transformed input outlives the call (the filter gradient reads it)
     float* Mx = (float*)((char*)ws + i2v_align(36 * (size_t)T * Cin * sizeof(float)));
     // row-split transforms only where the one-thread-per-(tile, channel) launch cannot fill the chip (layer3: 34 vs
     // 37 us per layer); on layer1/2 their redundant loads cost more than the parallelism buys (79 vs 57 us)
@@ -564,6 +564,20 @@ extern "C" int32_t i2v_conv3x3_winograd4_fwd(const float* x, const float* U, con
     return winograd4_impl(x, U, scale, shift, nullptr, y, B, H, W, Cin, Cout, relu, ws, ws_bytes, stream);
 }
 
+// Forward that leaves the transformed input V (36 x tiles x Cin floats, i2v_conv3x3_winograd4_v_bytes) in the caller's
+// buffer: a trained layer hands it to i2v_conv3x3_winograd4_wgrad instead of transforming x a second time.
+extern "C" size_t i2v_conv3x3_winograd4_v_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0) return 0;
+    return 36 * (size_t)B * ((H + 3) / 4) * ((W + 3) / 4) * Cin * sizeof(float);
+}
+
+extern "C" int32_t i2v_conv3x3_winograd4_fwd_keep(const float* x, const float* U, const float* scale, const float* shift,
+                                                  float* y, float* v_out, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                                                  int32_t Cout, int32_t relu, void* ws, size_t ws_bytes, void* stream) {
+    I2V_CHECK_ARG(v_out, "conv3x3_winograd4_fwd_keep: null V buffer");
+    return winograd4_impl(x, U, scale, shift, nullptr, y, B, H, W, Cin, Cout, relu, ws, ws_bytes, stream, v_out);
+}
+
 extern "C" int32_t i2v_conv3x3_winograd4_dgrad(const float* gy, const float* U, const float* out_scale, const float* mask,
                                                float* gx, int32_t B, int32_t H, int32_t W, int32_t Cout, int32_t Cin,
                                                void* ws, size_t ws_bytes, void* stream) {
@@ -581,10 +595,10 @@ extern "C" size_t i2v_conv3x3_winograd4_wgrad_workspace_bytes(int32_t B, int32_t
 
 // Filter gradient of a stride-1 / pad-1 3x3 layer in the F(4x4,3x3) domain: gw (Cout,3,3,Cin) = beta * gw +
 // row_scale[n] * wgrad(x, gy).  x (B,H,W,Cin), gy (B,H,W,Cout) NHWC; Cin % 4 == 0 and Cout % 4 == 0.
-extern "C" int32_t i2v_conv3x3_winograd4_wgrad(const float* x, const float* gy, const float* row_scale, float* gw,
-                                               int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, float beta,
-                                               void* ws, size_t ws_bytes, void* stream) {
-    I2V_CHECK_ARG(x && gy && gw && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_winograd4_wgrad: bad argument");
+static int winograd4_wgrad_impl(const float* x, const float* v_in, const float* gy, const float* row_scale, float* gw,
+                                int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, float beta,
+                                void* ws, size_t ws_bytes, void* stream) {
+    I2V_CHECK_ARG((x || v_in) && gy && gw && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_winograd4_wgrad: bad argument");
     I2V_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0, "conv3x3_winograd4_wgrad: Cin and Cout must be multiples of 4");
     I2V_CHECK_ARG(beta == 0.f || beta == 1.f, "conv3x3_winograd4_wgrad: beta must be 0 or 1");
     if (!ws || ws_bytes < i2v_conv3x3_winograd4_wgrad_workspace_bytes(B, H, W, Cin, Cout)) {
@@ -599,7 +613,8 @@ extern "C" int32_t i2v_conv3x3_winograd4_wgrad(const float* x, const float* gy, 
     float* X = (float*)((char*)Y + i2v_align(36 * (size_t)T * Cout * sizeof(float)));
     const int rows_env = g_i2v_tuning[I2V_TUNE_WINO_ROWS];
     const int rows = rows_env >= 0 ? rows_env : (T * Cin <= 98304 ? 1 : 0);
-    if (rows & 1) wino4_input_rows_kernel<<<dim3((unsigned)i2v_cdiv(T * Cin, 256), 6), 256, 0, st>>>(x, V, B, H, W, Cin, th, tw);
+    if (v_in) V = const_cast<float*>(v_in);         // the forward's transformed input (i2v_conv3x3_winograd4_fwd_keep)
+    else if (rows & 1) wino4_input_rows_kernel<<<dim3((unsigned)i2v_cdiv(T * Cin, 256), 6), 256, 0, st>>>(x, V, B, H, W, Cin, th, tw);
     else wino4_input_kernel<<<(unsigned)i2v_cdiv(T * Cin, 256), 256, 0, st>>>(x, V, B, H, W, Cin, th, tw);
     wino4_gy_kernel<<<(unsigned)i2v_cdiv(T * Cout, 256), 256, 0, st>>>(gy, Y, B, H, W, Cout, th, tw);
     int rc = i2v_gemm_tn_batched(V, Y, X, (int32_t)T, Cout, Cin, 36, T * Cin, T * Cout, (long long)Cout * Cin, stream);
@@ -607,4 +622,18 @@ extern "C" int32_t i2v_conv3x3_winograd4_wgrad(const float* x, const float* gy, 
     wino4_wgrad_final_kernel<<<(unsigned)i2v_cdiv((long long)Cout * Cin, 256), 256, 0, st>>>(X, gw, row_scale, Cout, Cin, beta);
     I2V_CHECK_LAUNCH("conv3x3_winograd4_wgrad");
     return I2V_OK;
+}
+
+extern "C" int32_t i2v_conv3x3_winograd4_wgrad(const float* x, const float* gy, const float* row_scale, float* gw,
+                                               int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, float beta,
+                                               void* ws, size_t ws_bytes, void* stream) {
+    return winograd4_wgrad_impl(x, nullptr, gy, row_scale, gw, B, H, W, Cin, Cout, beta, ws, ws_bytes, stream);
+}
+
+// Same with the input already in the Winograd domain (V of i2v_conv3x3_winograd4_fwd_keep on the same x).
+extern "C" int32_t i2v_conv3x3_winograd4_wgrad_v(const float* v, const float* gy, const float* row_scale, float* gw,
+                                                 int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, float beta,
+                                                 void* ws, size_t ws_bytes, void* stream) {
+    I2V_CHECK_ARG(v, "conv3x3_winograd4_wgrad_v: null V");
+    return winograd4_wgrad_impl(nullptr, v, gy, row_scale, gw, B, H, W, Cin, Cout, beta, ws, ws_bytes, stream);
 }

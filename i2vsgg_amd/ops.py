@@ -483,7 +483,7 @@ def _winograd_wgrad_ok(x, w_shape, stride, pad):
             and Cin >= WINOGRAD_TRAIN_MIN_C and Cout >= WINOGRAD_TRAIN_MIN_C)
 
 
-def _conv_wgrad_raw(x, g, w_shape, stride, pad, tag="wgrad", row_scale=None, winograd=False):
+def _conv_wgrad_raw(x, g, w_shape, stride, pad, tag="wgrad", row_scale=None, winograd=False, v=None):
     B, Cin, H, W = x.shape
     Cout, _, KH, KW = w_shape
     # small filters: the pixel reduction is split over workgroups and accumulated with atomics, which needs a
@@ -504,8 +504,12 @@ def _conv_wgrad_raw(x, g, w_shape, stride, pad, tag="wgrad", row_scale=None, win
         T = B * ((H + 3) // 4) * ((W + 3) // 4)
         with _Timed(2.0 * B * H * W * Cout * 9 * Cin, tag, "N%d K%d M%d (3x3 winograd F4)" % (Cout, 9 * Cin, B * H * W),
                     4 * (x.numel() + g.numel() + gw.numel())):
-            check(lib.i2v_conv3x3_winograd4_wgrad(ptr(x), ptr(g), ptr(row_scale), ptr(gw), B, H, W, Cin, Cout, beta, ptr(ws),
-                                                  ws.numel(), stream()), "conv3x3_winograd4_wgrad")
+            if v is not None:       # the forward's transformed input
+                check(lib.i2v_conv3x3_winograd4_wgrad_v(ptr(v), ptr(g), ptr(row_scale), ptr(gw), B, H, W, Cin, Cout, beta, ptr(ws),
+                                                        ws.numel(), stream()), "conv3x3_winograd4_wgrad_v")
+            else:
+                check(lib.i2v_conv3x3_winograd4_wgrad(ptr(x), ptr(g), ptr(row_scale), ptr(gw), B, H, W, Cin, Cout, beta, ptr(ws),
+                                                      ws.numel(), stream()), "conv3x3_winograd4_wgrad")
         return gw
     with _Timed(2.0 * B * g.shape[2] * g.shape[3] * Cout * KH * KW * Cin, tag,
                 "N%d K%d M%d" % (Cout, KH * KW * Cin, B * g.shape[2] * g.shape[3]) + (" (wgrad form)" if tag != "wgrad" else ""),
@@ -567,8 +571,11 @@ class _ConvFn(torch.autograd.Function):
         wino = (wino_ok and WINOGRAD_TRAIN and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and res is None and stride == 1
                 and pad == 1 and tuple(w.shape[2:]) == (3, 3)
                 and w.shape[1] >= WINOGRAD_TRAIN_MIN_C and w.shape[0] >= WINOGRAD_TRAIN_MIN_C and w.shape[1] % 4 == 0)
+        v = None
         if wino:
-            y = conv3x3_winograd(x, winograd_filter(w.detach(), 4), scale, shift, relu)
+            keep = WINOGRAD_KEEP_V and ctx.needs_input_grad[1] and _winograd_wgrad_ok(x, w.shape, stride, pad)
+            y, v = conv3x3_winograd(x, winograd_filter(w.detach(), 4), scale, shift, relu, keep_v=keep) if keep else \
+                (conv3x3_winograd(x, winograd_filter(w.detach(), 4), scale, shift, relu), None)
         else:
             y = _conv_fwd_raw(x, w, scale, shift, res, stride, pad, flags)
         ctx.wino = wino
@@ -577,12 +584,12 @@ class _ConvFn(torch.autograd.Function):
                                   and w.shape[1] >= WINOGRAD_TRAIN_MIN_C and w.shape[0] >= WINOGRAD_TRAIN_MIN_C
                                   and w.shape[1] % 4 == 0 and w.shape[0] % 4 == 0)
         ctx.cfg = (stride, pad, relu, scale is not None, shift is not None, res is not None)
-        ctx.save_for_backward(x, w, scale, y if relu else None)
+        ctx.save_for_backward(x, w, scale, y if relu else None, v)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w, scale, y = ctx.saved_tensors
+        x, w, scale, y, v = ctx.saved_tensors
         stride, pad, relu, has_scale, has_shift, has_res = ctx.cfg
         gy = as_nhwc(gy)
         M, N = gy.shape[0] * gy.shape[2] * gy.shape[3], gy.shape[1]
@@ -630,7 +637,7 @@ class _ConvFn(torch.autograd.Function):
             if fused is None or _conv_wgrad_sgd_raw(x, g, w, fused, stride, pad) != 0:
                 # Winograd filter gradient for every eligible 3x3 (the RPN's too: its FORWARD stays direct for the proposal
                 # ranking's sake, the filter gradient only feeds the next step's weights)
-                gw = _conv_wgrad_raw(x, g, w.shape, stride, pad, winograd=True)
+                gw = _conv_wgrad_raw(x, g, w.shape, stride, pad, winograd=True, v=v)
         return gx, gw, None, gbias, gres, None, None, None, None
 
 
@@ -698,8 +705,12 @@ class _BottleneckFn(torch.autograd.Function):
         x = as_nhwc(x)
         w1, w2, w3 = as_nhwc(w1), as_nhwc(w2), as_nhwc(w3)
         a1 = _conv_fwd_raw(x, w1, s1, b1, None, 1, 0, EPI_SCALE | EPI_RELU)
+        v2 = None
         if wino:
-            a2 = conv3x3_winograd(a1, winograd_filter(w2.detach(), 4), s2, b2, True)
+            a2 = conv3x3_winograd(a1, winograd_filter(w2.detach(), 4), s2, b2, True,
+                                  keep_v=WINOGRAD_KEEP_V and _winograd_wgrad_ok(a1, w2.shape, 1, 1))
+            if isinstance(a2, tuple):
+                a2, v2 = a2
         else:
             a2 = _conv_fwd_raw(a1, w2, s2, b2, None, 1, 1, EPI_SCALE | EPI_RELU)
         if wd is not None:
@@ -709,12 +720,12 @@ class _BottleneckFn(torch.autograd.Function):
             res = x
         out = _conv_fwd_raw(a2, w3, s3, b3, res, 1, 0, EPI_SCALE | EPI_RESIDUAL | EPI_RELU)
         ctx.flags = (bool(in_relu), bool(out_premasked), bool(wino), wd is not None)
-        ctx.save_for_backward(x, a1, a2, out, w1, w2, w3, wd, s1, s2, s3, sd)
+        ctx.save_for_backward(x, a1, a2, out, w1, w2, w3, wd, s1, s2, s3, sd, v2)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        x, a1, a2, out, w1, w2, w3, wd, s1, s2, s3, sd = ctx.saved_tensors
+        x, a1, a2, out, w1, w2, w3, wd, s1, s2, s3, sd, v2 = ctx.saved_tensors
         in_relu, premasked, wino, has_ds = ctx.flags
         need = ctx.needs_input_grad
         g = as_nhwc(g)
@@ -728,7 +739,7 @@ class _BottleneckFn(torch.autograd.Function):
         gw3 = _wgrad_scaled(a2, gpre, w3.shape, 0, s3) if need[3] else None
         g2 = _dgrad_fused(gpre, w3, a2.shape, 0, gy_scale=s3, out_scale=s2, mask=a2)         # gradient at conv2's raw output
         # conv2
-        gw2 = _conv_wgrad_raw(a1, g2, w2.shape, 1, 1, winograd=wino) if need[2] else None
+        gw2 = _conv_wgrad_raw(a1, g2, w2.shape, 1, 1, winograd=wino, v=v2) if need[2] else None
         if wino:
             g1 = _winograd_dgrad_fused(g2, winograd_filter_dgrad(w2), s1, a1)
         else:
@@ -1120,8 +1131,14 @@ def winograd_filter_dgrad(w):
     return U
 
 
-def conv3x3_winograd(x, U, scale=None, shift=None, relu=False, tag="fwd"):
-    """stride-1 / pad-1 3x3 convolution with a pre-transformed frozen filter U (ops.winograd_filter); forward only."""
+# I2V_WINOGRAD_KEEP_V=0: a trained 3x3 layer transforms its input again for the filter gradient instead of keeping the forward's
+# transformed input (36/16 of the activation's size per layer, ~1.9 GB over the 33 layers of an 8-frame instance_styleD step)
+WINOGRAD_KEEP_V = os.environ.get("I2V_WINOGRAD_KEEP_V", "1") != "0"
+
+
+def conv3x3_winograd(x, U, scale=None, shift=None, relu=False, tag="fwd", keep_v=False):
+    """stride-1 / pad-1 3x3 convolution with a pre-transformed frozen filter U (ops.winograd_filter); forward only.
+    ``keep_v`` (F(4x4,3x3) only): -> (y, V), V = the transformed input in a tensor of its own (for the filter gradient)."""
     _need_cuda(x, U)
     x = as_nhwc(x)
     B, Cin, H, W = x.shape
@@ -1138,6 +1155,11 @@ def conv3x3_winograd(x, U, scale=None, shift=None, relu=False, tag="fwd"):
     with _Timed(2.0 * B * H * W * Cout * 9 * Cin, tag,
                 "M%d N%d K%d (3x3 winograd F%d) gemmMB=%.2f" % (B * H * W, Cout, 9 * Cin, 4 if four else 2, gemm_mb),
                 4 * (x.numel() + 9 * Cout * Cin + y.numel())):
+        if keep_v and four:
+            v = torch.empty((lib.i2v_conv3x3_winograd4_v_bytes(B, H, W, Cin) // 4,), device=x.device, dtype=torch.float32)
+            check(lib.i2v_conv3x3_winograd4_fwd_keep(ptr(x), ptr(U), ptr(scale), ptr(shift), ptr(y), ptr(v), B, H, W, Cin, Cout,
+                                                     int(bool(relu)), ptr(ws), ws.numel(), stream()), "conv3x3_winograd4_fwd_keep")
+            return y, v
         check(fn(ptr(x), ptr(U), ptr(scale), ptr(shift), ptr(y), B, H, W, Cin, Cout, int(bool(relu)), ptr(ws), ws.numel(),
                  stream()), "conv3x3_winograd_fwd")
-    return y
+    return (y, None) if keep_v else y

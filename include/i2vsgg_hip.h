@@ -267,6 +267,15 @@ size_t  i2v_conv3x3_winograd4_wgrad_workspace_bytes(int32_t B, int32_t H, int32_
 int32_t i2v_conv3x3_winograd4_wgrad(const float* x, const float* gy, const float* row_scale, float* gw,
                                     int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, float beta,
                                     void* workspace, size_t workspace_bytes, void* stream);
+/* A trained layer transforms its input once: the forward leaves V (i2v_conv3x3_winograd4_v_bytes) in a caller buffer,
+ * the filter gradient of the same step reads it (`_wgrad_v`) instead of transforming x again. */
+size_t  i2v_conv3x3_winograd4_v_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin);
+int32_t i2v_conv3x3_winograd4_fwd_keep(const float* x, const float* U, const float* scale, const float* shift,
+                                       float* y, float* v_out, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                                       int32_t Cout, int32_t relu, void* workspace, size_t workspace_bytes, void* stream);
+int32_t i2v_conv3x3_winograd4_wgrad_v(const float* v, const float* gy, const float* row_scale, float* gw,
+                                      int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, float beta,
+                                      void* workspace, size_t workspace_bytes, void* stream);
 /* gw[z] (N x K) = gy[z]^T (M x N) . x[z] (M x K), z < nbatch (the plane GEMMs above); N % 4 == K % 4 == 0 */
 int32_t i2v_gemm_tn_batched(const float* x, const float* gy, float* gw, int32_t M, int32_t N, int32_t K,
                             int32_t nbatch, long long stride_x, long long stride_gy, long long stride_gw, void* stream);
