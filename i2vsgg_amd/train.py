@@ -480,14 +480,11 @@ class InstanceStyleDStep:
         self.world = parallel.world_size()
         self.eta, self.eta_style, self.style_lambda = eta, eta_style, style_lambda
         self.geom = (h, w)
-        ims, info = syn.frames(seed, n_frames, h, w)
-        imt, _ = syn.frames(seed + 100, n_frames, h, w)
-        gt, nb = syn.gt_boxes(seed, n_frames, n_gt, net.n_classes, cfg.MAX_NUM_GT_BOXES, h, w)
-        to = lambda a: torch.from_numpy(a).to(self.dev)
-        self.im_s, self.im_t, self.info, self.gt, self.nb = to(ims), to(imt), to(info), to(gt), to(nb)
+        self.n_frames, self.n_gt = n_frames, n_gt
         import os
         self.batched = os.environ.get("I2V_ISD_BATCHED", "1") != "0"
-        self.im_st = torch.cat((self.im_s, self.im_t), 0) if self.batched else None
+        self.im_s = self.im_t = self.im_st = self.info = self.gt = self.nb = None
+        self.reseed(seed)
         self.gt_t = torch.zeros((n_frames, 1, 5), device=self.dev)
         self.nb_t = torch.zeros((n_frames,), device=self.dev)
         self.opt = FusedSGD(list(net.named_parameters()), lr)
@@ -498,6 +495,32 @@ class InstanceStyleDStep:
         self.graph = None
         self.graph_error = None
         self._fitted = False
+
+    # ------------------------------------------------------------------ data side
+    def stage(self, im_s, info, gt, nb, im_t):
+        """Hand the next minibatch to the step: source frames (N,3,H,W) with ``im_info`` (N,3), ``gt_boxes``
+        (N,MAX_NUM_GT_BOXES,5) and ``num_boxes`` (N,) -- one roi_data_layer batch -- and N target frames.  Copies into static
+        device tensors on the caller's stream (a captured step is bound to their addresses and shapes)."""
+        if self.im_s is None:
+            t = lambda a: a.to(self.dev, torch.float32).clone()
+            self.im_s, self.im_t, self.info, self.gt, self.nb = t(im_s), t(im_t), t(info), t(gt), t(nb)
+            self.im_st = torch.cat((self.im_s, self.im_t), 0) if self.batched else None
+            return
+        if tuple(im_s.shape) != tuple(self.im_s.shape) or tuple(gt.shape) != tuple(self.gt.shape):
+            raise ValueError("InstanceStyleDStep.stage: the step is bound to the shapes of the first staged batch")
+        self.im_s.copy_(im_s); self.im_t.copy_(im_t); self.info.copy_(info); self.gt.copy_(gt); self.nb.copy_(nb)
+        if self.batched:
+            n = self.im_s.shape[0]
+            self.im_st[:n].copy_(im_s); self.im_st[n:].copy_(im_t)
+
+    def reseed(self, seed):
+        """Stage the synthetic minibatch of ``seed`` (frames, 8 GT boxes per source frame)."""
+        h, w = self.geom
+        ims, info = syn.frames(seed, self.n_frames, h, w)
+        imt, _ = syn.frames(seed + 100, self.n_frames, h, w)
+        gt, nb = syn.gt_boxes(seed, self.n_frames, self.n_gt, self.net.n_classes, cfg.MAX_NUM_GT_BOXES, h, w)
+        f = torch.from_numpy
+        self.stage(f(ims), f(info), f(gt), f(nb), f(imt))
 
     def _body(self):
         net = self.net
@@ -548,9 +571,27 @@ class InstanceStyleDStep:
         atl.image_size = (h, w) if on else None
         self.net.RCNN_proposal_target.device_sampling = on
 
-    def capture(self, warmup=2):
+    def capture(self, warmup=2, restore=False):
         """Device-side target sampling, eager warm-up, then the whole step as ONE HIP graph.  False (eager form kept,
-        ``graph_error`` says why) when capture fails."""
+        ``graph_error`` says why) when capture fails.  ``restore``: the warm-up steps are real training steps on the staged
+        batch; put parameters, momentum and the RNG state back afterwards.  ``warmup=0`` re-captures (after a learning-rate
+        change: the rates live in the captured kernel arguments)."""
+        saved = None
+        if restore and warmup:
+            state = [it["p"].data for it in self.opt.items] + [it["m"] for it in self.opt.items]
+            saved = (state, [t.clone() for t in state], torch.cuda.get_rng_state(self.dev))
+        try:
+            return self._capture(warmup)
+        finally:
+            if saved is not None:
+                torch.cuda.synchronize(self.dev)
+                with torch.no_grad():
+                    for t, sv in zip(saved[0], saved[1]):
+                        t.copy_(sv)
+                torch.cuda.set_rng_state(saved[2], self.dev)
+                self.opt.bump()
+
+    def _capture(self, warmup):
         self._device_sampling(True)
         s = torch.cuda.Stream(self.dev)
         s.wait_stream(torch.cuda.current_stream(self.dev))
@@ -600,10 +641,10 @@ def consistency_terms(d_inst, d_style, d_inst_t, d_style_t):
     return out
 
 
-def build_instance_styled_net(layers=101, n_cls=16, seed=0, device="cuda:0"):
+def build_instance_styled_net(layers=101, n_cls=16, seed=0, device="cuda:0", ic=False, gc=False, class_agnostic=False):
     from .model.faster_rcnn.resnet_instance_styleD_bilinear import resnet
     torch.manual_seed(seed)
-    net = resnet(tuple(range(n_cls)), layers)
+    net = resnet(tuple(range(n_cls)), layers, class_agnostic=class_agnostic, ic=ic, gc=gc)
     net.create_architecture()
     _randomise_bn(net, seed + 1)
     return net.to(device).train()
