@@ -941,3 +941,25 @@ def test_winograd_filter_gradient_vs_torch(B, C, N, H, W):
     assert float((got.double() - want).abs().max()) <= 2e-4 * scale, float((got.double() - want).abs().max()) / scale
     got = ops._conv_wgrad_raw(x, g, (N, C, 3, 3), 1, 1, winograd=True, row_scale=rs)
     assert float((got.double() - want * rs.double().view(-1, 1, 1, 1)).abs().max()) <= 2e-4 * 1.5 * scale
+
+
+@pytest.mark.parametrize("B,C,N,H,W,k", [(4, 1024, 256, 38, 63, 1), (4, 256, 1024, 38, 63, 1), (2, 128, 512, 75, 125, 1), (4, 64, 64, 75, 125, 3)])
+def test_filter_gradient_split_groups_on_one_xcd(B, C, N, H, W, k):
+    """Filter gradients whose split count is a multiple of 8 take the dispatch-index remap (a split's tiles share an XCD):
+    same result as with the remap off, and both equal float64 torch."""
+    from i2vsgg_amd import _lib, ops
+    torch.manual_seed(7)
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    x, g = cl(torch.randn(B, C, H, W, device=DEV)), cl(torch.randn(B, N, H, W, device=DEV))
+    want = torch.nn.grad.conv2d_weight(x.double(), (N, C, k, k), g.double(), 1, k // 2)
+    scale = float(want.abs().max())
+    assert _lib.lib.i2v_get_tuning(14) == 1
+    on = ops._conv_wgrad_raw(x, g, (N, C, k, k), 1, k // 2)
+    _lib.lib.i2v_set_tuning(14, 0)
+    try:
+        off = ops._conv_wgrad_raw(x, g, (N, C, k, k), 1, k // 2)
+    finally:
+        _lib.lib.i2v_set_tuning(14, 1)
+    assert float((on.double() - want).abs().max()) <= 1e-4 * scale
+    assert float((off.double() - want).abs().max()) <= 1e-4 * scale
+    assert float((on - off).abs().max()) <= 2e-5 * scale          # atomics: summation order differs
