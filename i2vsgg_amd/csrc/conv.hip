@@ -2059,8 +2059,8 @@ static int conv_dgrad_impl(const float* gy, const float* w, const float* gy_scal
     int rc = check_conv("conv_dgrad", gy, w, gx, B, H, W, Cin, Cout, KH, KW, stride, pad);
     if (rc) return rc;
     const bool fused = gy_scale || out_scale || res || mask;
-    if (fused && stride != 1) {
-        i2v_set_error("conv_dgrad_fused: stride 1 only (a strided layer takes i2v_conv_dgrad and separate passes)");
+    if (fused && stride != 1 && !(KH == 1 && KW == 1 && pad == 0)) {
+        i2v_set_error("conv_dgrad_fused: stride 1, or a strided 1x1 layer (other strided layers take i2v_conv_dgrad and separate passes)");
         return I2V_ERR_UNSUPPORTED;
     }
     I2V_CHECK_ARG(Cout % 4 == 0, "conv_dgrad: Cout must be a multiple of 4");
@@ -2089,8 +2089,8 @@ static int conv_dgrad_impl(const float* gy, const float* w, const float* gy_scal
             I2V_CHECK_ARG(KH - 1 - pad >= 0 && KW - 1 - pad >= 0, "conv_dgrad: padding larger than the filter");
             p.pad = KH - 1 - pad; p.pad_x = KW - 1 - pad;
             p.Ho = H; p.Wo = W; p.ostride = 1;
-        } else {                    // strided 1x1: every s-th pixel gets a value, the rest are zero
-            p.pad = 0; p.pad_x = 0; p.Ho = Ho; p.Wo = Wo; p.ostride = stride;
+        } else {                    // strided 1x1: every s-th pixel gets a value (epilogue operands are read at that pixel), the
+            p.pad = 0; p.pad_x = 0; p.Ho = Ho; p.Wo = Wo; p.ostride = stride;       // rest are zero -- res must be zero there too
             hipMemsetAsync(gx, 0, (size_t)B * H * W * Cin * sizeof(float), st);
         }
         rc = run_conv(p, st, split_ws, split_ws_bytes);

@@ -99,9 +99,9 @@ class Bottleneck(nn.Module):
         self._next = []
 
     def _fused(self):
-        """The whole block as one autograd node: stride 1 (a stride-1 projection on the skip branch included), gradients
-        being recorded, every filter training, no per-filter fused SGD registered for them."""
-        if not (ops.BLOCK_FUSED and self.stride == 1 and torch.is_grad_enabled()):
+        """The whole block as one autograd node: gradients being recorded, every filter training, no per-filter fused SGD
+        registered for them (strided blocks included: their stride sits on the two 1x1 layers reading the block input)."""
+        if not (ops.BLOCK_FUSED and torch.is_grad_enabled()) or (self.stride != 1 and self.downsample is None):
             return False
         ws = [self.conv1.weight, self.conv2.weight, self.conv3.weight] + ([self.downsample[0].weight] if self.downsample is not None else [])
         return all(w.requires_grad and w.data_ptr() not in ops.FUSED_SGD for w in ws) and self.conv1.cin % 4 == 0
@@ -124,7 +124,7 @@ class Bottleneck(nn.Module):
                 down = (self.downsample[0].weight,) + tuple(self.downsample[1].folded())
             nxt = self._next[0] if self._next else None
             return ops.bottleneck(x, self.conv1.weight, self.conv2.weight, self.conv3.weight, (s1, b1), (s2, b2), (s3, b3), down,
-                                  in_relu=self.in_relu, out_premasked=nxt is not None and nxt._fused())
+                                  in_relu=self.in_relu, out_premasked=nxt is not None and nxt._fused(), stride=self.stride)
         out = ops.conv2d(x, self.conv1.weight, s1, b1, None, self.stride, 0, relu=True)
         if WINOGRAD and not torch.is_grad_enabled() and self.conv2.cin >= WINOGRAD_MIN_CIN:
             # no gradient is being recorded (the detached SGG_emb backbone, eval): the 3x3 runs as Winograd F(2x2,3x3)
@@ -169,6 +169,10 @@ class C4Base(nn.Sequential):
         l1, c = make_layer(64, 64, blocks[0], 1)
         l2, c = make_layer(c, 128, blocks[1], 2)
         l3, c = make_layer(c, 256, blocks[2], 2)
+        # layer1's output has one consumer, layer2's first block: the pre-masked hand-over of the block backward crosses that
+        # boundary too.  layer2's output does not (netD_style taps it, forward(tap=True)), nor does layer3's (RPN, ROI pooling)
+        l2[0].in_relu = True
+        l1[-1]._next = [l2[0]]
         super().__init__(conv1, bn1, _Marker(), _Marker(), l1, l2, l3)
         self.out_channels = c
         self._w4 = None

@@ -647,18 +647,19 @@ class _ConvFn(torch.autograd.Function):
 BLOCK_FUSED = os.environ.get("I2V_BLOCK_FUSED", "1") != "0"
 
 
-def _dgrad_fused(g, w, in_shape, pad, gy_scale=None, out_scale=None, res=None, mask=None):
-    """gx = mask > 0 ? (dgrad(g * gy_scale, w) * out_scale + res) : 0 of a stride-1 layer (i2v_conv_dgrad_fused)."""
+def _dgrad_fused(g, w, in_shape, pad, gy_scale=None, out_scale=None, res=None, mask=None, stride=1):
+    """gx = mask > 0 ? (dgrad(g * gy_scale, w) * out_scale + res) : 0 of a stride-1 layer or a strided 1x1 layer (gx is then
+    zero off the stride grid, and so must ``res`` be) (i2v_conv_dgrad_fused)."""
     B, Cin, H, W = in_shape
     Cout, _, KH, KW = w.shape
     gx = torch.empty((B, Cin, H, W), device=g.device, dtype=torch.float32, memory_format=_CL)
     ws = workspace(lib.i2v_conv_dgrad_workspace_bytes(Cin, Cout, KH, KW), g.device, "dgrad")
     sws = _split_ws(g.device)
     extra = (res.numel() if res is not None else 0) + (mask.numel() if mask is not None else 0)
-    with _Timed(2.0 * B * H * W * Cout * KH * KW * Cin, "dgrad", "M%d N%d K%d +epi" % (B * H * W, Cin, KH * KW * Cout),
+    with _Timed(2.0 * B * g.shape[2] * g.shape[3] * Cout * KH * KW * Cin, "dgrad", "M%d N%d K%d +epi" % (B * H * W, Cin, KH * KW * Cout),
                 4 * (g.numel() + w.numel() + gx.numel() + extra)):
         check(lib.i2v_conv_dgrad_fused(ptr(g), ptr(w), ptr(gy_scale), ptr(out_scale), ptr(res), ptr(mask), ptr(gx), B, H, W,
-                                       Cin, Cout, KH, KW, 1, pad, ptr(ws), ws.numel(), ptr(sws), sws.numel(), stream()),
+                                       Cin, Cout, KH, KW, stride, pad, ptr(ws), ws.numel(), ptr(sws), sws.numel(), stream()),
               "conv_dgrad_fused")
     return gx
 
@@ -700,11 +701,11 @@ class _BottleneckFn(torch.autograd.Function):
     epilogue reads."""
 
     @staticmethod
-    def forward(ctx, x, w1, w2, w3, wd, s1, b1, s2, b2, s3, b3, sd, bd, in_relu, out_premasked, wino):
+    def forward(ctx, x, w1, w2, w3, wd, s1, b1, s2, b2, s3, b3, sd, bd, in_relu, out_premasked, wino, stride=1):
         _need_cuda(x, w1, w2, w3)
         x = as_nhwc(x)
         w1, w2, w3 = as_nhwc(w1), as_nhwc(w2), as_nhwc(w3)
-        a1 = _conv_fwd_raw(x, w1, s1, b1, None, 1, 0, EPI_SCALE | EPI_RELU)
+        a1 = _conv_fwd_raw(x, w1, s1, b1, None, stride, 0, EPI_SCALE | EPI_RELU)      # caffe style: the stride sits on conv1
         v2 = None
         if wino:
             a2 = conv3x3_winograd(a1, winograd_filter(w2.detach(), 4), s2, b2, True,
@@ -715,11 +716,12 @@ class _BottleneckFn(torch.autograd.Function):
             a2 = _conv_fwd_raw(a1, w2, s2, b2, None, 1, 1, EPI_SCALE | EPI_RELU)
         if wd is not None:
             wd = as_nhwc(wd)
-            res = _conv_fwd_raw(x, wd, sd, bd, None, 1, 0, EPI_SCALE)
+            res = _conv_fwd_raw(x, wd, sd, bd, None, stride, 0, EPI_SCALE)
         else:
             res = x
         out = _conv_fwd_raw(a2, w3, s3, b3, res, 1, 0, EPI_SCALE | EPI_RESIDUAL | EPI_RELU)
         ctx.flags = (bool(in_relu), bool(out_premasked), bool(wino), wd is not None)
+        ctx.stride = int(stride)
         ctx.save_for_backward(x, a1, a2, out, w1, w2, w3, wd, s1, s2, s3, sd, v2)
         return out
 
@@ -745,23 +747,29 @@ class _BottleneckFn(torch.autograd.Function):
         else:
             g1 = _dgrad_fused(g2, w2, a1.shape, 1, out_scale=s1, mask=a1)
         # conv1 (+ the skip branch)
-        gw1 = _conv_wgrad_raw(x, g1, w1.shape, 1, 0) if need[1] else None
+        st = ctx.stride
+        gw1 = _conv_wgrad_raw(x, g1, w1.shape, st, 0) if need[1] else None
         gwd = gx = None
         if has_ds and need[4]:
-            gwd = _wgrad_scaled(x, gpre, wd.shape, 0, sd)
+            gwd = _conv_wgrad_raw(x, gpre, wd.shape, st, 0, row_scale=sd)
         if need[0]:
-            skip = _dgrad_fused(gpre, wd, x.shape, 0, gy_scale=sd) if has_ds else gpre
-            gx = _dgrad_fused(g1, w1, x.shape, 0, res=skip, mask=x if in_relu else None)
-        return (gx, gw1, gw2, gw3, gwd) + (None,) * 11
+            # a strided block: both 1x1 data gradients live on the stride grid (zero elsewhere), so the skip projection's can
+            # be the residual operand of conv1's just as in the stride-1 case
+            skip = _dgrad_fused(gpre, wd, x.shape, 0, gy_scale=sd, stride=st) if has_ds else gpre
+            gx = _dgrad_fused(g1, w1, x.shape, 0, res=skip, mask=x if in_relu else None, stride=st)
+        return (gx, gw1, gw2, gw3, gwd) + (None,) * 12
 
 
-def bottleneck(x, w1, w2, w3, bn1, bn2, bn3, down=None, in_relu=False, out_premasked=False):
-    """A stride-1 bottleneck with frozen BNs whose filters train, as one autograd node (``_BottleneckFn``).  bn* = (scale,
-    shift) of the folded BN; ``down`` = (filter, scale, shift) of a stride-1 projection on the skip branch or None."""
+def bottleneck(x, w1, w2, w3, bn1, bn2, bn3, down=None, in_relu=False, out_premasked=False, stride=1):
+    """A bottleneck with frozen BNs whose filters train, as one autograd node (``_BottleneckFn``).  bn* = (scale, shift) of the
+    folded BN; ``down`` = (filter, scale, shift) of the projection on the skip branch or None; ``stride`` sits on conv1 and on
+    the projection (caffe style), a strided block always has the projection."""
+    if stride != 1 and down is None:
+        raise ValueError("a strided bottleneck needs the projection on its skip branch")
     wino = (WINOGRAD_TRAIN and w2.shape[1] >= WINOGRAD_TRAIN_MIN_C and w2.shape[0] >= WINOGRAD_TRAIN_MIN_C and w2.shape[1] % 4 == 0)
     wd, sd, bd = down if down is not None else (None, None, None)
     return _BottleneckFn.apply(x, w1, w2, w3, wd, bn1[0], bn1[1], bn2[0], bn2[1], bn3[0], bn3[1], sd, bd, bool(in_relu),
-                               bool(out_premasked), bool(wino))
+                               bool(out_premasked), bool(wino), int(stride))
 
 
 def conv2d(x, w, scale=None, shift=None, res=None, stride=1, pad=0, relu=False, winograd=False):

@@ -244,7 +244,7 @@ int32_t i2v_debug_clock_stamp(void* out2, void* stream);
  * the activation gradient (g = gy * (y > 0) * scale) the factors ride in the kernels that touch the data anyway:
  *   i2v_conv_dgrad_fused   gx = mask > 0 ? (dgrad(gy * gy_scale[cout], w) * out_scale[cin] + res) : 0
  *                          gy_scale: folded into the transposed filter; out_scale / res / mask: epilogue operands, each
- *                          may be NULL; res and mask have the shape of gx.  Stride 1 only (I2V_ERR_UNSUPPORTED otherwise).
+ *                          may be NULL; res and mask have the shape of gx.  Stride 1, or a strided 1x1 layer (then gx is zero off the stride grid and res must be too); I2V_ERR_UNSUPPORTED otherwise.
  *   i2v_conv_wgrad_scaled  gw[n] = row_scale[n] * wgrad(x, gy)[n]   (the BN scale that belongs on gy, applied once per
  *                          filter row where the reduction over the pixels ends); beta as in i2v_conv_wgrad.
  *   i2v_conv3x3_winograd4_dgrad  gx = mask > 0 ? (winograd F(4x4,3x3) data gradient * out_scale[cin]) : 0,

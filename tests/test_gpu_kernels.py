@@ -837,15 +837,16 @@ def _layer_reference(layer, x):
     return x
 
 
-@pytest.mark.parametrize("cin,planes,hw", [(64, 64, (30, 44)), (256, 64, (22, 36)), (512, 128, (14, 20))])
-def test_trained_bottleneck_stack_as_fused_autograd_nodes(cin, planes, hw):
+@pytest.mark.parametrize("cin,planes,hw,stride", [(64, 64, (30, 44), 1), (256, 64, (22, 36), 1), (512, 128, (14, 20), 1),
+                                                  (256, 128, (28, 40), 2), (512, 256, (15, 25), 2)])
+def test_trained_bottleneck_stack_as_fused_autograd_nodes(cin, planes, hw, stride):
     """ops._BottleneckFn (BN scale / ReLU mask / skip gradient folded into the data- and filter-gradient kernels, block-to-
     block hand-over of pre-masked gradients) against (a) plain torch fp32 autograd and (b) the layer-by-layer form
     (I2V_BLOCK_FUSED=0) on a 3-block layer: output, input gradient and every filter gradient."""
     from i2vsgg_amd import ops
     from i2vsgg_amd.model.faster_rcnn.layers import make_layer
     torch.manual_seed(3)
-    layer, _ = make_layer(cin, planes, 3, 1)
+    layer, _ = make_layer(cin, planes, 3, stride)
     layer = layer.to(DEV)
     for m in layer.modules():
         if hasattr(m, "running_var"):
@@ -853,7 +854,8 @@ def test_trained_bottleneck_stack_as_fused_autograd_nodes(cin, planes, hw):
             m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.2)
             m.invalidate()
     x0 = torch.relu(torch.randn(2, cin, *hw, device=DEV)).contiguous(memory_format=torch.channels_last)
-    gout = torch.randn(2, planes * 4, *hw, device=DEV).contiguous(memory_format=torch.channels_last)
+    ohw = tuple((d - 1) // stride + 1 for d in hw)          # 1x1 / stride s / pad 0
+    gout = torch.randn(2, planes * 4, *ohw, device=DEV).contiguous(memory_format=torch.channels_last)
     params = [p for p in layer.parameters() if p.requires_grad]
 
     def run(fn):
