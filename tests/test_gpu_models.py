@@ -488,7 +488,8 @@ def test_sgg_step_staged_batches_meet_their_features(cfg):
     assert len(set(round(x, 5) for x in l0)) == len(l0)                     # the batches differ
     for a, b in zip(l0, l1):
         assert abs(a - b) <= 1e-5 * abs(a), (l0, l1)
-    assert _rel_err(w1, w0) < 1e-5
+    # eager: one backbone pass over both frames; graph: one branch per frame -- other split-K factors, other fp32 rounding
+    assert _rel_err(w1, w0) < 5e-5
 
 
 def test_captured_step_is_idempotent_after_one_warmup(cfg):
