@@ -500,7 +500,8 @@ def _conv_wgrad_raw(x, g, w_shape, stride, pad, tag="wgrad", row_scale=None, win
         gw = torch.empty(w_shape, device=x.device, dtype=torch.float32, memory_format=_CL)
     if winograd and _winograd_wgrad_ok(x, w_shape, stride, pad):
         # stride-1 / pad-1 3x3 layer of a trained bottleneck: 36 plane GEMMs over the 4x4 tiles, a quarter of the MACs
-        ws = workspace(lib.i2v_conv3x3_winograd4_wgrad_workspace_bytes(B, H, W, Cin, Cout), x.device, "winograd")
+        # a scratch buffer of its own: filter gradients may run on a side branch beside the Winograd data gradients
+        ws = workspace(lib.i2v_conv3x3_winograd4_wgrad_workspace_bytes(B, H, W, Cin, Cout), x.device, "winograd_wgrad")
         T = B * ((H + 3) // 4) * ((W + 3) // 4)
         with _Timed(2.0 * B * H * W * Cout * 9 * Cin, tag, "N%d K%d M%d (3x3 winograd F4)" % (Cout, 9 * Cin, B * H * W),
                     4 * (x.numel() + g.numel() + gw.numel())):
@@ -684,6 +685,22 @@ def _winograd_dgrad_fused(g, U, out_scale, mask):
     return gx
 
 
+# Filter gradients of the block nodes on a side branch of the captured step (train.InstanceStyleDStep sets the stream): they
+# depend on the data-gradient chain but nothing in the backward depends on them, so they can fill the chip beside it.  One
+# edge per block (the side branch waits for the block's data gradients), one join before the gradient exchange.  The tensors
+# a side launch reads are kept referenced until the join (WGRAD_PENDING): in a captured step a block freed on the main
+# branch would otherwise be handed to a later main-branch allocation while the side branch still reads it.
+WGRAD_STREAM = None
+WGRAD_PENDING = []
+
+
+def join_wgrad_branch():
+    """Called by the step after backward(): the capturing stream waits for the filter-gradient branch."""
+    if WGRAD_STREAM is not None:
+        torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
+    WGRAD_PENDING.clear()
+
+
 class _BottleneckFn(torch.autograd.Function):
     """out = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + skip(x)) of a STRIDE-1 bottleneck with frozen BNs
     (resnet_instance_styleD_bilinear.py:181-217) as one autograd node.  The forward is the four fused-epilogue convs of the
@@ -737,26 +754,35 @@ class _BottleneckFn(torch.autograd.Function):
             gpre = torch.empty_like(g)
             M, N = g.shape[0] * g.shape[2] * g.shape[3], g.shape[1]
             check(lib.i2v_epilogue_bwd(ptr(g), ptr(out), None, ptr(gpre), None, None, M, N, 1, None, stream()), "epilogue_bwd")
-        # conv3: gy = gpre * s3
-        gw3 = _wgrad_scaled(a2, gpre, w3.shape, 0, s3) if need[3] else None
+        st = ctx.stride
+        # ---- data gradients (the chain the rest of the backward waits for)
         g2 = _dgrad_fused(gpre, w3, a2.shape, 0, gy_scale=s3, out_scale=s2, mask=a2)         # gradient at conv2's raw output
-        # conv2
-        gw2 = _conv_wgrad_raw(a1, g2, w2.shape, 1, 1, winograd=wino, v=v2) if need[2] else None
         if wino:
             g1 = _winograd_dgrad_fused(g2, winograd_filter_dgrad(w2), s1, a1)
         else:
             g1 = _dgrad_fused(g2, w2, a1.shape, 1, out_scale=s1, mask=a1)
-        # conv1 (+ the skip branch)
-        st = ctx.stride
-        gw1 = _conv_wgrad_raw(x, g1, w1.shape, st, 0) if need[1] else None
-        gwd = gx = None
-        if has_ds and need[4]:
-            gwd = _conv_wgrad_raw(x, gpre, wd.shape, st, 0, row_scale=sd)
+        gx = None
         if need[0]:
             # a strided block: both 1x1 data gradients live on the stride grid (zero elsewhere), so the skip projection's can
             # be the residual operand of conv1's just as in the stride-1 case
             skip = _dgrad_fused(gpre, wd, x.shape, 0, gy_scale=sd, stride=st) if has_ds else gpre
             gx = _dgrad_fused(g1, w1, x.shape, 0, res=skip, mask=x if in_relu else None, stride=st)
+
+        # ---- filter gradients (conv3: gy = gpre * s3 as a per-row factor), on the side branch when the step has one
+        def wgrads():
+            gw3 = _wgrad_scaled(a2, gpre, w3.shape, 0, s3) if need[3] else None
+            gw2 = _conv_wgrad_raw(a1, g2, w2.shape, 1, 1, winograd=wino, v=v2) if need[2] else None
+            gw1 = _conv_wgrad_raw(x, g1, w1.shape, st, 0) if need[1] else None
+            gwd = _conv_wgrad_raw(x, gpre, wd.shape, st, 0, row_scale=sd) if (has_ds and need[4]) else None
+            return gw1, gw2, gw3, gwd
+        side = WGRAD_STREAM
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+            WGRAD_PENDING.append((x, a1, a2, v2, gpre, g2, g1))
+            with torch.cuda.stream(side):
+                gw1, gw2, gw3, gwd = wgrads()
+        else:
+            gw1, gw2, gw3, gwd = wgrads()
         return (gx, gw1, gw2, gw3, gwd) + (None,) * 12
 
 

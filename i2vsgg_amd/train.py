@@ -483,6 +483,11 @@ class InstanceStyleDStep:
         self.n_frames, self.n_gt = n_frames, n_gt
         import os
         self.batched = os.environ.get("I2V_ISD_BATCHED", "1") != "0"
+        # filter gradients of the bottleneck nodes on a side branch of the step (ops.WGRAD_STREAM)
+        # (only with the one-pass backbone: a filter met twice in one backward would have its two gradients added on the main
+        # stream while the side branch may still be writing the first)
+        self.wgrad_branch = os.environ.get("I2V_WGRAD_BRANCH", "0") == "1" and self.dev.type == "cuda" and self.batched
+        self._wgrad_stream = torch.cuda.Stream(self.dev) if self.wgrad_branch else None
         self.im_s = self.im_t = self.im_st = self.info = self.gt = self.nb = None
         self.reseed(seed)
         self.gt_t = torch.zeros((n_frames, 1, 5), device=self.dev)
@@ -556,7 +561,12 @@ class InstanceStyleDStep:
                 vals.update(cst)
             vals["total"] = total
             self.opt.zero_grad()
-            (total / self.world).backward()
+            ops.WGRAD_STREAM = self._wgrad_stream if self.wgrad_branch else None
+            try:
+                (total / self.world).backward()
+                ops.join_wgrad_branch()
+            finally:
+                ops.WGRAD_STREAM = None
             parallel.all_reduce_grads(self.opt.params())
             self.opt.step()
             for k in self.names:

@@ -226,3 +226,33 @@ def test_instance_styled_staged_batch_equals_fresh_step(fresh_cfg):
     assert abs(got["dloss_s_style"] - want["dloss_s_style"]) <= 1e-3 * abs(want["dloss_s_style"]), (got, want)
     assert abs(got["det"] - want["det"]) <= 0.25 * want["det"], (got, want)
     assert got != first
+
+
+def test_instance_styled_filter_gradients_on_a_side_branch(fresh_cfg):
+    """I2V_WGRAD_BRANCH (off by default: -1 % of the step for +2.4 GB): the bottleneck nodes' filter gradients on
+    a second stream, one edge per block, joined before the update -- same losses and parameters as on one stream (eager,
+    host-side sampling from the same np.random stream, so the two runs are the same arithmetic up to atomics order)."""
+    cfg = fresh_cfg("res101", ["TRAIN.BATCH_SIZE", "16", "TRAIN.RPN_POST_NMS_TOP_N_TARGET", "16"])
+    from i2vsgg_amd import train
+
+    def run(branch):
+        torch.manual_seed(0)
+        np.random.seed(cfg.RNG_SEED)
+        net = train.build_instance_styled_net(101, device=DEV)
+        step = train.InstanceStyleDStep(net, 2, seed=3, device=DEV, h=256, w=320)
+        if branch:
+            step.wgrad_branch, step._wgrad_stream = True, torch.cuda.Stream()
+        out = []
+        for _ in range(3):
+            step()
+            out.append({k: float(v) for k, v in step.losses.items()})
+        torch.cuda.synchronize()
+        return out, net.RCNN_base[6][5].conv2.weight.detach().clone(), net.RCNN_base[4][0].conv1.weight.detach().clone()
+
+    a, wa, va = run(False)
+    b, wb, vb = run(True)
+    for x, y in zip(a, b):
+        for k in x:
+            assert abs(x[k] - y[k]) <= 2e-4 * max(abs(x[k]), 1e-6), (k, a, b)
+    assert float((wa - wb).abs().max()) <= 1e-5 * float(wa.abs().max())
+    assert float((va - vb).abs().max()) <= 1e-5 * float(va.abs().max())
