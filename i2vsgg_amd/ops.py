@@ -94,8 +94,12 @@ class _RoIAlignFn(torch.autograd.Function):
         shape, nhwc, ph, pw, scale, avg, out_nchw = ctx.meta
         B, C, H, W = shape
         gout = gout.contiguous() if out_nchw else gout.contiguous(memory_format=_CL)
-        gfeat = torch.empty(shape, device=gout.device, dtype=torch.float32,
-                            memory_format=_CL if nhwc else torch.contiguous_format).zero_()
+        # the scatter accumulates with atomics into zeros: inside a step they come from the step's pre-zeroed arena (one
+        # clear per step for every atomically accumulated output) instead of a fill kernel of their own
+        gfeat = ARENA.take(B, C, H, W) if (ARENA is not None and nhwc) else None
+        if gfeat is None:
+            gfeat = torch.empty(shape, device=gout.device, dtype=torch.float32,
+                                memory_format=_CL if nhwc else torch.contiguous_format).zero_()
         check(lib.i2v_roi_align_bwd(ptr(gout), LAYOUT_NCHW if out_nchw else LAYOUT_NHWC, ptr(rois), rois.size(0), ph, pw,
                                     scale, avg, ptr(gfeat), LAYOUT_NHWC if nhwc else LAYOUT_NCHW, B, C, H, W, stream()),
               "roi_align_bwd")
