@@ -230,29 +230,33 @@ def test_instance_styled_staged_batch_equals_fresh_step(fresh_cfg):
 
 def test_instance_styled_filter_gradients_on_a_side_branch(fresh_cfg):
     """I2V_WGRAD_BRANCH (off by default: -1 % of the step for +2.4 GB): the bottleneck nodes' filter gradients on
-    a second stream, one edge per block, joined before the update -- same losses and parameters as on one stream (eager,
-    host-side sampling from the same np.random stream, so the two runs are the same arithmetic up to atomics order)."""
+    a second stream, one edge per block, joined before the update -- the same losses and the same parameter UPDATE as on one
+    stream.  One step from identical weights (eager, host-side sampling from the same np.random stream): later steps sample
+    other proposals as soon as a score moves in its last bit, which is not what this test is about."""
     cfg = fresh_cfg("res101", ["TRAIN.BATCH_SIZE", "16", "TRAIN.RPN_POST_NMS_TOP_N_TARGET", "16"])
     from i2vsgg_amd import train
+    names = ["RCNN_base.4.0.conv1.weight", "RCNN_base.4.0.downsample.0.weight", "RCNN_base.5.0.conv2.weight",
+             "RCNN_base.6.5.conv2.weight", "RCNN_base.6.22.conv3.weight", "RCNN_top.0.1.conv1.weight"]
 
     def run(branch):
         torch.manual_seed(0)
         np.random.seed(cfg.RNG_SEED)
         net = train.build_instance_styled_net(101, device=DEV)
+        before = {k: v.detach().clone() for k, v in net.named_parameters() if k in names}
         step = train.InstanceStyleDStep(net, 2, seed=3, device=DEV, h=256, w=320)
         if branch:
             step.wgrad_branch, step._wgrad_stream = True, torch.cuda.Stream()
-        out = []
-        for _ in range(3):
-            step()
-            out.append({k: float(v) for k, v in step.losses.items()})
+        step()
         torch.cuda.synchronize()
-        return out, net.RCNN_base[6][5].conv2.weight.detach().clone(), net.RCNN_base[4][0].conv1.weight.detach().clone()
+        losses = {k: float(v) for k, v in step.losses.items()}
+        delta = {k: dict(net.named_parameters())[k].detach() - before[k] for k in names}
+        return losses, delta
 
-    a, wa, va = run(False)
-    b, wb, vb = run(True)
-    for x, y in zip(a, b):
-        for k in x:
-            assert abs(x[k] - y[k]) <= 2e-4 * max(abs(x[k]), 1e-6), (k, a, b)
-    assert float((wa - wb).abs().max()) <= 1e-5 * float(wa.abs().max())
-    assert float((va - vb).abs().max()) <= 1e-5 * float(va.abs().max())
+    a, da = run(False)
+    b, db = run(True)
+    for k in a:
+        assert abs(a[k] - b[k]) <= 1e-5 * max(abs(a[k]), 1e-6), (k, a, b)
+    for k in names:
+        assert float(da[k].abs().max()) > 0
+        # the update is ~1e-5 on weights of ~0.1: one ulp of a weight is 1e-3 of it
+        assert float((da[k] - db[k]).abs().max()) <= 1e-2 * float(da[k].abs().max()) + 3e-8, k
