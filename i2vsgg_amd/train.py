@@ -488,6 +488,11 @@ class InstanceStyleDStep:
         # stream while the side branch may still be writing the first)
         self.wgrad_branch = os.environ.get("I2V_WGRAD_BRANCH", "0") == "1" and self.dev.type == "cuda" and self.batched
         self._wgrad_stream = torch.cuda.Stream(self.dev) if self.wgrad_branch else None
+        # the captured step: source and target as two branches of the graph (_body_branches)
+        self.branches = os.environ.get("I2V_ISD_BRANCHES", "1") != "0" and self.dev.type == "cuda" and not self.wgrad_branch
+        self._branch_streams = [torch.cuda.Stream(self.dev) for _ in range(2)] if self.branches else []
+        self.ctx_src = ops.LaunchContext(self.dev) if self.branches else None
+        self.ctx_tgt = ops.LaunchContext(self.dev) if self.branches else None
         self.im_s = self.im_t = self.im_st = self.info = self.gt = self.nb = None
         self.reseed(seed)
         self.gt_t = torch.zeros((n_frames, 1, 5), device=self.dev)
@@ -574,6 +579,69 @@ class InstanceStyleDStep:
 
     eager_step = _body
 
+    def _body_branches(self):
+        """The captured form by default (``I2V_ISD_BRANCHES=0``: the one-pass form above): the source and the target forward /
+        backward as TWO BRANCHES of the step graph -- they are independent until their gradients meet (the reference runs
+        them one after the other, :271-296).  An 8-frame layer3 GEMM runs at 102 TF alone; two 4-frame chains side by side
+        reach 114 TF (tools/corun_probe.py): one chain's set-up / store phases lie under the other's K loops, with no edge
+        between the branches until the join.  Each branch owns a LaunchContext (arena, split-K workspace, scratch) and
+        returns its gradients through ``torch.autograd.grad`` (no AccumulateGrad on a shared ``.grad`` from two streams);
+        the capturing stream adds them after the join."""
+        net, main = self.net, torch.cuda.current_stream(self.dev)
+        params = self.opt.params()
+        self.opt.zero_grad()
+        s_src, s_tgt = self._branch_streams
+        vals, grads = {}, {}
+        s_src.wait_stream(main)
+        s_tgt.wait_stream(main)
+        # Each branch's autograd graph is gone before the other branch's forward starts (only detached values leave the
+        # block): a parameter's AccumulateGrad node lives as long as a graph references it and remembers the stream it was
+        # made on -- shared between the two branches the engine would synchronise their streams with each other.
+        def source():
+            out = net(self.im_s, self.info, self.gt, self.nb, target=False, eta=self.eta, eta_style=self.eta_style)
+            _, _, _, l_rpn_cls, l_rpn_box, l_cls, l_box, _, d_inst, d_style = out
+            v = {"det": l_rpn_cls.mean() + l_rpn_box.mean() + l_cls.mean() + l_box.mean(),
+                 "dloss_s": 0.5 * torch.mean(d_inst ** 2), "dloss_s_style": 0.5 * torch.mean(d_style ** 2)}
+            part = v["det"] + v["dloss_s"] + self.style_lambda * v["dloss_s_style"]
+            if self.cr:
+                v["source_adv_cst"] = _consistency_term(d_inst, d_style)
+                part = part + v["source_adv_cst"]
+            g = torch.autograd.grad(part / self.world, params, allow_unused=True)
+            v["_src"] = part
+            net.RCNN_rpn.rpn_loss_cls = net.RCNN_rpn.rpn_loss_box = 0      # the module keeps its last losses (rpn.py:89-108): they hold the graph
+            return {k: t.detach() for k, t in v.items()}, g
+
+        def target():
+            d_inst_t, d_style_t = net(self.im_t, self.info, self.gt_t, self.nb_t, target=True, eta=self.eta,
+                                      eta_style=self.eta_style)
+            v = {"dloss_t": 0.5 * torch.mean((1 - d_inst_t) ** 2), "dloss_t_style": 0.5 * torch.mean((1 - d_style_t) ** 2)}
+            part = v["dloss_t"] + self.style_lambda * v["dloss_t_style"]
+            if self.cr:
+                v["target_adv_cst"] = _consistency_term(d_inst_t, d_style_t)
+                part = part + v["target_adv_cst"]
+            g = torch.autograd.grad(part / self.world, params, allow_unused=True)
+            v["_tgt"] = part
+            return {k: t.detach() for k, t in v.items()}, g
+
+        with torch.cuda.stream(s_src), self.ctx_src:
+            v, grads["s"] = source()
+            vals.update(v)
+        with torch.cuda.stream(s_tgt), self.ctx_tgt:
+            v, grads["t"] = target()
+            vals.update(v)
+        main.wait_stream(s_src)
+        main.wait_stream(s_tgt)
+        both = [(a, b) for a, b in zip(grads["s"], grads["t"]) if a is not None and b is not None]
+        if both:
+            torch._foreach_add_([a for a, _ in both], [b for _, b in both])
+        for p, a, b in zip(params, grads["s"], grads["t"]):
+            p.grad = a if a is not None else b
+        vals["total"] = vals.pop("_src") + vals.pop("_tgt")
+        parallel.all_reduce_grads(params)
+        self.opt.step()
+        for k in self.names:
+            self.losses[k].copy_(vals[k].detach())
+
     def _device_sampling(self, on):
         h, w = self.geom
         atl = self.net.RCNN_rpn.RPN_anchor_target
@@ -603,19 +671,22 @@ class InstanceStyleDStep:
 
     def _capture(self, warmup):
         self._device_sampling(True)
+        body = self._body_branches if self.branches else self._body
         s = torch.cuda.Stream(self.dev)
         s.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(s):
             for i in range(warmup):
-                self._body()
+                body()
                 if i == 0:
-                    self.ctx.fit()
+                    for ctx in (self.ctx, self.ctx_src, self.ctx_tgt):
+                        if ctx is not None:
+                            ctx.fit()
         torch.cuda.current_stream(self.dev).wait_stream(s)
         torch.cuda.synchronize(self.dev)
         try:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                self._body()
+                body()
             self.graph = g
             return True
         except Exception as e:
@@ -635,6 +706,14 @@ class InstanceStyleDStep:
             self.graph.replay()
             self.opt.bump()
         return self.losses["total"]
+
+
+def _consistency_term(di, ds):
+    """One domain's term of ``consistency_terms`` below."""
+    per_roi = di.mean(3).mean(2)
+    rois_per_frame = per_roi.shape[0] // ds.shape[0]
+    prob = ds.reshape(ds.shape[0], -1)[:, :1].repeat(1, rois_per_frame).view(-1, 1)
+    return torch.nn.functional.mse_loss(per_roi, prob.detach())
 
 
 def consistency_terms(d_inst, d_style, d_inst_t, d_style_t):

@@ -260,3 +260,43 @@ def test_instance_styled_filter_gradients_on_a_side_branch(fresh_cfg):
         assert float(da[k].abs().max()) > 0
         # the update is ~1e-5 on weights of ~0.1: one ulp of a weight is 1e-3 of it
         assert float((da[k] - db[k]).abs().max()) <= 1e-2 * float(da[k].abs().max()) + 3e-8, k
+
+
+def test_instance_styled_two_branches_equal_one_pass(fresh_cfg):
+    """The captured step's default form -- source and target forward / backward as two branches of the graph, their
+    gradients added after the join (``InstanceStyleDStep._body_branches``) -- against the one-pass form on one stream: one
+    step from identical weights, eager with host-side sampling (same np.random stream): same losses, same parameter update;
+    and the captured two-branch step keeps training."""
+    cfg = fresh_cfg("res101", ["TRAIN.BATCH_SIZE", "16", "TRAIN.RPN_POST_NMS_TOP_N_TARGET", "16"])
+    from i2vsgg_amd import train
+    names = ["RCNN_base.4.0.conv1.weight", "RCNN_base.5.0.conv2.weight", "RCNN_base.6.22.conv3.weight",
+             "RCNN_top.0.1.conv1.weight", "RCNN_rpn.RPN_Conv.weight", "netD_pixel.conv1.weight", "netD_style.fc_1.weight",
+             "RCNN_cls_score.weight", "RCNN_bbox_pred.bias"]
+
+    def run(branches):
+        torch.manual_seed(0)
+        np.random.seed(cfg.RNG_SEED)
+        net = train.build_instance_styled_net(101, device=DEV)
+        before = {k: v.detach().clone() for k, v in net.named_parameters() if k in names}
+        step = train.InstanceStyleDStep(net, 2, seed=3, device=DEV, h=256, w=320, cr=True)
+        assert step.branches
+        (step._body_branches if branches else step._body)()
+        torch.cuda.synchronize()
+        losses = {k: float(v) for k, v in step.losses.items()}
+        delta = {k: dict(net.named_parameters())[k].detach() - before[k] for k in names}
+        return losses, delta, step
+
+    a, da, _ = run(False)
+    b, db, step = run(True)
+    for k in a:
+        assert abs(a[k] - b[k]) <= 1e-5 * max(abs(a[k]), 1e-6), (k, a, b)
+    for k in names:
+        assert float(da[k].abs().max()) > 0, k
+        assert float((da[k] - db[k]).abs().max()) <= 1e-2 * float(da[k].abs().max()) + 3e-8, k
+    assert step.capture(warmup=1), step.graph_error
+    w0 = step.net.RCNN_base[6][22].conv3.weight.detach().clone()
+    for _ in range(2):
+        step()
+    got = {k: float(v) for k, v in step.losses.items()}
+    assert all(np.isfinite(v) for v in got.values()), got
+    assert not torch.equal(w0, step.net.RCNN_base[6][22].conv3.weight.detach())
