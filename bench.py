@@ -148,10 +148,17 @@ def profile_eager(body, n_prof, dev):
     events cannot be read back from inside a graph replay."""
     import torch
     from i2vsgg_amd import ops
+    # An event pair brackets (idle time until the launch arrives) + (the kernel): with the device waiting for a host that
+    # needs 15-25 us of Python per launch, the pairs of 30-us kernels read 32-38 us depending on the box's CPU.  A ~10 ms
+    # GEMM in front of every profiled step keeps the device busy while the host queues the step behind it, so a pair
+    # measures its kernel (rocprofv3's durations of the same launches are the cross-check, profiles/README.md).
+    a = torch.randn(8192, 8192, device=dev)
     ops.PROFILE = []
     for _ in range(n_prof):
+        torch.mm(a, a)
         body()
     torch.cuda.synchronize(dev)
+    del a
     rec, ops.PROFILE = ops.PROFILE, None
     return [dict(t=e0.elapsed_time(e1) * 1e-3, flops=fl, tag=tag, desc=d, bytes=by) for e0, e1, fl, tag, d, by in rec]
 
