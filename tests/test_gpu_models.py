@@ -442,7 +442,9 @@ def test_sgg_step_back_to_back_replays_are_ordered(cfg):
     for own in (True, False):
         for _rep in range(2):
             got = run(own, False)
-            assert abs(got[0] - want[0]) < 1e-5 and abs(got[1] - want[1]) < 1e-6 * want[1], (own, got, want)
+            # the ordering failure this guards against shows as 2e-2 or NaN; 2e-4 leaves room for the fp32 atomics of the
+            # small split-K GEMMs (typically 2e-7, once 6e-5 in ~60 trajectories: DESIGN.md 5.2)
+            assert abs(got[0] - want[0]) < 2e-4 and abs(got[1] - want[1]) < 1e-6 * want[1], (own, got, want)
 
 
 def test_sgg_step_staged_batches_meet_their_features(cfg):
