@@ -228,3 +228,24 @@ def test_bench_fails_when_a_rank_does_not_come_up():
     rc, lines, err = _run_bench(["--gpus", "2", "--dry-run"], env={"I2V_BENCH_FAIL_RANK": "1"})
     assert rc != 0 and not lines
     assert "rank exited" in err
+
+
+def test_block_backward_protocol_wiring():
+    """The pre-masked gradient hand-over of ops._BottleneckFn is only wired where a block's output has exactly one
+    consumer: inside a layer and from layer1 into layer2 -- not across the layer2 tap (netD_style reads it),
+    not out of layer3 (RPN, ROI pooling), not into layer4 (its input is ROI-pooled, not a ReLU output)."""
+    from i2vsgg_amd.model.faster_rcnn.layers import C4Base, make_layer
+    base = C4Base((3, 4, 23))
+    l1, l2, l3 = base[4], base[5], base[6]
+    for layer in (l1, l2, l3):
+        for i, blk in enumerate(layer):
+            if i:
+                assert blk.in_relu and layer[i - 1]._next[0] is blk
+    assert not l1[0].in_relu                              # behind the frozen stem: no gradient leaves the block anyway
+    assert l2[0].in_relu and l1[-1]._next[0] is l2[0]     # layer1 -> layer2: one consumer
+    assert not l3[0].in_relu and l2[-1]._next == []       # the tap
+    assert l3[-1]._next == []
+    layer4, _ = make_layer(1024, 512, 3, 2)
+    assert not layer4[0].in_relu and layer4[1].in_relu and layer4[-1]._next == []
+    # no submodule was registered by the wiring: the state_dict keys stay the reference's
+    assert not any("_next" in k for k in base.state_dict())
