@@ -3,7 +3,7 @@
 launches of the multi-tensor SGD kernel), by queue, with the idle time in front of it on its queue; per-queue busy time and
 the time during which no kernel at all was running.
 
-usage: step_timeline.py kernel_trace.csv [anchor_kernel_substring] [periods_from_end]"""
+usage: step_timeline.py kernel_trace.csv [anchor_kernel_substring] [periods_from_end] [anchor_launches_per_step]"""
 import collections
 import csv
 import re
@@ -15,7 +15,8 @@ for r in csv.DictReader(open(sys.argv[1])):
 rows.sort()
 anchor = sys.argv[2] if len(sys.argv) > 2 else "sgd_momentum_multi"
 back = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-marks = [r[0] for r in rows if anchor in r[3]]
+per_step = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+marks = [r[0] for r in rows if anchor in r[3]][::per_step]
 t0, t1 = marks[-back - 1], marks[-back]
 win = [r for r in rows if t0 <= r[0] < t1]
 
