@@ -30,6 +30,38 @@ for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
             a[1] += float(r["Counter_Value"])
     per[counter] = {k: {"launches": n, "sum_kb": v} for k, (n, v) in sorted(agg.items(), key=lambda x: -x[1][1])[:16]}
 
+# optional third PMC pass (tools/profile_bench.sh): SQ_VALU_MFMA_BUSY_CYCLES, summed over the chip's 1024 SIMDs by rocprofv3.
+# Together with the trace pass's durations it gives the matrix-pipe utilisation from COUNTERS (not from a FLOP count):
+#   util = busy cycles / (1024 SIMDs x launch duration x shader clock).  The clock is the one the chip holds under this
+# load (2.06 GHz inside a lone conv_gemm_f32 launch, 2.22 GHz over the step: DESIGN.md 5.3 / 5.4); 2.1e9 is used here.
+CLOCK_HZ = 2.1e9
+mfma = collections.defaultdict(lambda: [0, 0.0])
+for f in glob.glob("%s/mfma/**/*counter_collection.csv" % out, recursive=True):
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != "SQ_VALU_MFMA_BUSY_CYCLES":
+            continue
+        a = mfma[short(r["Kernel_Name"])]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+dur = collections.defaultdict(lambda: [0, 0.0])
+for f in glob.glob("%s/trace/**/*kernel_stats.csv" % out, recursive=True):
+    for r in csv.DictReader(open(f)):
+        a = dur[short(r["Name"])]
+        a[0] += int(r["Calls"])
+        a[1] += float(r["TotalDurationNs"])
+
+
+def mfma_block(kernel):
+    n, busy = mfma.get(kernel, (0, 0.0))
+    c, ns = dur.get(kernel, (0, 0.0))
+    if not n or not c:
+        return None
+    per_launch, avg_ns = busy / n, ns / c
+    return {"launches": n, "mfma_busy_cycles_per_launch": per_launch, "avg_duration_us": avg_ns / 1e3,
+            "mfma_util_at_2.1GHz": per_launch / (1024.0 * avg_ns * 1e-9 * CLOCK_HZ),
+            "tflops_from_busy_cycles_f32_16x16x4": per_launch / 32.0 * 2048.0 / (avg_ns * 1e-9) / 1e12}
+
+
 def block(kernel):
     f = per["FETCH_SIZE"].get(kernel, {"launches": 0, "sum_kb": 0.0})
     w = per["WRITE_SIZE"].get(kernel, {"launches": 0, "sum_kb": 0.0})
@@ -46,6 +78,7 @@ summary = {
     "conv_gemm_f32": block("conv_gemm_f32"),
     "conv_igemm_f32": block("conv_igemm_f32"),
     "conv_wgrad2_f32": block("conv_wgrad2_f32"),
+    "mfma_utilisation_from_counters": {k: mfma_block(k) for k in ("conv_gemm_f32", "conv_igemm_f32", "conv_wgrad2_f32")},
     "per_kernel": per,
 }
 json.dump(summary, open(prefix + "_pmc_summary.json", "w"), indent=1)

@@ -9,6 +9,7 @@ rm -rf $out; mkdir -p $out
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o bench -- python3 bench.py --steps $steps --warmup $warm --no-cpu-baseline --no-also --no-graph > $out/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o bench -- python3 bench.py --steps $steps --warmup $warm --no-cpu-baseline --no-also --no-graph > $out/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o bench -- python3 bench.py --steps $steps --warmup $warm --no-cpu-baseline --no-also --no-graph > $out/write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $out/mfma -o bench -- python3 bench.py --steps $steps --warmup $warm --no-cpu-baseline --no-also --no-graph > $out/mfma.log 2>&1
 # every eager step of the run: capture warm-up (2) + W + K + the 3 event-timed steps of the roofline block, see bench.py
 python3 tools/pmc_summary.py $out $((steps + warm + 2 + 3)) gpurun_out/r02
 
@@ -18,6 +19,7 @@ rm -rf $out; mkdir -p $out
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o isd -- python3 bench.py --config instance_styled --no-graph --steps 4 --warmup 1 --no-cpu-baseline > $out/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -o isd -- python3 bench.py --config instance_styled --no-graph --steps 2 --warmup 1 --no-cpu-baseline > $out/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -o isd -- python3 bench.py --config instance_styled --no-graph --steps 2 --warmup 1 --no-cpu-baseline > $out/write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $out/mfma -o isd -- python3 bench.py --config instance_styled --no-graph --steps 2 --warmup 1 --no-cpu-baseline > $out/mfma.log 2>&1
 # eager steps of the PMC runs: 2 warm-ups + W + K + the 2 event-timed steps of the roofline block
 python3 tools/pmc_summary.py $out 7 gpurun_out/r02_instance_styled
 mv gpurun_out/r02_instance_styled_bench_kernel_stats.csv gpurun_out/r02_instance_styled_kernel_stats.csv
