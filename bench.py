@@ -198,9 +198,9 @@ def run_sgg(a, rank, world, dev, frames_per_rank=2):
 
     # ---- roofline of the dominant kernel: conv_igemm_f32 (MFMA-bound)
     n_prof = 3
-    ov, step.overlap = step.overlap, False
+    pp, step._pipelined = step._pipelined, False          # the profiled steps are sequential eager steps of the same objects
     rec = profile_eager(step._body, n_prof, dev)
-    step.overlap = ov
+    step._pipelined = pp
     # The dominant kernel of the step is conv_gemm_f32 (the pointwise layers of the bottlenecks: 60 of the ~110 GEMM launches
     # and most of the conv time): every call tagged [gemm] is exactly one launch of it, so flops / HIP-event time of those
     # calls is the kernel's own rate.  `all_conv` keeps the whole-backbone view (every i2v_conv_fwd / convolution _dgrad

@@ -27,6 +27,7 @@ SIGNATURES = {
     "i2v_roi_align_sampled_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _p, _i, _p]),
     "i2v_roi_align_sampled_bwd": (_i, [_p, _i, _p, _i, _i, _i, _f, _i, _p, _i, _i, _i, _i, _i, _p]),
     "i2v_roi_pool_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _f, _p, _p, _i, _p]),
+    "i2v_roi_pool_fwd_geom": (_i, [_p, _i, _i, _p, _l, _p, _i, _i, _i, _f, _p, _p, _i, _p]),
     "i2v_roi_pool_bwd": (_i, [_p, _p, _i, _p, _i, _i, _i, _p, _i, _i, _i, _i, _i, _p]),
     "i2v_nms_workspace_bytes": (_z, [_i, _i]),
     "i2v_nms_sorted": (_i, [_p, _i, _i, _f, _i, _p, _p, _p, _z, _p]),

@@ -255,11 +255,16 @@ roi_align_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ r
 __global__ void __launch_bounds__(256)
 roi_pool_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
                     int* __restrict__ argmax, int C, int H, int W, int PH, int PW, float scale, Strides fs,
-                    Strides os, int out_nchw) {
+                    Strides os, int out_nchw, const int* __restrict__ geom, long long cap_cells) {
     extern __shared__ float lds[];
     const int P = PH * PW;
     float* sval = lds;
     int* sarg = (int*)(lds + 64 * P);
+    if (geom) {                          // extent of the (NHWC, packed) maps read from device memory: i2v_roi_pool_fwd_geom
+        H = geom[0]; W = geom[1];
+        if (H <= 0 || W <= 0 || (long long)H * W > cap_cells) H = W = 0;       // does not fit the buffer: every bin empty
+        fs = feat_strides(I2V_LAYOUT_NHWC, C, H, W);
+    }
     const int chunks = (C + 63) / 64;
     const int r = blockIdx.x / chunks, c0 = (blockIdx.x % chunks) * 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -312,11 +317,16 @@ roi_pool_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ ro
 // cells are visited in the same (h, w) order per channel as above: same maxima, same first-maximum argmax.
 __global__ void __launch_bounds__(256)
 roi_pool_fwd_c128_kernel(const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
-                         int* __restrict__ argmax, int C, int H, int W, int PH, int PW, float scale, int out_nchw) {
+                         int* __restrict__ argmax, int C, int H, int W, int PH, int PW, float scale, int out_nchw,
+                         const int* __restrict__ geom, long long cap_cells) {
     extern __shared__ float lds[];
     const int P = PH * PW;
     float* sval = lds;
     int* sarg = (int*)(lds + 128 * P);
+    if (geom) {                          // i2v_roi_pool_fwd_geom: H, W live in device memory
+        H = geom[0]; W = geom[1];
+        if (H <= 0 || W <= 0 || (long long)H * W > cap_cells) H = W = 0;
+    }
     const int chunks = C / 128;
     const int r = blockIdx.x / chunks, c0 = (blockIdx.x % chunks) * 128;
     const int l32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
@@ -545,26 +555,45 @@ extern "C" int32_t i2v_roi_align_bwd(const float* gout, int32_t out_layout, cons
     return I2V_OK;
 }
 
+namespace {
+int32_t roi_pool_fwd_launch(const float* feat, int32_t feat_layout, int32_t B, int32_t C, int32_t H, int32_t W,
+                            const int32_t* geom, long long cap_cells, const float* rois, int32_t R, int32_t PH, int32_t PW,
+                            float scale, float* out, int32_t* argmax, int32_t out_layout, void* stream) {
+    I2V_CHECK_ARG(PH * PW <= 256, "roi_pool_fwd: pooled grid too large for the LDS stage");
+    Strides fs = feat_strides(feat_layout, C, H, W), os = out_strides(out_layout, C, PH, PW);
+    const int c128 = g_i2v_tuning[I2V_TUNE_ROIPOOL_C128];
+    if (c128 && feat_layout == I2V_LAYOUT_NHWC && C % 128 == 0 && (size_t)128 * PH * PW * 8 <= 64 * 1024) {
+        roi_pool_fwd_c128_kernel<<<R * (C / 128), 256, (size_t)128 * PH * PW * 8, (hipStream_t)stream>>>(
+            feat, rois, out, argmax, C, H, W, PH, PW, scale, out_layout == I2V_LAYOUT_NCHW, geom, cap_cells);
+        I2V_CHECK_LAUNCH("roi_pool_fwd");
+        return I2V_OK;
+    }
+    size_t lds = (size_t)64 * PH * PW * 8;
+    roi_pool_fwd_kernel<<<R * ((C + 63) / 64), 256, lds, (hipStream_t)stream>>>(
+        feat, rois, out, argmax, C, H, W, PH, PW, scale, fs, os, out_layout == I2V_LAYOUT_NCHW, geom, cap_cells);
+    I2V_CHECK_LAUNCH("roi_pool_fwd");
+    return I2V_OK;
+}
+}  // namespace
+
 extern "C" int32_t i2v_roi_pool_fwd(const float* feat, int32_t feat_layout, int32_t B, int32_t C, int32_t H,
                                     int32_t W, const float* rois, int32_t R, int32_t PH, int32_t PW, float scale,
                                     float* out, int32_t* argmax, int32_t out_layout, void* stream) {
     if (R == 0) return I2V_OK;          // empty roi set: nothing to do (tensors may have null storage)
     I2V_CHECK_ARG(feat && rois && out && argmax, "roi_pool_fwd: null pointer");
     I2V_CHECK_ARG(B > 0 && C > 0 && H > 0 && W > 0 && R >= 0 && PH > 0 && PW > 0, "roi_pool_fwd: bad shape");
-    I2V_CHECK_ARG(PH * PW <= 256, "roi_pool_fwd: pooled grid too large for the LDS stage");
-    Strides fs = feat_strides(feat_layout, C, H, W), os = out_strides(out_layout, C, PH, PW);
-    const int c128 = g_i2v_tuning[I2V_TUNE_ROIPOOL_C128];
-    if (c128 && feat_layout == I2V_LAYOUT_NHWC && C % 128 == 0 && (size_t)128 * PH * PW * 8 <= 64 * 1024) {
-        roi_pool_fwd_c128_kernel<<<R * (C / 128), 256, (size_t)128 * PH * PW * 8, (hipStream_t)stream>>>(
-            feat, rois, out, argmax, C, H, W, PH, PW, scale, out_layout == I2V_LAYOUT_NCHW);
-        I2V_CHECK_LAUNCH("roi_pool_fwd");
-        return I2V_OK;
-    }
-    size_t lds = (size_t)64 * PH * PW * 8;
-    roi_pool_fwd_kernel<<<R * ((C + 63) / 64), 256, lds, (hipStream_t)stream>>>(
-        feat, rois, out, argmax, C, H, W, PH, PW, scale, fs, os, out_layout == I2V_LAYOUT_NCHW);
-    I2V_CHECK_LAUNCH("roi_pool_fwd");
-    return I2V_OK;
+    return roi_pool_fwd_launch(feat, feat_layout, B, C, H, W, nullptr, 0, rois, R, PH, PW, scale, out, argmax, out_layout,
+                               stream);
+}
+
+extern "C" int32_t i2v_roi_pool_fwd_geom(const float* feat, int32_t B, int32_t C, const int32_t* geom, int64_t cap_cells,
+                                         const float* rois, int32_t R, int32_t PH, int32_t PW, float scale, float* out,
+                                         int32_t* argmax, int32_t out_layout, void* stream) {
+    if (R == 0) return I2V_OK;
+    I2V_CHECK_ARG(feat && geom && rois && out && argmax, "roi_pool_fwd_geom: null pointer");
+    I2V_CHECK_ARG(B > 0 && C > 0 && cap_cells > 0 && R >= 0 && PH > 0 && PW > 0, "roi_pool_fwd_geom: bad shape");
+    return roi_pool_fwd_launch(feat, I2V_LAYOUT_NHWC, B, C, 1, 1, geom, (long long)cap_cells, rois, R, PH, PW, scale, out,
+                               argmax, out_layout, stream);
 }
 
 extern "C" int32_t i2v_roi_pool_bwd(const float* gout, const int32_t* argmax, int32_t out_layout,

@@ -17,6 +17,9 @@ class ROIPool(nn.Module):
         self.out_nchw = out_nchw     # NCHW: the flatten order vrd.fc6 expects (resnet_SGG_emb.py:146)
 
     def forward(self, input, rois):
+        if isinstance(input, ops.PackedMaps):       # a captured step: the maps' extent is read on the device
+            return ops.roi_pool_packed(input, rois, self.output_size[0], self.output_size[1], self.spatial_scale,
+                                       out_nchw=self.out_nchw)
         return ops.roi_pool(input, rois, self.output_size[0], self.output_size[1], self.spatial_scale,
                             out_nchw=self.out_nchw)
 

@@ -5,20 +5,35 @@ from torch.utils.data.sampler import Sampler
 
 class sampler(Sampler):
     """Contiguous index blocks of ``batch_size`` in random block order, leftovers last
-    (net_utils.py:13-36) -- keeps images of similar aspect ratio (sorted roidb) in one batch."""
+    (net_utils.py:13-36) -- keeps images of similar aspect ratio (sorted roidb) in one batch.
 
-    def __init__(self, train_size, batch_size):
+    ``rank`` / ``world`` (one process per GPU instead of the reference's single-process DataParallel): every rank draws the
+    SAME block order (generator seeded with ``seed`` + the epoch count) and keeps the blocks rank, rank + world, ...; the
+    leftover images and the blocks that do not fill a round of all ranks are dropped, so every rank sees the same number
+    of minibatches per epoch.  The defaults are the reference's sampler."""
+
+    def __init__(self, train_size, batch_size, rank=0, world=1, seed=None):
         self.num_data = train_size
         self.batch_size = batch_size
         self.num_per_batch = train_size // batch_size
         self.leftover = torch.arange(self.num_per_batch * batch_size, train_size).long()
+        self.rank, self.world, self.seed, self.epoch = int(rank), int(world), seed, 0
 
     def __iter__(self):
-        starts = torch.randperm(self.num_per_batch).view(-1, 1) * self.batch_size
+        gen = None
+        if self.seed is not None:
+            gen = torch.Generator().manual_seed(int(self.seed) + self.epoch)
+        self.epoch += 1
+        order = torch.randperm(self.num_per_batch, generator=gen) if gen is not None else torch.randperm(self.num_per_batch)
+        if self.world > 1:
+            order = order[:self.num_per_batch // self.world * self.world][self.rank::self.world]
+        starts = order.view(-1, 1) * self.batch_size
         idx = (starts + torch.arange(self.batch_size).view(1, -1)).view(-1)
-        return iter(torch.cat((idx, self.leftover), 0))
+        return iter(idx if self.world > 1 else torch.cat((idx, self.leftover), 0))
 
     def __len__(self):
+        if self.world > 1:
+            return self.num_per_batch // self.world * self.batch_size
         return self.num_data
 
 

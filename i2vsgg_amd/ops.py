@@ -191,6 +191,46 @@ def roi_pool(feat, rois, pooled_h, pooled_w, spatial_scale, out_nchw=True, retur
     return (out, arg) if return_argmax else out
 
 
+class PackedMaps:
+    """B feature maps (NHWC, packed: map b at b*H*W*C) at the start of a flat buffer of ``B * cap_cells * C`` floats whose
+    extent (H, W) lives in DEVICE memory (``geom``: int32[2]).  What a captured step hands its ROI op when the size of the
+    maps changes from batch to batch (roi_data_layer pads every batch to its own size): the recorded launch reads H and W
+    at run time (``i2v_roi_pool_fwd_geom``)."""
+
+    def __init__(self, buf, n_maps, channels, geom):
+        _need_cuda(buf, geom)
+        if geom.dtype != torch.int32 or geom.numel() < 2 or not geom.is_contiguous():
+            raise ValueError("geom must be a contiguous int32 tensor [H, W]")
+        if buf.dtype != torch.float32 or not buf.is_contiguous():
+            raise ValueError("PackedMaps needs a contiguous fp32 buffer")
+        self.buf, self.n_maps, self.channels, self.geom = buf, int(n_maps), int(channels), geom
+        self.cap_cells = buf.numel() // (self.n_maps * self.channels)
+
+    @property
+    def device(self):
+        return self.buf.device
+
+    def view(self, h, w):
+        """The maps as a (B,C,h,w) channels_last tensor (host-side knowledge of the extent: tests, eager code)."""
+        n = self.n_maps * h * w * self.channels
+        return self.buf[:n].view(self.n_maps, h, w, self.channels).permute(0, 3, 1, 2)
+
+
+def roi_pool_packed(maps, rois, pooled_h, pooled_w, spatial_scale, out_nchw=True):
+    """Caffe ROIPool over ``PackedMaps`` (forward only: the SGG_emb loop detaches the feature map,
+    faster_rcnn_SGG_emb.py:148)."""
+    rois = _rois_f32(rois)
+    _need_cuda(rois)
+    R, C = rois.size(0), maps.channels
+    fmt = torch.contiguous_format if out_nchw else _CL
+    out = torch.empty((R, C, pooled_h, pooled_w), device=rois.device, dtype=torch.float32, memory_format=fmt)
+    arg = torch.empty((R, C, pooled_h, pooled_w), device=rois.device, dtype=torch.int32, memory_format=fmt)
+    check(lib.i2v_roi_pool_fwd_geom(ptr(maps.buf), maps.n_maps, C, ptr(maps.geom), maps.cap_cells, ptr(rois), R,
+                                    int(pooled_h), int(pooled_w), float(spatial_scale), ptr(out), ptr(arg),
+                                    LAYOUT_NCHW if out_nchw else LAYOUT_NHWC, stream()), "roi_pool_fwd_geom")
+    return out
+
+
 # ----------------------------------------------------------------------------- NMS / RPN
 def nms_sorted(dets, thresh, max_keep=0):
     """dets (n,5) or (n_img,n,5), rows in descending score order -> (keep int32 (n_img,n), num int32 (n_img,)),

@@ -101,6 +101,13 @@ class FusedSGD:
         for it in self.items:
             it["p"].grad = None
 
+    def lr_of(self, name):
+        """The learning rate the optimizer holds for parameter ``name`` (what a resumed run shows and decays from)."""
+        for it in self.items:
+            if it["name"] == name:
+                return it["lr"]
+        return self.items[0]["lr"]
+
     def scale_lr(self, k):
         for it in self.items:
             it["lr"] *= k
@@ -137,25 +144,108 @@ def synthetic_sgg_batch(seed, n_frames, n_boxes=32, n_pairs=32, n_rel=62, n_cls=
     return im, info, annos
 
 
+def sgg_head_inputs(annos, info, n_rel):
+    """Head inputs of one minibatch on the host, exact sizes (faster_rcnn_SGG_emb.py:170-245 for every frame of the batch;
+    frames without an annotated relation contribute nothing, :177-183): ``annos`` one annotation dict per frame (unscaled
+    pixel boxes, as in the ``source_gt_rels`` pickle), ``info`` (n_frames,3) im_info rows [h, w, scale].
+    -> dict of numpy arrays: boxes (nb,5), relb (np,5) [frame index in column 0], labels (np,n_rel), ixs / ixo (np,) rows of
+    ``boxes``, bounds (np,2,4) integer bounds of the 32x32 dual masks, wrow (np,) = 1 / (pairs of the frame * frames with
+    pairs): sum_r wrow[r] * mean_c BCE is the mean over frames of the per-frame BCE mean."""
+    from .model.faster_rcnn.faster_rcnn_SGG_emb import build_pair_tables
+    boxes, relb, bounds, labels, ixs, ixo, counts, off = [], [], [], [], [], [], [], 0
+    for f, anno in enumerate(annos):
+        if anno is None or len(anno["rels"]) < 1:
+            continue
+        gt, union, bnd, lab, s, o = build_pair_tables(anno, float(info[f][2]), float(info[f][0]), float(info[f][1]), n_rel)
+        b5 = np.zeros((gt.shape[0], 5), np.float32); b5[:, 0] = f; b5[:, 1:] = gt
+        r5 = np.zeros((union.shape[0], 5), np.float32); r5[:, 0] = f; r5[:, 1:] = union
+        boxes.append(b5); relb.append(r5); bounds.append(bnd); labels.append(lab)
+        ixs.append(s + off); ixo.append(o + off); counts.append(lab.shape[0]); off += gt.shape[0]
+    if not counts:
+        return None
+    cat = np.concatenate
+    return dict(boxes=cat(boxes), relb=cat(relb), labels=cat(labels).astype(np.float32), ixs=cat(ixs).astype(np.int64),
+                ixo=cat(ixo).astype(np.int64), bounds=cat(bounds).astype(np.int32),
+                wrow=cat([np.full((c,), 1.0 / (c * len(counts)), np.float32) for c in counts]))
+
+
+def _rasterize_host(bounds, channels=4):
+    """(n,2,4) integer [x1,y1,x2,y2) -> (n,channels,32,32) float32 dual masks (resnet_SGG_emb.py:246-256); channels 2.. are
+    the zero pad that keeps conv_lo.0's gathers 16-byte wide."""
+    n = bounds.shape[0]
+    m = np.zeros((n, channels, 32, 32), np.float32)
+    ar = np.arange(32)
+    b = bounds.reshape(n, 2, 4, 1)
+    xs = (ar[None, None, :] >= b[:, :, 0]) & (ar[None, None, :] < b[:, :, 2])          # (n,2,32)
+    ys = (ar[None, None, :] >= b[:, :, 1]) & (ar[None, None, :] < b[:, :, 3])
+    m[:, :2] = (ys[:, :, :, None] & xs[:, :, None, :]).astype(np.float32)
+    return m
+
+
 class _Slot:
     """One minibatch worth of head inputs packed into ONE device buffer (256-B aligned fields), so that moving a
-    batch between pipeline stages is a single copy whatever the number of fields."""
+    batch between pipeline stages is a single copy whatever the number of fields.  ``layout``: name -> (shape, dtype).
+    ``host=True`` adds two pinned host mirrors of the same layout: a batch is assembled in one of them and crosses PCIe as
+    ONE asynchronous copy."""
 
-    def __init__(self, fields, device):
+    def __init__(self, layout, device, host=False):
+        self.layout = {k: (tuple(sh), dt) for k, (sh, dt) in layout.items()}
         self.spec, off = [], 0
-        for name, t in fields.items():
-            nbytes = t.numel() * t.element_size()
-            self.spec.append((name, off, nbytes, t.dtype, tuple(t.shape)))
+        for name, (shape, dt) in self.layout.items():
+            nbytes = int(np.prod(shape)) * torch.empty((), dtype=dt).element_size()
+            self.spec.append((name, off, nbytes, dt, shape))
             off += (nbytes + 255) // 256 * 256
-        self.buf = torch.zeros(max(off, 256), dtype=torch.uint8, device=device)
+        self.nbytes = max(off, 256)
+        self.buf = torch.zeros(self.nbytes, dtype=torch.uint8, device=device)
         self.views = {name: self.buf[o:o + n].view(dt).view(shape) for name, o, n, dt, shape in self.spec}
+        self._host, self._turn = [], 0
+        if host:
+            for _ in range(2):
+                hb = torch.zeros(self.nbytes, dtype=torch.uint8).pin_memory()
+                hv = {name: hb[o:o + n].view(dt).view(shape).numpy() for name, o, n, dt, shape in self.spec}
+                self._host.append((hb, hv, torch.cuda.Event()))
 
-    def same_layout(self, fields):
-        return [(n, dt, sh) for n, _, _, dt, sh in self.spec] == [(n, t.dtype, tuple(t.shape)) for n, t in fields.items()]
+    def same_layout(self, layout):
+        return self.layout == {k: (tuple(sh), dt) for k, (sh, dt) in layout.items()}
 
     def write(self, fields):
+        """Device tensors of exactly the slot's shapes (one small copy per field)."""
         for name, t in fields.items():
             self.views[name].copy_(t)
+
+    def write_host(self, fields):
+        """numpy arrays, each at most as large as its field along axis 0: zero-padded to the slot's capacity in a pinned
+        mirror, then ONE asynchronous H2D copy on the current stream."""
+        hb, hv, ev = self._host[self._turn]
+        self._turn ^= 1
+        ev.synchronize()                         # the copy that last read this mirror has finished (two calls ago)
+        for name, a in fields.items():
+            dst = hv[name]
+            n = a.shape[0] if a.ndim else 0
+            if a.ndim and n > dst.shape[0]:
+                raise ValueError("field %s: %d rows exceed the slot's capacity %d" % (name, n, dst.shape[0]))
+            if a.ndim:
+                dst[:n] = a
+                dst[n:] = 0
+            else:
+                dst[...] = a
+        self.buf.copy_(hb, non_blocking=True)
+        ev.record()
+
+
+class _FrameSet:
+    """What the backbone half of the SGG_emb step owns for ONE minibatch size (n, H, W): the staged frames, one launch
+    context per frame branch and the captured graph of the step whose backbone half has this size."""
+
+    def __init__(self, key, device, n_ctx, arena):
+        n, h, w = key
+        self.key = key
+        self.im = torch.zeros((n, 4, h, w), device=device).contiguous(memory_format=torch.channels_last)
+        self.ctx = [ops.LaunchContext(device, arena=arena) for _ in range(n_ctx)]
+        self.fh = self.fw = None      # extent of the C4 map, known after the first pass
+        self.graph = None             # None: not captured yet; False: capture failed (eager launches for this size)
+        self.fitted = False
+        self.tick = 0
 
 
 class SGGEmbStep:
@@ -165,21 +255,33 @@ class SGGEmbStep:
     relation-head forward + backward, one gradient exchange (world > 1), one SGD(momentum) update of ``vrd.*``.
 
     Schedule (``overlap``, the default with HIP graphs): the backbone is frozen in this loop, so the backbone pass of
-    the NEXT minibatch does not depend on this step's update.  The whole step is ONE captured graph with two branches
-    between a fork and a join: [head fwd + bwd (+ exchange) + SGD of batch k] beside [backbone of batch k+1].  The
-    branches own disjoint device state (``ops.LaunchContext``: zero arena, split-K workspace, scratch) and meet only at
-    graph edges: the feature-map hand-off (one 20 MB copy before the fork) and the join.  There is one graph launch
+    the NEXT minibatch does not depend on this step's update.  The whole step is ONE captured graph with branches
+    between a fork and a join: [head fwd + bwd (+ exchange) + SGD of batch k] beside [backbone of batch k+1, one branch per
+    frame].  The branches own disjoint device state (``ops.LaunchContext``: zero arena, split-K workspace, scratch) and
+    meet only at graph edges: the feature-map hand-off (one copy before the fork) and the join.  There is one graph launch
     per step on the caller's stream, no side stream, no event and no priority for a caller to get wrong.
 
     Minibatches move through a three-slot pipeline so that ``stage()`` may be called at any time between steps:
-    ``stage(b)`` writes the frames of b (read by the NEXT call's backbone branch) and its head inputs into the ``in``
+    ``stage(b)`` writes the frames of b (read by the NEXT call's backbone branches) and its head inputs into the ``in``
     slot; each call starts with cur <- nxt, nxt <- in (two small copies inside the graph) and then runs head(cur) beside
     backbone(frames).  A batch staged before call k is therefore consumed by the backbone in call k and by the head in
     call k+1 -- features and boxes / labels of one batch always meet.  ``overlap=False`` (and eager mode): backbone and
-    head of the staged batch in the same call."""
+    head of the staged batch in the same call.
+
+    Minibatches of a data loader differ in size (the loader pads every batch to its own aspect ratio,
+    roibatchLoader.py:162-190) and in the number of boxes and pairs per frame.  The captured step takes them all:
+      * the head half is size-free: boxes / pairs are zero-padded to a CAPACITY (``n_boxes`` / ``n_pairs`` per frame; pad
+        rows carry loss weight 0, so their gradient is exactly zero), the feature maps sit packed at the start of a
+        capacity buffer and the ROI op reads their extent from device memory (``ops.PackedMaps``; the extent travels
+        through the slots with the batch);
+      * the backbone half is captured once per frame size: ``shapes[(n, H, W)]`` holds the staged frames, the per-frame
+        launch contexts (arenas sized for that size) and the graph [rotate, hand-off, fork, head | backbone(n, H, W), join];
+        a call replays the graph of the size staged last.  At most ``max_graphs`` graphs are kept (least recently used
+        goes first); they share one memory pool, since no two of them ever run at the same time.
+    """
 
     def __init__(self, net, n_frames, vrd_lr=1e-4, seed=1, device="cuda:0", h=600, w=1000, n_boxes=32, n_pairs=32,
-                 use_graph=True, fuse_sgd=True, zero_arena=True, overlap=None):
+                 use_graph=True, fuse_sgd=True, zero_arena=True, overlap=None, max_graphs=16, trace_rows=0, stage_synthetic=True):
         import os
         self.net, self.dev, self.n_frames = net, torch.device(device), n_frames
         self.world = parallel.world_size()
@@ -193,142 +295,310 @@ class SGGEmbStep:
         self.opt = FusedSGD([(n, p) for n, p in net.named_parameters() if n.startswith("vrd.")], vrd_lr)
         self.fused = self.opt.fuse_wgrad() if fuse_sgd else []
         self.loss = torch.zeros((), device=self.dev)
-        self.graph = None
         self.graph_error = None
         self.use_graph = use_graph
         if overlap is None:
             overlap = os.environ.get("I2V_OVERLAP", "1") != "0"
-        self.overlap = bool(overlap) and use_graph
-        self.ctx_bb = ops.LaunchContext(self.dev, arena=zero_arena)        # backbone branch
+        self.overlap = bool(overlap) and use_graph       # the schedule asked for; in force once capture() has succeeded
+        self._pipelined = False                          # (until then a call is the sequential eager step)
+        self._graphs_on = False
+        self.zero_arena = zero_arena
         self.bb_split = os.environ.get("I2V_BB_SPLIT", "1") == "1" and use_graph and n_frames > 1
-        self.ctx_frames = [ops.LaunchContext(self.dev, arena=zero_arena) for _ in range(n_frames)] if self.bb_split else []
         self._frame_streams = [torch.cuda.Stream(self.dev) for _ in range(n_frames)] if self.bb_split else []
+        self._side = None
         self.ctx_head = ops.LaunchContext(self.dev, arena=zero_arena)      # head branch
-        self.im = self.fmap = self.fmap_head = None
+        self.ctx_bb = ops.LaunchContext(self.dev, arena=zero_arena)        # eager backbone passes (any size)
+        self.shapes, self.max_graphs, self._tick, self._pool = {}, int(max_graphs), 0, None
+        self.cap_boxes, self.cap_pairs = n_frames * n_boxes, n_frames * n_pairs      # rows of the padded head inputs
+        self.cap_cells = 0
+        self.fmap_flat = self.fmap_head_flat = None
         self.cur = self.nxt = self.inp = None
+        self._staged = None           # key of the frame set staged last
+        self._fmap_key = None         # key of the frame set whose features ``fmap_flat`` holds
         self.primed = False
-        self.reseed(seed)
+        self.trace = torch.zeros((trace_rows, len(self.TRACE_COLS)), device=self.dev, dtype=torch.float64) if trace_rows else None
+        self._trace_i = torch.zeros((1,), device=self.dev, dtype=torch.long)
+        if stage_synthetic:           # a loop fed by a data loader stages its own first minibatch (``stage_batch``)
+            self.reseed(seed)
+
+    @property
+    def lag(self):
+        """1 when a call trains the batch staged BEFORE the one staged last (the overlapped schedule in force), else 0."""
+        return 1 if self._pipelined else 0
+
+    # ------------------------------------------------------------------ compatibility views
+    @property
+    def graph(self):
+        """The captured graph of the frame size staged last (None when that size runs on eager launches)."""
+        fs = self.shapes.get(self._staged)
+        return (fs.graph or None) if fs is not None else None
+
+    @property
+    def im(self):
+        return self.shapes[self._staged].im
+
+    @property
+    def fmap(self):
+        """Feature maps of the last backbone pass as a (n,1024,h,w) channels_last view."""
+        fs = self.shapes[self._fmap_key]
+        n, c = fs.key[0], self._channels
+        return self.fmap_flat[:n * fs.fh * fs.fw * c].view(n, fs.fh, fs.fw, c).permute(0, 3, 1, 2)
 
     # ------------------------------------------------------------------ data side
+    def _layout(self, nb, npair):
+        f32, i64 = torch.float32, torch.long
+        return {"boxes": ((nb, 5), f32), "relb": ((npair, 5), f32), "labels": ((npair, self.net.vrd.n_rel), f32),
+                "ixs": ((npair,), i64), "ixo": ((npair,), i64), "masks": ((npair, 4, 32, 32), f32),
+                "wrow": ((npair,), f32), "extent": ((2,), torch.int32)}
+
     def _synthetic(self, seed):
-        """SURVEY.md 8d config 2 as device tensors: frames in the layout the device front-end emits (ops.image_prep:
-        NHWC with the stem's zero fourth channel) + the head inputs of faster_rcnn_SGG_emb.py:170-245."""
-        from .model.faster_rcnn.faster_rcnn_SGG_emb import build_pair_tables, rasterize_masks
+        """frames in the layout the device front-end emits (ops.image_prep: NHWC with the stem's
+        zero fourth channel) + the host-side head inputs of faster_rcnn_SGG_emb.py:170-245."""
         h, w, n_boxes, n_pairs = self.geom
         head = self.net.vrd
         im, info, annos = synthetic_sgg_batch(seed, self.n_frames, n_boxes, n_pairs, head.n_rel, head.n_obj, h, w)
         head.source_gt_rels = annos
         self.paths = sorted(annos, key=lambda s: int(s[1:]))
-        boxes, relb, bounds, labels, ixs, ixo, counts, off = [], [], [], [], [], [], [], 0
-        for f, path in enumerate(self.paths):
-            gt, union, bnd, lab, s, o = build_pair_tables(annos[path], float(info[f][2]), float(info[f][0]),
-                                                          float(info[f][1]), head.n_rel)
-            b5 = np.zeros((gt.shape[0], 5), np.float32); b5[:, 0] = f; b5[:, 1:] = gt
-            r5 = np.zeros((union.shape[0], 5), np.float32); r5[:, 0] = f; r5[:, 1:] = union
-            boxes.append(b5); relb.append(r5); bounds.append(bnd); labels.append(lab)
-            ixs.append(s + off); ixo.append(o + off); counts.append(lab.shape[0]); off += gt.shape[0]
-        t = lambda a, dt=torch.float32: torch.from_numpy(np.concatenate(a)).to(self.dev, dt)
+        fields = sgg_head_inputs([annos[p] for p in self.paths], info, head.n_rel)
         im4 = torch.zeros((im.shape[0], 4) + tuple(im.shape[2:]), device=self.dev).contiguous(memory_format=torch.channels_last)
         im4[:, :3] = torch.from_numpy(im).to(self.dev)
-        fields = dict(boxes=t(boxes), relb=t(relb), labels=t(labels), ixs=t(ixs, torch.long), ixo=t(ixo, torch.long),
-                      # 2 zero channels: the float4 pad of conv_lo.0, done once by the data side
-                      masks=torch.nn.functional.pad(rasterize_masks(np.concatenate(bounds), self.dev), (0, 0, 0, 0, 0, 2)),
-                      wrow=torch.cat([torch.full((c,), 1.0 / (c * len(counts))) for c in counts]).to(self.dev))
-        return im4, torch.from_numpy(info).to(self.dev), fields
+        return im4, info, fields
 
-    def stage(self, im4, info, fields):
-        """Hand the NEXT minibatch to the step: frames (N,4,H,W) channels_last + head inputs.  Ordered on the caller's
-        stream like everything else: it may be called right after ``__call__`` returns, the copies queue behind the
-        step that is still running.  Shapes must match the first staged batch once a graph has been captured."""
-        if self.inp is None or (self.graph is None and not self.inp.same_layout(fields)):
-            self.cur, self.nxt, self.inp = (_Slot(fields, self.dev) for _ in range(3))
-            for k, v in self.cur.views.items():
-                setattr(self, k, v)                      # the head reads the ``cur`` slot
-            self.im, self.info = im4.clone(memory_format=torch.preserve_format), info.clone()
-            self.n_rows = int(fields["boxes"].shape[0] + fields["relb"].shape[0])
-            for slot in (self.cur, self.nxt, self.inp):
-                slot.write(fields)
-            self.primed = False
-            return
-        if not self.inp.same_layout(fields) or im4.shape != self.im.shape:
-            raise ValueError("SGGEmbStep.stage: the captured graph is bound to the shapes of the first staged batch")
-        if self.tp and self.graph is None:
-            parallel.assert_same_rows(fields["boxes"].shape[0] + fields["relb"].shape[0], "boxes + pairs")
-        self.im.copy_(im4)
-        self.info.copy_(info)
-        self.inp.write(fields)
+    def _frames(self, key):
+        fs = self.shapes.get(key)
+        if fs is None:
+            fs = self.shapes[key] = _FrameSet(key, self.dev, key[0] if self.bb_split else 1, self.zero_arena)
+        self._tick += 1
+        fs.tick = self._tick
+        return fs
+
+    def _geom_dev(self, fs):
+        if getattr(fs, "_geom", None) is None:
+            fs._geom = torch.tensor([fs.fh, fs.fw], dtype=torch.int32, device=self.dev)
+        return fs._geom
+
+    def _grow(self, nb, npair):
+        """Padded head inputs too small for this batch: new capacity (multiples of 16 rows), every graph is stale."""
+        if self.tp:
+            raise ValueError("SGGEmbStep: %d boxes / %d pairs exceed the capacity %d / %d; with fc6 cut across the ranks every "
+                             "rank must hold the same number of rows -- construct the step with larger n_boxes / n_pairs"
+                             % (nb, npair, self.cap_boxes, self.cap_pairs))
+        up = lambda n, cap: max(cap, (n + 15) // 16 * 16)
+        self.cap_boxes, self.cap_pairs = up(nb, self.cap_boxes), up(npair, self.cap_pairs)
+        self.invalidate_graphs()
+
+    def stage(self, frames, info, fields):
+        """Hand the NEXT minibatch to the step.  ``frames``: (n,4,H,W) channels_last device tensor (the device front-end's
+        blob), or (n,3,H,W) float frames on the device or the host (a roibatchLoader batch; pinned host memory crosses
+        asynchronously).  ``info``: (n,3) im_info rows.  ``fields``: ``sgg_head_inputs`` of the batch.  Ordered on the
+        caller's stream like everything else: it may be called right after ``__call__`` returns, the copies queue behind
+        the step that is still running."""
+        if fields is None:
+            raise ValueError("SGGEmbStep.stage: a minibatch without an annotated relation (the reference loop skips it, "
+                             "faster_rcnn_SGG_emb.py:177-183)")
+        n, _, H, W = frames.shape
+        if int(n) != self.n_frames:
+            raise ValueError("SGGEmbStep.stage: %d frames, the step was built for %d" % (n, self.n_frames))
+        key = (int(n), int(H), int(W))
+        fs = self._frames(key)
+        if frames.shape[1] == 4 and frames.is_cuda:
+            fs.im.copy_(frames)
+        else:
+            src = frames if frames.is_cuda else frames.to(self.dev, non_blocking=True)
+            fs.im[:, :3].copy_(src)                              # NCHW3 -> NHWC4 (channel 3 stays zero): one strided copy
+        self.info = np.asarray(info, np.float32).reshape(-1, 3) if not torch.is_tensor(info) else info.detach().cpu().numpy().reshape(-1, 3)
+        nb, npair = fields["boxes"].shape[0], fields["relb"].shape[0]
+        self.n_rows = nb + npair
+        host = {k: v for k, v in fields.items() if k != "bounds"}
+        host["masks"] = _rasterize_host(fields["bounds"])
+        if not self.use_graph:
+            # eager launches: exact sizes, nothing is padded
+            lay = self._layout(nb, npair)
+            if self.inp is None or not self.inp.same_layout(lay):
+                self.cur, self.nxt = (_Slot(lay, self.dev) for _ in range(2))
+                self.inp = _Slot(lay, self.dev, host=True)
+                self._bind()
+            if self.tp:
+                parallel.assert_same_rows(self.n_rows, "boxes + pairs")
+        else:
+            if nb > self.cap_boxes or npair > self.cap_pairs:
+                self._grow(nb, npair)
+            lay = self._layout(self.cap_boxes, self.cap_pairs)
+            if self.inp is None or not self.inp.same_layout(lay):
+                old = (self.cur, self.nxt) if self.inp is not None else None
+                self.cur, self.nxt = (_Slot(lay, self.dev) for _ in range(2))
+                self.inp = _Slot(lay, self.dev, host=True)
+                self._bind()
+                if old is not None and self._pipelined:          # batches in flight move to the larger slots
+                    for new, o in zip((self.cur, self.nxt), old):
+                        for name, v in o.views.items():
+                            new.views[name][tuple(slice(0, d) for d in v.shape)].copy_(v)
+        host["extent"] = np.zeros((2,), np.int32)                # (h, w) of the C4 maps; filled by _measure() for a new size
+        if fs.fh is not None:
+            host["extent"][:] = (fs.fh, fs.fw)
+        self.inp.write_host(host)
+        self._staged = key
+        first = not self.primed and self.cur is not None and not self._pipelined
+        if first and not getattr(self, "_filled", False):
+            # the very first batch: every stage of the pipeline starts out holding it
+            self.cur.buf.copy_(self.inp.buf); self.nxt.buf.copy_(self.inp.buf)
+            self._filled = True
+
+    def _bind(self):
+        for k, v in self.cur.views.items():
+            setattr(self, k, v)                                  # the head reads the ``cur`` slot
+        self._filled = False
+
+    def stage_batch(self, data):
+        """One roibatchLoader(path_return=True) minibatch as the DataLoader collates it -- (im_data (n,3,H,W), im_info (n,3),
+        gt_boxes, num_boxes, paths) -- looked up in ``vrd.source_gt_rels`` by the last path component as the reference loop
+        does (trainval_net_SGG_emb.py:211-217).  Returns False for the batches the reference skips (a frame outside the
+        aspect-ratio range, :209-210; no annotated relation in any frame, faster_rcnn_SGG_emb.py:177-183)."""
+        if not isinstance(data, (list, tuple)) or len(data) <= 2:
+            return False
+        info = data[1].detach().cpu().numpy().reshape(-1, 3)
+        rels = self.net.vrd.source_gt_rels
+        fields = sgg_head_inputs([rels.get(str(p).split("/")[-1]) for p in data[4]], info, self.net.vrd.n_rel)
+        if fields is None:
+            return False
+        self.stage(data[0], info, fields)
+        return True
 
     def reseed(self, seed):
         """Stage the synthetic minibatch of ``seed`` (the data layer's job; resident before the timed region)."""
         self.stage(*self._synthetic(seed))
 
+    # ------------------------------------------------------------------ feature-map buffers
+    _channels = 1024
+
+    def _reserve_cells(self, cells):
+        if cells <= self.cap_cells:
+            return
+        n = self.n_frames * self._channels * cells
+        new, new_h = torch.zeros(n, device=self.dev), torch.zeros(n, device=self.dev)
+        if self.fmap_flat is not None:
+            new[:self.fmap_flat.numel()].copy_(self.fmap_flat)
+            new_h[:self.fmap_head_flat.numel()].copy_(self.fmap_head_flat)
+        self.fmap_flat, self.fmap_head_flat, self.cap_cells = new, new_h, cells
+        self.invalidate_graphs()                                 # they hold the old buffers' addresses
+
+    def reserve(self, h, w):
+        """Size the feature-map buffers for frames of up to (h, w) pixels (a loop that knows its largest minibatch avoids
+        re-capturing when it arrives)."""
+        self._reserve_cells(((h + 15) // 16 + 1) * ((w + 15) // 16 + 1))
+
+    def _store_fmap(self, fs, fm, f=None):
+        """Feature maps of frame set ``fs`` (all frames, or frame f) into the packed buffer."""
+        n, c = fs.key[0], self._channels
+        cells = fs.fh * fs.fw
+        dst = self.fmap_flat[:n * cells * c].view(n, fs.fh, fs.fw, c).permute(0, 3, 1, 2)
+        (dst if f is None else dst[f:f + 1]).copy_(fm)
+
+    def _measure(self, fs):
+        """First sight of a frame size: one eager pass tells the extent of its C4 map (and sizes the eager arena)."""
+        if fs.fh is None:
+            with self.ctx_bb, torch.no_grad():
+                fm = self.net.RCNN_base(fs.im[:1])
+            self._channels = int(fm.shape[1])
+            fs.fh, fs.fw = int(fm.shape[2]), int(fm.shape[3])
+            self._reserve_cells(fs.fh * fs.fw)
+            if self._staged == fs.key and self.inp is not None:      # the batch staged for this size carries its extent
+                g = self._geom_dev(fs)
+                self.inp.views["extent"].copy_(g)
+                if not self._pipelined:
+                    self.cur.views["extent"].copy_(g); self.nxt.views["extent"].copy_(g)
+
     # ------------------------------------------------------------------ the two halves of a step
     def _rotate(self):
-        if self.overlap:
+        if self._pipelined:
             self.cur.buf.copy_(self.nxt.buf)
             self.nxt.buf.copy_(self.inp.buf)
         else:
             self.cur.buf.copy_(self.inp.buf)
 
-    def _backbone(self):
+    def _backbone(self, fs):
         with self.ctx_bb:
             with torch.no_grad():
-                fmap = self.net.RCNN_base(self.im)
-            if self.fmap is None:
-                self.fmap = torch.empty_like(fmap)
-            self.fmap.copy_(fmap)           # static address across replays; 20 MB, ~8 us
+                fmap = self.net.RCNN_base(fs.im)
+            self._store_fmap(fs, fmap)           # static address across replays; 20 MB, ~8 us
+        self._fmap_key = fs.key
 
-    def _backbone_per_frame(self, join=True):
+    def _backbone_per_frame(self, fs, join=True):
         """Captured form with ``bb_split``: the frames of the minibatch are independent chains of ~100 short kernels each
         (a layer3 GEMM of one frame runs ~15 us, a quarter of it set-up, first-load latency and the store tail with the
         matrix pipe idle).  One graph branch per frame: the kernels of the two chains are co-resident on every CU, the
         fixed phases of one lie under the K loops of the other."""
         main = torch.cuda.current_stream(self.dev)
-        n = self.im.shape[0]
+        n = fs.key[0]
         for f in range(n):
             st = self._frame_streams[f]
             st.wait_stream(main)
             with torch.cuda.stream(st):
-                with self.ctx_frames[f]:
+                with fs.ctx[f]:
                     with torch.no_grad():
-                        fm = self.net.RCNN_base(self.im[f:f + 1])
-                    self.fmap[f:f + 1].copy_(fm)
+                        fm = self.net.RCNN_base(fs.im[f:f + 1])
+                    self._store_fmap(fs, fm, f)
         if join:
             for f in range(n):
                 main.wait_stream(self._frame_streams[f])
+        self._fmap_key = fs.key
 
-    def _head(self):
+    TRACE_COLS = ("loss", "features", "scores", "embedding", "rng_canary", "fc7_weight", "fc6_weight_head", "boxes", "labels")
+
+    def _head(self, fs=None):
         with self.ctx_head:
-            fmap = self.fmap_head if self.overlap else self.fmap
-            score, _ = self.net.vrd.forward_device(fmap, self.boxes, self.relb, self.masks, self.ixs, self.ixo)
+            if self.use_graph:        # packed maps, extent from the batch's slot: the launches are the same for every size
+                src = self.fmap_head_flat if self._pipelined else self.fmap_flat
+                fmap = ops.PackedMaps(src, self.n_frames, self._channels, self.cur.views["extent"])
+            else:
+                fmap = self.fmap
+            score, x = self.net.vrd.forward_device(fmap, self.boxes, self.relb, self.masks, self.ixs, self.ixo)
             loss = ops.bce_rows(score, self.labels, self.wrow)     # sum_r wrow[r] * mean_c BCE: one kernel each way
+            if self.trace is not None:
+                self._record(loss, fmap, score, x)
             self.opt.zero_grad()
             (loss / self.world).backward()
             self.loss.copy_(loss.detach())
             parallel.all_reduce_grads(self.opt.params())           # world > 1: RCCL, captured with the rest of the branch
             self.opt.step()
 
+    @torch.no_grad()
+    def _record(self, loss, fmap, score, x):
+        """Diagnostic rows (``trace_rows``): per step, checksums of everything the head forward read and produced, written by
+        the step itself (inside the graph) so that two trajectories can be compared step by step and tensor by tensor
+        without putting anything but the graph launch on the caller's stream."""
+        v = self.net.vrd
+        d = lambda t: torch.linalg.vector_norm(t.detach().reshape(-1).float(), 2, dtype=torch.float64)    # accumulated in double
+        feats = fmap.buf if isinstance(fmap, ops.PackedMaps) else fmap
+        row = torch.stack([loss.detach().double(), d(feats), d(score), d(x), torch.rand((), device=self.dev).double(),
+                           d(v.fc7.fc.weight), d(v.fc6.fc.weight.view(-1)[:1 << 22]), d(self.boxes), d(self.labels)])
+        i = self._trace_i.clamp(max=self.trace.shape[0] - 1)
+        self.trace.index_copy_(0, i, row.view(1, -1))
+        self._trace_i.add_(1)
+
     def _body(self):
-        """Eager form, and what the sequential graph captures: backbone, then head, of the staged batch."""
+        """Sequential form (eager, and what the sequential graph captures): backbone, then head, of the staged batch."""
+        fs = self.shapes[self._staged]
+        self._measure(fs)
         self._rotate()
-        self._backbone()
+        self._backbone(fs)
         self._head()
 
-    def _body_overlapped(self):
-        """What the overlapped graph captures.  Fork / join through the capturing stream: everything the side stream
-        does lies between ``side.wait_stream(main)`` and ``main.wait_stream(side)``, i.e. inside the graph."""
+    def _body_overlapped(self, fs):
+        """What the overlapped graph of frame set ``fs`` captures.  Fork / join through the capturing stream: everything a
+        side stream does lies between ``side.wait_stream(main)`` and ``main.wait_stream(side)``, i.e. inside the graph."""
         main = torch.cuda.current_stream(self.dev)
         self._rotate()
-        self.fmap_head.copy_(self.fmap)     # hand-off: features of the batch now in ``cur`` (computed by the previous call)
+        self.fmap_head_flat.copy_(self.fmap_flat)   # hand-off: features of the batch now in ``cur`` (computed by the previous call)
         if self.bb_split:                   # one branch per frame, forked from the capturing stream itself (a fork inside a
-            self._backbone_per_frame(join=False)      # forked branch crashes hipStreamEndCapture on ROCm 7.2)
+            self._backbone_per_frame(fs, join=False)      # forked branch crashes hipStreamEndCapture on ROCm 7.2)
             self._head()
             for st in self._frame_streams:
                 main.wait_stream(st)
             return
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
-            self._backbone()                # batch k+1
+            self._backbone(fs)              # batch k+1
         self._head()                        # batch k
         main.wait_stream(self._side)
 
@@ -336,37 +606,61 @@ class SGGEmbStep:
         """Overlapped schedule only: backbone pass of the batch staged first, so that the first call's head finds its
         features (``nxt`` <- ``in`` as a call would have done)."""
         if self.overlap and not self.primed:
+            fs = self.shapes[self._staged]
+            self._measure(fs)
             self.nxt.buf.copy_(self.inp.buf)
-            self._backbone()
-            if self.fmap_head is None:
-                self.fmap_head = torch.empty_like(self.fmap)
+            self._backbone(fs)
         self.primed = True
 
+    # ------------------------------------------------------------------ capture
+    def invalidate_graphs(self):
+        """Drop every captured graph (a learning-rate change -- rates live in the captured kernel arguments --, a capacity
+        change, new feature-map buffers).  They are captured again on first use."""
+        dropped = False
+        for fs in self.shapes.values():
+            dropped |= bool(fs.graph)
+            fs.graph = None
+        if dropped:
+            import gc
+            gc.collect()
+            torch.cuda.synchronize(self.dev)
+
     def capture(self, warmup=2, restore=False):
-        """Warm up eagerly (sizes the arenas, fills the allocator), then capture the step into ONE HIP graph.
-        Returns False (and keeps the eager form, ``graph_error`` says why) when graphs are off or capture fails.
-        ``restore``: the warm-up steps are real training steps on the staged batch; put parameters, momentum and the RNG
-        state back afterwards (a training loop that must not see them).  ``warmup=0`` re-captures (after a learning-rate
-        change: rates live in the captured kernel arguments)."""
+        """Warm up eagerly (sizes the arenas, fills the allocator), then capture the step for the staged frame size into ONE
+        HIP graph (other sizes are captured when they are first staged).  Returns False (and keeps the eager form,
+        ``graph_error`` says why) when graphs are off or capture fails.  ``restore``: the warm-up steps are real training
+        steps on the staged batch; put parameters, momentum and the RNG state back afterwards (a training loop that must
+        not see them).  ``warmup=0`` re-captures (after a learning-rate change: rates live in the captured kernel
+        arguments)."""
         saved = None
         if restore and warmup:
-            state = [it["p"].data for it in self.opt.items] + [it["m"] for it in self.opt.items]
-            saved = (state, [t.clone() for t in state], torch.cuda.get_rng_state(self.dev))
+            saved = self._snapshot()
         try:
             return self._capture(warmup)
         finally:
             if saved is not None:
-                torch.cuda.synchronize(self.dev)
-                with torch.no_grad():
-                    for t, sv in zip(saved[0], saved[1]):
-                        t.copy_(sv)
-                torch.cuda.set_rng_state(saved[2], self.dev)
-                self.opt.bump()
+                self._restore(saved)
+
+    def _snapshot(self):
+        state = [it["p"].data for it in self.opt.items] + [it["m"] for it in self.opt.items]
+        return (state, [t.clone() for t in state], torch.cuda.get_rng_state(self.dev))
+
+    def _restore(self, saved):
+        torch.cuda.synchronize(self.dev)
+        with torch.no_grad():
+            for t, sv in zip(saved[0], saved[1]):
+                t.copy_(sv)
+        torch.cuda.set_rng_state(saved[2], self.dev)
+        self.opt.bump()
 
     def _capture(self, warmup):
         if self.tp:
-            parallel.assert_same_rows(self.n_rows, "boxes + pairs")
-        ov, self.overlap = self.overlap, False          # the warm-up steps are sequential eager steps
+            parallel.assert_same_rows(self.cap_boxes + self.cap_pairs if self.use_graph else self.n_rows, "boxes + pairs")
+        if warmup == 0:
+            self.invalidate_graphs()
+        fs = self.shapes[self._staged]
+        self._measure(fs)
+        pipelined, self._pipelined = self._pipelined, False     # the warm-up steps are sequential eager steps
         s = torch.cuda.Stream(self.dev)
         s.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(s):
@@ -377,46 +671,84 @@ class SGGEmbStep:
                     self.ctx_head.fit()
         torch.cuda.current_stream(self.dev).wait_stream(s)
         torch.cuda.synchronize(self.dev)
-        self.overlap = ov
+        self._pipelined = pipelined
         if not self.use_graph:
             return False
-        if self.bb_split:                               # size the per-frame arenas: two eager per-frame passes
+        if self.overlap and not self._pipelined:
+            self._pipelined = True
+            self.prime()
+            torch.cuda.synchronize(self.dev)
+        ok = self._capture_frames(fs)
+        if ok:
+            self._graphs_on = True
+        elif not self._graphs_on:
+            self._pipelined = False      # nothing was ever captured: plain sequential eager steps (the documented fall-back)
+            self.overlap = False
+        return ok
+
+    def _capture_frames(self, fs):
+        """Capture the step whose backbone half works on frame set ``fs``.  Nothing here changes the training state: the
+        per-frame arenas are sized by eager backbone passes into scratch outputs (the backbone is frozen), the head half is
+        recorded, not run."""
+        self._measure(fs)
+        if self._pipelined and self.bb_split and not fs.fitted:
             for _rep in range(2):
-                for f, ctx in enumerate(self.ctx_frames):
+                for f, ctx in enumerate(fs.ctx):
                     with ctx:
                         with torch.no_grad():
-                            self.net.RCNN_base(self.im[f:f + 1])
+                            self.net.RCNN_base(fs.im[f:f + 1])
                     ctx.fit()
             torch.cuda.synchronize(self.dev)
-        self.graph = None
+        fs.fitted = True
+        live = [f for f in self.shapes.values() if f.graph]
+        if len(live) >= self.max_graphs:                          # least recently used goes
+            min(live, key=lambda f: f.tick).graph = None
+        fmap_key = self._fmap_key
         try:
             g = torch.cuda.CUDAGraph()
-            if self.overlap:
-                self.prime()
-                torch.cuda.synchronize(self.dev)
-                self._side = torch.cuda.Stream(self.dev)
-                with torch.cuda.graph(g):
-                    self._body_overlapped()
+            if self._pool is None:
+                self._pool = torch.cuda.graph_pool_handle()
+            torch.cuda.synchronize(self.dev)
+            if self._pipelined:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(self.dev)
+                with torch.cuda.graph(g, pool=self._pool):
+                    self._body_overlapped(fs)
             else:
-                with torch.cuda.graph(g):
-                    self._body()
-            self.graph = g
+                with torch.cuda.graph(g, pool=self._pool):
+                    self._rotate()
+                    self._backbone(fs)
+                    self._head()
+            fs.graph = g
             return True
-        except Exception as e:      # report, fall back to eager launches
-            self.graph = None
-            self.overlap = False
+        except Exception as e:      # report, fall back to eager launches for this size
+            fs.graph = False
             self.graph_error = repr(e)
             torch.cuda.synchronize(self.dev)
             return False
+        finally:
+            self._fmap_key = fmap_key        # recording is not running: the buffer still holds what it held
 
     def __call__(self):
         """One step on the caller's current stream (any stream, the legacy default stream included: see
-        ``_graph_launch_guard``).  Returns the device scalar holding the loss of the batch the head just processed."""
-        if self.graph is None:
-            self._body()
+        ``_graph_launch_guard``).  Returns the device scalar holding the loss of the batch the head just processed.
+        Before a successful ``capture()`` a call is the sequential eager step."""
+        fs = self.shapes[self._staged]
+        if self._graphs_on:
+            if fs.graph is None:
+                self._capture_frames(fs)         # first sight of this frame size (or the graphs were invalidated)
+            self._tick += 1
+            fs.tick = self._tick
+            if fs.graph:
+                _graph_launch_guard()
+                fs.graph.replay()
+                self._fmap_key = fs.key
+            elif self._pipelined:
+                self._body_overlapped(fs)        # this size could not be captured: the same schedule on eager launches
+            else:
+                self._body()
         else:
-            _graph_launch_guard()
-            self.graph.replay()
+            self._body()
         self.opt.bump()
         return self.loss
 
@@ -462,6 +794,25 @@ class _SplitBatch(torch.autograd.Function):
         return out, None
 
 
+class _DomainSet:
+    """What the instance_styleD step owns for ONE pair of minibatch sizes (source (n,Hs,Ws), target (n,Ht,Wt)) and one
+    ``im_info[0]`` (the anchor-target layer's inside test follows it, anchor_target_layer.py:85-86): the staged frames,
+    the launch contexts and the captured graph."""
+
+    def __init__(self, key, device, batched, branches):
+        n, hs, ws, ht, wt = key[:5]
+        z = lambda h, w: torch.zeros((n, 3, h, w), device=device)
+        self.key = key
+        self.im_s, self.im_t = z(hs, ws), z(ht, wt)
+        self.im_st = torch.zeros((2 * n, 3, hs, ws), device=device) if (batched and (hs, ws) == (ht, wt)) else None
+        self.ctx = ops.LaunchContext(device)
+        self.ctx_src = ops.LaunchContext(device) if branches else None
+        self.ctx_tgt = ops.LaunchContext(device) if branches else None
+        self.graph = None             # None: not captured yet; False: capture failed (eager launches for this key)
+        self.fitted = False
+        self.tick = 0
+
+
 class InstanceStyleDStep:
     """One D+G adversarial step (trainval_net_instance_styleD_bilinear.py:262-341): source forward with
     detection + RPN losses and 0.5*mean(d^2) for both discriminators, target forward with
@@ -471,10 +822,16 @@ class InstanceStyleDStep:
     Eager by default with the target layers sampling on the host from the reference's np.random stream (bit parity with
     the reference's RNG contract; two small D2H copies per step).  ``capture()`` switches the target layers to
     device-side sampling (same subsample sizes, torch's generator) and records the whole step -- both forwards, the
-    backward, the gradient exchange and the update -- into ONE HIP graph."""
+    backward, the gradient exchange and the update -- into ONE HIP graph.
+
+    The two data loaders of the loop pad every minibatch to its own aspect ratio (roibatchLoader.py:162-190), so source
+    and target frames come in several sizes.  ``stage()`` takes any; a graph is captured the first time a (source size,
+    target size) pair is met -- after one eager step at that size that sizes the arenas and fills the host-built caches
+    (anchor grids), whose effect on parameters, momentum and the RNG stream is undone -- and replayed from then on; at most
+    ``max_graphs`` are kept, in one shared memory pool (no two of them ever run at the same time)."""
 
     def __init__(self, net, n_frames, lr=5e-4, eta=0.1, eta_style=0.001, style_lambda=1.0, seed=3, device="cuda:0",
-                 h=600, w=1000, n_gt=8, cr=False):
+                 h=600, w=1000, n_gt=8, cr=False, max_graphs=32, stage_synthetic=True):
         self.net, self.dev = net, torch.device(device)
         self.cr = cr                  # --cr: consistency regularisation between instance- and image-level D (:299-312)
         self.world = parallel.world_size()
@@ -491,37 +848,72 @@ class InstanceStyleDStep:
         # the captured step: source and target as two branches of the graph (_body_branches)
         self.branches = os.environ.get("I2V_ISD_BRANCHES", "1") != "0" and self.dev.type == "cuda" and not self.wgrad_branch
         self._branch_streams = [torch.cuda.Stream(self.dev) for _ in range(2)] if self.branches else []
-        self.ctx_src = ops.LaunchContext(self.dev) if self.branches else None
-        self.ctx_tgt = ops.LaunchContext(self.dev) if self.branches else None
-        self.im_s = self.im_t = self.im_st = self.info = self.gt = self.nb = None
-        self.reseed(seed)
+        self.sets, self.max_graphs, self._tick, self._pool = {}, int(max_graphs), 0, None
+        self._cur = None              # the _DomainSet staged last
+        self._graphs_on = False
+        mg = int(cfg.MAX_NUM_GT_BOXES)
+        self.info = torch.zeros((n_frames, 3), device=self.dev)        # shared by every size: a captured step reads them
+        self.info_t = torch.zeros((n_frames, 3), device=self.dev)
+        self.gt = torch.zeros((n_frames, mg, 5), device=self.dev)
+        self.nb = torch.zeros((n_frames,), device=self.dev)
         self.gt_t = torch.zeros((n_frames, 1, 5), device=self.dev)
         self.nb_t = torch.zeros((n_frames,), device=self.dev)
+        if stage_synthetic:           # a loop fed by data loaders stages its own first minibatch (``stage_batch``)
+            self.reseed(seed)
         self.opt = FusedSGD(list(net.named_parameters()), lr)
-        self.ctx = ops.LaunchContext(self.dev)
         self.names = ["total", "det", "dloss_s", "dloss_t", "dloss_s_style", "dloss_t_style"] + \
             (["source_adv_cst", "target_adv_cst"] if cr else [])
         self.losses = {k: torch.zeros((), device=self.dev) for k in self.names}     # static addresses: a captured step writes here
-        self.graph = None
         self.graph_error = None
-        self._fitted = False
+
+    # ------------------------------------------------------------------ compatibility views
+    @property
+    def graph(self):
+        return (self._cur.graph or None) if self._cur is not None else None
+
+    im_s = property(lambda self: self._cur.im_s)
+    im_t = property(lambda self: self._cur.im_t)
+    im_st = property(lambda self: self._cur.im_st)
+    ctx = property(lambda self: self._cur.ctx)
+    ctx_src = property(lambda self: self._cur.ctx_src)
+    ctx_tgt = property(lambda self: self._cur.ctx_tgt)
 
     # ------------------------------------------------------------------ data side
-    def stage(self, im_s, info, gt, nb, im_t):
+    def stage(self, im_s, info, gt, nb, im_t, info_t=None):
         """Hand the next minibatch to the step: source frames (N,3,H,W) with ``im_info`` (N,3), ``gt_boxes``
-        (N,MAX_NUM_GT_BOXES,5) and ``num_boxes`` (N,) -- one roi_data_layer batch -- and N target frames.  Copies into static
-        device tensors on the caller's stream (a captured step is bound to their addresses and shapes)."""
-        if self.im_s is None:
-            t = lambda a: a.to(self.dev, torch.float32).clone()
-            self.im_s, self.im_t, self.info, self.gt, self.nb = t(im_s), t(im_t), t(info), t(gt), t(nb)
-            self.im_st = torch.cat((self.im_s, self.im_t), 0) if self.batched else None
-            return
-        if tuple(im_s.shape) != tuple(self.im_s.shape) or tuple(gt.shape) != tuple(self.gt.shape):
-            raise ValueError("InstanceStyleDStep.stage: the step is bound to the shapes of the first staged batch")
-        self.im_s.copy_(im_s); self.im_t.copy_(im_t); self.info.copy_(info); self.gt.copy_(gt); self.nb.copy_(nb)
-        if self.batched:
-            n = self.im_s.shape[0]
-            self.im_st[:n].copy_(im_s); self.im_st[n:].copy_(im_t)
+        (N,MAX_NUM_GT_BOXES,5) and ``num_boxes`` (N,) -- one roi_data_layer batch -- and N target frames with their
+        ``im_info`` (default: the source's).  Host tensors cross PCIe here (pinned ones asynchronously); everything is
+        copied into static device tensors on the caller's stream (a captured step is bound to their addresses)."""
+        n, _, hs, ws = im_s.shape
+        ht, wt = int(im_t.shape[2]), int(im_t.shape[3])
+        if int(n) != self.n_frames or int(im_t.shape[0]) != self.n_frames:
+            raise ValueError("InstanceStyleDStep.stage: %d source / %d target frames, the step was built for %d"
+                             % (n, im_t.shape[0], self.n_frames))
+        if tuple(gt.shape[1:]) != tuple(self.gt.shape[1:]):
+            raise ValueError("InstanceStyleDStep.stage: gt_boxes must be (N, MAX_NUM_GT_BOXES = %d, 5)" % self.gt.shape[1])
+        info_t = info if info_t is None else info_t
+        info0 = info[0].tolist()                    # a loader's im_info is a host tensor: no synchronisation
+        key = (int(n), int(hs), int(ws), ht, wt, int(info0[0]), int(info0[1]))
+        ds = self.sets.get(key)
+        if ds is None:
+            ds = self.sets[key] = _DomainSet(key, self.dev, self.batched, self.branches)
+        self._tick += 1
+        ds.tick = self._tick
+        self._cur = ds
+        self.info0 = (int(info0[0]), int(info0[1]))
+        cp = lambda dst, src: dst.copy_(src, non_blocking=True)
+        cp(ds.im_s, im_s); cp(ds.im_t, im_t); cp(self.info, info); cp(self.info_t, info_t); cp(self.gt, gt); cp(self.nb, nb)
+        if ds.im_st is not None:
+            ds.im_st[:n].copy_(ds.im_s); ds.im_st[n:].copy_(ds.im_t)
+
+    def stage_batch(self, data_s, data_t):
+        """One minibatch of each of the loop's two ``roibatchLoader`` iterators as the DataLoader collates them
+        (trainval_net_instance_styleD_bilinear.py:236-291): source (im_data, im_info, gt_boxes, num_boxes), target
+        (im_data, im_info, ...) whose boxes are not used.  Returns False for the batches the reference skips (:241-252)."""
+        if not isinstance(data_s, (list, tuple)) or not isinstance(data_t, (list, tuple)) or len(data_s) < 4 or len(data_t) < 2:
+            return False
+        self.stage(data_s[0], data_s[1], data_s[2], data_s[3], data_t[0], data_t[1])
+        return True
 
     def reseed(self, seed):
         """Stage the synthetic minibatch of ``seed`` (frames, 8 GT boxes per source frame)."""
@@ -535,7 +927,8 @@ class InstanceStyleDStep:
     def _body(self):
         net = self.net
         with self.ctx:
-            if self.batched:
+            batched = self.batched and self.im_st is not None      # one pass needs source and target frames of one size
+            if batched:
                 # ONE backbone pass over the source and the target frames (the reference makes two, :271 and :293; with
                 # frozen BN they are the same arithmetic): half the launches of the trunk's forward, data-gradient and
                 # filter-gradient kernels, each over twice the pixels, and no accumulation adds between two backward
@@ -550,11 +943,11 @@ class InstanceStyleDStep:
             loss = l_rpn_cls.mean() + l_rpn_box.mean() + l_cls.mean() + l_box.mean()
             dloss_s = 0.5 * torch.mean(d_inst ** 2)
             dloss_s_style = 0.5 * torch.mean(d_style ** 2)
-            if self.batched:
-                d_inst_t, d_style_t = net.forward_features(ft, f1t, self.info, self.gt_t, self.nb_t, True, self.eta,
+            if batched:
+                d_inst_t, d_style_t = net.forward_features(ft, f1t, self.info_t, self.gt_t, self.nb_t, True, self.eta,
                                                            self.eta_style)
             else:
-                d_inst_t, d_style_t = net(self.im_t, self.info, self.gt_t, self.nb_t, target=True, eta=self.eta,
+                d_inst_t, d_style_t = net(self.im_t, self.info_t, self.gt_t, self.nb_t, target=True, eta=self.eta,
                                           eta_style=self.eta_style)
             dloss_t = 0.5 * torch.mean((1 - d_inst_t) ** 2)
             dloss_t_style = 0.5 * torch.mean((1 - d_style_t) ** 2)
@@ -612,7 +1005,7 @@ class InstanceStyleDStep:
             return {k: t.detach() for k, t in v.items()}, g
 
         def target():
-            d_inst_t, d_style_t = net(self.im_t, self.info, self.gt_t, self.nb_t, target=True, eta=self.eta,
+            d_inst_t, d_style_t = net(self.im_t, self.info_t, self.gt_t, self.nb_t, target=True, eta=self.eta,
                                       eta_style=self.eta_style)
             v = {"dloss_t": 0.5 * torch.mean((1 - d_inst_t) ** 2), "dloss_t_style": 0.5 * torch.mean((1 - d_style_t) ** 2)}
             part = v["dloss_t"] + self.style_lambda * v["dloss_t_style"]
@@ -643,68 +1036,108 @@ class InstanceStyleDStep:
             self.losses[k].copy_(vals[k].detach())
 
     def _device_sampling(self, on):
-        h, w = self.geom
         atl = self.net.RCNN_rpn.RPN_anchor_target
         atl.device_sampling = on
-        atl.image_size = (h, w) if on else None
+        # the inside-anchor test follows im_info[0] (anchor_target_layer.py:85-86); its value is known on the host from the
+        # staged batch, so the layer needs no device read -- and a captured step is keyed by it (``_DomainSet``)
+        atl.image_size = self.info0 if on else None
         self.net.RCNN_proposal_target.device_sampling = on
 
+    def _snapshot(self):
+        state = [it["p"].data for it in self.opt.items] + [it["m"] for it in self.opt.items]
+        return (state, [t.clone() for t in state], torch.cuda.get_rng_state(self.dev))
+
+    def _restore(self, saved):
+        torch.cuda.synchronize(self.dev)
+        with torch.no_grad():
+            for t, sv in zip(saved[0], saved[1]):
+                t.copy_(sv)
+        torch.cuda.set_rng_state(saved[2], self.dev)
+        self.opt.bump()
+
+    def invalidate_graphs(self):
+        """Drop every captured graph (a learning-rate change: the rates live in the captured kernel arguments); they are
+        captured again on first use, into the same memory pool."""
+        dropped = False
+        for ds in self.sets.values():
+            dropped |= bool(ds.graph)
+            ds.graph = None
+        if dropped:
+            import gc
+            gc.collect()
+            torch.cuda.synchronize(self.dev)
+
     def capture(self, warmup=2, restore=False):
-        """Device-side target sampling, eager warm-up, then the whole step as ONE HIP graph.  False (eager form kept,
-        ``graph_error`` says why) when capture fails.  ``restore``: the warm-up steps are real training steps on the staged
-        batch; put parameters, momentum and the RNG state back afterwards.  ``warmup=0`` re-captures (after a learning-rate
-        change: the rates live in the captured kernel arguments)."""
-        saved = None
-        if restore and warmup:
-            state = [it["p"].data for it in self.opt.items] + [it["m"] for it in self.opt.items]
-            saved = (state, [t.clone() for t in state], torch.cuda.get_rng_state(self.dev))
+        """Device-side target sampling, eager warm-up, then the whole step for the staged sizes as ONE HIP graph (other
+        sizes are captured when they are first staged).  False (eager form kept, host-side sampling restored, ``graph_error``
+        says why) when capture fails.  ``restore``: the warm-up steps are real training steps on the staged batch; put
+        parameters, momentum and the RNG state back afterwards.  ``warmup=0`` re-captures (after a learning-rate change:
+        the rates live in the captured kernel arguments)."""
+        if warmup == 0:
+            self.invalidate_graphs()
+        ok = self._capture_set(self._cur, warmup, restore)
+        if ok:
+            self._graphs_on = True
+        elif not self._graphs_on:
+            self._device_sampling(False)         # the eager form keeps the np.random contract it documents
+        return ok
+
+    def _capture_set(self, ds, warmup, restore):
+        saved = self._snapshot() if (restore and warmup) else None
         try:
-            return self._capture(warmup)
+            self._device_sampling(True)
+            body = self._body_branches if self.branches else self._body
+            s = torch.cuda.Stream(self.dev)
+            s.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(s):
+                for i in range(warmup):
+                    body()
+                    if i == 0 and not ds.fitted:
+                        for ctx in (ds.ctx, ds.ctx_src, ds.ctx_tgt):
+                            if ctx is not None:
+                                ctx.fit()
+                        ds.fitted = True
+            torch.cuda.current_stream(self.dev).wait_stream(s)
+            torch.cuda.synchronize(self.dev)
         finally:
             if saved is not None:
-                torch.cuda.synchronize(self.dev)
-                with torch.no_grad():
-                    for t, sv in zip(saved[0], saved[1]):
-                        t.copy_(sv)
-                torch.cuda.set_rng_state(saved[2], self.dev)
-                self.opt.bump()
-
-    def _capture(self, warmup):
-        self._device_sampling(True)
-        body = self._body_branches if self.branches else self._body
-        s = torch.cuda.Stream(self.dev)
-        s.wait_stream(torch.cuda.current_stream(self.dev))
-        with torch.cuda.stream(s):
-            for i in range(warmup):
-                body()
-                if i == 0:
-                    for ctx in (self.ctx, self.ctx_src, self.ctx_tgt):
-                        if ctx is not None:
-                            ctx.fit()
-        torch.cuda.current_stream(self.dev).wait_stream(s)
-        torch.cuda.synchronize(self.dev)
+                self._restore(saved)
+        live = [d for d in self.sets.values() if d.graph]
+        if len(live) >= self.max_graphs:                          # least recently used goes
+            min(live, key=lambda d: d.tick).graph = None
         try:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            if self._pool is None:
+                self._pool = torch.cuda.graph_pool_handle()
+            with torch.cuda.graph(g, pool=self._pool):
                 body()
-            self.graph = g
+            ds.graph = g
             return True
         except Exception as e:
-            self.graph = None
+            ds.graph = False
             self.graph_error = repr(e)
             torch.cuda.synchronize(self.dev)
             return False
 
     def __call__(self):
-        if self.graph is None:
-            self._body()
-            if not self._fitted:            # eager use: size the arena of atomically accumulated outputs after the first step
-                self.ctx.fit()
-                self._fitted = True
-        else:
-            _graph_launch_guard()
-            self.graph.replay()
+        ds = self._cur
+        if self._graphs_on:
+            if ds.graph is None:
+                # first sight of this pair of sizes (or the graphs were invalidated): one eager step sizes its arenas and fills
+                # the host-built caches, its effect on the training state is undone, then the step is recorded
+                self._capture_set(ds, 0 if ds.fitted else 1, True)
+            if ds.graph:
+                _graph_launch_guard()
+                ds.graph.replay()
+            else:
+                self._device_sampling(True)
+                (self._body_branches if self.branches else self._body)()
             self.opt.bump()
+        else:
+            self._body()
+            if not ds.fitted:               # eager use: size the arena of atomically accumulated outputs after the first step
+                ds.ctx.fit()
+                ds.fitted = True
         return self.losses["total"]
 
 

@@ -89,6 +89,14 @@ int32_t i2v_roi_align_sampled_bwd(const float* grad_out, int32_t out_layout, con
 int32_t i2v_roi_pool_fwd(const float* feat, int32_t feat_layout, int32_t B, int32_t C, int32_t H, int32_t W,
                          const float* rois, int32_t R, int32_t pooled_h, int32_t pooled_w,
                          float spatial_scale, float* out, int32_t* argmax, int32_t out_layout, void* stream);
+/* The same forward with the extent of the maps read from DEVICE memory: geom[0] = H, geom[1] = W (int32).  `feat` holds
+ * B packed NHWC maps of H*W cells (map b at b*H*W*C) at the start of a buffer of at least B*cap_cells*C floats.  A launch
+ * recorded in a HIP graph thereby serves every map size that fits the buffer: the captured relation-head step consumes
+ * roi_data_layer batches whose padded image size differs from batch to batch (roibatchLoader.py:162-190) without one
+ * graph per size.  H*W > cap_cells (or H, W <= 0) yields zeros / argmax -1, never an out-of-bounds read. */
+int32_t i2v_roi_pool_fwd_geom(const float* feat, int32_t B, int32_t C, const int32_t* geom, int64_t cap_cells,
+                              const float* rois, int32_t R, int32_t pooled_h, int32_t pooled_w, float spatial_scale,
+                              float* out, int32_t* argmax, int32_t out_layout, void* stream);
 int32_t i2v_roi_pool_bwd(const float* grad_out, const int32_t* argmax, int32_t out_layout,
                          const float* rois, int32_t R, int32_t pooled_h, int32_t pooled_w,
                          float* grad_feat, int32_t feat_layout, int32_t B, int32_t C, int32_t H, int32_t W,

@@ -181,30 +181,6 @@ def test_res50_yml_full_frame_plumbing(fresh_cfg):
     step.opt.unfuse()
 
 
-def test_instance_styled_training_script_round_trip(fresh_cfg, tmp_path):
-    """trainval_instance_styled.py (the reference's trainval_net_instance_styleD_bilinear.py loop on the HIP path) at a small
-    frame size: two epochs of the captured step with a new staged minibatch every iteration, a checkpoint in the reference's
-    layout, resume into a third epoch; the checkpoint's model keys are the reference's state_dict keys."""
-    import trainval_instance_styled as tv
-    common = ["--bs", "2", "--iters_per_epoch", "3", "--disp_interval", "3", "--height", "256", "--width", "320",
-              "--save_dir", str(tmp_path), "--lr_decay_step", "1", "--set", "TRAIN.BATCH_SIZE", "16",
-              "TRAIN.RPN_POST_NMS_TOP_N_TARGET", "16"]
-    tv.main(["--epochs", "2"] + common)
-    path = tmp_path / "res101" / "synthetic" / "instance_styleD_session_1_epoch_2.pth"
-    ck = torch.load(path, map_location="cpu")
-    assert ck["epoch"] == 2 and ck["pooling_mode"] == "align" and ck["class_agnostic"] is False
-    for k in ("RCNN_base.0.weight", "RCNN_base.6.22.conv3.weight", "RCNN_top.0.2.bn3.running_var", "netD_pixel.conv1.weight",
-              "netD_style.fc_1.weight", "RCNN_rpn.RPN_Conv.weight", "RCNN_cls_score.bias"):
-        assert k in ck["model"], k
-    assert all(torch.isfinite(v).all() for v in ck["model"].values() if v.is_floating_point())
-    lrs = {round(g["lr"], 10) for g in ck["optimizer"]["param_groups"]}
-    assert lrs == {round(5e-4 * 0.1, 10), round(2 * 5e-4 * 0.1, 10)}          # one decay; biases at twice the rate
-    tv.main(["--epochs", "3", "--r", "--checkepoch", "2"] + common)
-    ck3 = torch.load(tmp_path / "res101" / "synthetic" / "instance_styleD_session_1_epoch_3.pth", map_location="cpu")
-    assert ck3["epoch"] == 3
-    assert not torch.equal(ck3["model"]["RCNN_base.6.22.conv3.weight"], ck["model"]["RCNN_base.6.22.conv3.weight"])
-
-
 def test_instance_styled_staged_batch_equals_fresh_step(fresh_cfg):
     """stage() on a captured step: the losses of the replay on a newly staged minibatch equal those of a fresh step object
     built on that minibatch with the same parameters (device-side sampling draws differ: detection loss within 25 %,

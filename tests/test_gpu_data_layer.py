@@ -1,0 +1,261 @@
+"""The training steps behind the reference's data path: ``combined_roidb -> roibatchLoader -> DataLoader(sampler)``
+(trainval_net_SGG_emb.py:77-91,204-217; trainval_net_instance_styleD_bilinear.py:73-97,236-291) with minibatches that differ
+in image size (the loader pads every batch to its own aspect ratio, roibatchLoader.py:162-190) and in boxes / pairs per
+frame -- through the CAPTURED steps (one HIP graph per frame size, boxes / pairs padded to a capacity), against the eager
+un-padded step on the same batches."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+SET = ["ANCHOR_SCALES", "[8, 16, 32]", "ANCHOR_RATIOS", "[0.5,1,2]", "MAX_NUM_GT_BOXES", "30", "TRAIN.SCALES", "(192,)"]
+
+
+@pytest.fixture()
+def small_cfg():
+    """cfgs/res101.yml at a 192-px shorter side; the global cfg singleton is put back afterwards."""
+    from i2vsgg_amd.model.utils import config as c
+    saved = copy.deepcopy(dict(c.cfg))
+
+    def load(extra=()):
+        c.cfg_from_file(c.default_cfg_file("res101"))
+        c.cfg_from_list(SET + list(extra))
+        return c.cfg
+    yield load
+    c._merge_a_into_b(c.AttrDict(saved), c.cfg)
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def _loader(name, bs, seed, flipped=False, paths=True):
+    from i2vsgg_amd.model.utils import config as c
+    from i2vsgg_amd.model.utils.net_utils import sampler
+    from i2vsgg_amd.roi_data_layer.roibatchLoader import roibatchLoader
+    from i2vsgg_amd.roi_data_layer.roidb import combined_roidb
+    c.cfg.TRAIN.USE_FLIPPED = flipped
+    imdb, roidb, ratio_list, ratio_index = combined_roidb(name)
+    ds = roibatchLoader(roidb, ratio_list, ratio_index, bs, imdb.num_classes, training=True, path_return=paths)
+    dl = torch.utils.data.DataLoader(ds, batch_size=bs, sampler=sampler(len(roidb), bs, seed=seed), pin_memory=True)
+    return imdb, dl
+
+
+def test_roi_pool_with_device_side_extent_equals_the_static_kernel():
+    """i2v_roi_pool_fwd_geom (H, W read from device memory, maps packed at the start of a larger buffer) == i2v_roi_pool_fwd
+    for every extent that fits; an extent that does not fit yields zeros instead of reading out of bounds."""
+    from i2vsgg_amd import ops, synthetic as syn
+    rng = np.random.default_rng(2)
+    cap = 16 * 24
+    for C in (1024, 96):
+        buf = torch.zeros(2 * cap * C, device=DEV)
+        for (h, w) in ((12, 22), (16, 12), (16, 24), (5, 7)):
+            fm = torch.from_numpy(np.abs(rng.standard_normal((2, C, h, w), dtype=np.float32))).to(DEV) \
+                .contiguous(memory_format=torch.channels_last)
+            rois = np.zeros((9, 5), np.float32)
+            rois[:, 0] = rng.integers(0, 2, 9)
+            rois[:, 1:] = syn.boxes(h * w, 9, h * 16, w * 16, 8, 200)
+            rois[0, 1:] = (0, 0, 0, 0)                                  # the pad row of a capacity-padded batch
+            rois_d = torch.from_numpy(rois).to(DEV)
+            buf.zero_()
+            buf[:fm.numel()].copy_(fm.permute(0, 2, 3, 1).reshape(-1))
+            geom = torch.tensor([h, w], dtype=torch.int32, device=DEV)
+            maps = ops.PackedMaps(buf, 2, C, geom)
+            for nchw in (True, False):
+                want = ops.roi_pool(fm, rois_d, 7, 7, 1 / 16.0, out_nchw=nchw)
+                got = ops.roi_pool_packed(maps, rois_d, 7, 7, 1 / 16.0, out_nchw=nchw)
+                assert torch.equal(got, want), (C, h, w, nchw)
+            assert torch.equal(maps.view(h, w), fm)
+        big = torch.tensor([40, 40], dtype=torch.int32, device=DEV)
+        assert float(ops.roi_pool_packed(ops.PackedMaps(buf, 2, C, big), rois_d, 7, 7, 1 / 16.0).abs().max()) == 0.0
+
+
+def test_sgg_captured_step_consumes_loader_batches_of_varying_size(small_cfg):
+    """SGG_emb: 8 loader minibatches of 2 frames in >= 3 sizes, 4-32 boxes and 2-32 pairs per frame, through (a) the eager
+    un-padded step and (b) the captured, overlapped step (capacity-padded head inputs that have to grow once, one graph per
+    frame size, extent of the maps read on the device): the same per-batch losses (1e-3; measured ~1e-6) and the same
+    weights, with the pipeline's one-call lag."""
+    small_cfg()
+    from i2vsgg_amd import train
+    imdb, dl = _loader("synthetic_20_v", 2, seed=3)
+    rels = imdb.gt_rels(62)
+    batches = [d for d in dl][:8]
+    sizes = {tuple(d[0].shape[2:]) for d in batches}
+    assert len(sizes) >= 3, sizes
+    rows = [sum(len(rels[p.split("/")[-1]]["boxes"]) for p in d[4]) for d in batches]
+    assert len(set(rows)) >= 4 and max(rows) > 32           # boxes per batch vary and exceed the initial capacity below
+
+    def make(use_graph):
+        net = train.build_sgg_net(layers=50, seed=5, device=DEV)
+        net.vrd.dropout = False
+        net.vrd.source_gt_rels = rels
+        step = train.SGGEmbStep(net, 2, device=DEV, n_boxes=16, n_pairs=8, use_graph=use_graph, stage_synthetic=False)
+        return net, step
+
+    # (a) eager, exact sizes
+    net, step = make(False)
+    want = []
+    for d in batches:
+        assert step.stage_batch(d)
+        want.append(float(step()))
+    w_want = net.vrd.fc7.fc.weight.detach().cpu().numpy().copy()
+    step.opt.unfuse()
+    assert len({round(x, 5) for x in want}) == len(want)     # the batches differ
+
+    # (b) captured + overlapped, padded to a capacity
+    net, step = make(True)
+    assert step.stage_batch(batches[0])
+    assert step.capture(warmup=1, restore=True) and step.overlap and step.lag == 1, step.graph_error
+    cap0 = (step.cap_boxes, step.cap_pairs)
+    keep = torch.zeros(len(batches), device=DEV)
+    for k, d in enumerate(batches[1:]):
+        assert step.stage_batch(d)
+        keep[k].copy_(step())                  # head of batch k beside the backbone of batch k+1
+    keep[len(batches) - 1].copy_(step.flush())
+    torch.cuda.synchronize()
+    got = keep.tolist()
+    w_got = net.vrd.fc7.fc.weight.detach().cpu().numpy().copy()
+    graphs = sum(1 for fs in step.shapes.values() if fs.graph)
+    step.opt.unfuse()
+    assert step.graph_error is None, step.graph_error
+    assert graphs == len(sizes) and set(k[1:] for k in step.shapes) == sizes
+    assert (step.cap_boxes, step.cap_pairs) != cap0          # the capacity grew (and every graph was captured again)
+    assert step.cap_boxes >= max(rows)
+    for a, b in zip(want, got):
+        assert abs(a - b) <= 1e-3 * abs(a), (want, got)
+    assert _rel(w_got, w_want) < 1e-4
+
+
+def test_sgg_padded_rows_have_no_effect(small_cfg):
+    """Capacity padding is exact: the same batch through the captured step with a tight and with a generous capacity gives
+    the same loss and the same update (pad rows carry loss weight 0: zero gradient; dropout off)."""
+    small_cfg()
+    from i2vsgg_amd import train
+    imdb, dl = _loader("synthetic_10_v", 2, seed=1)
+    rels = imdb.gt_rels(62)
+    d = next(iter(dl))
+    out = []
+    for nb, npair in ((32, 32), (48, 64)):
+        net = train.build_sgg_net(layers=50, seed=5, device=DEV)
+        net.vrd.dropout = False
+        net.vrd.source_gt_rels = rels
+        step = train.SGGEmbStep(net, 2, device=DEV, n_boxes=nb, n_pairs=npair, overlap=False, stage_synthetic=False)
+        assert step.stage_batch(d)
+        assert step.capture(warmup=1, restore=True), step.graph_error
+        losses = [float(step()) for _ in range(3)]
+        out.append((losses, net.vrd.fc7.fc.weight.detach().cpu().numpy().copy(), net.vrd.fc_rel.fc.bias.detach().cpu().numpy().copy()))
+        step.opt.unfuse()
+    (l0, w0, b0), (l1, w1, b1) = out
+    assert l0[0] != l0[2]
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 1e-5 * abs(a), (l0, l1)
+    assert _rel(w1, w0) < 1e-5 and _rel(b1, b0) < 1e-5
+
+
+def test_instance_styled_captured_step_consumes_loader_batches_of_varying_size(small_cfg):
+    """instance_styleD: 6 (source, target) loader minibatch pairs in >= 3 size combinations through the captured step -- one
+    HIP graph per (source size, target size), captured on first sight -- and through the same step on eager launches: the
+    same per-batch losses (1e-3).  Both runs sample anchors / ROIs on the device from the same generator state (the captured
+    form's sampler), with the rates at zero so that batch k's losses do not depend on the batches before it; a second
+    captured run with the default rate trains."""
+    cfg = small_cfg(["TRAIN.BATCH_SIZE", "16", "TRAIN.RPN_POST_NMS_TOP_N_TARGET", "16"])
+    from i2vsgg_amd import train
+    _, dl_s = _loader("synthetic_12_v", 2, seed=2, flipped=True, paths=False)
+    _, dl_t = _loader("synthetic_10_v_7", 2, seed=5, flipped=True, paths=False)
+    pairs = list(zip([d for d in dl_s][:6], [d for d in dl_t][:6]))
+    keys = {(tuple(s[0].shape[2:]), tuple(t[0].shape[2:])) for s, t in pairs}
+    assert len(keys) >= 3, keys
+    assert any(a != b for a, b in keys)                      # source and target sizes differ within a step
+
+    def run(graph, lr):
+        torch.manual_seed(0)
+        np.random.seed(cfg.RNG_SEED)
+        net = train.build_instance_styled_net(101, device=DEV)
+        step = train.InstanceStyleDStep(net, 2, lr=lr, device=DEV, stage_synthetic=False)
+        w0 = net.RCNN_base[6][22].conv3.weight.detach().clone()
+        out = []
+        assert step.stage_batch(*pairs[0])
+        if graph:
+            assert step.capture(warmup=1, restore=True), step.graph_error
+        torch.manual_seed(7)                                 # both runs draw their samples from the same generator state
+        for k, (s, t) in enumerate(pairs):
+            if k:
+                assert step.stage_batch(s, t)
+            if graph:
+                step()
+            else:
+                step._device_sampling(True)
+                step._body_branches()
+            out.append({n: float(v) for n, v in step.losses.items()})
+        moved = not torch.equal(w0, net.RCNN_base[6][22].conv3.weight.detach())
+        n_graphs = sum(1 for d in step.sets.values() if d.graph)
+        return out, moved, n_graphs, step.graph_error
+
+    want, moved, _, _ = run(False, 0.0)
+    assert not moved
+    got, moved, n_graphs, err = run(True, 0.0)
+    assert err is None, err
+    assert n_graphs == len(keys) and not moved
+    for a, b in zip(want, got):
+        for n in a:
+            assert np.isfinite(b[n]) and abs(a[n] - b[n]) <= 1e-3 * max(abs(a[n]), 1e-6), (n, want, got)
+    assert len({round(d["total"], 4) for d in got}) == len(got)          # the batches differ
+    trained, moved, n_graphs, err = run(True, 5e-4)
+    assert err is None and moved and n_graphs == len(keys)
+    assert all(np.isfinite(v) for d in trained for v in d.values()), trained
+
+
+def test_training_scripts_run_through_the_data_layer(small_cfg, tmp_path):
+    """trainval_sgg_emb.py / trainval_instance_styled.py (the reference loops on the HIP path) fed by
+    combined_roidb -> roibatchLoader -> DataLoader(sampler) on synthetic imdbs whose frames differ in size: two epochs of
+    the captured steps, reference-layout checkpoints (``epoch`` = the next epoch, reference file names and state_dict keys),
+    resume into a third epoch with the learning-rate decay of that epoch applied (round-2 advice: a resumed run dropped
+    it)."""
+    import trainval_instance_styled as tv
+    import trainval_sgg_emb as ts
+    # ---- SGG_emb
+    common = ["--bs", "2", "--imdb_name", "synthetic_12_v", "--scale", "192", "--disp_interval", "3", "--net", "res50",
+              "--save_dir", str(tmp_path), "--lr_decay_step", "1", "--lr_decay_gamma", "0.5", "--vrd_lr", "1e-4"]
+    ts.main(["--epochs", "2"] + common)
+    name = tmp_path / "res50" / "synthetic" / "SGG_emb_p_prior_adap_synthetic_pre_det_session_1_epoch_2_step_5_un.pth"
+    ck = torch.load(name, map_location="cpu")
+    assert ck["epoch"] == 3 and ck["pooling_mode"] == "align"
+    for k in ("RCNN_base.0.weight", "vrd.fc6.fc.weight", "vrd.prd_sem_embeddings.2.bias", "vrd.conv_lo.2.conv.weight"):
+        assert k in ck["model"], k
+    assert all(torch.isfinite(v).all() for v in ck["model"].values() if v.is_floating_point())
+    lrs = {round(g["lr"], 12) for g in ck["optimizer"]["param_groups"]}
+    assert lrs == {round(1e-4 * 0.5, 12), round(2e-4 * 0.5, 12)}          # one decay (epoch 2); biases at twice the rate
+    ts.main(["--epochs", "3", "--r", "--load_name", str(name)] + common)
+    ck3 = torch.load(str(name).replace("epoch_2", "epoch_3"), map_location="cpu")
+    assert ck3["epoch"] == 4
+    lrs = {round(g["lr"], 12) for g in ck3["optimizer"]["param_groups"]}
+    assert lrs == {round(1e-4 * 0.25, 12), round(2e-4 * 0.25, 12)}        # the resumed epoch 3 decayed once more
+    assert not torch.equal(ck3["model"]["vrd.fc7.fc.weight"], ck["model"]["vrd.fc7.fc.weight"])
+    assert torch.equal(ck3["model"]["RCNN_base.6.5.conv3.weight"], ck["model"]["RCNN_base.6.5.conv3.weight"])     # frozen here
+    # ---- instance_styleD
+    common = ["--bs", "2", "--imdb_name", "synthetic_6_v", "--imdb_name_target", "synthetic_5_v_7", "--scale", "192",
+              "--iters_per_epoch", "3", "--disp_interval", "3", "--save_dir", str(tmp_path), "--lr_decay_step", "1", "--set",
+              "TRAIN.BATCH_SIZE", "16", "TRAIN.RPN_POST_NMS_TOP_N_TARGET", "16"]
+    tv.main(["--epochs", "2"] + common)
+    name = tmp_path / "res101" / "synthetic" / ("instance_pixel_styleD_bilinear_cr_False_source_synthetic_target_synthetic_t_"
+                                                "session_1_lr_0.0005_epoch_2_bs_2_mscoco.pth")
+    ck = torch.load(name, map_location="cpu")
+    assert ck["epoch"] == 3 and ck["pooling_mode"] == "align" and ck["class_agnostic"] is False
+    for k in ("RCNN_base.0.weight", "RCNN_base.6.22.conv3.weight", "RCNN_top.0.2.bn3.running_var", "netD_pixel.conv1.weight",
+              "netD_style.fc_1.weight", "RCNN_rpn.RPN_Conv.weight", "RCNN_cls_score.bias"):
+        assert k in ck["model"], k
+    assert all(torch.isfinite(v).all() for v in ck["model"].values() if v.is_floating_point())
+    lrs = {round(g["lr"], 10) for g in ck["optimizer"]["param_groups"]}
+    assert lrs == {round(5e-4 * 0.1, 10), round(2 * 5e-4 * 0.1, 10)}          # one decay; biases at twice the rate
+    tv.main(["--epochs", "3", "--r", "--load_name", str(name)] + common)
+    ck3 = torch.load(str(name).replace("epoch_2", "epoch_3"), map_location="cpu")
+    assert ck3["epoch"] == 4
+    lrs = {round(g["lr"], 10) for g in ck3["optimizer"]["param_groups"]}
+    assert lrs == {round(5e-4 * 0.01, 10), round(2 * 5e-4 * 0.01, 10)}        # the decay of the resumed epoch is applied
+    assert not torch.equal(ck3["model"]["RCNN_base.6.22.conv3.weight"], ck["model"]["RCNN_base.6.22.conv3.weight"])

@@ -63,6 +63,81 @@ def test_roi_data_layer_api():
     assert sorted(int(i) for i in idx) == list(range(10)) and [int(i) for i in idx[-2:]] == [8, 9]
 
 
+def test_varied_synthetic_imdb_feeds_batches_of_several_sizes():
+    """``synthetic_<n>_v``: frames in five resolutions / four aspect-ratio groups with 3-12 boxes each; the loader pads every
+    minibatch to its own aspect ratio (roibatchLoader.py:162-190), so a training loop sees several (H, W); relation
+    annotations are keyed by the last path component, as trainval_net_SGG_emb.py:217 looks them up."""
+    from i2vsgg_amd.model.utils import config as c
+    from i2vsgg_amd.model.utils.net_utils import sampler
+    from i2vsgg_amd.roi_data_layer.roidb import combined_roidb
+    from i2vsgg_amd.roi_data_layer.roibatchLoader import roibatchLoader
+    saved = (c.cfg.TRAIN.USE_FLIPPED, c.cfg.TRAIN.SCALES)
+    c.cfg.TRAIN.USE_FLIPPED, c.cfg.TRAIN.SCALES = False, (96,)
+    try:
+        imdb, roidb, ratio_list, ratio_index = combined_roidb("synthetic_20_v")
+        assert len({(e["height"], e["width"]) for e in roidb}) == 5 and len({len(e["boxes"]) for e in roidb}) >= 4
+        assert np.all(np.diff(ratio_list) >= 0) and ratio_list[0] < 1 < ratio_list[-1]
+        ds = roibatchLoader(roidb, ratio_list, ratio_index, 2, imdb.num_classes, training=True, path_return=True)
+        dl = torch.utils.data.DataLoader(ds, batch_size=2, sampler=sampler(len(roidb), 2, seed=3))
+        np.random.seed(1)
+        batches = list(dl)
+        assert len(batches) == 10 and all(len(b) == 5 for b in batches)
+        sizes = {tuple(b[0].shape[2:]) for b in batches}
+        assert len(sizes) >= 3 and all(min(s) == 96 for s in sizes)
+        for b in batches:                       # im_info carries the PADDED size (roibatchLoader.py:168,180)
+            assert b[1][:, 0].tolist() == [b[0].shape[2]] * 2 and b[1][:, 1].tolist() == [b[0].shape[3]] * 2
+        rels = imdb.gt_rels(62)
+        assert set(rels) == {p.split("/")[-1] for b in batches for p in b[4]}
+        assert len({len(a["boxes"]) for a in rels.values()}) >= 5
+        for a in rels.values():
+            assert all(0 <= s < len(a["boxes"]) and 0 <= o < len(a["boxes"]) and s != o and 0 <= r < 62 for s, o, r in a["rels"])
+        other = combined_roidb("synthetic_20_v_7")[1]
+        assert not np.array_equal(other[0]["boxes"], roidb[0]["boxes"])
+    finally:
+        c.cfg.TRAIN.USE_FLIPPED, c.cfg.TRAIN.SCALES = saved
+
+
+def test_rank_sharded_sampler_partitions_the_block_order():
+    """One process per GPU: every rank draws the same block order and keeps every world-th block -- disjoint, equally many
+    minibatches per rank, blocks still contiguous (one aspect-ratio group per minibatch), a new order every epoch."""
+    from i2vsgg_amd.model.utils.net_utils import sampler
+    samplers = [sampler(23, 2, rank=r, world=3, seed=5) for r in range(3)]
+    first = [[int(i) for i in s] for s in samplers]
+    assert all(len(x) == len(samplers[0]) == 6 for x in first)
+    flat = sorted(i for x in first for i in x)
+    assert len(set(flat)) == 18 and all(b == a + 1 for x in first for a, b in zip(x[0::2], x[1::2])) and all(a % 2 == 0 for x in first for a in x[0::2])
+    second = [[int(i) for i in s] for s in samplers]
+    assert second != first and len({i for x in second for i in x}) == 18
+    ref = sampler(10, 4)                         # the reference's form: every index once, leftovers last
+    idx = [int(i) for i in ref]
+    assert sorted(idx) == list(range(10)) and idx[-2:] == [8, 9] and len(ref) == 10
+
+
+def test_sgg_head_inputs_of_a_minibatch():
+    """train.sgg_head_inputs: faster_rcnn_SGG_emb.py:170-245 for every frame of a minibatch -- rows of frame f carry f in
+    column 0, pair indices point into the concatenated box table, a frame without an annotated relation contributes nothing
+    (:177-183), the row weights make sum_r w[r] * mean_c BCE the mean over frames of the per-frame mean; the host
+    rasteriser equals the device one."""
+    from i2vsgg_amd import synthetic as syn, train
+    from i2vsgg_amd.model.faster_rcnn.faster_rcnn_SGG_emb import build_pair_tables, rasterize_masks
+    a0 = syn.relation_annotation(1, 7, 5, 62, 16, 360, 640)
+    a1 = {"boxes": [[1, 2, 30, 40]], "box_classes": [3], "rels": []}
+    a2 = syn.relation_annotation(2, 12, 9, 62, 16, 360, 640)
+    info = np.array([[192, 342, 0.5333], [192, 342, 0.5333], [192, 342, 0.5333]], np.float32)
+    f = train.sgg_head_inputs([a0, a1, a2], info, 62)
+    assert f["boxes"].shape == (19, 5) and f["relb"].shape == (14, 5) and f["labels"].shape == (14, 62)
+    assert f["boxes"][:7, 0].tolist() == [0] * 7 and f["boxes"][7:, 0].tolist() == [2] * 12
+    assert f["relb"][:5, 0].tolist() == [0] * 5 and f["relb"][5:, 0].tolist() == [2] * 9
+    assert f["ixs"][:5].max() < 7 and f["ixs"][5:].min() >= 7 and f["ixo"][5:].max() < 19
+    np.testing.assert_allclose(f["wrow"], [1 / 10.0] * 5 + [1 / 18.0] * 9, rtol=1e-6)
+    gt, union, bnd, lab, s, o = build_pair_tables(a2, float(info[2][2]), 192.0, 342.0, 62)
+    assert np.array_equal(f["boxes"][7:, 1:], gt.astype(np.float32)) and np.array_equal(f["relb"][5:, 1:], union.astype(np.float32))
+    assert np.array_equal(f["ixs"][5:], s + 7) and np.array_equal(f["labels"][5:], lab) and np.array_equal(f["bounds"][5:], bnd)
+    m = train._rasterize_host(f["bounds"])
+    assert m.shape == (14, 4, 32, 32) and np.array_equal(m[:, :2], rasterize_masks(f["bounds"], "cpu").numpy()) and not m[:, 2:].any()
+    assert train.sgg_head_inputs([a1, None], info, 62) is None
+
+
 def test_shard_frames_is_a_partition():
     from i2vsgg_amd.parallel import shard_frames
     for n, w in ((16, 8), (32, 8), (5, 2), (3, 4)):

@@ -1,10 +1,15 @@
 #!/usr/bin/env python3
-"""Relation-head training loop with the reference's CLI surface (trainval_net_SGG_emb.py:189-320), on the HIP path.
+"""Relation-head training loop with the reference's CLI surface and data path (trainval_net_SGG_emb.py:73-320), on the HIP
+path: ``combined_roidb -> roibatchLoader(path_return=True) -> DataLoader(sampler)`` feeds the step exactly as the
+reference loop is fed (:77-91, :204-217); the step is the captured, overlapped ``train.SGGEmbStep`` (one HIP graph per
+frame size, boxes / pairs padded to a capacity), so minibatches may differ in image size and in boxes / pairs per frame.
 
-No dataset is reachable offline, so frames / annotations come from the seeded synthetic source
-(i2vsgg_amd.synthetic); with a real imdb registered through roi_data_layer.roidb.register_imdb the same loop
-runs on it.  Flags keep the reference names (lib/model/utils/parser_func.py): --net, --bs, --epochs, --lr,
---vrd_lr, --lr_decay_step, --lr_decay_gamma, --o, --num_classes, --num_relations, --cuda, --disp_interval.
+No dataset is reachable offline: ``--imdb_name synthetic_<n>_v`` (the default) is a seeded imdb whose frames come in five
+resolutions and whose annotations (``imdb.gt_rels``: the ``source_gt_rels`` pickle's layout) vary from frame to frame; a
+real imdb registered with ``roi_data_layer.roidb.register_imdb`` plus ``--source_gt_rels_path`` runs through the same loop.
+Flags keep the reference names (lib/model/utils/parser_func.py): --dataset, --net, --bs, --nw, --start_epoch, --epochs,
+--lr, --vrd_lr, --lr_decay_step, --lr_decay_gamma, --o, --num_classes, --num_relations, --s, --r, --load_name,
+--adaptation, --save_dir, --disp_interval.
 """
 import argparse
 import os
@@ -19,12 +24,16 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
-def parse_args():
+def parse_args(argv=None):
     p = argparse.ArgumentParser(description="Train the SGG_emb relation head (pre_det) on MI355X")
+    p.add_argument("--dataset", default="synthetic")
+    p.add_argument("--imdb_name", default="synthetic_64_v", help="roidb to train on (combined_roidb name; a+b concatenates)")
     p.add_argument("--net", default="res101", choices=["res101", "res50"])
     p.add_argument("--bs", dest="batch_size", type=int, default=2, help="frames per step (per GPU)")
+    p.add_argument("--nw", dest="num_workers", type=int, default=0)
+    p.add_argument("--start_epoch", type=int, default=1)
     p.add_argument("--epochs", dest="max_epochs", type=int, default=1)
-    p.add_argument("--iters_per_epoch", type=int, default=10)
+    p.add_argument("--iters_per_epoch", type=int, default=0, help="0: train_size / bs as the reference (:187)")
     p.add_argument("--lr", type=float, default=1.0)
     p.add_argument("--vrd_lr", type=float, default=1e-4)
     p.add_argument("--lr_decay_step", type=int, default=1)
@@ -33,44 +42,49 @@ def parse_args():
     p.add_argument("--num_classes", type=int, default=16)
     p.add_argument("--num_relations", type=int, default=62)
     p.add_argument("--vrd_task", default="pre_det")
+    p.add_argument("--adaptation", default="adap")
+    p.add_argument("--source_gt_rels_path", default="")
     p.add_argument("--cuda", action="store_true", default=True)
     p.add_argument("--disp_interval", type=int, default=5)
-    p.add_argument("--height", type=int, default=600)
-    p.add_argument("--width", type=int, default=1000)
+    p.add_argument("--scale", type=int, default=0, help="shorter image side (cfg.TRAIN.SCALES; 0: the yml's 600)")
     p.add_argument("--save_dir", default="models", help="checkpoints go to <save_dir>/<net>/<dataset> (reference layout)")
-    p.add_argument("--dataset", default="synthetic")
     p.add_argument("--s", dest="session", type=int, default=1)
-    p.add_argument("--r", dest="resume", action="store_true", help="resume from --checksession / --checkepoch")
+    p.add_argument("--r", dest="resume", action="store_true", help="resume from --load_name (or --checksession / --checkepoch)")
+    p.add_argument("--load_name", default="")
     p.add_argument("--checksession", type=int, default=1)
     p.add_argument("--checkepoch", type=int, default=1)
     p.add_argument("--no-save", action="store_true")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of the captured step")
     p.add_argument("--set", dest="set_cfgs", nargs=argparse.REMAINDER, default=None)
-    return p.parse_args()
+    return p.parse_args(argv)
 
 
-def checkpoint_name(a, session, epoch):
-    return os.path.join(a.save_dir, a.net, a.dataset, "SGG_emb_%d_%d.pth" % (session, epoch))
+def checkpoint_name(a, session, epoch, step):
+    """trainval_net_SGG_emb.py:293-300: <save_dir>/<net>/<dataset>/SGG_emb_p_prior_{adaptation}_{dataset}_pre_det_
+    session_{s}_epoch_{e}_step_{last step index}_un.pth"""
+    return os.path.join(a.save_dir, a.net, a.dataset, "SGG_emb_p_prior_%s_%s_%s_session_%d_epoch_%d_step_%d_un.pth" % (
+        a.adaptation, a.dataset, a.vrd_task, session, epoch, step))
 
 
-def save_checkpoint(a, net, opt, epoch, rank):
-    """The reference's per-epoch dict (trainval_net_instance_styleD_bilinear.py:421-434; net_utils.py:119-120) with
-    the model under the reference's state_dict keys.  A column-parallel fc6 is reassembled first (every rank takes part
-    in the gather, rank 0 writes), so the file loads on any number of GPUs and under the reference's layer shapes."""
+def save_checkpoint(a, net, opt, epoch, last_step, rank):
+    """The reference's per-epoch dict (:310-317; net_utils.py:119-120): ``epoch`` holds the NEXT epoch, the model sits
+    under the reference's state_dict keys.  A column-parallel fc6 is reassembled first (every rank takes part in the
+    gather, rank 0 writes), so the file loads on any number of GPUs and under the reference's layer shapes."""
     w6, b6 = net.vrd.gather_fc6()
     if rank != 0:
         return None
+    from i2vsgg_amd.model.utils.config import cfg
     model = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     model["vrd.fc6.fc.weight"], model["vrd.fc6.fc.bias"] = w6.detach().cpu(), b6.detach().cpu()
-    path = checkpoint_name(a, a.session, epoch)
+    path = checkpoint_name(a, a.session, epoch, last_step)
     os.makedirs(os.path.dirname(path), exist_ok=True)
-    torch.save({"session": a.session, "epoch": epoch, "model": model, "optimizer": opt.state_dict(),
-                "pooling_mode": "pool", "class_agnostic": False}, path)
+    torch.save({"session": a.session, "epoch": epoch + 1, "model": model, "optimizer": opt.state_dict(),
+                "pooling_mode": cfg.POOLING_MODE, "class_agnostic": False}, path)
     return path
 
 
-def load_checkpoint(a, net, opt, dev):
-    path = checkpoint_name(a, a.checksession, a.checkepoch)
+def load_checkpoint(path, net, opt):
+    """-> the epoch to start at (the file's ``epoch`` entry, as trainval_net_instance_styleD_bilinear.py:190-191 reads it)."""
     ck = torch.load(path, map_location="cpu")
     model = dict(ck["model"])
     if net.vrd.tp is not None:                   # this run cuts fc6 by columns: keep this rank's shard
@@ -89,56 +103,99 @@ def load_checkpoint(a, net, opt, dev):
                 n = m.shape[0] // world
                 sd["state"][g["params"][0]]["momentum_buffer"] = m[rk * n:(rk + 1) * n]
     opt.load_state_dict(sd)
-    return ck["epoch"], path
+    opt.bump()
+    return int(ck["epoch"])
 
 
-def main():
-    a = parse_args()
+def main(argv=None):
+    a = parse_args(argv)
     from i2vsgg_amd import parallel, train
     from i2vsgg_amd.model.utils import config as c
+    from i2vsgg_amd.model.utils.net_utils import sampler
+    from i2vsgg_amd.roi_data_layer.roibatchLoader import roibatchLoader
+    from i2vsgg_amd.roi_data_layer.roidb import combined_roidb
     rank, world, dev = parallel.init_from_env()
     c.cfg_from_file(c.default_cfg_file(a.net))
     c.cfg_from_list(["ANCHOR_SCALES", "[8, 16, 32]", "ANCHOR_RATIOS", "[0.5,1,2]", "MAX_NUM_GT_BOXES", "30"])
+    if a.scale:
+        c.cfg_from_list(["TRAIN.SCALES", "(%d,)" % a.scale])
     if a.set_cfgs:
         c.cfg_from_list(a.set_cfgs)
     np.random.seed(c.cfg.RNG_SEED)
+    torch.manual_seed(c.cfg.RNG_SEED)
+
+    # ---- the data path of the reference loop (:73-91)
+    c.cfg.TRAIN.USE_FLIPPED = False
+    imdb, roidb, ratio_list, ratio_index = combined_roidb(a.imdb_name)
+    train_size = len(roidb)
+    if rank == 0:
+        print("%d source roidb entries" % train_size)
+    sampler_batch = sampler(train_size, a.batch_size, rank=rank, world=world, seed=c.cfg.RNG_SEED)
+    dataset_s = roibatchLoader(roidb, ratio_list, ratio_index, a.batch_size, imdb.num_classes, training=True, path_return=True)
+    dataloader_s = torch.utils.data.DataLoader(dataset_s, batch_size=a.batch_size, sampler=sampler_batch,
+                                               num_workers=a.num_workers, pin_memory=dev.type == "cuda")
+    iters_per_epoch = a.iters_per_epoch or (train_size // a.batch_size // world)
+
     net = train.build_sgg_net(101 if a.net == "res101" else 50, a.num_relations, a.num_classes, device=dev)
-    vrd_lr = a.vrd_lr
-    seed_of = lambda epoch, it: 1000 * epoch + it * world + rank           # the data layer's role is played by reseed()
-    step = train.SGGEmbStep(net, a.batch_size, vrd_lr=vrd_lr, seed=seed_of(1, 0), device=dev, h=a.height, w=a.width,
-                            use_graph=not a.no_graph and dev.type == "cuda")
-    start_epoch = 1
+    if a.source_gt_rels_path:
+        import pickle
+        with open(a.source_gt_rels_path, "rb") as f:
+            net.vrd.source_gt_rels = pickle.load(f, encoding="bytes")
+    elif hasattr(imdb, "gt_rels"):
+        net.vrd.source_gt_rels = imdb.gt_rels(a.num_relations)
+    else:
+        raise SystemExit("no relation annotations: pass --source_gt_rels_path")
+    step = train.SGGEmbStep(net, a.batch_size, vrd_lr=a.vrd_lr, device=dev, use_graph=not a.no_graph and dev.type == "cuda",
+                            stage_synthetic=False)
+    start_epoch = a.start_epoch
     if a.resume:
-        done, path = load_checkpoint(a, net, step.opt, dev)
-        start_epoch = done + 1
-        for _ in range(done // a.lr_decay_step):
-            vrd_lr *= a.lr_decay_gamma
+        path = a.load_name or checkpoint_name(a, a.checksession, a.checkepoch, iters_per_epoch - 1)
+        start_epoch = load_checkpoint(path, net, step.opt)
         if rank == 0:
-            print("resumed %s (epoch %d)" % (path, done))
-    # batches in training order; the first one is staged before the capture (the overlapped pipeline is primed with it)
-    seeds = [seed_of(e, it) for e in range(start_epoch, a.max_epochs + 1) for it in range(a.iters_per_epoch)]
-    if not seeds:
+            print("loaded checkpoint %s (start epoch %d)" % (path, start_epoch))
+    vrd_lr = step.opt.lr_of("vrd.fc7.fc.weight")        # the rate the optimizer holds (a resumed one carries its decays)
+    if start_epoch > a.max_epochs:
         return
-    step.reseed(seeds[0])
-    # the step the loop runs IS the benchmarked one: one captured graph per step, fused wgrad+SGD, head of batch k beside
-    # the backbone of batch k+1.  The warm-up steps of the capture leave no trace in parameters, momentum or RNG state
+
+    data_iter = [iter(dataloader_s)]
+
+    def stage_next():
+        """The next minibatch the reference loop would train on (:204-217: batches it skips are skipped here)."""
+        for _ in range(4 * len(dataloader_s) + 4):
+            try:
+                data = next(data_iter[0])
+            except StopIteration:
+                data_iter[0] = iter(dataloader_s)
+                data = next(data_iter[0])
+            if step.stage_batch(data):
+                return
+        raise SystemExit("the data loader yields no trainable minibatch")
+
+    total = (a.max_epochs - start_epoch + 1) * iters_per_epoch
+    stage_next()
+    # the step the loop runs IS the benchmarked one: one captured graph per step (and frame size), fused wgrad+SGD, head of
+    # batch k beside the backbone of batch k+1.  The warm-up steps of the capture leave no trace in parameters, momentum or
+    # RNG state
     graphed = step.capture(warmup=2, restore=True)
     if rank == 0:
         print("step: %s" % ("HIP graph, overlapped" if graphed and step.overlap else "HIP graph" if graphed
-                            else "eager (%s)" % step.graph_error))
-    lag = 1 if (graphed and step.overlap) else 0        # overlapped: call k trains batch k while the backbone runs batch k+1
+                            else "eager (%s)" % (step.graph_error or "--no-graph")))
     pos = 0
     for epoch in range(start_epoch, a.max_epochs + 1):
-        if epoch > 1 and (epoch - 1) % a.lr_decay_step == 0 and epoch != start_epoch:
-            vrd_lr *= a.lr_decay_gamma                       # adjust_learning_rate (net_utils.py:113-116)
-            step.opt.scale_lr(a.lr_decay_gamma)
+        if epoch > 1 and (epoch - 1) % a.lr_decay_step == 0:
+            step.opt.scale_lr(a.lr_decay_gamma)              # adjust_learning_rate (net_utils.py:113-116), :196-199
+            vrd_lr = step.opt.lr_of("vrd.fc7.fc.weight")
             if graphed:
                 graphed = step.capture(warmup=0)             # rates live in the captured kernel arguments
+                if not graphed and rank == 0:
+                    print("re-capture failed, eager launches from here: %s" % step.graph_error)
+        lag = 1 if step.lag else 0          # overlapped: call k trains batch k while the backbone runs batch k+1
         t0, acc = time.time(), torch.zeros((), device=dev)
-        for it in range(a.iters_per_epoch):
-            ahead = pos + lag                                # the batch this call's backbone pass works on
-            if ahead < len(seeds) and ahead > 0:
-                step.reseed(seeds[ahead])                    # queued behind the running step, no host synchronisation
+        for it in range(iters_per_epoch):
+            # overlapped: the batch staged now is the backbone's in this call and the head's in the next one (none is staged
+            # for the very last call: its backbone branch has nothing new to do).  Sequential: the batch of this call
+            if (lag and pos + 1 < total) or (not lag and pos > 0):
+                stage_next()                                 # queued behind the running step, no host synchronisation
             acc += step()                                    # loss of batch ``pos``
             pos += 1
             if (it + 1) % a.disp_interval == 0:
@@ -146,11 +203,12 @@ def main():
                 acc.zero_()
                 if rank == 0:
                     dt = time.time() - t0
-                    print("[epoch %2d][iter %4d/%4d] loss: %.4f, vrd_lr: %.2e, %.1f frames/s" % (
-                        epoch, it + 1, a.iters_per_epoch, loss, vrd_lr, world * a.batch_size * a.disp_interval / dt))
+                    print("[session %d][epoch %2d][iter %4d/%4d] loss: %.4f, lr: %.2e, vrd_lr: %.2e, %.1f frames/s" % (
+                        a.session, epoch, it + 1, iters_per_epoch, loss, a.lr, vrd_lr,
+                        world * a.batch_size * a.disp_interval / dt))
                 t0 = time.time()
         if not a.no_save:
-            path = save_checkpoint(a, net, step.opt, epoch, rank)
+            path = save_checkpoint(a, net, step.opt, epoch, iters_per_epoch - 1, rank)
             if rank == 0:
                 print("save model: %s" % path)
     step.opt.unfuse()
