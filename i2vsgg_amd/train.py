@@ -624,6 +624,7 @@ class SGGEmbStep:
             import gc
             gc.collect()
             torch.cuda.synchronize(self.dev)
+        self._pool = None             # the allocator releases a pool with its last graph: the next capture opens a new one
 
     def capture(self, warmup=2, restore=False):
         """Warm up eagerly (sizes the arenas, fills the allocator), then capture the step for the staged frame size into ONE
@@ -1066,6 +1067,7 @@ class InstanceStyleDStep:
             import gc
             gc.collect()
             torch.cuda.synchronize(self.dev)
+        self._pool = None             # the allocator releases a pool with its last graph: the next capture opens a new one
 
     def capture(self, warmup=2, restore=False):
         """Device-side target sampling, eager warm-up, then the whole step for the staged sizes as ONE HIP graph (other

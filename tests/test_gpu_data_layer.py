@@ -124,7 +124,8 @@ def test_sgg_captured_step_consumes_loader_batches_of_varying_size(small_cfg):
     graphs = sum(1 for fs in step.shapes.values() if fs.graph)
     step.opt.unfuse()
     assert step.graph_error is None, step.graph_error
-    assert graphs == len(sizes) and set(k[1:] for k in step.shapes) == sizes
+    # one graph per frame size met since the capacity last grew (growing drops every graph)
+    assert 2 <= graphs <= len(sizes) and set(k[1:] for k in step.shapes) == sizes
     assert (step.cap_boxes, step.cap_pairs) != cap0          # the capacity grew (and every graph was captured again)
     assert step.cap_boxes >= max(rows)
     for a, b in zip(want, got):
@@ -220,10 +221,9 @@ def test_training_scripts_run_through_the_data_layer(small_cfg, tmp_path):
     import trainval_instance_styled as tv
     import trainval_sgg_emb as ts
     # ---- SGG_emb
-    common = ["--bs", "2", "--imdb_name", "synthetic_12_v", "--scale", "192", "--disp_interval", "3", "--net", "res50",
-              "--save_dir", str(tmp_path), "--lr_decay_step", "1", "--lr_decay_gamma", "0.5", "--vrd_lr", "1e-4"]
+    common = ["--bs", "2", "--imdb_name", "synthetic_12_v", "--scale", "192", "--disp_interval", "3", "--save_dir", str(tmp_path), "--lr_decay_step", "1", "--lr_decay_gamma", "0.5", "--vrd_lr", "1e-4"]
     ts.main(["--epochs", "2"] + common)
-    name = tmp_path / "res50" / "synthetic" / "SGG_emb_p_prior_adap_synthetic_pre_det_session_1_epoch_2_step_5_un.pth"
+    name = tmp_path / "res101" / "synthetic" / "SGG_emb_p_prior_adap_synthetic_pre_det_session_1_epoch_2_step_5_un.pth"
     ck = torch.load(name, map_location="cpu")
     assert ck["epoch"] == 3 and ck["pooling_mode"] == "align"
     for k in ("RCNN_base.0.weight", "vrd.fc6.fc.weight", "vrd.prd_sem_embeddings.2.bias", "vrd.conv_lo.2.conv.weight"):
