@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="sgg", choices=["sgg", "instance_styled", "joint", "res50"])
+    ap.add_argument("--data", default="resident", choices=["resident", "loader"],
+                    help="resident: one synthetic minibatch resident in HBM (the headline); loader: roibatchLoader minibatches of "
+                         "varying size staged from pinned host memory every step (config sgg; also reported beside the headline)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="headline only: skip the configs[2] measurement")
@@ -273,6 +276,68 @@ def run_sgg(a, rank, world, dev, frames_per_rank=2):
     return line, step, net
 
 
+# ----------------------------------------------------------------------------- configs[1] fed by the data layer
+def run_sgg_loader(a, rank, world, dev, frames_per_rank=2, n_batches=8):
+    """The same step fed as the reference loop is fed (trainval_net_SGG_emb.py:77-91,204-217): combined_roidb ->
+    roibatchLoader(path_return=True) -> DataLoader(sampler) on a synthetic imdb whose frames come in five resolutions with
+    4-32 boxes and 2-32 annotated pairs each.  ``n_batches`` collated minibatches are kept in pinned host memory (the loader's
+    own CPU time -- synthetic pixels, the host resize -- is reported separately: its workers run beside the GPU); every
+    timed step stages one of them (frames and packed head inputs cross PCIe, pair tables are built on the host) and replays
+    the captured step of that minibatch's size."""
+    import torch
+    from i2vsgg_amd import train
+    from i2vsgg_amd.model.utils import config as c
+    from i2vsgg_amd.model.utils.net_utils import sampler
+    from i2vsgg_amd.roi_data_layer.roibatchLoader import roibatchLoader
+    from i2vsgg_amd.roi_data_layer.roidb import combined_roidb
+    c.cfg.TRAIN.USE_FLIPPED = False
+    imdb, roidb, ratio_list, ratio_index = combined_roidb("synthetic_%d_v" % (2 * n_batches * frames_per_rank * world))
+    ds = roibatchLoader(roidb, ratio_list, ratio_index, frames_per_rank, imdb.num_classes, training=True, path_return=True)
+    dl = torch.utils.data.DataLoader(ds, batch_size=frames_per_rank, pin_memory=True,
+                                     sampler=sampler(len(roidb), frames_per_rank, rank=rank, world=world, seed=c.cfg.RNG_SEED))
+    t0 = time.perf_counter()
+    batches = []
+    for d in dl:
+        batches.append(d)
+        if len(batches) == n_batches:
+            break
+    loader_ms = 1e3 * (time.perf_counter() - t0) / len(batches)
+    net = train.build_sgg_net(a.layers, device=dev)
+    net.vrd.source_gt_rels = imdb.gt_rels(net.vrd.n_rel)
+    step = train.SGGEmbStep(net, frames_per_rank, device=dev, use_graph=not a.no_graph, stage_synthetic=False)
+    for d in batches:                     # the feature-map buffers fit the largest minibatch from the start
+        step.reserve(int(d[0].shape[2]), int(d[0].shape[3]))
+    assert step.stage_batch(batches[0])
+    graphed = step.capture(warmup=2)
+    pos = [0]
+
+    def fn():
+        pos[0] += 1
+        step.stage_batch(batches[pos[0] % len(batches)])
+        step()
+    for _ in range(len(batches) + 1):     # every frame size met once: its graph is captured outside the timed region
+        fn()
+    elapsed = timed_steps(fn, a.warmup, a.steps, dev)
+    sizes = sorted({tuple(int(v) for v in d[0].shape[2:]) for d in batches})
+    rels = net.vrd.source_gt_rels
+    nb = [sum(len(rels[p.split("/")[-1]]["boxes"]) for p in d[4]) for d in batches]
+    line = {
+        "metric": "frames/sec (600x1000, 32 ROI/frame)", "value": world * frames_per_rank * a.steps / elapsed,
+        "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "loader: %d collated roibatchLoader minibatches in pinned host memory, one staged per step (H2D of the frames "
+                "and the packed head inputs inside the timed region)" % len(batches),
+        "config": {"workload": "BASELINE.json configs[%d] fed by roi_data_layer: cfgs/res101.yml, SGG_emb fwd+bwd+SGD, %d frames/GPU, "
+                               "shorter side 600, minibatch sizes %s, %d-%d boxes per minibatch, ResNet-%d C4" % (
+                                   3 if world > 1 else 1, frames_per_rank, sizes, min(nb), max(nb), a.layers),
+                   "frames_per_gpu": frames_per_rank, "hip_graph": bool(graphed), "graph_error": step.graph_error,
+                   "graphs": sum(1 for fs in step.shapes.values() if fs.graph), "frame_sizes": sizes,
+                   "head_capacity_rows": [step.cap_boxes, step.cap_pairs],
+                   "loader_cpu_ms_per_minibatch": loader_ms, "loss": float(step.loss)},
+    }
+    return line, step, net
+
+
 # ----------------------------------------------------------------------------- configs[2]
 def run_instance_styled(a, rank, world, dev, steps, warmup, frames_per_rank=4):
     import numpy as np
@@ -432,14 +497,26 @@ def main():
     c.cfg_from_list(SET_CFGS)
 
     keep = []
-    if a.config == "sgg":
+    if a.config == "sgg" and a.data == "loader":
+        line, step, net = run_sgg_loader(a, rank, world, dev)
+        keep += [step, net]
+    elif a.config == "sgg":
         line, step, net = run_sgg(a, rank, world, dev)
         keep += [step, net]
+        if world == 1 and not a.no_also:
+            # the same step fed by the data layer (varying minibatch sizes, staged from the host every step)
+            step.opt.unfuse()
+            torch.cuda.empty_cache()
+            ld, s1, n1 = run_sgg_loader(a, rank, world, dev)
+            line["also"] = {"sgg_loader": {k: ld[k] for k in ("value", "unit", "ms_per_step", "steps", "data", "config")}}
+            s1.opt.unfuse()
+            del s1, n1
+            torch.cuda.empty_cache()
         if world == 1 and not a.no_also:
             # configs[2] under the same driver clock: fewer steps (a step is ~15x longer), its own roofline block
             torch.cuda.empty_cache()
             also, s2, n2 = run_instance_styled(a, rank, world, dev, steps=max(4, a.steps // 4), warmup=2)
-            line["also"] = {"instance_styled": also}
+            line.setdefault("also", {})["instance_styled"] = also
             keep += [s2, n2]
     elif a.config == "instance_styled":
         line, step, net = run_instance_styled(a, rank, world, dev, a.steps, a.warmup)
