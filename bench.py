@@ -130,6 +130,152 @@ def cpu_baseline(threads_list):
     return out
 
 
+def _median_time(fn, warm=2, timed=5):
+    ts = []
+    for it in range(warm + timed):
+        t0 = time.perf_counter()
+        fn()
+        if it >= warm:
+            ts.append(time.perf_counter() - t0)
+    return sorted(ts)[len(ts) // 2]
+
+
+def cpu_baseline_stages(threads):
+    """the CPU oracle stage by stage at ``threads`` torch threads, ONE 600x1000 frame / 32 ROIs (2
+    warm-up + 5 timed, median; the two stages that take seconds per pass -- the vrd head 1 + 3, the configs[2] D+G step 1 + 2 --
+    so that the whole CPU leg stays near 30 s): backbone fwd, RPN head + proposal layer (decode, sort, the
+    reference's greedy NMS 12000 -> 2000), RoIAlignAvg fwd / bwd, layer4 head, netD_pixel and netD_style fwd + bwd, vrd head
+    fwd + bwd, and the instance_styleD D+G step on 1 source + 1 target frame (every stage under autograd, SGD update).
+    -> {stage: {"ms": median, "frames_per_s": ...}}.  ROIAlign / ROIPool / NMS are the oracle's C (one thread)."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    from i2vsgg_amd import synthetic as syn, train
+    from i2vsgg_amd.model.faster_rcnn.faster_rcnn_SGG_emb import build_pair_tables
+    from oracle import cops, nets, rpn
+    torch.set_num_threads(threads)
+    p = {}
+    p.update(syn.backbone_params(0, 101, top=True))
+    p.update(syn.rpn_params(10, std=0.02))
+    p.update(syn.det_head_params(11, 16))
+    p.update(syn.netd_params(12))
+    im, info = syn.frames(3, 1, 600, 1000)
+    imt, _ = syn.frames(103, 1, 600, 1000)
+    gt, nb = syn.gt_boxes(3, 1, 8, 16, 30, 600, 1000)
+    x = torch.from_numpy(im)
+    out = {}
+    with torch.no_grad():
+        feat, feat1 = nets.extract_feature(x, p)
+        out["backbone_fwd"] = _median_time(lambda: nets.extract_feature(x, p))
+
+        def rpn_stage():
+            cls, prob, box = nets.rpn_head(feat, p)
+            return rpn.proposal_layer(prob[:, 9:].numpy(), box.numpy(), info, 12000, 2000, 0.7)
+        rois_all, _ = rpn_stage()
+        out["rpn_head_proposal_nms"] = _median_time(rpn_stage)
+    rois = np.ascontiguousarray(rois_all[0, :32]).astype(np.float32)
+    fnp = feat.numpy()
+    pooled_np = cops.roi_align_avg_fwd(fnp, rois, 7, 7, 1.0 / 16.0)
+    out["roi_align_avg_fwd"] = _median_time(lambda: cops.roi_align_avg_fwd(fnp, rois, 7, 7, 1.0 / 16.0))
+    g = np.ones_like(pooled_np)
+    out["roi_align_avg_bwd"] = _median_time(lambda: cops.roi_align_avg_bwd(g, rois, fnp.shape, 1.0 / 16.0))
+    pooled = torch.from_numpy(pooled_np)
+    with torch.no_grad():
+        out["layer4_head_fwd"] = _median_time(lambda: nets.head_to_tail(pooled, p))
+    train_keys = [k for k in p if (k.startswith("netD_") or k.startswith("RCNN_rpn") or k.startswith("RCNN_cls") or
+                                   k.startswith("RCNN_bbox") or ((".conv" in k or "downsample.0" in k) and not k.startswith("RCNN_base.0")))]
+    for k in train_keys:
+        p[k].requires_grad_()
+
+    def zero():
+        for k in train_keys:
+            p[k].grad = None
+
+    def dpix():
+        zero()
+        (0.5 * (nets.netd_pixel(pooled, p, 0.1) ** 2).mean()).backward()
+    out["netD_pixel_fwd_bwd"] = _median_time(dpix)
+    f1 = feat1.detach()
+
+    def dsty():
+        zero()
+        (0.5 * (nets.netd_style(f1, p, 0.001) ** 2).mean()).backward()
+    out["netD_style_fwd_bwd"] = _median_time(dsty)
+    # vrd head, 32 boxes + 32 pairs (the relation step's head; its end-to-end figure is cpu_baseline.value)
+    v = {k: t.requires_grad_() for k, t in syn.vrd_params(13).items()}
+    _, _, annos = train.synthetic_sgg_batch(1, 1)
+    bx, union, bounds, labels, ixs, ixo = build_pair_tables(annos["f0"], 1.0, 600.0, 1000.0, 62)
+    b5 = np.zeros((bx.shape[0], 5), np.float32); b5[:, 1:] = bx
+    r5 = np.zeros((union.shape[0], 5), np.float32); r5[:, 1:] = union
+    masks = train._rasterize_host(bounds, 2)
+    prd = syn.word_vectors(21, 62)
+
+    def vrd():
+        for t in v.values():
+            t.grad = None
+        sc, _ = nets.vrd_head(fnp, b5, r5, masks, ixs, ixo, prd, v, training=True)
+        F.binary_cross_entropy_with_logits(sc, torch.from_numpy(labels)).backward()
+    out["vrd_head_fwd_bwd"] = _median_time(vrd, warm=1, timed=3)
+
+    # ---- configs[2] on the CPU: D+G step, 1 source + 1 target frame, every trained stage under autograd
+    class RoiAlignAvg(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, f, r):
+            ctx.r, ctx.shape = r, tuple(f.shape)
+            return torch.from_numpy(cops.roi_align_avg_fwd(f.detach().numpy(), r, 7, 7, 1.0 / 16.0))
+
+        @staticmethod
+        def backward(ctx, go):
+            return torch.from_numpy(cops.roi_align_avg_bwd(np.ascontiguousarray(go.numpy()), ctx.r, ctx.shape, 1.0 / 16.0)), None
+    opt = torch.optim.SGD([p[k] for k in train_keys], lr=5e-4, momentum=0.9, weight_decay=5e-4)
+    rs = np.random.RandomState(3)
+
+    def side(frames, target):
+        ft, ft1 = nets.extract_feature(frames, p)
+        d_style = nets.netd_style(ft1, p, 0.001)
+        cls, prob, box = nets.rpn_head(ft, p)
+        post = 32 if target else 2000
+        r_all, _ = rpn.proposal_layer(prob[:, 9:].detach().numpy(), box.detach().numpy(), info, 12000, post, 0.7)
+        loss = 0.0
+        if not target:
+            fh, fw = ft.shape[2], ft.shape[3]
+            L, T, IW, OW = rpn.anchor_target_layer(fh, fw, gt, info, rs)
+            pair = cls.view(1, 2, 9 * fh, fw).permute(0, 2, 3, 1).reshape(-1, 2)
+            lab = torch.from_numpy(L).reshape(-1)
+            keep = lab.ne(-1).nonzero().view(-1)
+            loss = F.cross_entropy(pair[keep], lab[keep].long())
+            d = torch.from_numpy(IW) * (box - torch.from_numpy(T))
+            ad = d.abs()
+            near = (ad < 1.0 / 9.0).float()
+            loss = loss + (torch.from_numpy(OW) * (d * d * 4.5 * near + (ad - 0.5 / 9.0) * (1 - near))).sum((1, 2, 3)).mean()
+            rb, lab_o, tg, inw, outw = rpn.proposal_target_layer(r_all, gt, rs, batch_size=32)
+            r32 = np.ascontiguousarray(rb.reshape(-1, 5)).astype(np.float32)
+        else:
+            r32 = np.ascontiguousarray(r_all.reshape(-1, 5)).astype(np.float32)
+        pl = RoiAlignAvg.apply(ft, r32)
+        d_inst = nets.netd_pixel(pl, p, 0.1)
+        if target:
+            return 0.5 * ((1 - d_inst) ** 2).mean() + 0.5 * ((1 - d_style) ** 2).mean()
+        h = nets.head_to_tail(pl, p)
+        lo = torch.from_numpy(lab_o.reshape(-1)).long()
+        bp = F.linear(h, p["RCNN_bbox_pred.weight"], p["RCNN_bbox_pred.bias"])
+        bp = torch.gather(bp.view(-1, 16, 4), 1, lo.view(-1, 1, 1).expand(-1, 1, 4)).squeeze(1)
+        cs = F.linear(h, p["RCNN_cls_score.weight"], p["RCNN_cls_score.bias"])
+        d = torch.from_numpy(inw.reshape(-1, 4)) * (bp - torch.from_numpy(tg.reshape(-1, 4)))
+        ad = d.abs()
+        near = (ad < 1.0).float()
+        l_box = (torch.from_numpy(outw.reshape(-1, 4)) * (d * d * 0.5 * near + (ad - 0.5) * (1 - near))).sum(1).mean()
+        return loss + F.cross_entropy(cs, lo) + l_box + 0.5 * (d_inst ** 2).mean() + 0.5 * (d_style ** 2).mean()
+
+    def dg_step():
+        opt.zero_grad()
+        (side(x, False) + side(torch.from_numpy(imt), True)).backward()
+        opt.step()
+    out["instance_styled_dg_step_1+1_frames"] = _median_time(dg_step, warm=1, timed=2)
+    res = {k: {"ms": 1e3 * t, "frames_per_s": (2.0 if k.startswith("instance_styled") else 1.0) / t} for k, t in out.items()}
+    return res
+
+
 # ----------------------------------------------------------------------------- measurement helpers
 def timed_steps(step_fn, warmup, steps, dev):
     import torch
@@ -406,6 +552,20 @@ def run_joint(a, rank, world, dev, frames_per_rank=4):
         dstep()
         sstep()
     elapsed = timed_steps(both, a.warmup, a.steps, dev)
+    # ---- roofline of the dominant kernel of the joint step: every conv_gemm_f32 launch of both halves (the pointwise layers of
+    # the detector's trained trunk, forward and data gradient, and of the relation net's frozen trunk), HIP events around every
+    # call of eager steps of the same objects
+    n_prof = 2
+    pp, sstep._pipelined = sstep._pipelined, False
+
+    def eager_both():
+        dstep.eager_step()
+        sstep._body()
+    rec = profile_eager(eager_both, n_prof, dev)
+    sstep._pipelined = pp
+    gemm = [r for r in rec if r["tag"] in ("fwd", "dgrad") and ("[gemm]" in r["desc"] or "+epi" in r["desc"]) and "winograd" not in r["desc"]]
+    t_gemm, f_gemm = sum(r["t"] for r in gemm), sum(r["flops"] for r in gemm)
+    achieved = f_gemm / max(t_gemm, 1e-12) / 1e12
     line = {
         "metric": "frames/sec (600x1000, 32 ROI/frame)", "value": world * frames_per_rank * a.steps / elapsed,
         "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
@@ -415,7 +575,16 @@ def run_joint(a, rank, world, dev, frames_per_rank=4):
                                    frames_per_rank, frames_per_rank, frames_per_rank),
                    "frames_per_gpu": frames_per_rank, "hip_graph": [bool(dgraph), bool(sgraph)],
                    "parallelism": "dp%d (RCCL all-reduce of 202 MB + the vrd gradients)" % world,
-                   "loss_sgg": float(sstep.loss), "loss_det": float(dstep.losses["total"])},
+                   "loss_sgg": float(sstep.loss), "loss_det": float(dstep.losses["total"]),
+                   "losses_det": {k: float(v) for k, v in dstep.losses.items()},
+                   "max_mem_GB": torch.cuda.max_memory_allocated(dev) / 2 ** 30},
+        "roofline": {"bound": "mfma", "kernel": "conv_gemm_f32 / conv_igemm_f32 pointwise launches of both halves (forward and fused data "
+                                                "gradient of the 1x1 layers; one launch per call)",
+                     "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS,
+                     "traffic": None, "launches_per_step": len(gemm) // n_prof, "avg_launch_us": 1e6 * t_gemm / max(len(gemm), 1),
+                     "gflop_per_step": f_gemm / n_prof / 1e9, "by_kind": by_kind(rec, n_prof),
+                     "note": "2*M*N*K of the launches / their summed durations (HIP events on the launch stream, %d eager joint "
+                             "steps of the same objects); the timed region replays the two captured graphs" % n_prof},
     }
     return line, (dstep, sstep), (det, sgg)
 
@@ -532,11 +701,15 @@ def main():
         # the GPU box grants a CPU share (16 cores per GPU), not the whole host: never oversubscribe
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         threads = min(16, cores)
-        sec = cpu_baseline(sorted({threads, min(8, threads)}, reverse=True))
+        sec = cpu_baseline([threads])
+        stages = cpu_baseline_stages(threads)
         line["cpu_baseline"] = {"value": 1.0 / sec[threads], "unit": "frames/s", "cores": threads, "kind": "port",
                                 "sample": "1 frame 600x1000: ResNet-101 C4 fwd + vrd head fwd/bwd/SGD for 32 boxes + 32 pairs; 2 "
                                           "warm-up + 5 timed, median %.2f s" % sec[threads],
-                                "frames_per_s_by_threads": {str(k): 1.0 / v for k, v in sec.items()}}
+                                "stages": stages,
+                                "stages_sample": "the oracle stage by stage on ONE 600x1000 frame / 32 ROIs, same protocol; "
+                                                 "instance_styled_dg_step_1+1_frames = the configs[2] D+G step (fwd, bwd, SGD) on 1 "
+                                                 "source + 1 target frame, 1 warm-up + 2 timed; vrd_head_fwd_bwd 1 + 3 (frames_per_s counts both frames)"}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if torch.distributed.is_available() and torch.distributed.is_initialized():

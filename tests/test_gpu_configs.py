@@ -276,3 +276,35 @@ def test_instance_styled_two_branches_equal_one_pass(fresh_cfg):
     got = {k: float(v) for k, v in step.losses.items()}
     assert all(np.isfinite(v) for v in got.values()), got
     assert not torch.equal(w0, step.net.RCNN_base[6][22].conv3.weight.detach())
+
+
+def test_joint_step_full_size_on_one_gpu(fresh_cfg):
+    """configs[4] on ONE rank (its 8-GPU form shards these frames): bench.py's ``run_joint`` composition
+    at full size -- one instance_styleD D+G step (4 source + 4 target frames of 600x1000, ResNet-101) followed by one SGG_emb
+    step on 4 frames, both nets, both graphs, both optimizers resident in one process: finite losses, both nets train, the
+    line carries a roofline block and the peak memory."""
+    import argparse
+    import bench
+    fresh_cfg("res101", bench.SET_CFGS[6:])
+    a = argparse.Namespace(layers=101, no_graph=False, warmup=1, steps=3)
+    line, (dstep, sstep), (det, sgg) = bench.run_joint(a, 0, 1, torch.device(DEV))
+    try:
+        cfgd = line["config"]
+        assert cfgd["hip_graph"] == [True, True], (dstep.graph_error, sstep.graph_error)
+        assert all(np.isfinite(v) for v in cfgd["losses_det"].values()) and np.isfinite(cfgd["loss_sgg"]), cfgd
+        assert 0.0 < cfgd["loss_sgg"] < 1.0 and cfgd["loss_det"] > 0.0
+        assert line["value"] > 0 and line["unit"] == "frames/s" and line["n_gpus"] == 1
+        r = line["roofline"]
+        assert r["bound"] == "mfma" and 0.05 < r["frac"] < 1.0 and r["launches_per_step"] > 100, r
+        assert 5.0 < cfgd["max_mem_GB"] < 120.0, cfgd["max_mem_GB"]
+        # both nets train: one more joint step moves a trunk filter of the detector and the relation head
+        w_det = det.RCNN_base[6][22].conv3.weight.detach().clone()
+        w_sgg = sgg.vrd.fc7.fc.weight.detach().clone()
+        frozen = sgg.RCNN_base[6][22].conv3.weight.detach().clone()
+        dstep(); sstep()
+        torch.cuda.synchronize()
+        assert not torch.equal(w_det, det.RCNN_base[6][22].conv3.weight.detach())
+        assert not torch.equal(w_sgg, sgg.vrd.fc7.fc.weight.detach())
+        assert torch.equal(frozen, sgg.RCNN_base[6][22].conv3.weight.detach())      # the relation net's trunk is frozen (:148)
+    finally:
+        sstep.opt.unfuse()
