@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libi2vsgg_hip.so")
-SOURCES = ["api.cpp", "roi_ops.hip", "rpn.hip", "conv.hip", "heads.hip", "image.hip", "winograd.hip", "dstyle.hip"]
+SOURCES = ["api.cpp", "roi_ops.hip", "rpn.hip", "conv.hip", "heads.hip", "image.hip", "winograd.hip", "dstyle.hip", "fcfold.hip"]
 # -ffp-contract=off: box / IoU / ROIAlign arithmetic must round once per operation like the
 # reference's CPU path (no FMA contraction), or NMS threshold decisions can flip.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
@@ -14,7 +14,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=o
 # MFMA accumulators in VGPRs, not AGPRs: measured on MI355X (tools/micro/mfma_rate.hip, tools/conv_ablate.py) a
 # back-to-back v_mfma_f32_16x16x4_f32 stream issues every 32 cycles with VGPR accumulators but only every ~45
 # cycles in the AGPR form hipcc picks by default for these kernels.
-EXTRA = {"conv.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "dstyle.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+EXTRA = {"conv.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "dstyle.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
+         "fcfold.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 STAMP = os.path.join(HERE, "build", "stamp.json")

@@ -36,9 +36,16 @@ class FusedSGD:
                 lr=lr * ((T.DOUBLE_BIAS + 1) if is_bias else 1),
                 wd=(wd if T.BIAS_DECAY else 0.0) if is_bias else wd))
 
-    def fuse_wgrad(self, min_numel=1 << 24):
+    def fuse_wgrad(self, min_numel=1 << 24, defer=None):
         """Fuse the update of large filters into their wgrad epilogue (single-GPU only: with data
-        parallelism the gradient must be all-reduced before the update).  Returns the fused names."""
+        parallelism the gradient must be all-reduced before the update).  Returns the fused names.
+        ``defer`` (``I2V_DEFER_FC=1``; OFF by default): 2-D filters among them additionally get a pending-update slot
+        (ops.DeferredUpdate): their update is applied by the NEXT forward on its pass over the filter (i2v_fc_fold_fwd).
+        Correct and parity-tested, but measured slower than forward + fused update as separate kernels (fc6: 1.41 ms against
+        0.43 + 0.79; the headline step 5.0 ms against 4.65 -- DESIGN.md section 5.5), so the step does not use it."""
+        import os
+        if defer is None:
+            defer = os.environ.get("I2V_DEFER_FC", "0") == "1"
         names = []
         for it in self.items:
             p = it["p"]
@@ -48,11 +55,33 @@ class FusedSGD:
                 ops.FUSED_SGD[p.data_ptr()] = (it["m"], it["lr"], self.momentum, it["wd"])
                 self._fused_keys.append(p.data_ptr())
                 names.append(it["name"])
+                if defer and p.dim() == 2 and p.is_cuda and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0:
+                    ops.DEFERRED_SGD[p.data_ptr()] = ops.DeferredUpdate(p)
         return names
 
+    def flush_pending(self):
+        """Apply the updates the deferred layers still hold (before anything outside the training step reads their filters:
+        checkpoints, evaluation, a learning-rate change)."""
+        for k in self._fused_keys:
+            st = ops.DEFERRED_SGD.get(k)
+            if st is not None:
+                st.flush()
+
+    def pending_state(self):
+        """Tensors + host state of the pending updates (for a snapshot of the training state)."""
+        sts = [ops.DEFERRED_SGD[k] for k in self._fused_keys if k in ops.DEFERRED_SGD]
+        return [t for st in sts for t in st.tensors()], [(st.rows, st.armed) for st in sts]
+
+    def restore_pending(self, host):
+        sts = [ops.DEFERRED_SGD[k] for k in self._fused_keys if k in ops.DEFERRED_SGD]
+        for st, (rows, armed) in zip(sts, host):
+            st.rows, st.armed = rows, armed
+
     def unfuse(self):
+        self.flush_pending()
         for k in self._fused_keys:
             ops.FUSED_SGD.pop(k, None)
+            ops.DEFERRED_SGD.pop(k, None)
         self._fused_keys = []
 
     def __del__(self):
@@ -73,11 +102,13 @@ class FusedSGD:
     def state_dict(self):
         """torch.optim.SGD's layout (param_groups + state[i]['momentum_buffer']) in named_parameters order, so that a
         checkpoint written here resumes under torch.optim.SGD and vice versa."""
+        self.flush_pending()
         return {"state": {i: {"momentum_buffer": it["m"].detach().clone()} for i, it in enumerate(self.items)},
                 "param_groups": [{"lr": it["lr"], "momentum": self.momentum, "weight_decay": it["wd"], "params": [i],
                                   "name": it["name"]} for i, it in enumerate(self.items)]}
 
     def load_state_dict(self, sd):
+        self.flush_pending()
         groups = sd["param_groups"]
         flat = [pi for g in groups for pi in g["params"]]
         if len(flat) != len(self.items):
@@ -109,6 +140,7 @@ class FusedSGD:
         return self.items[0]["lr"]
 
     def scale_lr(self, k):
+        self.flush_pending()            # a pending update belongs to the step that computed it: applied at that step's rate
         for it in self.items:
             it["lr"] *= k
             ent = ops.FUSED_SGD.get(it["p"].data_ptr())
@@ -643,8 +675,9 @@ class SGGEmbStep:
                 self._restore(saved)
 
     def _snapshot(self):
-        state = [it["p"].data for it in self.opt.items] + [it["m"] for it in self.opt.items]
-        return (state, [t.clone() for t in state], torch.cuda.get_rng_state(self.dev))
+        pend, host = self.opt.pending_state()
+        state = [it["p"].data for it in self.opt.items] + [it["m"] for it in self.opt.items] + pend
+        return (state, [t.clone() for t in state], torch.cuda.get_rng_state(self.dev), host)
 
     def _restore(self, saved):
         torch.cuda.synchronize(self.dev)
@@ -652,6 +685,7 @@ class SGGEmbStep:
             for t, sv in zip(saved[0], saved[1]):
                 t.copy_(sv)
         torch.cuda.set_rng_state(saved[2], self.dev)
+        self.opt.restore_pending(saved[3])
         self.opt.bump()
 
     def _capture(self, warmup):
@@ -1045,8 +1079,9 @@ class InstanceStyleDStep:
         self.net.RCNN_proposal_target.device_sampling = on
 
     def _snapshot(self):
-        state = [it["p"].data for it in self.opt.items] + [it["m"] for it in self.opt.items]
-        return (state, [t.clone() for t in state], torch.cuda.get_rng_state(self.dev))
+        pend, host = self.opt.pending_state()
+        state = [it["p"].data for it in self.opt.items] + [it["m"] for it in self.opt.items] + pend
+        return (state, [t.clone() for t in state], torch.cuda.get_rng_state(self.dev), host)
 
     def _restore(self, saved):
         torch.cuda.synchronize(self.dev)
@@ -1054,6 +1089,7 @@ class InstanceStyleDStep:
             for t, sv in zip(saved[0], saved[1]):
                 t.copy_(sv)
         torch.cuda.set_rng_state(saved[2], self.dev)
+        self.opt.restore_pending(saved[3])
         self.opt.bump()
 
     def invalidate_graphs(self):

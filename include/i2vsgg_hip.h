@@ -233,7 +233,8 @@ size_t  i2v_conv_split_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t 
 #define I2V_TUNE_ROIALIGN_COLS       12   /* 1 (default): ROIAlign forward on column-pair workgroups (one memory round trip) */
 #define I2V_TUNE_WGRAD_PER_CU        13   /* workgroups per CU a split-over-pixels wgrad launch aims for (default 4) */
 #define I2V_TUNE_WGRAD_XCD           14   /* 1 (default): a filter-gradient split's tiles share an XCD when the split count is a multiple of 8 */
-#define I2V_TUNE_COUNT               15
+#define I2V_TUNE_FC_FOLD             15   /* diagnostic ablation bits of i2v_fc_fold_fwd (0 = the kernel as shipped): 1 no gradient MFMAs, 2 no forward MFMAs, 4 no x loads, 8 no filter / momentum stores, 16 no xp staging */
+#define I2V_TUNE_COUNT               16
 int32_t i2v_set_tuning(int32_t key, int32_t value);
 int32_t i2v_get_tuning(int32_t key);
 /* tuning hook: cfg < 0 = cost model; else low byte = tile shape 0..5 (0xFF = cost model),
@@ -334,6 +335,17 @@ int32_t i2v_conv3x3_winograd4_fwd(const float* x, const float* U, const float* s
 int32_t i2v_conv_wgrad_sgd(const float* x, const float* gy, float* w, float* m, int32_t B, int32_t H, int32_t W,
                            int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                            float lr, float momentum, float weight_decay, void* stream);
+
+/* A large linear layer with ONE pass over its filter per training step (vrd.fc6, resnet_SGG_emb.py:83,:146-151, under the
+ * optimizer step of trainval_net_SGG_emb.py:253-255): the SGD(momentum) update left pending by the previous step's backward --
+ * gw = g_pending^T x_pending, g' = gw + wd*w, m = mom*m + g', w -= lr*m -- is applied tile by tile while this step's forward
+ * y[r][n] += sum_k x[r][k] w[n][k] (+ bias[n]) streams the filter, on the fresh tile.  x (M,K), x_pending (M_pending,K),
+ * g_pending (M_pending,N) row-major; w, m (N,K) updated in place; y (M,N) must arrive zeroed (accumulated with fp32 atomics).
+ * *pending_valid (device int32) == 0: no update, plain forward.  i2v_fc_fold_supported: rows <= 128, N % 64 == 0, K % 64 == 0. */
+int32_t i2v_fc_fold_supported(int32_t M, int32_t M_pending, int32_t N, int32_t K);
+int32_t i2v_fc_fold_fwd(const float* x, const float* x_pending, const float* g_pending, const int32_t* pending_valid,
+                        float* w, float* m, const float* bias, float* y, int32_t M, int32_t M_pending, int32_t N, int32_t K,
+                        float lr, float momentum, float weight_decay, void* stream);
 
 /* epilogue backward, one streaming pass: g_pre = gy * (y>0) [relu]; g = g_pre * scale[n] (scale may be NULL);
  * gbias[n] += column sums of g_pre.  g, gpre and gbias may each be NULL; in-place (g == gy or gpre == gy) allowed.

@@ -27,6 +27,11 @@ def oracle():
 DEV = "cuda:0"
 
 
+def _rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
 def _rois_cases(rng, B, H, W, scale=16.0, n=24):
     """ROIs incl. degenerate (x2<x1), sub-pixel, out-of-image and full-image boxes."""
     bx = syn.boxes(int(rng.integers(1 << 30)), n, H * scale, W * scale, 16, min(H, W) * scale * 0.9)
@@ -965,3 +970,60 @@ def test_filter_gradient_split_groups_on_one_xcd(B, C, N, H, W, k):
     assert float((on.double() - want).abs().max()) <= 1e-4 * scale
     assert float((off.double() - want).abs().max()) <= 1e-4 * scale
     assert float((on - off).abs().max()) <= 2e-5 * scale          # atomics: summation order differs
+
+
+def test_deferred_fc_update_equals_the_fused_update():
+    """i2v_fc_fold_fwd (vrd.fc6 / fc7 in the relation step): the SGD(momentum) update left pending by step i's backward and
+    applied inside step i+1's forward GEMM gives the outputs, filters and momenta of the undeferred schedule (forward, then
+    the fused filter-gradient + SGD kernel) -- rows < 128, pending and current minibatches of different sizes, a K that does
+    not fill every K range, data gradients on and off, flush() of the last update."""
+    from i2vsgg_amd import ops
+    rng = np.random.default_rng(23)
+    for (N, K, rows, need_gx) in ((192, 1600, (64, 37, 128, 100), False), (256, 4096, (128, 128, 128), True)):
+        w0 = (rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
+        b0 = rng.standard_normal((N,), dtype=np.float32) * 0.1
+        xs = [rng.standard_normal((m, K), dtype=np.float32) for m in rows]
+        gys = [rng.standard_normal((m, N), dtype=np.float32) for m in rows]
+        res = []
+        for deferred in (False, True):
+            w = torch.from_numpy(w0.copy()).to(DEV).requires_grad_()
+            b = torch.from_numpy(b0.copy()).to(DEV).requires_grad_()
+            m = torch.full((N, K), 0.01, device=DEV)
+            ops.FUSED_SGD[w.data_ptr()] = (m, 1e-2, 0.9, 5e-4)
+            if deferred:
+                ops.DEFERRED_SGD[w.data_ptr()] = ops.DeferredUpdate(w)
+            ys, gxs, gbs = [], [], []
+            try:
+                for x_np, gy_np in zip(xs, gys):
+                    x = torch.from_numpy(x_np).to(DEV).requires_grad_(need_gx)
+                    y = ops.linear(x, w, b, relu=True)
+                    y.backward(torch.from_numpy(gy_np).to(DEV))
+                    ys.append(y.detach().cpu().numpy().copy())
+                    gxs.append(x.grad.cpu().numpy().copy() if need_gx else None)
+                    gbs.append(b.grad.cpu().numpy().copy())
+                    b.grad = None
+                    if w.grad is not None:           # a shape the fused filter-gradient + SGD kernel does not take: separate update
+                        assert not deferred
+                        ops.sgd_momentum_(w.data, w.grad, m, 1e-2, 0.9, 5e-4)
+                        w.grad = None
+                if deferred:
+                    st = ops.DEFERRED_SGD[w.data_ptr()]
+                    assert st.armed and st.rows == rows[-1]
+                    with torch.no_grad():
+                        y_eval = ops.linear(torch.from_numpy(xs[0]).to(DEV), w, b, relu=True)     # a reader outside the loop: flushes first
+                    assert not st.armed and int(st.valid) == 0
+                else:
+                    with torch.no_grad():
+                        y_eval = ops.linear(torch.from_numpy(xs[0]).to(DEV), w, b, relu=True)
+            finally:
+                ops.FUSED_SGD.clear()
+                ops.DEFERRED_SGD.clear()
+            res.append((ys, gxs, gbs, w.detach().cpu().numpy().copy(), m.cpu().numpy().copy(), y_eval.cpu().numpy().copy()))
+        (y0, gx0, gb0, wa, ma, e0), (y1, gx1, gb1, wb, mb, e1) = res
+        assert not np.array_equal(wa, w0)
+        for i in range(len(rows)):
+            assert _rel_err(y1[i], y0[i]) < 1e-5, (N, K, i)
+            assert _rel_err(gb1[i], gb0[i]) < 1e-5
+            if need_gx:
+                assert _rel_err(gx1[i], gx0[i]) < 1e-5
+        assert _rel_err(wb, wa) < 1e-6 and _rel_err(mb, ma) < 1e-5 and _rel_err(e1, e0) < 1e-5

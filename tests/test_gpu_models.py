@@ -394,6 +394,7 @@ def test_sgg_step_schedules_match_single_graph(cfg):
         assert step.capture(warmup=1) == (mode != "eager"), step.graph_error
         assert step.overlap == (mode == "overlap")
         losses = [float(step().item()) for _ in range(4)]
+        step.opt.flush_pending()            # fc6 / fc7 hold their last update until the next forward (fused update only)
         torch.cuda.synchronize()
         res[key] = (losses, net.vrd.fc7.fc.weight.detach().cpu().numpy().copy())
         step.opt.unfuse()
