@@ -87,6 +87,8 @@ SIGNATURES = {
     "i2v_l2norm_rows_bwd": (_i, [_p, _p, _p, _p, _i, _i, _f, _p]),
     "i2v_bce_rows_fwd": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "i2v_bce_rows_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
+    "i2v_pair_gather_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "i2v_pair_gather_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "i2v_dpixel_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "i2v_dpixel_bwd_workspace_bytes": (_z, []),
     "i2v_dpixel_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p, _z, _p]),

@@ -280,18 +280,26 @@ l2norm_bwd_kernel(const float* __restrict__ g, const float* __restrict__ y, cons
 }
 
 // loss = sum_r w[r] * mean_c bce(z[r][c], t[r][c]),  bce = max(z,0) - z*t + log1p(exp(-|z|))   (BCEWithLogitsLoss)
+// ONE workgroup: a wave per row, rows dealt round robin, the four per-wave sums folded in a fixed order -- no atomics, no
+// clear of the scalar in front of the kernel, the same bits every run (the tensor is ~64 x 62).
 __global__ void __launch_bounds__(256)
 bce_rows_fwd_kernel(const float* __restrict__ z, const float* __restrict__ t, const float* __restrict__ w,
                     float* __restrict__ loss, int rows, int cols) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= rows) return;
-    float s = 0.f;
-    for (int c = lane; c < cols; c += 64) {
-        const float zz = z[(long long)row * cols + c], tt = t[(long long)row * cols + c];
-        s += fmaxf(zz, 0.f) - zz * tt + log1pf(expf(-fabsf(zz)));
+    __shared__ float part[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float acc = 0.f;
+    for (int row = wave; row < rows; row += 4) {
+        float s = 0.f;
+        for (int c = lane; c < cols; c += 64) {
+            const float zz = z[(long long)row * cols + c], tt = t[(long long)row * cols + c];
+            s += fmaxf(zz, 0.f) - zz * tt + log1pf(expf(-fabsf(zz)));
+        }
+        for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh);
+        acc += s / (float)cols * w[row];
     }
-    for (int sh = 32; sh > 0; sh >>= 1) s += __shfl_xor(s, sh);
-    if (lane == 0) atomicAdd(loss, s / (float)cols * w[row]);
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = ((part[0] + part[1]) + part[2]) + part[3];
 }
 __global__ void bce_rows_bwd_kernel(const float* __restrict__ z, const float* __restrict__ t, const float* __restrict__ w,
                                     const float* __restrict__ gloss, float* __restrict__ gz, int rows, int cols) {
@@ -302,6 +310,45 @@ __global__ void bce_rows_bwd_kernel(const float* __restrict__ z, const float* __
         const float zz = z[i];
         const float sg = 1.f / (1.f + expf(-zz));
         gz[i] = (sg - t[i]) * (w[row] / (float)cols) * gl;
+    }
+}
+
+// Subject / object rows of the relation pairs (resnet_SGG_emb.py:170-176: index_select twice, cat): out[p] = [obj[ixs[p]] |
+// obj[ixo[p]]].  Backward as a GATHER over the pairs, one wave per box row: gobj[b] = sum_{p: ixs[p] == b} g[p][:E] +
+// sum_{p: ixo[p] == b} g[p][E:] in pair order -- no atomics, no clear, the same bits every run (tens of pairs per frame).
+__global__ void __launch_bounds__(256)
+pair_gather_fwd_kernel(const float* __restrict__ obj, const long long* __restrict__ ixs, const long long* __restrict__ ixo,
+                       float* __restrict__ out, int n_pairs, int n_box, int E) {
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (p >= n_pairs) return;
+    const long long s = ixs[p], o = ixo[p];
+    const bool sok = s >= 0 && s < n_box, ook = o >= 0 && o < n_box;
+    for (int c = lane; c < E; c += 64) {
+        out[(long long)p * 2 * E + c] = sok ? obj[s * E + c] : 0.f;
+        out[(long long)p * 2 * E + E + c] = ook ? obj[o * E + c] : 0.f;
+    }
+}
+__global__ void __launch_bounds__(256)
+pair_gather_bwd_kernel(const float* __restrict__ g, const long long* __restrict__ ixs, const long long* __restrict__ ixo,
+                       float* __restrict__ gobj, int n_pairs, int n_box, int E) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= n_box) return;
+    for (int c0 = 0; c0 < E; c0 += 64 * 4) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < n_pairs; ++p) {
+            const bool hs = ixs[p] == b, ho = ixo[p] == b;          // uniform per wave
+            if (!hs && !ho) continue;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + u * 64 + lane;
+                if (c < E) a[u] += (hs ? g[(long long)p * 2 * E + c] : 0.f) + (ho ? g[(long long)p * 2 * E + E + c] : 0.f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * 64 + lane;
+            if (c < E) gobj[(long long)b * E + c] = a[u];
+        }
     }
 }
 
@@ -410,9 +457,7 @@ extern "C" int32_t i2v_l2norm_rows_bwd(const float* g, const float* y, const flo
 extern "C" int32_t i2v_bce_rows_fwd(const float* z, const float* t, const float* w, float* loss, int32_t rows,
                                     int32_t cols, void* stream) {
     I2V_CHECK_ARG(z && t && w && loss && rows >= 0 && cols > 0, "bce_rows_fwd: bad argument");
-    hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream);
-    if (rows == 0) return I2V_OK;
-    bce_rows_fwd_kernel<<<i2v_cdiv(rows, 4), 256, 0, (hipStream_t)stream>>>(z, t, w, loss, rows, cols);
+    bce_rows_fwd_kernel<<<1, 256, 0, (hipStream_t)stream>>>(z, t, w, loss, rows, cols);
     I2V_CHECK_LAUNCH("bce_rows_fwd");
     return I2V_OK;
 }
@@ -424,5 +469,23 @@ extern "C" int32_t i2v_bce_rows_bwd(const float* z, const float* t, const float*
     bce_rows_bwd_kernel<<<(int)fmin((double)i2v_cdiv(n, 256), 4096.0), 256, 0, (hipStream_t)stream>>>(z, t, w, gloss, gz,
                                                                                                    rows, cols);
     I2V_CHECK_LAUNCH("bce_rows_bwd");
+    return I2V_OK;
+}
+
+extern "C" int32_t i2v_pair_gather_fwd(const float* obj, const int64_t* ixs, const int64_t* ixo, float* out, int32_t n_pairs,
+                                       int32_t n_box, int32_t emb, void* stream) {
+    I2V_CHECK_ARG(obj && ixs && ixo && out && n_pairs >= 0 && n_box > 0 && emb > 0, "pair_gather_fwd: bad argument");
+    if (n_pairs == 0) return I2V_OK;
+    pair_gather_fwd_kernel<<<i2v_cdiv(n_pairs, 4), 256, 0, (hipStream_t)stream>>>(obj, (const long long*)ixs, (const long long*)ixo,
+                                                                                 out, n_pairs, n_box, emb);
+    I2V_CHECK_LAUNCH("pair_gather_fwd");
+    return I2V_OK;
+}
+extern "C" int32_t i2v_pair_gather_bwd(const float* g, const int64_t* ixs, const int64_t* ixo, float* gobj, int32_t n_pairs,
+                                       int32_t n_box, int32_t emb, void* stream) {
+    I2V_CHECK_ARG(g && ixs && ixo && gobj && n_pairs >= 0 && n_box > 0 && emb > 0, "pair_gather_bwd: bad argument");
+    pair_gather_bwd_kernel<<<i2v_cdiv(n_box, 4), 256, 0, (hipStream_t)stream>>>(g, (const long long*)ixs, (const long long*)ixo,
+                                                                               gobj, n_pairs, n_box, emb);
+    I2V_CHECK_LAUNCH("pair_gather_bwd");
     return I2V_OK;
 }

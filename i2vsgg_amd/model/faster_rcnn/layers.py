@@ -114,29 +114,30 @@ class Bottleneck(nn.Module):
                 self._wino_u, self._wino_key = ops.winograd_filter(w.detach(), WINOGRAD), key
         return self._wino_u
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        """``out`` (forward-only callers): the block's result is written into this channels_last tensor."""
         s1, b1 = self.bn1.folded()
         s2, b2 = self.bn2.folded()
         s3, b3 = self.bn3.folded()
-        if self._fused() and x.is_cuda:
+        if out is None and self._fused() and x.is_cuda:
             down = None
             if self.downsample is not None:
                 down = (self.downsample[0].weight,) + tuple(self.downsample[1].folded())
             nxt = self._next[0] if self._next else None
             return ops.bottleneck(x, self.conv1.weight, self.conv2.weight, self.conv3.weight, (s1, b1), (s2, b2), (s3, b3), down,
                                   in_relu=self.in_relu, out_premasked=nxt is not None and nxt._fused(), stride=self.stride)
-        out = ops.conv2d(x, self.conv1.weight, s1, b1, None, self.stride, 0, relu=True)
+        h = ops.conv2d(x, self.conv1.weight, s1, b1, None, self.stride, 0, relu=True)
         if WINOGRAD and not torch.is_grad_enabled() and self.conv2.cin >= WINOGRAD_MIN_CIN:
             # no gradient is being recorded (the detached SGG_emb backbone, eval): the 3x3 runs as Winograd F(2x2,3x3)
             # with the filter transformed once -- 4x fewer MACs with F(4x4,3x3) (layer3: 63 -> 37 us per layer)
-            out = ops.conv3x3_winograd(out, self._winograd_filter(), s2, b2, relu=True)
+            h = ops.conv3x3_winograd(h, self._winograd_filter(), s2, b2, relu=True)
         else:
-            out = ops.conv2d(out, self.conv2.weight, s2, b2, None, 1, 1, relu=True, winograd=bool(WINOGRAD))   # trained: F(4x4) fwd + dgrad
+            h = ops.conv2d(h, self.conv2.weight, s2, b2, None, 1, 1, relu=True, winograd=bool(WINOGRAD))   # trained: F(4x4) fwd + dgrad
         res = x
         if self.downsample is not None:
             sd, bd = self.downsample[1].folded()
             res = ops.conv2d(x, self.downsample[0].weight, sd, bd, None, self.stride, 0, relu=False)
-        return ops.conv2d(out, self.conv3.weight, s3, b3, res, 1, 0, relu=True)   # +residual, ReLU fused
+        return ops.conv2d(h, self.conv3.weight, s3, b3, res, 1, 0, relu=True, out=out)   # +residual, ReLU fused
 
 
 def make_layer(inplanes, planes, blocks, stride):
@@ -198,11 +199,19 @@ class C4Base(nn.Sequential):
         x = ops.conv2d(x4, self._stem_weight(), s, b, None, 2, 3, relu=True)
         return ops.maxpool3x3s2(x)
 
-    def forward(self, im, tap=False):
+    def forward(self, im, tap=False, out=None):
+        """``out`` (no gradient being recorded): the C4 map is written into this channels_last tensor by the last layer."""
         x = self.stem(im)
         x = self[4](x)
         feat1 = self[5](x)
-        feat = self[6](feat1)
+        if out is None:
+            feat = self[6](feat1)
+        else:
+            blocks = list(self[6])
+            feat = feat1
+            for blk in blocks[:-1]:
+                feat = blk(feat)
+            feat = blocks[-1](feat, out=out)
         return (feat, feat1) if tap else feat
 
 

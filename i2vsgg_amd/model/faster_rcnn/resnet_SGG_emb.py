@@ -101,9 +101,12 @@ class vrd(nn.Module):
                                         self._dev(SpatialFea), self._dev(ix1, torch.long), self._dev(ix2, torch.long))
         return scores, x.detach().cpu().numpy()
 
-    def forward_device(self, fmap, boxes, rel_boxes, spatial, ix1, ix2):
+    def forward_device(self, fmap, boxes, rel_boxes, spatial, ix1, ix2, rois=None, ix12=None):
+        """``rois`` / ``ix12`` (optional): cat(boxes, rel_boxes) and cat(ix1, ix2) when the caller already holds them in one
+        buffer (a training step packs them so on the host)."""
         nb = boxes.size(0)
-        rois = torch.cat((boxes, rel_boxes), 0)
+        if rois is None:
+            rois = torch.cat((boxes, rel_boxes), 0)
         pooled = self.roi_pool(fmap, rois)                       # (nb+nr, 1024, 7, 7), NCHW flatten order
         x6 = pooled.view(pooled.size(0), -1)
         if self.tp is None:
@@ -116,9 +119,7 @@ class vrd(nn.Module):
         h_box, h_rel = torch.split(h, [nb, h.size(0) - nb])      # one cat in the backward (two slices = 2 fills + 2 copies + add)
         obj = self.so_vis_embeddings(h_box)
         x = self.fc8(h_rel)
-        nr = ix1.numel()
-        so = obj.index_select(0, torch.cat((ix1, ix2)))          # one gather / one index_add instead of two each
-        x_so = self.fc_so(so.view(2, nr, -1).permute(1, 0, 2).reshape(nr, -1))     # [subject | object] per pair: one copy
+        x_so = self.fc_so(ops.pair_gather(obj, ix1, ix2))        # [subject | object] per pair: one kernel each way
         lo = self.conv_lo(spatial)
         lo = self.fc_lov(lo.reshape(lo.size(0), -1))
         x = self.fc_rel(self.fc_fusion(torch.cat((x, x_so, lo), 1)))

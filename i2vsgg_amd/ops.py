@@ -451,14 +451,21 @@ def _split_ws(device):
     return ws.buf
 
 
-def _conv_fwd_raw(x, w, scale, shift, res, stride, pad, flags):
+def _conv_fwd_raw(x, w, scale, shift, res, stride, pad, flags, out=None):
     B, Cin, H, W = x.shape
     Cout, _, KH, KW = w.shape
     Ho = (H + 2 * pad - KH) // stride + 1
     Wo = (W + 2 * pad - KW) // stride + 1
     y = None
     sws = _split_ws(x.device)
-    if ARENA is not None and lib.i2v_conv_fwd_splits(B, H, W, Cin, Cout, KH, KW, stride, pad, sws.numel()) == 1:
+    atomics = lib.i2v_conv_fwd_splits(B, H, W, Cin, Cout, KH, KW, stride, pad, sws.numel()) == 1
+    if out is not None and not atomics:
+        # the caller's buffer (a step's static feature-map buffer: no copy afterwards); only when the launch does not
+        # accumulate into its output
+        if tuple(out.shape) != (B, Cout, Ho, Wo) or not out.is_contiguous(memory_format=_CL) or out.dtype != torch.float32:
+            raise ValueError("conv2d(out=...): needs a (%d,%d,%d,%d) channels_last fp32 tensor" % (B, Cout, Ho, Wo))
+        y = out
+    if y is None and ARENA is not None and atomics:
         y = ARENA.take(B, Cout, Ho, Wo)
         if y is not None:
             flags |= EPI_ZEROED
@@ -476,6 +483,9 @@ def _conv_fwd_raw(x, w, scale, shift, res, stride, pad, flags):
                 4 * (x.numel() + w.numel() + y.numel() + (res.numel() if res is not None else 0))):
         check(lib.i2v_conv_fwd(ptr(x), ptr(w), ptr(scale), ptr(shift), ptr(res), ptr(y), B, H, W, Cin, Cout, KH, KW,
                                stride, pad, flags, ptr(sws), sws.numel(), stream()), "conv_fwd")
+    if out is not None and y is not out:
+        out.copy_(y)
+        return out
     return y
 
 
@@ -944,10 +954,19 @@ def bottleneck(x, w1, w2, w3, bn1, bn2, bn3, down=None, in_relu=False, out_prema
                                bool(out_premasked), bool(wino), int(stride))
 
 
-def conv2d(x, w, scale=None, shift=None, res=None, stride=1, pad=0, relu=False, winograd=False):
-    """Implicit-GEMM conv with fused epilogue.  x (B,Cin,H,W), w (Cout,Cin,KH,KW); Cin % 4 == 0."""
+def conv2d(x, w, scale=None, shift=None, res=None, stride=1, pad=0, relu=False, winograd=False, out=None):
+    """Implicit-GEMM conv with fused epilogue.  x (B,Cin,H,W), w (Cout,Cin,KH,KW); Cin % 4 == 0.
+    ``out`` (no gradient being recorded only): the result is written into this channels_last tensor."""
     B, Cin, H, W = x.shape
     Cout, _, KH, KW = w.shape
+    if out is not None:
+        if torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+            raise ValueError("conv2d(out=...) is a forward-only path")
+        flags = (EPI_SCALE if scale is not None else EPI_BIAS if shift is not None else 0) | (EPI_RESIDUAL if res is not None else 0) | \
+            (EPI_RELU if relu else 0)
+        _need_cuda(x, w)
+        return _conv_fwd_raw(as_nhwc(x), as_nhwc(w), scale, shift, as_nhwc(res) if res is not None else None, int(stride), int(pad),
+                             flags, out=out)
     if pad == 0 and KH == H and KW == W and (KH > 1 or KW > 1) and res is None:
         # the filter covers the whole input (vrd.conv_lo's 8x8 layer): one output pixel, i.e. a linear layer
         # over the NHWC-flattened map.  As a conv its dgrad is a full correlation with 63 of 64 taps masked.
@@ -1286,8 +1305,39 @@ class _BceRowsFn(torch.autograd.Function):
 
 
 def bce_rows(z, t, w):
-    """sum_r w[r] * mean_c BCEWithLogits(z[r,c], t[r,c]) as one device scalar (forward and backward one kernel each)."""
+    """sum_r w[r] * mean_c BCEWithLogits(z[r,c], t[r,c]) as one device scalar (forward and backward one kernel each; the
+    forward is one workgroup with a fixed summation order: no clear, no atomics)."""
     return _BceRowsFn.apply(z, t, w)
+
+
+class _PairGatherFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, obj, ixs, ixo):
+        _need_cuda(obj, ixs, ixo)
+        obj, ixs, ixo = obj.contiguous(), ixs.contiguous(), ixo.contiguous()
+        nb, E = obj.shape
+        out = torch.empty((ixs.numel(), 2 * E), device=obj.device, dtype=torch.float32)
+        check(lib.i2v_pair_gather_fwd(ptr(obj), ptr(ixs), ptr(ixo), ptr(out), ixs.numel(), nb, E, stream()), "pair_gather_fwd")
+        ctx.save_for_backward(ixs, ixo)
+        ctx.shape = (nb, E)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ixs, ixo = ctx.saved_tensors
+        nb, E = ctx.shape
+        gobj = torch.empty((nb, E), device=g.device, dtype=torch.float32)
+        check(lib.i2v_pair_gather_bwd(ptr(g.contiguous()), ptr(ixs), ptr(ixo), ptr(gobj), ixs.numel(), nb, E, stream()),
+              "pair_gather_bwd")
+        return gobj, None, None
+
+
+def pair_gather(obj, ixs, ixo):
+    """[obj[ixs] | obj[ixo]] per relation pair: (n_pairs, 2*emb) from obj (n_box, emb), ixs / ixo int64 -- one kernel each way
+    (the aten form is index_select, permute + copy forward; copy, zeros, index_add_ backward), deterministic backward."""
+    if ixs.dtype != torch.long or ixo.dtype != torch.long:
+        raise ValueError("pair_gather needs int64 indices")
+    return _PairGatherFn.apply(obj, ixs, ixo)
 
 
 def winograd_filter(w, m=2):

@@ -293,12 +293,12 @@ class SGGEmbStep:
     meet only at graph edges: the feature-map hand-off (one copy before the fork) and the join.  There is one graph launch
     per step on the caller's stream, no side stream, no event and no priority for a caller to get wrong.
 
-    Minibatches move through a three-slot pipeline so that ``stage()`` may be called at any time between steps:
+    Minibatches move through a two-slot pipeline so that ``stage()`` may be called at any time between steps:
     ``stage(b)`` writes the frames of b (read by the NEXT call's backbone branches) and its head inputs into the ``in``
-    slot; each call starts with cur <- nxt, nxt <- in (two small copies inside the graph) and then runs head(cur) beside
-    backbone(frames).  A batch staged before call k is therefore consumed by the backbone in call k and by the head in
-    call k+1 -- features and boxes / labels of one batch always meet.  ``overlap=False`` (and eager mode): backbone and
-    head of the staged batch in the same call.
+    slot; a call runs head(``cur``) beside backbone(frames) and ends with cur <- in (one small copy inside the graph, behind
+    the head).  A batch staged before call k is therefore consumed by the backbone in call k and by the head in call k+1 --
+    features and boxes / labels of one batch always meet.  ``overlap=False`` (and eager mode): backbone and head of the
+    staged batch in the same call.
 
     Minibatches of a data loader differ in size (the loader pads every batch to its own aspect ratio,
     roibatchLoader.py:162-190) and in the number of boxes and pairs per frame.  The captured step takes them all:
@@ -327,6 +327,7 @@ class SGGEmbStep:
         self.opt = FusedSGD([(n, p) for n, p in net.named_parameters() if n.startswith("vrd.")], vrd_lr)
         self.fused = self.opt.fuse_wgrad() if fuse_sgd else []
         self.loss = torch.zeros((), device=self.dev)
+        self._seed = torch.full((), 1.0 / max(self.world, 1), device=self.dev)
         self.graph_error = None
         self.use_graph = use_graph
         if overlap is None:
@@ -344,7 +345,7 @@ class SGGEmbStep:
         self.cap_boxes, self.cap_pairs = n_frames * n_boxes, n_frames * n_pairs      # rows of the padded head inputs
         self.cap_cells = 0
         self.fmap_flat = self.fmap_head_flat = None
-        self.cur = self.nxt = self.inp = None
+        self.cur = self.inp = None    # head inputs: ``inp`` is written by stage(), ``cur`` read by the head
         self._staged = None           # key of the frame set staged last
         self._fmap_key = None         # key of the frame set whose features ``fmap_flat`` holds
         self.primed = False
@@ -379,9 +380,10 @@ class SGGEmbStep:
     # ------------------------------------------------------------------ data side
     def _layout(self, nb, npair):
         f32, i64 = torch.float32, torch.long
-        return {"boxes": ((nb, 5), f32), "relb": ((npair, 5), f32), "labels": ((npair, self.net.vrd.n_rel), f32),
-                "ixs": ((npair,), i64), "ixo": ((npair,), i64), "masks": ((npair, 4, 32, 32), f32),
-                "wrow": ((npair,), f32), "extent": ((2,), torch.int32)}
+        # boxes and union boxes in ONE roi table (the head pools them in one pass), subject and object indices in one index
+        # vector: what the head would otherwise concatenate every step
+        return {"rois": ((nb + npair, 5), f32), "labels": ((npair, self.net.vrd.n_rel), f32), "ix12": ((2 * npair,), i64),
+                "masks": ((npair, 4, 32, 32), f32), "wrow": ((npair,), f32), "extent": ((2,), torch.int32)}
 
     def _synthetic(self, seed):
         """frames in the layout the device front-end emits (ops.image_prep: NHWC with the stem's
@@ -441,15 +443,14 @@ class SGGEmbStep:
         self.info = np.asarray(info, np.float32).reshape(-1, 3) if not torch.is_tensor(info) else info.detach().cpu().numpy().reshape(-1, 3)
         nb, npair = fields["boxes"].shape[0], fields["relb"].shape[0]
         self.n_rows = nb + npair
-        host = {k: v for k, v in fields.items() if k != "bounds"}
-        host["masks"] = _rasterize_host(fields["bounds"])
+        host_masks = _rasterize_host(fields["bounds"])
         if not self.use_graph:
             # eager launches: exact sizes, nothing is padded
             lay = self._layout(nb, npair)
             if self.inp is None or not self.inp.same_layout(lay):
-                self.cur, self.nxt = (_Slot(lay, self.dev) for _ in range(2))
+                self.cur = _Slot(lay, self.dev)
                 self.inp = _Slot(lay, self.dev, host=True)
-                self._bind()
+                self._bind(nb, npair)
             if self.tp:
                 parallel.assert_same_rows(self.n_rows, "boxes + pairs")
         else:
@@ -457,28 +458,42 @@ class SGGEmbStep:
                 self._grow(nb, npair)
             lay = self._layout(self.cap_boxes, self.cap_pairs)
             if self.inp is None or not self.inp.same_layout(lay):
-                old = (self.cur, self.nxt) if self.inp is not None else None
-                self.cur, self.nxt = (_Slot(lay, self.dev) for _ in range(2))
+                old, old_caps = (self.cur if self.inp is not None else None), getattr(self, "_caps", None)
+                self.cur = _Slot(lay, self.dev)
                 self.inp = _Slot(lay, self.dev, host=True)
-                self._bind()
-                if old is not None and self._pipelined:          # batches in flight move to the larger slots
-                    for new, o in zip((self.cur, self.nxt), old):
-                        for name, v in o.views.items():
-                            new.views[name][tuple(slice(0, d) for d in v.shape)].copy_(v)
-        host["extent"] = np.zeros((2,), np.int32)                # (h, w) of the C4 maps; filled by _measure() for a new size
+                self._bind(self.cap_boxes, self.cap_pairs)
+                if old is not None and self._pipelined:          # the batch in flight moves to the larger slot
+                    ob, op = old_caps
+                    o, n = old.views, self.cur.views
+                    n["rois"][:ob].copy_(o["rois"][:ob]); n["rois"][self.cap_boxes:self.cap_boxes + op].copy_(o["rois"][ob:])
+                    n["ix12"][:op].copy_(o["ix12"][:op]); n["ix12"][self.cap_pairs:self.cap_pairs + op].copy_(o["ix12"][op:])
+                    for name in ("labels", "masks", "wrow"):
+                        n[name][:op].copy_(o[name])
+                    n["extent"].copy_(o["extent"])
+        cb, cp = (nb, npair) if not self.use_graph else (self.cap_boxes, self.cap_pairs)
+        rois = np.zeros((cb + cp, 5), np.float32)
+        rois[:nb], rois[cb:cb + npair] = fields["boxes"], fields["relb"]
+        ix12 = np.zeros((2 * cp,), np.int64)
+        ix12[:npair], ix12[cp:cp + npair] = fields["ixs"], fields["ixo"]
+        host = {"rois": rois, "labels": fields["labels"], "ix12": ix12, "masks": host_masks, "wrow": fields["wrow"],
+                "extent": np.zeros((2,), np.int32)}                  # (h, w) of the C4 maps; filled by _measure() for a new size
         if fs.fh is not None:
             host["extent"][:] = (fs.fh, fs.fw)
         self.inp.write_host(host)
         self._staged = key
         first = not self.primed and self.cur is not None and not self._pipelined
         if first and not getattr(self, "_filled", False):
-            # the very first batch: every stage of the pipeline starts out holding it
-            self.cur.buf.copy_(self.inp.buf); self.nxt.buf.copy_(self.inp.buf)
+            # the very first batch: the head's slot starts out holding it
+            self.cur.buf.copy_(self.inp.buf)
             self._filled = True
 
-    def _bind(self):
-        for k, v in self.cur.views.items():
-            setattr(self, k, v)                                  # the head reads the ``cur`` slot
+    def _bind(self, nb, npair):
+        """The head reads the ``cur`` slot: its fields, and the box / pair halves of the packed ones, as attributes."""
+        v = self.cur.views
+        self.rois, self.ix12, self.labels, self.masks, self.wrow = v["rois"], v["ix12"], v["labels"], v["masks"], v["wrow"]
+        self.boxes, self.relb = v["rois"][:nb], v["rois"][nb:]
+        self.ixs, self.ixo = v["ix12"][:npair], v["ix12"][npair:]
+        self._caps = (nb, npair)
         self._filled = False
 
     def stage_batch(self, data):
@@ -519,12 +534,12 @@ class SGGEmbStep:
         re-capturing when it arrives)."""
         self._reserve_cells(((h + 15) // 16 + 1) * ((w + 15) // 16 + 1))
 
-    def _store_fmap(self, fs, fm, f=None):
-        """Feature maps of frame set ``fs`` (all frames, or frame f) into the packed buffer."""
+    def _fmap_dst(self, fs, f=None):
+        """Where the feature maps of frame set ``fs`` (all frames, or frame f) live in the packed buffer: the backbone's last
+        layer writes there (``RCNN_base(..., out=)``: no copy afterwards)."""
         n, c = fs.key[0], self._channels
-        cells = fs.fh * fs.fw
-        dst = self.fmap_flat[:n * cells * c].view(n, fs.fh, fs.fw, c).permute(0, 3, 1, 2)
-        (dst if f is None else dst[f:f + 1]).copy_(fm)
+        dst = self.fmap_flat[:n * fs.fh * fs.fw * c].view(n, fs.fh, fs.fw, c).permute(0, 3, 1, 2)
+        return dst if f is None else dst[f:f + 1]
 
     def _measure(self, fs):
         """First sight of a frame size: one eager pass tells the extent of its C4 map (and sizes the eager arena)."""
@@ -538,21 +553,25 @@ class SGGEmbStep:
                 g = self._geom_dev(fs)
                 self.inp.views["extent"].copy_(g)
                 if not self._pipelined:
-                    self.cur.views["extent"].copy_(g); self.nxt.views["extent"].copy_(g)
+                    self.cur.views["extent"].copy_(g)
 
     # ------------------------------------------------------------------ the two halves of a step
     def _rotate(self):
+        """Sequential schedule: the head of this call works on the batch staged last."""
+        if not self._pipelined:
+            self.cur.buf.copy_(self.inp.buf)
+
+    def _rotate_after_head(self):
+        """Overlapped schedule: the head of call k reads ``cur`` = batch k-1 while the backbone branches work on the frames of
+        batch k; once the head is done, batch k's head inputs (still in ``inp``: the next stage() is ordered behind this call)
+        move to ``cur`` for call k+1.  ONE small copy per step."""
         if self._pipelined:
-            self.cur.buf.copy_(self.nxt.buf)
-            self.nxt.buf.copy_(self.inp.buf)
-        else:
             self.cur.buf.copy_(self.inp.buf)
 
     def _backbone(self, fs):
         with self.ctx_bb:
             with torch.no_grad():
-                fmap = self.net.RCNN_base(fs.im)
-            self._store_fmap(fs, fmap)           # static address across replays; 20 MB, ~8 us
+                self.net.RCNN_base(fs.im, out=self._fmap_dst(fs))          # static address across replays
         self._fmap_key = fs.key
 
     def _backbone_per_frame(self, fs, join=True):
@@ -568,8 +587,7 @@ class SGGEmbStep:
             with torch.cuda.stream(st):
                 with fs.ctx[f]:
                     with torch.no_grad():
-                        fm = self.net.RCNN_base(fs.im[f:f + 1])
-                    self._store_fmap(fs, fm, f)
+                        self.net.RCNN_base(fs.im[f:f + 1], out=self._fmap_dst(fs, f))
         if join:
             for f in range(n):
                 main.wait_stream(self._frame_streams[f])
@@ -584,15 +602,17 @@ class SGGEmbStep:
                 fmap = ops.PackedMaps(src, self.n_frames, self._channels, self.cur.views["extent"])
             else:
                 fmap = self.fmap
-            score, x = self.net.vrd.forward_device(fmap, self.boxes, self.relb, self.masks, self.ixs, self.ixo)
+            score, x = self.net.vrd.forward_device(fmap, self.boxes, self.relb, self.masks, self.ixs, self.ixo,
+                                                   rois=self.rois, ix12=self.ix12)
             loss = ops.bce_rows(score, self.labels, self.wrow)     # sum_r wrow[r] * mean_c BCE: one kernel each way
             if self.trace is not None:
                 self._record(loss, fmap, score, x)
             self.opt.zero_grad()
-            (loss / self.world).backward()
+            loss.backward(self._seed)                              # d(loss / world): a resident scalar, no division node
             self.loss.copy_(loss.detach())
             parallel.all_reduce_grads(self.opt.params())           # world > 1: RCCL, captured with the rest of the branch
             self.opt.step()
+        self._rotate_after_head()
 
     @torch.no_grad()
     def _record(self, loss, fmap, score, x):
@@ -636,11 +656,11 @@ class SGGEmbStep:
 
     def prime(self):
         """Overlapped schedule only: backbone pass of the batch staged first, so that the first call's head finds its
-        features (``nxt`` <- ``in`` as a call would have done)."""
+        features (``cur`` <- ``in`` as the end of a call would have done)."""
         if self.overlap and not self.primed:
             fs = self.shapes[self._staged]
             self._measure(fs)
-            self.nxt.buf.copy_(self.inp.buf)
+            self.cur.buf.copy_(self.inp.buf)
             self._backbone(fs)
         self.primed = True
 

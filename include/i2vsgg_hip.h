@@ -383,7 +383,8 @@ int32_t i2v_dstyle_fused_fwd(const float* x, const float* w1, const float* b1, c
  * l2norm_rows: y = x / max(||x||_2, eps) per row = F.normalize(x, p=2, dim=1) (resnet_SGG_emb.py:210-213) and its
  *   backward gx = (g - y (g.y)) / max(||x||, eps); inv_norm (rows) is kept for the backward.
  * bce_rows: loss = sum_r w[r] * mean_c BCEWithLogits(z[r][c], t[r][c]) (faster_rcnn_SGG_emb.py:269 with the per-frame
- *   mean folded into w) -> one device scalar; backward gz = (sigmoid(z) - t) * w[r] / cols * gloss[0]. */
+ *   mean folded into w) -> one device scalar, written (not accumulated) by a single workgroup in a fixed summation
+ *   order; backward gz = (sigmoid(z) - t) * w[r] / cols * gloss[0]. */
 int32_t i2v_l2norm_rows_fwd(const float* x, float* y, float* inv_norm, int32_t rows, int32_t cols, float eps, void* stream);
 int32_t i2v_l2norm_rows_bwd(const float* g, const float* y, const float* inv_norm, float* gx, int32_t rows, int32_t cols,
                             float eps, void* stream);
@@ -391,6 +392,14 @@ int32_t i2v_bce_rows_fwd(const float* z, const float* t, const float* w, float* 
                          void* stream);
 int32_t i2v_bce_rows_bwd(const float* z, const float* t, const float* w, const float* gloss, float* gz, int32_t rows,
                          int32_t cols, void* stream);
+
+/* Subject / object rows of the relation pairs (resnet_SGG_emb.py:170-176: two index_selects + cat):
+ * out[p] = [obj[ixs[p]] | obj[ixo[p]]] (n_pairs, 2*emb) from obj (n_box, emb); an index outside [0, n_box) yields zeros.
+ * Backward: gobj (n_box, emb) written in full (no clear needed), pair contributions summed in pair order (deterministic). */
+int32_t i2v_pair_gather_fwd(const float* obj, const int64_t* ixs, const int64_t* ixo, float* out, int32_t n_pairs,
+                            int32_t n_box, int32_t emb, void* stream);
+int32_t i2v_pair_gather_bwd(const float* g, const int64_t* ixs, const int64_t* ixo, float* gobj, int32_t n_pairs,
+                            int32_t n_box, int32_t emb, void* stream);
 
 /* ---- netD_pixel, fused (instance-level discriminator) ---------------------------------
  * replaces netD_pixel.forward (resnet_instance_styleD_bilinear.py:38-83: GRL, conv1 1024->512 + ReLU, conv2

@@ -1027,3 +1027,37 @@ def test_deferred_fc_update_equals_the_fused_update():
             if need_gx:
                 assert _rel_err(gx1[i], gx0[i]) < 1e-5
         assert _rel_err(wb, wa) < 1e-6 and _rel_err(mb, ma) < 1e-5 and _rel_err(e1, e0) < 1e-5
+
+
+def test_pair_gather_and_single_workgroup_bce_match_torch():
+    """ops.pair_gather ([obj[ixs] | obj[ixo]] per relation pair, resnet_SGG_emb.py:170-176) forward and backward against
+    index_select / cat under autograd (repeated and unused rows, a pad index pair (0, 0)); ops.bce_rows against
+    F.binary_cross_entropy_with_logits with the per-frame means folded into row weights, bit-stable across runs."""
+    from i2vsgg_amd import ops
+    g = torch.Generator().manual_seed(4)
+    obj = torch.randn(37, 300, generator=g).to(DEV).requires_grad_()
+    ixs = torch.tensor([3, 3, 0, 36, 5, 0, 0, 12, 3], device=DEV)
+    ixo = torch.tensor([4, 9, 0, 1, 5, 0, 0, 3, 36], device=DEV)
+    gy = torch.randn(9, 600, generator=g).to(DEV)
+    out = ops.pair_gather(obj, ixs, ixo)
+    out.backward(gy)
+    got_g = obj.grad.clone()
+    obj.grad = None
+    ref = torch.cat((obj.index_select(0, ixs), obj.index_select(0, ixo)), 1)
+    ref.backward(gy)
+    assert torch.equal(out, ref)
+    torch.testing.assert_close(got_g, obj.grad, rtol=1e-6, atol=1e-6)
+    assert float(got_g[20].abs().max()) == 0.0                   # a box no pair refers to: zeros, written not accumulated
+    z = torch.randn(64, 62, generator=g).to(DEV).requires_grad_()
+    t = (torch.rand(64, 62, generator=g) < 0.05).float().to(DEV)
+    w = torch.cat((torch.full((40,), 1 / 80.0), torch.full((20,), 1 / 40.0), torch.zeros(4))).to(DEV)      # 2 frames + 4 pad rows
+    a = ops.bce_rows(z, t, w)
+    a.backward()
+    ga = z.grad.clone()
+    z.grad = None
+    per = torch.nn.functional.binary_cross_entropy_with_logits(z, t, reduction="none").mean(1)
+    b = 0.5 * (per[:40].mean() + per[40:60].mean())
+    b.backward()
+    assert abs(float(a) - float(b)) < 1e-6 * abs(float(b))
+    torch.testing.assert_close(ga, z.grad, rtol=1e-5, atol=1e-9)
+    assert all(float(ops.bce_rows(z.detach(), t, w)) == float(a) for _ in range(5))
