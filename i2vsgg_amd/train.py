@@ -856,10 +856,12 @@ class _DomainSet:
 
     def __init__(self, key, device, batched, branches):
         n, hs, ws, ht, wt = key[:5]
-        z = lambda h, w: torch.zeros((n, 3, h, w), device=device)
+        # frames live in the layout the stem consumes (NHWC, zero fourth channel: ops.image_prep's blob): stage() does the
+        # NCHW3 -> NHWC4 placement once, outside the step, instead of a fill + a copy per branch inside it
+        z = lambda b, h, w: torch.zeros((b, 4, h, w), device=device).contiguous(memory_format=torch.channels_last)
         self.key = key
-        self.im_s, self.im_t = z(hs, ws), z(ht, wt)
-        self.im_st = torch.zeros((2 * n, 3, hs, ws), device=device) if (batched and (hs, ws) == (ht, wt)) else None
+        self.im_s, self.im_t = z(n, hs, ws), z(n, ht, wt)
+        self.im_st = z(2 * n, hs, ws) if (batched and (hs, ws) == (ht, wt)) else None
         self.ctx = ops.LaunchContext(device)
         self.ctx_src = ops.LaunchContext(device) if branches else None
         self.ctx_tgt = ops.LaunchContext(device) if branches else None
@@ -957,7 +959,9 @@ class InstanceStyleDStep:
         self._cur = ds
         self.info0 = (int(info0[0]), int(info0[1]))
         cp = lambda dst, src: dst.copy_(src, non_blocking=True)
-        cp(ds.im_s, im_s); cp(ds.im_t, im_t); cp(self.info, info); cp(self.info_t, info_t); cp(self.gt, gt); cp(self.nb, nb)
+        dev3 = lambda t: t if t.is_cuda else t.to(self.dev, non_blocking=True)
+        ds.im_s[:, :3].copy_(dev3(im_s)); ds.im_t[:, :3].copy_(dev3(im_t))
+        cp(self.info, info); cp(self.info_t, info_t); cp(self.gt, gt); cp(self.nb, nb)
         if ds.im_st is not None:
             ds.im_st[:n].copy_(ds.im_s); ds.im_st[n:].copy_(ds.im_t)
 
