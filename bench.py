@@ -276,6 +276,11 @@ def cpu_baseline_stages(threads):
     return res
 
 
+def train_mod():
+    from i2vsgg_amd import train
+    return train
+
+
 # ----------------------------------------------------------------------------- measurement helpers
 def timed_steps(step_fn, warmup, steps, dev):
     import torch
@@ -312,7 +317,7 @@ def profile_eager(body, n_prof, dev):
     return [dict(t=e0.elapsed_time(e1) * 1e-3, flops=fl, tag=tag, desc=d, bytes=by) for e0, e1, fl, tag, d, by in rec]
 
 
-def pmc_traffic(kernel_key, names=("r02_pmc_summary.json", "r01_pmc_summary.json")):
+def pmc_traffic(kernel_key, names=("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json")):
     """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ for this round
     (rocprofv3 cannot run inside the timed process); None when there is no summary."""
     for name in names:
@@ -510,7 +515,7 @@ def run_instance_styled(a, rank, world, dev, steps, warmup, frames_per_rank=4):
     achieved = f_wg_exec / max(t_wg, 1e-12) / 1e12
     # the PMC passes of THIS configuration (tools/profile_bench.sh isd), not the headline's (whose conv_wgrad2_f32 launches
     # are the relation head's skinny GEMMs)
-    traffic, traffic_src = pmc_traffic("conv_wgrad2_f32", ("r02_instance_styled_pmc_summary.json",))
+    traffic, traffic_src = pmc_traffic("conv_wgrad2_f32", ("r03_instance_styled_pmc_summary.json", "r02_instance_styled_pmc_summary.json"))
     line = {
         "metric": "frames/sec (600x1000, 32 ROI/frame)", "value": world * 2 * frames_per_rank * steps / elapsed,
         "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
@@ -680,6 +685,26 @@ def main():
             line["also"] = {"sgg_loader": {k: ld[k] for k in ("value", "unit", "ms_per_step", "steps", "data", "config")}}
             s1.opt.unfuse()
             del s1, n1
+            torch.cuda.empty_cache()
+        if world == 1 and not a.no_also:
+            # what bounds the step, NOT the metric: the same step with the K loops of the pointwise / plain GEMMs on
+            # the bf16 matrix pipe as a three-term split (I2V_TUNE_GEMM_X3: 16-bit-mantissa products, fp32 everything else)
+            from i2vsgg_amd._lib import lib as _l
+            _l.i2v_set_tuning(16, 1)
+            try:
+                nx = train_mod().build_sgg_net(a.layers, device=dev)
+                sx = train_mod().SGGEmbStep(nx, 2, seed=1 + rank, device=dev, use_graph=not a.no_graph)
+                sx.capture(warmup=2)
+                el = timed_steps(sx, a.warmup, a.steps, dev)
+                line["also"]["sgg_gemm_x3"] = {
+                    "value": world * 2 * a.steps / el, "unit": "frames/s", "ms_per_step": 1e3 * el / a.steps, "steps": a.steps,
+                    "dtype": "f32 in / out / accumulate; products of the pointwise and plain GEMMs as hi*hi + hi*lo + lo*hi on bf16 MFMA "
+                             "(16 mantissa bits): REDUCED precision, an experiment, not the metric",
+                    "loss": float(sx.loss), "loss_fp32": line["config"]["loss"]}
+                sx.opt.unfuse()
+                del sx, nx
+            finally:
+                _l.i2v_set_tuning(16, 0)
             torch.cuda.empty_cache()
         if world == 1 and not a.no_also:
             # configs[2] under the same driver clock: fewer steps (a step is ~15x longer), its own roofline block

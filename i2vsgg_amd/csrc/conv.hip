@@ -23,6 +23,8 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int BK = 16;          // k per LDS stage of the wgrad kernel
 constexpr int KTAB_MAX = 2560;  // filter-tap table entries (K/4): KH*KW*Cin <= 10240 for non-1x1 filters
@@ -695,7 +697,13 @@ conv_igemm_f32(const ConvP p_in) {
 // 16-B store per fragment, no LDS round trip, no barrier.  Staging, swizzled LDS image and the K loop are conv_igemm_f32's.
 // Split-K (<= kSplitInKernelMax): partial tiles go to the caller's workspace in REGISTER order (fragment, wave, lane), the
 // last workgroup to arrive sums them in split order -- same protocol as conv_igemm_f32, whole-wave 1-KB rows.
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool CLK = false, bool MASK = false>
+// X3 (opt-in, I2V_TUNE_GEMM_X3; the default build of every step is the fp32 MFMA): the products run on the bf16 matrix
+// pipe as a THREE-term split -- each fp32 operand is staged as hi = bf16(x), lo = bf16(x - hi) (16 mantissa bits together)
+// and a * b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi, accumulated in fp32 by v_mfma_f32_16x16x32_bf16: one 16-cycle MFMA covers
+// 32 k where the fp32 form needs eight 32-cycle ones, so the K loop costs 3/16 of its fp32 time; the dropped a_lo b_lo term is
+// 2^-16 of a product.  Inputs, outputs, accumulators and the epilogue stay fp32; the LDS row (32 k) keeps its 128 bytes
+// (16-byte columns 0-3 = hi of k 8c..8c+7, columns 4-7 = lo), the accumulator layout is that of every 16x16 MFMA.
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool CLK = false, bool MASK = false, bool X3 = false>
 __global__ void __launch_bounds__(THREADS)
 conv_gemm_f32(const ConvP p_in) {
     ConvP p = p_in;
@@ -757,16 +765,31 @@ conv_gemm_f32(const ConvP p_in) {
         for (int q = 0; q < B_LD; ++q)
             rb[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, b_vk[q] | kinv, so, 0));
     };
+    // X3: four fp32 (k = 4 kc .. 4 kc + 3) -> four hi bf16 (8 bytes into column kc/2, half kc&1) + four lo bf16 (column 4 + kc/2)
+    auto split_store = [&](float* rowp, int row, float4 v) {
+        const bf16x4 hi = __builtin_convertvector((f32x4){v.x, v.y, v.z, v.w}, bf16x4);
+        const f32x4 hf = __builtin_convertvector(hi, f32x4);
+        const bf16x4 lo = __builtin_convertvector((f32x4){v.x - hf[0], v.y - hf[1], v.z - hf[2], v.w - hf[3]}, bf16x4);
+        const int sw = (row >> 1) & 7;
+        *(bf16x4*)&rowp[((((kc >> 1)) ^ sw) << 2) + ((kc & 1) << 1)] = hi;
+        *(bf16x4*)&rowp[(((4 + (kc >> 1)) ^ sw) << 2) + ((kc & 1) << 1)] = lo;
+    };
     auto sstore = [&](int S) {
 #pragma unroll
         for (int q = 0; q < A_LD; ++q) {
             const int row = (tid >> 3) + q * (THREADS / 8);
-            if (row < BM) *(float4*)&As[S][row * BKS + ((kc ^ ((row >> 1) & 7)) << 2)] = ra[q];
+            if (row < BM) {
+                if constexpr (X3) split_store(&As[S][row * BKS], row, ra[q]);
+                else *(float4*)&As[S][row * BKS + ((kc ^ ((row >> 1) & 7)) << 2)] = ra[q];
+            }
         }
 #pragma unroll
         for (int q = 0; q < B_LD; ++q) {
             const int row = (tid >> 3) + q * (THREADS / 8);
-            if (row < BN) *(float4*)&Bs[S][row * BKS + ((kc ^ ((row >> 1) & 7)) << 2)] = rb[q];
+            if (row < BN) {
+                if constexpr (X3) split_store(&Bs[S][row * BKS], row, rb[q]);
+                else *(float4*)&Bs[S][row * BKS + ((kc ^ ((row >> 1) & 7)) << 2)] = rb[q];
+            }
         }
     };
     if (p.knob > 0) {                     // experiment (I2V_TUNE_STAGGER): co-resident workgroups start ~knob kcycles apart
@@ -823,6 +846,31 @@ conv_gemm_f32(const ConvP p_in) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     auto compute = [&](int buf) {
+        if constexpr (X3) {
+            // lane (fr, fg): 8 bf16 = k 8 fg .. 8 fg + 7 of row fr, hi from column fg, lo from column 4 + fg: one MFMA covers the stage
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = (wm * TM + i) * 16 + fr;
+                ah[i] = *(const bf16x8*)&As[buf][row * BKS + ((fg ^ ((row >> 1) & 7)) << 2)];
+                al[i] = *(const bf16x8*)&As[buf][row * BKS + (((4 + fg) ^ ((row >> 1) & 7)) << 2)];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = (wn * TN + j) * 16 + fr;
+                bh[j] = *(const bf16x8*)&Bs[buf][row * BKS + ((fg ^ ((row >> 1) & 7)) << 2)];
+                bl[j] = *(const bf16x8*)&Bs[buf][row * BKS + (((4 + fg) ^ ((row >> 1) & 7)) << 2)];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {          // small terms first; weights are the ROW operand as below
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+                }
+            return;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             float4 av[TM], bv[TN];
@@ -1098,7 +1146,11 @@ void launch_tile(const ConvP& p, bool spec, hipStream_t st) {
         const size_t lds_g = (size_t)(2 * (BM + BN) * BKS) * sizeof(float);
         if (p.flags & I2V_EPI_MASK) conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true><<<grid, THREADS, lds_g, st>>>(p);
         else if (p.clk) conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, true><<<grid, THREADS, lds_g, st>>>(p);
-        else conv_gemm_f32<WAVES_M, WAVES_N, TM, TN><<<grid, THREADS, lds_g, st>>>(p);
+        else if (g_i2v_tuning[I2V_TUNE_GEMM_X3]) {      // opt-in: 3-term bf16 split on the bf16 matrix pipe
+            static bool once_x = [] { set_max_lds(conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, false, true>); return true; }();
+            (void)once_x;
+            conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, false, true><<<grid, THREADS, lds_g, st>>>(p);
+        } else conv_gemm_f32<WAVES_M, WAVES_N, TM, TN><<<grid, THREADS, lds_g, st>>>(p);
         return;
     }
     if (spec) conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, true><<<grid, 2 * THREADS, lds, st>>>(p);

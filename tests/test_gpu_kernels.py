@@ -1061,3 +1061,46 @@ def test_pair_gather_and_single_workgroup_bce_match_torch():
     assert abs(float(a) - float(b)) < 1e-6 * abs(float(b))
     torch.testing.assert_close(ga, z.grad, rtol=1e-5, atol=1e-9)
     assert all(float(ops.bce_rows(z.detach(), t, w)) == float(a) for _ in range(5))
+
+
+def test_gemm_three_term_bf16_split_is_opt_in_and_16_bit_accurate():
+    """I2V_TUNE_GEMM_X3 (off by default): the pointwise / plain-GEMM kernel with its products on the bf16 matrix pipe as
+    hi*hi + hi*lo + lo*hi.  (1) operands that are exact in bf16 (small integers) give the fp32 kernel's bits -- the layout of
+    the split LDS image and of the 16x16x32 fragments is right for every tile shape, K tails, split-K, the fused epilogue;
+    (2) random fp32 operands agree with the fp32 kernel to ~2^-16 of the output scale; (3) the switch is off unless set."""
+    from i2vsgg_amd import ops
+    from i2vsgg_amd._lib import lib
+    X3 = 16
+    assert lib.i2v_get_tuning(X3) == 0
+    rng = np.random.default_rng(31)
+    shapes = [(4788, 256, 1024), (2394, 1024, 256), (600, 64, 256), (9375, 128, 512), (128, 4096, 4096), (333, 100, 36)]
+    try:
+        for (M, K, N) in shapes:
+            for integers in (True, False):
+                if integers:
+                    x = rng.integers(-8, 9, (M, K)).astype(np.float32)
+                    w = rng.integers(-4, 5, (N, K)).astype(np.float32)
+                else:
+                    x = rng.standard_normal((M, K), dtype=np.float32)
+                    w = (rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
+                xd = torch.from_numpy(x).to(DEV).view(M, K, 1, 1).contiguous(memory_format=torch.channels_last)
+                wd = torch.from_numpy(w).to(DEV).view(N, K, 1, 1).contiguous(memory_format=torch.channels_last)
+                sc = torch.from_numpy(rng.uniform(0.5, 1.5, N).astype(np.float32)).to(DEV) if not integers else None
+                sh = torch.from_numpy(rng.uniform(-1, 1, N).astype(np.float32)).to(DEV) if not integers else None
+                res = torch.from_numpy(rng.standard_normal((M, N), dtype=np.float32)).to(DEV).view(M, N, 1, 1) if not integers else None
+                out = []
+                for mode in (0, 1):
+                    lib.i2v_set_tuning(X3, mode)
+                    with torch.no_grad():
+                        out.append(ops.conv2d(xd, wd, sc, sh, res, 1, 0, relu=not integers).view(M, N).cpu().numpy())
+                if integers:
+                    assert np.array_equal(out[0], out[1]), (M, K, N)
+                else:
+                    ref = np.maximum((x.astype(np.float64) @ w.astype(np.float64).T) * sc.cpu().numpy() + sh.cpu().numpy()
+                                     + res.view(M, N).cpu().numpy(), 0)
+                    scale = np.abs(ref).max()
+                    e32, e3 = np.abs(out[0] - ref).max() / scale, np.abs(out[1] - ref).max() / scale
+                    assert e32 < 3e-6 and e3 < 4e-5, (M, K, N, e32, e3)
+                    assert not np.array_equal(out[0], out[1])
+    finally:
+        lib.i2v_set_tuning(X3, 0)

@@ -27,7 +27,7 @@ else:
     body = step._body_branches
 body()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     body()
     torch.cuda.synchronize()
 rows = []
@@ -44,3 +44,11 @@ for a in prof.key_averages(group_by_stack_n=8):
 print("aten ops with device time in one eager %s step: %d calls" % (which, sum(r[0] for r in rows)))
 for n, t, k, f in sorted(rows, key=lambda r: -r[0]):
     print("%4d %8.1f us  %-34s %s" % (n, t, k, f))
+
+print("\nlargest by device time, with input shapes:")
+big = []
+for a in prof.key_averages(group_by_input_shape=True):
+    if a.device_time_total > 0 and a.key.startswith("aten::"):
+        big.append((a.device_time_total, a.count, a.key, str(a.input_shapes)[:110]))
+for t, n, k, sh in sorted(big, reverse=True)[:45]:
+    print("%8.1f us %4d  %-26s %s" % (t, n, k, sh))
