@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="sgg", choices=["sgg", "instance_styled", "joint", "res50"])
-    ap.add_argument("--data", default="resident", choices=["resident", "loader"],
+    ap.add_argument("--data", default="resident", choices=["resident", "loader", "loader_u8"],
                     help="resident: one synthetic minibatch resident in HBM (the headline); loader: roibatchLoader minibatches of "
                          "varying size staged from pinned host memory every step (config sgg; also reported beside the headline)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
@@ -428,7 +428,7 @@ def run_sgg(a, rank, world, dev, frames_per_rank=2):
 
 
 # ----------------------------------------------------------------------------- configs[1] fed by the data layer
-def run_sgg_loader(a, rank, world, dev, frames_per_rank=2, n_batches=8):
+def run_sgg_loader(a, rank, world, dev, frames_per_rank=2, n_batches=8, u8=False):
     """The same step fed as the reference loop is fed (trainval_net_SGG_emb.py:77-91,204-217): combined_roidb ->
     roibatchLoader(path_return=True) -> DataLoader(sampler) on a synthetic imdb whose frames come in five resolutions with
     4-32 boxes and 2-32 annotated pairs each.  ``n_batches`` collated minibatches are kept in pinned host memory (the loader's
@@ -439,16 +439,21 @@ def run_sgg_loader(a, rank, world, dev, frames_per_rank=2, n_batches=8):
     from i2vsgg_amd import train
     from i2vsgg_amd.model.utils import config as c
     from i2vsgg_amd.model.utils.net_utils import sampler
-    from i2vsgg_amd.roi_data_layer.roibatchLoader import roibatchLoader
+    from i2vsgg_amd.roi_data_layer.roibatchLoader import collate_device_prep, roibatchLoader
     from i2vsgg_amd.roi_data_layer.roidb import combined_roidb
     c.cfg.TRAIN.USE_FLIPPED = False
     imdb, roidb, ratio_list, ratio_index = combined_roidb("synthetic_%d_v" % (2 * n_batches * frames_per_rank * world))
-    ds = roibatchLoader(roidb, ratio_list, ratio_index, frames_per_rank, imdb.num_classes, training=True, path_return=True)
-    dl = torch.utils.data.DataLoader(ds, batch_size=frames_per_rank, pin_memory=True,
+    # u8: the device front-end form of the loader (uint8 frames as decoded; BGR swap, mean subtraction, resize and canvas
+    # placement by i2v_image_prep inside the timed region)
+    ds = roibatchLoader(roidb, ratio_list, ratio_index, frames_per_rank, imdb.num_classes, training=True, path_return=True,
+                        device_prep=u8)
+    dl = torch.utils.data.DataLoader(ds, batch_size=frames_per_rank, pin_memory=True, collate_fn=collate_device_prep if u8 else None,
                                      sampler=sampler(len(roidb), frames_per_rank, rank=rank, world=world, seed=c.cfg.RNG_SEED))
     t0 = time.perf_counter()
     batches = []
     for d in dl:
+        if u8 and (not isinstance(d, list) or int(d[1][0][1]) <= 0):
+            continue                      # a square-trim minibatch goes through the host form in a training loop
         batches.append(d)
         if len(batches) == n_batches:
             break
@@ -456,28 +461,33 @@ def run_sgg_loader(a, rank, world, dev, frames_per_rank=2, n_batches=8):
     net = train.build_sgg_net(a.layers, device=dev)
     net.vrd.source_gt_rels = imdb.gt_rels(net.vrd.n_rel)
     step = train.SGGEmbStep(net, frames_per_rank, device=dev, use_graph=not a.no_graph, stage_synthetic=False)
+    hw = (lambda d: (int(d[1][0][1]), int(d[1][0][2]))) if u8 else (lambda d: (int(d[0].shape[2]), int(d[0].shape[3])))
+    stage = step.stage_batch_u8 if u8 else step.stage_batch
     for d in batches:                     # the feature-map buffers fit the largest minibatch from the start
-        step.reserve(int(d[0].shape[2]), int(d[0].shape[3]))
-    assert step.stage_batch(batches[0])
+        step.reserve(*hw(d))
+    assert stage(batches[0])
     graphed = step.capture(warmup=2)
     pos = [0]
 
     def fn():
         pos[0] += 1
-        step.stage_batch(batches[pos[0] % len(batches)])
+        stage(batches[pos[0] % len(batches)])
         step()
     for _ in range(len(batches) + 1):     # every frame size met once: its graph is captured outside the timed region
         fn()
     elapsed = timed_steps(fn, a.warmup, a.steps, dev)
-    sizes = sorted({tuple(int(v) for v in d[0].shape[2:]) for d in batches})
+    sizes = sorted({hw(d) for d in batches})
     rels = net.vrd.source_gt_rels
     nb = [sum(len(rels[p.split("/")[-1]]["boxes"]) for p in d[4]) for d in batches]
     line = {
         "metric": "frames/sec (600x1000, 32 ROI/frame)", "value": world * frames_per_rank * a.steps / elapsed,
         "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "loader: %d collated roibatchLoader minibatches in pinned host memory, one staged per step (H2D of the frames "
-                "and the packed head inputs inside the timed region)" % len(batches),
+        "data": ("loader: %d collated roibatchLoader minibatches in pinned host memory, one staged per step (H2D of the frames "
+                 "and the packed head inputs inside the timed region)" % len(batches)) if not u8 else
+                ("loader, device front-end: %d roibatchLoader(device_prep=True) minibatches (uint8 frames as decoded) in pinned host "
+                 "memory, one staged per step: H2D of the uint8 frames, BGR swap / mean subtraction / resize / canvas placement on "
+                 "the device (i2v_image_prep) and the packed head inputs inside the timed region" % len(batches)),
         "config": {"workload": "BASELINE.json configs[%d] fed by roi_data_layer: cfgs/res101.yml, SGG_emb fwd+bwd+SGD, %d frames/GPU, "
                                "shorter side 600, minibatch sizes %s, %d-%d boxes per minibatch, ResNet-%d C4" % (
                                    3 if world > 1 else 1, frames_per_rank, sizes, min(nb), max(nb), a.layers),
@@ -671,8 +681,8 @@ def main():
     c.cfg_from_list(SET_CFGS)
 
     keep = []
-    if a.config == "sgg" and a.data == "loader":
-        line, step, net = run_sgg_loader(a, rank, world, dev)
+    if a.config == "sgg" and a.data in ("loader", "loader_u8"):
+        line, step, net = run_sgg_loader(a, rank, world, dev, u8=a.data == "loader_u8")
         keep += [step, net]
     elif a.config == "sgg":
         line, step, net = run_sgg(a, rank, world, dev)
@@ -683,6 +693,11 @@ def main():
             torch.cuda.empty_cache()
             ld, s1, n1 = run_sgg_loader(a, rank, world, dev)
             line["also"] = {"sgg_loader": {k: ld[k] for k in ("value", "unit", "ms_per_step", "steps", "data", "config")}}
+            s1.opt.unfuse()
+            del s1, n1
+            torch.cuda.empty_cache()
+            ld, s1, n1 = run_sgg_loader(a, rank, world, dev, u8=True)
+            line["also"]["sgg_loader_u8"] = {k: ld[k] for k in ("value", "unit", "ms_per_step", "steps", "data", "config")}
             s1.opt.unfuse()
             del s1, n1
             torch.cuda.empty_cache()

@@ -73,7 +73,8 @@ class SyntheticImdb:
         return len(self.image_index)
 
     def image_path_at(self, i):
-        return "synthetic://%s/%06d" % (self.name, i)
+        # by image INDEX, as imdb.image_path_at does: the flipped copy of a frame (image_index is doubled) has its frame's path
+        return "synthetic://%s/%06d" % (self.name, self.image_index[i])
 
     def image_id_at(self, i):
         return i

@@ -279,6 +279,62 @@ class _Slot:
         ev.record()
 
 
+class _Uploader:
+    """Host frames -> device on a COPY stream, two staging buffers per shape: the PCIe transfer of minibatch k+1 runs beside
+    the step that is still computing (a 2 x 3 x 600 x 1000 fp32 minibatch is 14.4 MB = 0.6 ms at 25 GB/s; queued on the compute
+    stream it sat in front of every graph launch: bench.py --data loader 5.26 ms per step against 4.61 resident).  ``upload``
+    returns a device tensor that is valid on the caller's CURRENT stream (an event edge), ``consumed`` marks the point after
+    which its buffer may be overwritten."""
+
+    def __init__(self, device):
+        self.dev = torch.device(device)
+        # Normal priority.  Measured (tools/loader_probe.py, relation step, 14.4 MB of frames per step): the transfer costs the
+        # step 0.35-0.4 ms although it is queued a step ahead on its own stream -- it runs as a blit kernel and only gets its
+        # turn when the step's branches drain.  A HIGH-priority copy stream (I2V_UPLOAD_PRIORITY=-1) hides it when every
+        # minibatch has one size (4.74 -> 4.86 ms instead of 5.15) but doubles the step (8.7-9.5 ms) as soon as the loop
+        # alternates between the graphs of two sizes -- so it is not the default.
+        import os
+        self.stream = torch.cuda.Stream(self.dev, priority=int(os.environ.get("I2V_UPLOAD_PRIORITY", "0")))
+        self.rings = {}
+
+    def upload(self, frames):
+        # ONE ring of two byte buffers for every shape: upload k+2 waits for the consumer of upload k whatever their shapes, so
+        # at most two transfers are ever queued ahead of the step
+        nbytes = frames.numel() * frames.element_size()
+        ring = self.rings.setdefault("ring", {"i": 0, "buf": [None, None], "free": [None, None]})
+        i = ring["i"]
+        ring["i"] ^= 1
+        if ring["buf"][i] is None or ring["buf"][i].numel() < nbytes:
+            ring["buf"][i] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=self.dev)
+        dst = ring["buf"][i][:nbytes].view(frames.dtype).view(frames.shape)
+        if ring["free"][i] is not None:
+            self.stream.wait_event(ring["free"][i])          # the copy that last READ this buffer (two uploads ago) is done
+        with torch.cuda.stream(self.stream):
+            dst.copy_(frames, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(self.stream)
+        torch.cuda.current_stream(self.dev).wait_event(done)
+        return dst, (ring, i)
+
+    def consumed(self, token):
+        ring, i = token
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        ring["free"][i] = ev
+
+
+def _place_u8(uploader, frames_u8, meta, dst):
+    """The device front-end of a ``roibatchLoader(device_prep=True)`` minibatch: every decoded uint8 frame crosses PCIe as it
+    is (copy stream) and ``i2v_image_prep`` writes the mean-subtracted, resized BGR image into its slot of ``dst`` (n,4,H,W)
+    channels_last, which is cleared first (the canvas around an image is zero padding, roibatchLoader.py:162-181)."""
+    dst.zero_()
+    for f, u8 in enumerate(frames_u8):
+        flipped, target = bool(meta[f][0]), int(meta[f][4])
+        src, token = uploader.upload(u8)
+        ops.image_prep(src, cfg.PIXEL_MEANS, target, flipped=flipped, rgb=True, blob=dst[f:f + 1])
+        uploader.consumed(token)
+
+
 class _FrameSet:
     """What the backbone half of the SGG_emb step owns for ONE minibatch size (n, H, W): the staged frames, one launch
     context per frame branch and the captured graph of the step whose backbone half has this size."""
@@ -360,6 +416,7 @@ class SGGEmbStep:
         self.cap_cells = 0
         self.fmap_flat = self.fmap_head_flat = None
         self.cur = self.inp = None    # head inputs: ``inp`` is written by stage(), ``cur`` read by the head
+        self._uploader = None
         self._staged = None           # key of the frame set staged last
         self._fmap_key = None         # key of the frame set whose features ``fmap_flat`` holds
         self.primed = False
@@ -444,16 +501,28 @@ class SGGEmbStep:
         if fields is None:
             raise ValueError("SGGEmbStep.stage: a minibatch without an annotated relation (the reference loop skips it, "
                              "faster_rcnn_SGG_emb.py:177-183)")
-        n, _, H, W = frames.shape
+        placer = None
+        if callable(frames):                 # (key, placer): the frames are written into the frame set by the caller
+            placer = frames
+            n, H, W = self._pending_key
+        else:
+            n, _, H, W = frames.shape
         if int(n) != self.n_frames:
             raise ValueError("SGGEmbStep.stage: %d frames, the step was built for %d" % (n, self.n_frames))
         key = (int(n), int(H), int(W))
         fs = self._frames(key)
-        if frames.shape[1] == 4 and frames.is_cuda:
+        if placer is not None:
+            placer(fs)
+        elif frames.shape[1] == 4 and frames.is_cuda:
             fs.im.copy_(frames)
-        else:
-            src = frames if frames.is_cuda else frames.to(self.dev, non_blocking=True)
-            fs.im[:, :3].copy_(src)                              # NCHW3 -> NHWC4 (channel 3 stays zero): one strided copy
+        elif frames.is_cuda:
+            fs.im[:, :3].copy_(frames)                           # NCHW3 -> NHWC4 (channel 3 stays zero): one strided copy
+        else:                                                    # host frames: PCIe on the copy stream, beside the running step
+            if self._uploader is None:
+                self._uploader = _Uploader(self.dev)
+            src, token = self._uploader.upload(frames)
+            fs.im[:, :3].copy_(src)
+            self._uploader.consumed(token)
         self.info = np.asarray(info, np.float32).reshape(-1, 3) if not torch.is_tensor(info) else info.detach().cpu().numpy().reshape(-1, 3)
         nb, npair = fields["boxes"].shape[0], fields["relb"].shape[0]
         self.n_rows = nb + npair
@@ -523,6 +592,27 @@ class SGGEmbStep:
         if fields is None:
             return False
         self.stage(data[0], info, fields)
+        return True
+
+    def stage_batch_u8(self, data):
+        """One ``roibatchLoader(device_prep=True, path_return=True)`` minibatch (``collate_device_prep``): uint8 frames as
+        decoded + meta; the image work runs on the device (``_place_u8``), a quarter of the float blob's bytes cross PCIe.
+        Same contract as ``stage_batch`` otherwise; a minibatch the device front-end does not take (the square trim) -> False."""
+        if not isinstance(data, (list, tuple)) or len(data) <= 2:
+            return False
+        frames, meta = data[0], data[1].numpy()
+        if int(meta[0][1]) <= 0 or int(meta[0][2]) <= 0:
+            return False
+        hc, wc = int(meta[0][1]), int(meta[0][2])
+        info = np.array([[hc, wc, m[3]] for m in meta], np.float32)
+        rels = self.net.vrd.source_gt_rels
+        fields = sgg_head_inputs([rels.get(str(p).split("/")[-1]) for p in data[4]], info, self.net.vrd.n_rel)
+        if fields is None:
+            return False
+        if self._uploader is None:
+            self._uploader = _Uploader(self.dev)
+        self._pending_key = (len(frames), hc, wc)
+        self.stage(lambda fs: _place_u8(self._uploader, frames, meta, fs.im), info, fields)
         return True
 
     def reseed(self, seed):
@@ -921,6 +1011,7 @@ class InstanceStyleDStep:
         self._branch_streams = [torch.cuda.Stream(self.dev) for _ in range(2)] if self.branches else []
         self.sets, self.max_graphs, self._tick, self._pool = {}, int(max_graphs), 0, None
         self._cur = None              # the _DomainSet staged last
+        self._uploader = None
         self._graphs_on = False
         mg = int(cfg.MAX_NUM_GT_BOXES)
         self.info = torch.zeros((n_frames, 3), device=self.dev)        # shared by every size: a captured step reads them
@@ -950,7 +1041,7 @@ class InstanceStyleDStep:
     ctx_tgt = property(lambda self: self._cur.ctx_tgt)
 
     # ------------------------------------------------------------------ data side
-    def stage(self, im_s, info, gt, nb, im_t, info_t=None):
+    def stage(self, im_s, info, gt, nb, im_t, info_t=None, placers=None):
         """Hand the next minibatch to the step: source frames (N,3,H,W) with ``im_info`` (N,3), ``gt_boxes``
         (N,MAX_NUM_GT_BOXES,5) and ``num_boxes`` (N,) -- one roi_data_layer batch -- and N target frames with their
         ``im_info`` (default: the source's).  Host tensors cross PCIe here (pinned ones asynchronously); everything is
@@ -973,11 +1064,38 @@ class InstanceStyleDStep:
         self._cur = ds
         self.info0 = (int(info0[0]), int(info0[1]))
         cp = lambda dst, src: dst.copy_(src, non_blocking=True)
-        dev3 = lambda t: t if t.is_cuda else t.to(self.dev, non_blocking=True)
-        ds.im_s[:, :3].copy_(dev3(im_s)); ds.im_t[:, :3].copy_(dev3(im_t))
+        for k, (dst, src) in enumerate(((ds.im_s, im_s), (ds.im_t, im_t))):
+            if placers is not None:                              # the device front-end writes the frames itself (_place_u8)
+                placers[k](dst)
+            elif src.is_cuda:
+                dst[:, :3].copy_(src)
+            else:                                                # host frames: PCIe on the copy stream, beside the running step
+                if self._uploader is None:
+                    self._uploader = _Uploader(self.dev)
+                dev3, token = self._uploader.upload(src.float() if src.dtype != torch.float32 else src)
+                dst[:, :3].copy_(dev3)
+                self._uploader.consumed(token)
         cp(self.info, info); cp(self.info_t, info_t); cp(self.gt, gt); cp(self.nb, nb)
         if ds.im_st is not None:
             ds.im_st[:n].copy_(ds.im_s); ds.im_st[n:].copy_(ds.im_t)
+
+    def stage_batch_u8(self, data_s, data_t):
+        """The same with ``roibatchLoader(device_prep=True)`` minibatches (``collate_device_prep``): uint8 frames, the image work
+        on the device.  False when either minibatch cannot go that way (the square trim) or would be skipped."""
+        ok = lambda d: isinstance(d, (list, tuple)) and len(d) >= 4 and int(d[1][0][1]) > 0 and int(d[1][0][2]) > 0
+        if not ok(data_s) or not ok(data_t):
+            return False
+        ms, mt = data_s[1].numpy(), data_t[1].numpy()
+        info = torch.tensor([[m[1], m[2], m[3]] for m in ms], dtype=torch.float32)
+        info_t = torch.tensor([[m[1], m[2], m[3]] for m in mt], dtype=torch.float32)
+        n = len(data_s[0])
+        key_shapes = (torch.empty((n, 0, int(ms[0][1]), int(ms[0][2]))), torch.empty((n, 0, int(mt[0][1]), int(mt[0][2]))))
+        if self._uploader is None:
+            self._uploader = _Uploader(self.dev)
+        self.stage(key_shapes[0], info, data_s[2], data_s[3], key_shapes[1], info_t,
+                   placers=(lambda dst: _place_u8(self._uploader, data_s[0], ms, dst),
+                            lambda dst: _place_u8(self._uploader, data_t[0], mt, dst)))
+        return True
 
     def stage_batch(self, data_s, data_t):
         """One minibatch of each of the loop's two ``roibatchLoader`` iterators as the DataLoader collates them

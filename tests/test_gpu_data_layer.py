@@ -212,6 +212,61 @@ def test_instance_styled_captured_step_consumes_loader_batches_of_varying_size(s
     assert all(np.isfinite(v) for d in trained for v in d.values()), trained
 
 
+def test_device_front_end_loader_equals_the_host_loader(small_cfg):
+    """``roibatchLoader(device_prep=True)`` + ``stage_batch_u8`` (uint8 frames across PCIe, BGR swap / flip / mean subtraction /
+    resize / canvas placement by ``i2v_image_prep``) stages the same bits as the host form (``get_minibatch`` + the loader's
+    padding) for every minibatch size, flipped frames included -- frames, im_info, head inputs -- so the captured relation
+    step returns identical losses either way."""
+    small_cfg()
+    from i2vsgg_amd import train
+    from i2vsgg_amd.model.utils import config as c
+    from i2vsgg_amd.model.utils.net_utils import sampler
+    from i2vsgg_amd.roi_data_layer.roibatchLoader import collate_device_prep, roibatchLoader
+    from i2vsgg_amd.roi_data_layer.roidb import combined_roidb
+    c.cfg.TRAIN.USE_FLIPPED = True
+    imdb, roidb, ratio_list, ratio_index = combined_roidb("synthetic_10_v")
+    mk = lambda dp: torch.utils.data.DataLoader(
+        roibatchLoader(roidb, ratio_list, ratio_index, 2, imdb.num_classes, training=True, path_return=True, device_prep=dp),
+        batch_size=2, sampler=sampler(len(roidb), 2, seed=9), pin_memory=True, collate_fn=collate_device_prep if dp else None)
+    np.random.seed(4)
+    host = list(mk(False))
+    np.random.seed(4)
+    dev = list(mk(True))
+    assert len(host) == len(dev) == 10
+    rels = imdb.gt_rels(62)
+    rels.update({k: v for k, v in rels.items()})
+    net = train.build_sgg_net(layers=50, seed=5, device=DEV)
+    net.vrd.dropout = False
+    net.vrd.source_gt_rels = rels
+    step = train.SGGEmbStep(net, 2, vrd_lr=0.0, device=DEV, stage_synthetic=False)
+    assert step.stage_batch(host[0]) and step.capture(warmup=1, restore=True), step.graph_error
+    checked = flipped = 0
+    sizes = set()
+    for h, d in zip(host, dev):
+        assert torch.equal(h[2], d[2]) and torch.equal(h[3], d[3]) and list(h[4]) == list(d[4])
+        if int(d[1][0][1]) == 0:                       # square trim: the device form hands it back
+            assert not step.stage_batch_u8(d)
+            continue
+        assert step.stage_batch(h)
+        want_im, want_info = step.im.clone(), step.info.copy()
+        la = float(step()); la2 = float(step.flush())
+        want_slot = step.inp.buf.clone()               # after the call: a size met for the first time gets its extent there
+        assert step.stage_batch_u8(d)
+        assert torch.equal(step.im, want_im), tuple(h[0].shape)
+        assert torch.equal(step.im[:, :3].cpu(), h[0]) and float(step.im[:, 3].abs().max()) == 0.0
+        diff = [name for name, o, nb, dt, sh in step.inp.spec
+                if not torch.equal(step.inp.buf[o:o + nb], want_slot[o:o + nb])]
+        assert not diff and np.array_equal(step.info, want_info), (diff, step.info, want_info)
+        lb = float(step()); lb2 = float(step.flush())
+        assert abs(la2 - lb2) <= 1e-6 * abs(la2), (la2, lb2)     # rates are zero: the same bits in, the same loss out (up to
+        #                                                           the fp32 atomics of the head's split-K GEMMs, ~1e-7)
+        checked += 1
+        flipped += int(d[1][:, 0].sum())
+        sizes.add(tuple(h[0].shape[2:]))
+    step.opt.unfuse()
+    assert checked >= 6 and flipped >= 2 and len(sizes) >= 3, (checked, flipped, sizes)
+
+
 def test_training_scripts_run_through_the_data_layer(small_cfg, tmp_path):
     """trainval_sgg_emb.py / trainval_instance_styled.py (the reference loops on the HIP path) fed by
     combined_roidb -> roibatchLoader -> DataLoader(sampler) on synthetic imdbs whose frames differ in size: two epochs of
