@@ -314,3 +314,7 @@ def test_training_scripts_run_through_the_data_layer(small_cfg, tmp_path):
     lrs = {round(g["lr"], 10) for g in ck3["optimizer"]["param_groups"]}
     assert lrs == {round(5e-4 * 0.01, 10), round(2 * 5e-4 * 0.01, 10)}        # the decay of the resumed epoch is applied
     assert not torch.equal(ck3["model"]["RCNN_base.6.22.conv3.weight"], ck["model"]["RCNN_base.6.22.conv3.weight"])
+    # ---- both loops once more with the device front-end (uint8 frames, image work on the GPU)
+    ts.main(["--epochs", "1", "--bs", "2", "--imdb_name", "synthetic_12_v", "--scale", "192", "--disp_interval", "3", "--save_dir",
+             str(tmp_path / "u8"), "--device_prep", "--no-save"])
+    tv.main(["--epochs", "1", "--device_prep", "--no-save"] + common)

@@ -58,6 +58,10 @@ def parse_args(argv=None):
     p.add_argument("--checksession", type=int, default=1)
     p.add_argument("--checkepoch", type=int, default=1)
     p.add_argument("--no-save", action="store_true")
+    p.add_argument("--device_prep", action="store_true",
+                   help="the loaders hand over uint8 frames as decoded; BGR swap, mean subtraction, resize and batch padding run on "
+                        "the GPU (roibatchLoader(device_prep=True) + stage_batch_u8).  Minibatches the reference would crop to a "
+                        "square (target ratio exactly 1) are skipped in this mode")
     p.add_argument("--no-graph", action="store_true", help="eager launches (host-side target sampling from np.random, the "
                                                            "reference's RNG contract) instead of the captured step")
     p.add_argument("--set", dest="set_cfgs", nargs=argparse.REMAINDER, default=None)
@@ -98,7 +102,7 @@ def main(argv=None):
     from i2vsgg_amd import parallel, train
     from i2vsgg_amd.model.utils import config as c
     from i2vsgg_amd.model.utils.net_utils import sampler
-    from i2vsgg_amd.roi_data_layer.roibatchLoader import roibatchLoader
+    from i2vsgg_amd.roi_data_layer.roibatchLoader import collate_device_prep, roibatchLoader
     from i2vsgg_amd.roi_data_layer.roidb import combined_roidb
     rank, world, dev = parallel.init_from_env()
     c.cfg_from_file(c.default_cfg_file(a.net))
@@ -119,8 +123,9 @@ def main(argv=None):
         print("%d source roidb entries\n%d target roidb entries" % (train_size, train_size_t))
     pin = dev.type == "cuda"
     mk = lambda rdb, rl, ri, n, seed: torch.utils.data.DataLoader(
-        roibatchLoader(rdb, rl, ri, a.batch_size, imdb.num_classes, training=True), batch_size=a.batch_size,
-        sampler=sampler(n, a.batch_size, rank=rank, world=world, seed=seed), num_workers=a.num_workers, pin_memory=pin)
+        roibatchLoader(rdb, rl, ri, a.batch_size, imdb.num_classes, training=True, device_prep=a.device_prep), batch_size=a.batch_size,
+        sampler=sampler(n, a.batch_size, rank=rank, world=world, seed=seed), num_workers=a.num_workers, pin_memory=pin,
+        collate_fn=collate_device_prep if a.device_prep else None)
     dataloader_s = mk(roidb, ratio_list, ratio_index, train_size, c.cfg.RNG_SEED)
     dataloader_t = mk(roidb_t, ratio_list_t, ratio_index_t, train_size_t, c.cfg.RNG_SEED + 1)
     iters_per_epoch = a.iters_per_epoch or (train_size // a.batch_size // world)
@@ -151,7 +156,8 @@ def main(argv=None):
     def stage_next():
         """The next (source, target) pair of minibatches the reference loop would train on (:239-256)."""
         for _ in range(4 * len(dataloader_s) + 4):
-            if step.stage_batch(draw("s", dataloader_s), draw("t", dataloader_t)):
+            ds_, dt_ = draw("s", dataloader_s), draw("t", dataloader_t)
+            if (step.stage_batch_u8(ds_, dt_) if a.device_prep else step.stage_batch(ds_, dt_)):
                 return
         raise SystemExit("the data loaders yield no trainable minibatch")
 

@@ -54,6 +54,10 @@ def parse_args(argv=None):
     p.add_argument("--checksession", type=int, default=1)
     p.add_argument("--checkepoch", type=int, default=1)
     p.add_argument("--no-save", action="store_true")
+    p.add_argument("--device_prep", action="store_true",
+                   help="the loaders hand over uint8 frames as decoded; BGR swap, mean subtraction, resize and batch padding run on "
+                        "the GPU (roibatchLoader(device_prep=True) + stage_batch_u8).  Minibatches the reference would crop to a "
+                        "square (target ratio exactly 1) are skipped in this mode")
     p.add_argument("--no-graph", action="store_true", help="eager launches instead of the captured step")
     p.add_argument("--set", dest="set_cfgs", nargs=argparse.REMAINDER, default=None)
     return p.parse_args(argv)
@@ -113,7 +117,7 @@ def main(argv=None):
     from i2vsgg_amd import parallel, train
     from i2vsgg_amd.model.utils import config as c
     from i2vsgg_amd.model.utils.net_utils import sampler
-    from i2vsgg_amd.roi_data_layer.roibatchLoader import roibatchLoader
+    from i2vsgg_amd.roi_data_layer.roibatchLoader import collate_device_prep, roibatchLoader
     from i2vsgg_amd.roi_data_layer.roidb import combined_roidb
     rank, world, dev = parallel.init_from_env()
     c.cfg_from_file(c.default_cfg_file(a.net))
@@ -132,9 +136,11 @@ def main(argv=None):
     if rank == 0:
         print("%d source roidb entries" % train_size)
     sampler_batch = sampler(train_size, a.batch_size, rank=rank, world=world, seed=c.cfg.RNG_SEED)
-    dataset_s = roibatchLoader(roidb, ratio_list, ratio_index, a.batch_size, imdb.num_classes, training=True, path_return=True)
+    dataset_s = roibatchLoader(roidb, ratio_list, ratio_index, a.batch_size, imdb.num_classes, training=True, path_return=True,
+                               device_prep=a.device_prep)
     dataloader_s = torch.utils.data.DataLoader(dataset_s, batch_size=a.batch_size, sampler=sampler_batch,
-                                               num_workers=a.num_workers, pin_memory=dev.type == "cuda")
+                                               num_workers=a.num_workers, pin_memory=dev.type == "cuda",
+                                               collate_fn=collate_device_prep if a.device_prep else None)
     iters_per_epoch = a.iters_per_epoch or (train_size // a.batch_size // world)
 
     net = train.build_sgg_net(101 if a.net == "res101" else 50, a.num_relations, a.num_classes, device=dev)
@@ -168,7 +174,7 @@ def main(argv=None):
             except StopIteration:
                 data_iter[0] = iter(dataloader_s)
                 data = next(data_iter[0])
-            if step.stage_batch(data):
+            if (step.stage_batch_u8(data) if a.device_prep else step.stage_batch(data)):
                 return
         raise SystemExit("the data loader yields no trainable minibatch")
 
