@@ -87,6 +87,13 @@ SIGNATURES = {
     "i2v_l2norm_rows_bwd": (_i, [_p, _p, _p, _p, _i, _i, _f, _p]),
     "i2v_bce_rows_fwd": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "i2v_bce_rows_bwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _p]),
+    "i2v_half_mse_fwd": (_i, [_p, _l, _f, _p, _p]),
+    "i2v_half_mse_bwd": (_i, [_p, _l, _f, _p, _p, _p]),
+    "i2v_smooth_l1_fwd": (_i, [_p, _p, _p, _p, _l, _i, _i, _f, _p, _p]),
+    "i2v_smooth_l1_bwd": (_i, [_p, _p, _p, _p, _l, _i, _i, _f, _p, _p, _p]),
+    "i2v_bbox_transform": (_i, [_p, _i, _p, _i, _p, _i, _i, _p, _p, _p]),
+    "i2v_signed_sqrt_fwd": (_i, [_p, _p, _l, _p]),
+    "i2v_signed_sqrt_bwd": (_i, [_p, _p, _p, _l, _p]),
     "i2v_pair_gather_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "i2v_pair_gather_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "i2v_dpixel_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),

@@ -489,3 +489,145 @@ extern "C" int32_t i2v_pair_gather_bwd(const float* g, const int64_t* ixs, const
     I2V_CHECK_LAUNCH("pair_gather_bwd");
     return I2V_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// The small arithmetic of the detector's losses and target layers as one kernel per direction (round 3).  Each of these is
+// 6-25 aten launches on tensors of a few thousand elements (trainval_net_instance_styleD_bilinear.py:276-296,
+// net_utils.py:122-136, bbox_transform.py:36-75, resnet_instance_styleD_bilinear.py:137-139): launch-bound.  Reductions run in
+// ONE workgroup with a fixed summation order: no atomics, no clear in front, the same bits every run.
+namespace {
+
+__device__ inline float block_sum_1024(float v, float* sh) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+    return t;                                   // valid in thread 0
+}
+
+// out = 0.5 * mean((d - target)^2): 0.5*mean(d^2) (target 0) and 0.5*mean((1-d)^2) (target 1) of :276-296
+__global__ void __launch_bounds__(1024) half_mse_fwd_kernel(const float* __restrict__ d, long long n, float target, float* __restrict__ out) {
+    __shared__ float sh[16];
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) { const float e = d[i] - target; s += e * e; }
+    const float t = block_sum_1024(s, sh);
+    if (threadIdx.x == 0) out[0] = 0.5f * (t / (float)n);
+}
+__global__ void half_mse_bwd_kernel(const float* __restrict__ d, long long n, float target, const float* __restrict__ gout, float* __restrict__ gd) {
+    const float k = gout[0] / (float)n;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) gd[i] = k * (d[i] - target);
+}
+
+// net_utils.py:122-136: d = inw * (pred - tgt); l = outw * (|d| < 1/s2 ? 0.5 s2 d^2 : |d| - 0.5/s2); sum over everything but the
+// batch axis, mean over the batch = total / rows.  inw / outw hold one weight per ``wdiv`` consecutive elements.
+__global__ void __launch_bounds__(1024)
+smooth_l1_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, const float* __restrict__ inw,
+                     const float* __restrict__ outw, long long n, int wdiv, float s2, float inv_rows, float* __restrict__ out) {
+    __shared__ float sh[16];
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+        const long long wi = i / wdiv;
+        const float dd = inw[wi] * (pred[i] - tgt[i]), ad = fabsf(dd);
+        s += outw[wi] * (ad < 1.f / s2 ? dd * dd * (s2 * 0.5f) : ad - 0.5f / s2);
+    }
+    const float t = block_sum_1024(s, sh);
+    if (threadIdx.x == 0) out[0] = t * inv_rows;
+}
+__global__ void smooth_l1_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ tgt, const float* __restrict__ inw,
+                                     const float* __restrict__ outw, long long n, int wdiv, float s2, float inv_rows,
+                                     const float* __restrict__ gout, float* __restrict__ gpred) {
+    const float k = gout[0] * inv_rows;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const long long wi = i / wdiv;
+        const float w = inw[wi], dd = w * (pred[i] - tgt[i]), ad = fabsf(dd);
+        const float dl = ad < 1.f / s2 ? s2 * dd : (dd > 0.f ? 1.f : (dd < 0.f ? -1.f : 0.f));
+        gpred[i] = k * outw[wi] * w * dl;
+    }
+}
+
+// bbox_transform.py:36-75: regression targets of (B,N,4) gt boxes against (N,4) or (B,N,4) example boxes, optionally
+// normalised (t - mean) / std (proposal_target_layer_cascade.py:104-106)
+__global__ void bbox_transform_kernel(const float* __restrict__ ex, int ex_batched, const float* __restrict__ gt, int gt_stride,
+                                      float* __restrict__ out, long long rows, int N, float4 mean, float4 stdv, int normalize) {
+    for (long long r = blockIdx.x * (long long)blockDim.x + threadIdx.x; r < rows; r += (long long)gridDim.x * blockDim.x) {
+        const float* e = ex + (ex_batched ? r : r % N) * 4;
+        const float* g = gt + r * gt_stride;
+        const float ew = e[2] - e[0] + 1.f, eh = e[3] - e[1] + 1.f, ecx = e[0] + 0.5f * ew, ecy = e[1] + 0.5f * eh;
+        const float gw = g[2] - g[0] + 1.f, gh = g[3] - g[1] + 1.f, gcx = g[0] + 0.5f * gw, gcy = g[1] + 0.5f * gh;
+        float4 t = make_float4((gcx - ecx) / ew, (gcy - ecy) / eh, logf(gw / ew), logf(gh / eh));
+        if (normalize) { t.x = (t.x - mean.x) / stdv.x; t.y = (t.y - mean.y) / stdv.y; t.z = (t.z - mean.z) / stdv.z; t.w = (t.w - mean.w) / stdv.w; }
+        *(float4*)(out + r * 4) = t;
+    }
+}
+
+// resnet_instance_styleD_bilinear.py:137: sqrt(relu(z)) - sqrt(relu(-z)) = sign(z) sqrt(|z|); backward g * 0.5 / sqrt(|z|), 0 at z = 0
+__global__ void signed_sqrt_fwd_kernel(const float* __restrict__ z, float* __restrict__ y, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = z[i];
+        y[i] = v > 0.f ? sqrtf(v) : (v < 0.f ? -sqrtf(-v) : 0.f);
+    }
+}
+__global__ void signed_sqrt_bwd_kernel(const float* __restrict__ z, const float* __restrict__ g, float* __restrict__ gz, long long n) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = fabsf(z[i]);
+        gz[i] = v > 0.f ? g[i] * (0.5f / sqrtf(v)) : 0.f;
+    }
+}
+
+inline int ew_grid(long long n) { return (int)fmin((double)i2v_cdiv(n, 256), 2048.0); }
+
+}  // namespace
+
+extern "C" int32_t i2v_half_mse_fwd(const float* d, int64_t n, float target, float* out, void* stream) {
+    I2V_CHECK_ARG(d && out && n > 0, "half_mse_fwd: bad argument");
+    half_mse_fwd_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(d, n, target, out);
+    I2V_CHECK_LAUNCH("half_mse_fwd");
+    return I2V_OK;
+}
+extern "C" int32_t i2v_half_mse_bwd(const float* d, int64_t n, float target, const float* gout, float* gd, void* stream) {
+    I2V_CHECK_ARG(d && gout && gd && n > 0, "half_mse_bwd: bad argument");
+    half_mse_bwd_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(d, n, target, gout, gd);
+    I2V_CHECK_LAUNCH("half_mse_bwd");
+    return I2V_OK;
+}
+extern "C" int32_t i2v_smooth_l1_fwd(const float* pred, const float* tgt, const float* inw, const float* outw, int64_t n,
+                                     int32_t per_weight, int32_t rows, float sigma, float* out, void* stream) {
+    I2V_CHECK_ARG(pred && tgt && inw && outw && out && n > 0 && per_weight > 0 && rows > 0 && sigma > 0.f, "smooth_l1_fwd: bad argument");
+    smooth_l1_fwd_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(pred, tgt, inw, outw, n, per_weight, sigma * sigma, 1.f / (float)rows, out);
+    I2V_CHECK_LAUNCH("smooth_l1_fwd");
+    return I2V_OK;
+}
+extern "C" int32_t i2v_smooth_l1_bwd(const float* pred, const float* tgt, const float* inw, const float* outw, int64_t n,
+                                     int32_t per_weight, int32_t rows, float sigma, const float* gout, float* gpred, void* stream) {
+    I2V_CHECK_ARG(pred && tgt && inw && outw && gout && gpred && n > 0 && per_weight > 0 && rows > 0 && sigma > 0.f, "smooth_l1_bwd: bad argument");
+    smooth_l1_bwd_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(pred, tgt, inw, outw, n, per_weight, sigma * sigma,
+                                                                     1.f / (float)rows, gout, gpred);
+    I2V_CHECK_LAUNCH("smooth_l1_bwd");
+    return I2V_OK;
+}
+extern "C" int32_t i2v_bbox_transform(const float* ex, int32_t ex_batched, const float* gt, int32_t gt_stride, float* out, int32_t B,
+                                      int32_t N, const float* means4, const float* stds4, void* stream) {
+    I2V_CHECK_ARG(ex && gt && out && B > 0 && N > 0 && gt_stride >= 4, "bbox_transform: bad argument");
+    const int norm = means4 && stds4;
+    const float4 m = norm ? make_float4(means4[0], means4[1], means4[2], means4[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 sd = norm ? make_float4(stds4[0], stds4[1], stds4[2], stds4[3]) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const long long rows = (long long)B * N;
+    bbox_transform_kernel<<<ew_grid(rows), 256, 0, (hipStream_t)stream>>>(ex, ex_batched, gt, gt_stride, out, rows, N, m, sd, norm);
+    I2V_CHECK_LAUNCH("bbox_transform");
+    return I2V_OK;
+}
+extern "C" int32_t i2v_signed_sqrt_fwd(const float* z, float* y, int64_t n, void* stream) {
+    I2V_CHECK_ARG(z && y && n > 0, "signed_sqrt_fwd: bad argument");
+    signed_sqrt_fwd_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(z, y, n);
+    I2V_CHECK_LAUNCH("signed_sqrt_fwd");
+    return I2V_OK;
+}
+extern "C" int32_t i2v_signed_sqrt_bwd(const float* z, const float* g, float* gz, int64_t n, void* stream) {
+    I2V_CHECK_ARG(z && g && gz && n > 0, "signed_sqrt_bwd: bad argument");
+    signed_sqrt_bwd_kernel<<<ew_grid(n), 256, 0, (hipStream_t)stream>>>(z, g, gz, n);
+    I2V_CHECK_LAUNCH("signed_sqrt_bwd");
+    return I2V_OK;
+}

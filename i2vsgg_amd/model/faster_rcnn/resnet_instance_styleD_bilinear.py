@@ -81,8 +81,11 @@ class netD_style(nn.Module):
             x1 = ops.linear(rows, self.fc_1.weight, self.fc_1.bias)
             x2 = ops.linear(rows, self.fc_2.weight, self.fc_2.bias)
             z = ops.dstyle_pool(x1.view(b, h * w, -1), x2.view(b, h * w, -1), self.dim, self.rank)
-        z = torch.sqrt(F.relu(z)) - torch.sqrt(F.relu(-z))
-        z = F.normalize(z, p=2, dim=1)
+        if z.is_cuda:       # sign(z) sqrt|z| and the row normalisation: one kernel each, each way (the aten form is ~24 launches)
+            z = ops.l2norm_rows(ops.signed_sqrt(z))
+        else:
+            z = torch.sqrt(F.relu(z)) - torch.sqrt(F.relu(-z))
+            z = F.normalize(z, p=2, dim=1)
         d = torch.sigmoid(ops.linear(z, self.fc1.weight, self.fc1.bias))
         return (d, z) if self.context else d
 

@@ -100,9 +100,14 @@ class _ProposalTargetLayer(nn.Module):
         gt_sel = torch.gather(gt_boxes, 1, gsel.unsqueeze(2).expand(-1, -1, 5))
         labels = torch.where(torch.arange(R, device=dev).view(1, R) >= nfg, torch.zeros_like(gt_sel[:, :, 4]),
                              gt_sel[:, :, 4])                                      # :196-197
-        tg = bbox_transform_batch(rois[:, :, 1:5], gt_sel[:, :, :4])
-        if T.BBOX_NORMALIZE_TARGETS_PRECOMPUTED:
-            tg = (tg - self._c("BBOX_NORMALIZE_MEANS", dev)) / self._c("BBOX_NORMALIZE_STDS", dev)
+        if rois.is_cuda:      # transform + normalisation in one kernel (gt_sel's rows are 5 wide: the box is its first four columns)
+            norm = bool(T.BBOX_NORMALIZE_TARGETS_PRECOMPUTED)
+            tg = ops.bbox_transform(rois[:, :, 1:5], gt_sel, T.BBOX_NORMALIZE_MEANS if norm else None,
+                                    T.BBOX_NORMALIZE_STDS if norm else None)
+        else:
+            tg = bbox_transform_batch(rois[:, :, 1:5], gt_sel[:, :, :4])
+            if T.BBOX_NORMALIZE_TARGETS_PRECOMPUTED:
+                tg = (tg - self._c("BBOX_NORMALIZE_MEANS", dev)) / self._c("BBOX_NORMALIZE_STDS", dev)
         fgmask = (labels > 0).unsqueeze(2).float()
         targets = tg * fgmask
         inw = fgmask * self._c("BBOX_INSIDE_WEIGHTS", dev).view(1, 1, 4)

@@ -55,7 +55,14 @@ def grad_reverse(x, lambd=1.0):
 
 
 def _smooth_l1_loss(bbox_pred, bbox_targets, bbox_inside_weights, bbox_outside_weights, sigma=1.0, dim=[1]):
-    """net_utils.py:122-136."""
+    """net_utils.py:122-136.  On the GPU, with every axis but 0 summed (both call sites of the detector) and weights that need
+    no gradient: one kernel each way (ops.smooth_l1); else the reference's expression."""
+    if bbox_pred.is_cuda and sorted(dim) == list(range(1, bbox_pred.dim())) and not bbox_targets.requires_grad and \
+            not bbox_inside_weights.requires_grad and not bbox_outside_weights.requires_grad and \
+            bbox_inside_weights.numel() == bbox_outside_weights.numel() and bbox_pred.numel() % max(bbox_inside_weights.numel(), 1) == 0 and \
+            bbox_targets.shape == bbox_pred.shape and _trailing_group(bbox_pred, bbox_inside_weights):
+        from i2vsgg_amd import ops
+        return ops.smooth_l1(bbox_pred, bbox_targets, bbox_inside_weights, bbox_outside_weights, sigma)
     s2 = sigma ** 2
     d = bbox_inside_weights * (bbox_pred - bbox_targets)
     ad = d.abs()
@@ -64,6 +71,19 @@ def _smooth_l1_loss(bbox_pred, bbox_targets, bbox_inside_weights, bbox_outside_w
     for i in sorted(dim, reverse=True):
         loss = loss.sum(i)
     return loss.mean()
+
+
+def _trailing_group(pred, w):
+    """w broadcasts against pred by repeating each weight over a trailing group: same shape, or same leading axes with the
+    remaining ones of length 1."""
+    if w.shape == pred.shape:
+        return True
+    if w.dim() != pred.dim():
+        return False
+    k = 0
+    while k < pred.dim() and w.shape[k] == pred.shape[k]:
+        k += 1
+    return all(d == 1 for d in w.shape[k:])
 
 
 def adjust_learning_rate(optimizer, decay=0.1):

@@ -1340,6 +1340,107 @@ def pair_gather(obj, ixs, ixo):
     return _PairGatherFn.apply(obj, ixs, ixo)
 
 
+class _HalfMseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, d, target):
+        _need_cuda(d)
+        d = d.contiguous()
+        out = torch.empty((), device=d.device, dtype=torch.float32)
+        check(lib.i2v_half_mse_fwd(ptr(d), d.numel(), float(target), ptr(out), stream()), "half_mse_fwd")
+        ctx.save_for_backward(d)
+        ctx.target = float(target)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        gd = torch.empty_like(d)
+        check(lib.i2v_half_mse_bwd(ptr(d), d.numel(), ctx.target, ptr(g.contiguous()), ptr(gd), stream()), "half_mse_bwd")
+        return gd, None
+
+
+def half_mse(d, target=0.0):
+    """0.5 * mean((d - target)^2) as one kernel each way: the discriminator terms of
+    trainval_net_instance_styleD_bilinear.py:276-296 (0.5*mean(d**2), 0.5*mean((1-d)**2))."""
+    return _HalfMseFn.apply(d, target)
+
+
+class _SmoothL1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, tgt, inw, outw, sigma, rows):
+        _need_cuda(pred, tgt, inw, outw)
+        pred, tgt, inw, outw = pred.contiguous(), tgt.contiguous(), inw.contiguous(), outw.contiguous()
+        n = pred.numel()
+        if tgt.numel() != n or inw.numel() != outw.numel() or n % inw.numel():
+            raise ValueError("smooth_l1: shapes %s %s %s %s" % (tuple(pred.shape), tuple(tgt.shape), tuple(inw.shape), tuple(outw.shape)))
+        per = n // inw.numel()
+        out = torch.empty((), device=pred.device, dtype=torch.float32)
+        check(lib.i2v_smooth_l1_fwd(ptr(pred), ptr(tgt), ptr(inw), ptr(outw), n, per, int(rows), float(sigma), ptr(out), stream()),
+              "smooth_l1_fwd")
+        ctx.save_for_backward(pred, tgt, inw, outw)
+        ctx.cfg = (per, int(rows), float(sigma))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, tgt, inw, outw = ctx.saved_tensors
+        per, rows, sigma = ctx.cfg
+        gp = torch.empty_like(pred)
+        check(lib.i2v_smooth_l1_bwd(ptr(pred), ptr(tgt), ptr(inw), ptr(outw), pred.numel(), per, rows, sigma, ptr(g.contiguous()),
+                                    ptr(gp), stream()), "smooth_l1_bwd")
+        return gp, None, None, None, None, None
+
+
+def smooth_l1(pred, tgt, inw, outw, sigma=1.0):
+    """net_utils._smooth_l1_loss (net_utils.py:122-136) for the two call sites of the detector: the weights either match pred
+    element for element or carry one value per trailing group (``(B,N,1)`` against ``(B,N,4)``); summed over everything but
+    axis 0, averaged over axis 0.  Gradient w.r.t. pred only.  One kernel each way."""
+    return _SmoothL1Fn.apply(pred, tgt, inw, outw, float(sigma), int(pred.shape[0]))
+
+
+def bbox_transform(ex, gt, means=None, stds=None):
+    """bbox_transform_batch (bbox_transform.py:36-75) in one kernel: ex (N,4) or (B,N,4), gt (B,N,>=4) with the box in its first
+    four columns -> (B,N,4); ``means`` / ``stds`` (4 floats each): the normalised targets of
+    proposal_target_layer_cascade.py:104-106.  No gradient."""
+    import ctypes
+    _need_cuda(ex, gt)
+    ex = ex.contiguous().float()
+    gt = gt.float()
+    if gt.stride(-1) != 1 or gt.dim() != 3 or gt.stride(1) != gt.shape[2] or gt.stride(0) != gt.shape[1] * gt.shape[2]:
+        gt = gt.contiguous()
+    B, N = gt.shape[0], gt.shape[1]
+    if ex.shape[-2] != N or ex.shape[-1] != 4:
+        raise ValueError("bbox_transform: ex %s against gt %s" % (tuple(ex.shape), tuple(gt.shape)))
+    out = torch.empty((B, N, 4), device=gt.device, dtype=torch.float32)
+    f4 = lambda v: (ctypes.c_float * 4)(*[float(t) for t in v]) if v is not None else None
+    check(lib.i2v_bbox_transform(ptr(ex), int(ex.dim() == 3), ptr(gt), int(gt.shape[2]), ptr(out), B, N, f4(means), f4(stds),
+                                 stream()), "bbox_transform")
+    return out
+
+
+class _SignedSqrtFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z):
+        _need_cuda(z)
+        z = z.contiguous()
+        y = torch.empty_like(z)
+        check(lib.i2v_signed_sqrt_fwd(ptr(z), ptr(y), z.numel(), stream()), "signed_sqrt_fwd")
+        ctx.save_for_backward(z)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (z,) = ctx.saved_tensors
+        gz = torch.empty_like(z)
+        check(lib.i2v_signed_sqrt_bwd(ptr(z), ptr(g.contiguous()), ptr(gz), z.numel(), stream()), "signed_sqrt_bwd")
+        return gz
+
+
+def signed_sqrt(z):
+    """sqrt(relu(z)) - sqrt(relu(-z)) (netD_style, resnet_instance_styleD_bilinear.py:137) as one kernel each way."""
+    return _SignedSqrtFn.apply(z)
+
+
 def winograd_filter(w, m=2):
     """(Cout,Cin,3,3) filter -> Winograd-domain filter, done once for a frozen filter: (16,Cout,Cin) for F(2x2,3x3)
     (``m=2``), (36,Cout,Cin) for F(4x4,3x3) (``m=4``)."""

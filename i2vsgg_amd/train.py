@@ -1132,16 +1132,16 @@ class InstanceStyleDStep:
                 out = net(self.im_s, self.info, self.gt, self.nb, target=False, eta=self.eta, eta_style=self.eta_style)
             _, _, _, l_rpn_cls, l_rpn_box, l_cls, l_box, _, d_inst, d_style = out
             loss = l_rpn_cls.mean() + l_rpn_box.mean() + l_cls.mean() + l_box.mean()
-            dloss_s = 0.5 * torch.mean(d_inst ** 2)
-            dloss_s_style = 0.5 * torch.mean(d_style ** 2)
+            dloss_s = ops.half_mse(d_inst)                  # 0.5 * mean(d^2) (:276-277), one kernel each way
+            dloss_s_style = ops.half_mse(d_style)
             if batched:
                 d_inst_t, d_style_t = net.forward_features(ft, f1t, self.info_t, self.gt_t, self.nb_t, True, self.eta,
                                                            self.eta_style)
             else:
                 d_inst_t, d_style_t = net(self.im_t, self.info_t, self.gt_t, self.nb_t, target=True, eta=self.eta,
                                           eta_style=self.eta_style)
-            dloss_t = 0.5 * torch.mean((1 - d_inst_t) ** 2)
-            dloss_t_style = 0.5 * torch.mean((1 - d_style_t) ** 2)
+            dloss_t = ops.half_mse(d_inst_t, 1.0)           # 0.5 * mean((1 - d)^2) (:294-295)
+            dloss_t_style = ops.half_mse(d_style_t, 1.0)
             total = loss + dloss_s + dloss_t + self.style_lambda * (dloss_s_style + dloss_t_style)
             vals = dict(det=loss, dloss_s=dloss_s, dloss_t=dloss_t, dloss_s_style=dloss_s_style, dloss_t_style=dloss_t_style)
             if self.cr:
@@ -1185,7 +1185,7 @@ class InstanceStyleDStep:
             out = net(self.im_s, self.info, self.gt, self.nb, target=False, eta=self.eta, eta_style=self.eta_style)
             _, _, _, l_rpn_cls, l_rpn_box, l_cls, l_box, _, d_inst, d_style = out
             v = {"det": l_rpn_cls.mean() + l_rpn_box.mean() + l_cls.mean() + l_box.mean(),
-                 "dloss_s": 0.5 * torch.mean(d_inst ** 2), "dloss_s_style": 0.5 * torch.mean(d_style ** 2)}
+                 "dloss_s": ops.half_mse(d_inst), "dloss_s_style": ops.half_mse(d_style)}
             part = v["det"] + v["dloss_s"] + self.style_lambda * v["dloss_s_style"]
             if self.cr:
                 v["source_adv_cst"] = _consistency_term(d_inst, d_style)
@@ -1198,7 +1198,7 @@ class InstanceStyleDStep:
         def target():
             d_inst_t, d_style_t = net(self.im_t, self.info_t, self.gt_t, self.nb_t, target=True, eta=self.eta,
                                       eta_style=self.eta_style)
-            v = {"dloss_t": 0.5 * torch.mean((1 - d_inst_t) ** 2), "dloss_t_style": 0.5 * torch.mean((1 - d_style_t) ** 2)}
+            v = {"dloss_t": ops.half_mse(d_inst_t, 1.0), "dloss_t_style": ops.half_mse(d_style_t, 1.0)}
             part = v["dloss_t"] + self.style_lambda * v["dloss_t_style"]
             if self.cr:
                 v["target_adv_cst"] = _consistency_term(d_inst_t, d_style_t)

@@ -402,6 +402,29 @@ int32_t i2v_pair_gather_fwd(const float* obj, const int64_t* ixs, const int64_t*
 int32_t i2v_pair_gather_bwd(const float* g, const int64_t* ixs, const int64_t* ixo, float* gobj, int32_t n_pairs,
                             int32_t n_box, int32_t emb, void* stream);
 
+/* ---- the small arithmetic of the detector's losses and target layers, one kernel per direction (each replaces 6-25 launch-bound
+ * aten kernels).  Scalar outputs are WRITTEN by one workgroup in a fixed summation order (no clear in front, no atomics).
+ *   half_mse:    out = 0.5 * mean((d - target)^2): the discriminator terms of trainval_net_instance_styleD_bilinear.py:276-296
+ *                (target 0: 0.5*mean(d^2); target 1: 0.5*mean((1-d)^2)); backward gd = gout * (d - target) / n.
+ *   smooth_l1:   net_utils.py:122-136 (_smooth_l1_loss): sum over all n elements of outw * huber_sigma(inw * (pred - tgt)) / rows
+ *                (= the mean over the batch axis of the per-image sums); inw / outw carry one weight per `per_weight` consecutive
+ *                elements (4: the (B,N,1) weights of rpn.py:100-101; 1: the (R,4) weights of the RCNN box loss).  Gradient
+ *                w.r.t. pred only.
+ *   bbox_transform: bbox_transform.py:36-75 (bbox_transform_batch): targets (B,N,4) of gt boxes (row stride gt_stride >= 4 floats)
+ *                against ex boxes (N,4) shared by the images or (B,N,4); means4 / stds4 non-NULL: (t - mean) / std
+ *                (proposal_target_layer_cascade.py:104-106).  means4 / stds4 are HOST pointers.
+ *   signed_sqrt: sqrt(relu(z)) - sqrt(relu(-z)) of netD_style.forward (resnet_instance_styleD_bilinear.py:137) and its backward. */
+int32_t i2v_half_mse_fwd(const float* d, int64_t n, float target, float* out, void* stream);
+int32_t i2v_half_mse_bwd(const float* d, int64_t n, float target, const float* gout, float* gd, void* stream);
+int32_t i2v_smooth_l1_fwd(const float* pred, const float* tgt, const float* inw, const float* outw, int64_t n, int32_t per_weight,
+                          int32_t rows, float sigma, float* out, void* stream);
+int32_t i2v_smooth_l1_bwd(const float* pred, const float* tgt, const float* inw, const float* outw, int64_t n, int32_t per_weight,
+                          int32_t rows, float sigma, const float* gout, float* gpred, void* stream);
+int32_t i2v_bbox_transform(const float* ex, int32_t ex_batched, const float* gt, int32_t gt_stride, float* out, int32_t B, int32_t N,
+                           const float* means4, const float* stds4, void* stream);
+int32_t i2v_signed_sqrt_fwd(const float* z, float* y, int64_t n, void* stream);
+int32_t i2v_signed_sqrt_bwd(const float* z, const float* g, float* gz, int64_t n, void* stream);
+
 /* ---- netD_pixel, fused (instance-level discriminator) ---------------------------------
  * replaces netD_pixel.forward (resnet_instance_styleD_bilinear.py:38-83: GRL, conv1 1024->512 + ReLU, conv2
  * 512->128 + ReLU, conv3 128->1, sigmoid, optional context vector = mean of the 128-d features over the ROI's

@@ -1104,3 +1104,76 @@ def test_gemm_three_term_bf16_split_is_opt_in_and_16_bit_accurate():
                     assert not np.array_equal(out[0], out[1])
     finally:
         lib.i2v_set_tuning(X3, 0)
+
+
+def test_fused_loss_and_target_arithmetic_matches_the_torch_expressions():
+    """ops.half_mse / smooth_l1 / bbox_transform / signed_sqrt (one kernel per direction each) against the expressions they
+    replace: the discriminator terms of trainval_net_instance_styleD_bilinear.py:276-296, net_utils._smooth_l1_loss (:122-136)
+    at both call sites of the detector, bbox_transform_batch (+ the normalisation of proposal_target_layer_cascade.py:104-106)
+    and the signed square root of netD_style (resnet_instance_styleD_bilinear.py:137) -- values and gradients."""
+    from i2vsgg_amd import ops
+    g = torch.Generator().manual_seed(11)
+    rnd = lambda *sh: torch.randn(*sh, generator=g).to(DEV)
+    # half_mse
+    for target in (0.0, 1.0):
+        d = torch.sigmoid(rnd(128, 1, 7, 7)).requires_grad_()
+        a = ops.half_mse(d, target)
+        (3.0 * a).backward()
+        ga = d.grad.clone(); d.grad = None
+        b = 0.5 * torch.mean((target - d) ** 2)
+        (3.0 * b).backward()
+        torch.testing.assert_close(a, b, rtol=1e-6, atol=0)
+        torch.testing.assert_close(ga, d.grad, rtol=1e-5, atol=1e-10)
+
+    def ref_smooth(pred, tgt, inw, outw, sigma, dim):
+        s2 = sigma ** 2
+        dd = inw * (pred - tgt)
+        ad = dd.abs()
+        near = (ad < 1.0 / s2).detach().float()
+        loss = outw * (dd * dd * (s2 / 2.0) * near + (ad - 0.5 / s2) * (1.0 - near))
+        for i in sorted(dim, reverse=True):
+            loss = loss.sum(i)
+        return loss.mean()
+    # smooth L1: the RPN site ((B,N,4) against (B,N,1) weights, sigma 3, dims [1,2]) and the RCNN site ((R,4), sigma 1, dim [1])
+    for shape, wshape, sigma, dim in (((4, 21546, 4), (4, 21546, 1), 3.0, [1, 2]), ((128, 4), (128, 4), 1.0, [1])):
+        pred = (rnd(*shape) * 0.5).requires_grad_()
+        tgt = rnd(*shape) * 0.5
+        inw = (torch.rand(*wshape, generator=g) < 0.3).float().to(DEV)
+        outw = inw * 0.01 + (torch.rand(*wshape, generator=g) < 0.1).float().to(DEV) * 0.02
+        a = ops.smooth_l1(pred, tgt, inw, outw, sigma)
+        a.backward()
+        ga = pred.grad.clone(); pred.grad = None
+        b = ref_smooth(pred, tgt, inw, outw, sigma, dim)
+        b.backward()
+        torch.testing.assert_close(a, b, rtol=2e-6, atol=0)
+        torch.testing.assert_close(ga, pred.grad, rtol=1e-5, atol=1e-10)
+    # bbox transform: shared anchors, batched rois with 5-wide gt rows and normalisation
+    from i2vsgg_amd.model.rpn.bbox_transform import _whc
+    def ref_bt(ex, gt):
+        ew, eh, ecx, ecy = _whc(ex); gw, gh, gcx, gcy = _whc(gt)
+        return torch.stack(((gcx - ecx) / ew, (gcy - ecy) / eh, torch.log(gw / ew), torch.log(gh / eh)), -1)
+    def boxes(*sh):
+        xy = torch.rand(*sh, 2, generator=g) * 500
+        wh = torch.rand(*sh, 2, generator=g) * 300 + 4
+        return torch.cat((xy, xy + wh), -1).to(DEV)
+    anc, gt = boxes(8151), boxes(4, 8151)
+    torch.testing.assert_close(ops.bbox_transform(anc, gt), ref_bt(anc, gt), rtol=1e-6, atol=1e-6)
+    rois5 = torch.cat((torch.zeros(4, 32, 1, device=DEV), boxes(4, 32)), 2)
+    gt5 = torch.cat((boxes(4, 32), torch.ones(4, 32, 1, device=DEV)), 2)
+    means, stds = (0.0, 0.0, 0.0, 0.0), (0.1, 0.1, 0.2, 0.2)
+    want = (ref_bt(rois5[:, :, 1:5], gt5[:, :, :4]) - torch.tensor(means, device=DEV)) / torch.tensor(stds, device=DEV)
+    torch.testing.assert_close(ops.bbox_transform(rois5[:, :, 1:5], gt5, means, stds), want, rtol=1e-6, atol=1e-6)
+    # signed square root
+    z = (rnd(4, 512) * 3).requires_grad_()
+    with torch.no_grad():
+        z[0, :5] = 0.0
+    a = ops.signed_sqrt(z)
+    w = rnd(4, 512)
+    (a * w).sum().backward()
+    ga = z.grad.clone(); z.grad = None
+    b = torch.sqrt(torch.relu(z)) - torch.sqrt(torch.relu(-z))
+    (b * w).sum().backward()
+    torch.testing.assert_close(a, b, rtol=1e-6, atol=0)
+    live = z.detach() != 0
+    torch.testing.assert_close(ga[live], z.grad[live], rtol=1e-5, atol=0)
+    assert float(ga[~live].abs().max()) == 0.0               # aten gives NaN there (inf * 0 through sqrt'); the kernel gives 0
