@@ -11,7 +11,7 @@ path = sys.argv[1]
 anchor = sys.argv[2] if len(sys.argv) > 2 else "roi_pool_fwd"
 per = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 OURS = ("conv_", "wino", "roi_", "sgd_", "bce_", "l2norm", "epilogue", "maxpool", "nms", "sort_", "dstyle", "dpixel", "rpn_", "bbox_",
-        "weight_dgrad", "fc_fold", "gather_dets", "write_rois", "image_prep", "det_", "pair_gather", "dp_transpose")
+        "weight_dgrad", "fc_fold", "gather_dets", "write_rois", "image_prep", "det_", "pair_gather", "dp_transpose", "half_mse", "smooth_l1", "signed_sqrt")
 rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"] for r in rows]
 idx = [i for i, n in enumerate(names) if anchor in n]
