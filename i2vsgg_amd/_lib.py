@@ -63,6 +63,7 @@ SIGNATURES = {
     "i2v_conv3x3_winograd4_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "i2v_conv3x3_winograd4_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _z, _p]),
     "i2v_gemm_tn_batched": (_i, [_p, _p, _p, _i, _i, _i, _i, _l, _l, _l, _p]),
+    "i2v_gemm_tn_batched_acc": (_i, [_p, _p, _p, _i, _i, _i, _i, _l, _l, _l, _p]),
     "i2v_conv3x3_winograd4_v_bytes": (_z, [_i, _i, _i, _i]),
     "i2v_conv3x3_winograd4_fwd_keep": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "i2v_conv3x3_winograd4_wgrad_v": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _z, _p]),

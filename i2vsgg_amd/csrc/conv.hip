@@ -2222,6 +2222,8 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, const flo
 
 // gw[z] (N x K) = gy[z]^T (M x N) . x[z] (M x K) for z < nbatch: the element-wise planes of a Winograd filter gradient
 // (csrc/winograd.hip).  gw is overwritten; the batches of gw must be contiguous when the reduction is split (one clear).
+static thread_local float g_tn_beta = 0.f;      // i2v_gemm_tn_batched_acc
+
 extern "C" int32_t i2v_gemm_tn_batched(const float* x, const float* gy, float* gw, int32_t M, int32_t N, int32_t K,
                                        int32_t nbatch, long long stride_x, long long stride_gy, long long stride_gw,
                                        void* stream) {
@@ -2239,9 +2241,19 @@ extern "C" int32_t i2v_gemm_tn_batched(const float* x, const float* gy, float* g
         i2v_set_error("gemm_tn_batched: operand larger than 2 GiB per batch");
         return I2V_ERR_UNSUPPORTED;
     }
-    launch_wgrad(p, 0.f, false, (hipStream_t)stream);
+    launch_wgrad(p, g_tn_beta, false, (hipStream_t)stream);
     I2V_CHECK_LAUNCH("gemm_tn_batched");
     return I2V_OK;
+}
+
+// The same accumulating into gw (gw += sum; the caller has cleared or pre-loaded it): no memset node in front.
+extern "C" int32_t i2v_gemm_tn_batched_acc(const float* x, const float* gy, float* gw, int32_t M, int32_t N, int32_t K,
+                                           int32_t nbatch, long long stride_x, long long stride_gy, long long stride_gw,
+                                           void* stream) {
+    g_tn_beta = 1.f;
+    const int32_t rc = i2v_gemm_tn_batched(x, gy, gw, M, N, K, nbatch, stride_x, stride_gy, stride_gw, stream);
+    g_tn_beta = 0.f;
+    return rc;
 }
 
 extern "C" int32_t i2v_conv_wgrad(const float* x, const float* gy, float* gw, int32_t B, int32_t H, int32_t W,

@@ -407,9 +407,13 @@ __device__ inline void gt6(const float x[6], float o[3]) {           // G^T x
 }
 
 __global__ void __launch_bounds__(256)
-wino4_gy_kernel(const float* __restrict__ gy, float* __restrict__ Y, int B, int H, int W, int N, int th, int tw) {
+wino4_gy_kernel(const float* __restrict__ gy, float* __restrict__ Y, int B, int H, int W, int N, int th, int tw,
+                float* __restrict__ zero_ptr, long long zero_n4) {
     const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     const long long T = (long long)B * th * tw;
+    // side job: clear the accumulator of the 36 plane GEMMs that follow (they accumulate over pixel splits with atomics) --
+    // a memset node per trained 3x3 layer and step otherwise (41 per instance_styleD step)
+    for (long long i = idx; i < zero_n4; i += (long long)gridDim.x * blockDim.x) ((float4*)zero_ptr)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (idx >= T * N) return;
     const int n = (int)(idx % N);
     const long long t = idx / N;
@@ -616,8 +620,8 @@ static int winograd4_wgrad_impl(const float* x, const float* v_in, const float* 
     if (v_in) V = const_cast<float*>(v_in);         // the forward's transformed input (i2v_conv3x3_winograd4_fwd_keep)
     else if (rows & 1) wino4_input_rows_kernel<<<dim3((unsigned)i2v_cdiv(T * Cin, 256), 6), 256, 0, st>>>(x, V, B, H, W, Cin, th, tw);
     else wino4_input_kernel<<<(unsigned)i2v_cdiv(T * Cin, 256), 256, 0, st>>>(x, V, B, H, W, Cin, th, tw);
-    wino4_gy_kernel<<<(unsigned)i2v_cdiv(T * Cout, 256), 256, 0, st>>>(gy, Y, B, H, W, Cout, th, tw);
-    int rc = i2v_gemm_tn_batched(V, Y, X, (int32_t)T, Cout, Cin, 36, T * Cin, T * Cout, (long long)Cout * Cin, stream);
+    wino4_gy_kernel<<<(unsigned)i2v_cdiv(T * Cout, 256), 256, 0, st>>>(gy, Y, B, H, W, Cout, th, tw, X, 9ll * Cout * Cin);
+    int rc = i2v_gemm_tn_batched_acc(V, Y, X, (int32_t)T, Cout, Cin, 36, T * Cin, T * Cout, (long long)Cout * Cin, stream);
     if (rc) return rc;
     wino4_wgrad_final_kernel<<<(unsigned)i2v_cdiv((long long)Cout * Cin, 256), 256, 0, st>>>(X, gw, row_scale, Cout, Cin, beta);
     I2V_CHECK_LAUNCH("conv3x3_winograd4_wgrad");

@@ -1131,7 +1131,7 @@ class InstanceStyleDStep:
             else:
                 out = net(self.im_s, self.info, self.gt, self.nb, target=False, eta=self.eta, eta_style=self.eta_style)
             _, _, _, l_rpn_cls, l_rpn_box, l_cls, l_box, _, d_inst, d_style = out
-            loss = l_rpn_cls.mean() + l_rpn_box.mean() + l_cls.mean() + l_box.mean()
+            loss = _mean1(l_rpn_cls) + _mean1(l_rpn_box) + _mean1(l_cls) + _mean1(l_box)
             dloss_s = ops.half_mse(d_inst)                  # 0.5 * mean(d^2) (:276-277), one kernel each way
             dloss_s_style = ops.half_mse(d_style)
             if batched:
@@ -1184,7 +1184,7 @@ class InstanceStyleDStep:
         def source():
             out = net(self.im_s, self.info, self.gt, self.nb, target=False, eta=self.eta, eta_style=self.eta_style)
             _, _, _, l_rpn_cls, l_rpn_box, l_cls, l_box, _, d_inst, d_style = out
-            v = {"det": l_rpn_cls.mean() + l_rpn_box.mean() + l_cls.mean() + l_box.mean(),
+            v = {"det": _mean1(l_rpn_cls) + _mean1(l_rpn_box) + _mean1(l_cls) + _mean1(l_box),
                  "dloss_s": ops.half_mse(d_inst), "dloss_s_style": ops.half_mse(d_style)}
             part = v["det"] + v["dloss_s"] + self.style_lambda * v["dloss_s_style"]
             if self.cr:
@@ -1333,6 +1333,12 @@ class InstanceStyleDStep:
                 ds.ctx.fit()
                 ds.fitted = True
         return self.losses["total"]
+
+
+def _mean1(t):
+    """``t.mean()`` of the loop (trainval_net_instance_styleD_bilinear.py:276-279) without a reduction kernel when t holds one
+    element (the detector returns its four losses as 1-element tensors)."""
+    return t.reshape(()) if t.numel() == 1 else t.mean()
 
 
 def _consistency_term(di, ds):

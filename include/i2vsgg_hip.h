@@ -289,6 +289,9 @@ int32_t i2v_conv3x3_winograd4_wgrad_v(const float* v, const float* gy, const flo
 /* gw[z] (N x K) = gy[z]^T (M x N) . x[z] (M x K), z < nbatch (the plane GEMMs above); N % 4 == K % 4 == 0 */
 int32_t i2v_gemm_tn_batched(const float* x, const float* gy, float* gw, int32_t M, int32_t N, int32_t K,
                             int32_t nbatch, long long stride_x, long long stride_gy, long long stride_gw, void* stream);
+/* the same accumulating into gw (gw += ...: cleared or pre-loaded by the caller; no memset in front) */
+int32_t i2v_gemm_tn_batched_acc(const float* x, const float* gy, float* gw, int32_t M, int32_t N, int32_t K,
+                            int32_t nbatch, long long stride_x, long long stride_gy, long long stride_gw, void* stream);
 size_t  i2v_conv_dgrad_workspace_bytes(int32_t Cin, int32_t Cout, int32_t KH, int32_t KW);
 int32_t i2v_conv_dgrad(const float* gy, const float* w, float* gx, int32_t B, int32_t H, int32_t W,
                        int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
