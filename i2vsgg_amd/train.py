@@ -280,11 +280,16 @@ class _Slot:
 
 
 class _Uploader:
-    """Host frames -> device on a COPY stream, two staging buffers per shape: the PCIe transfer of minibatch k+1 runs beside
-    the step that is still computing (a 2 x 3 x 600 x 1000 fp32 minibatch is 14.4 MB = 0.6 ms at 25 GB/s; queued on the compute
-    stream it sat in front of every graph launch: bench.py --data loader 5.26 ms per step against 4.61 resident).  ``upload``
-    returns a device tensor that is valid on the caller's CURRENT stream (an event edge), ``consumed`` marks the point after
-    which its buffer may be overwritten."""
+    """Host frames -> device.  Default: on the caller's stream, in front of the step (a 2 x 3 x 600 x 1000 fp32 minibatch is
+    14.4 MB = 0.6 ms at 25 GB/s: bench.py --data loader 5.2 ms per step against 4.6 resident).
+    ``I2V_UPLOAD_STREAM=1``: on a COPY stream with two staging buffers and event edges both ways, so that the transfer of
+    minibatch k+1 runs beside the step that is still computing (measured 5.26 -> 5.03 ms).  OFF by default: with it, a
+    process that had created several step objects crashed in hipGraphLaunch (a host segfault, reproducible for one order of the
+    test files, gone with the option off: tests/test_gpu_configs.py followed by tests/test_gpu_data_layer.py) -- torch hands out
+    32 pooled streams per device round robin, so after a few step objects the "copy" stream IS a stream some later capture
+    forks or captures on; the default keeps every transfer on the stream the step replays on.
+    ``upload`` returns a device tensor that is valid on the caller's CURRENT stream, ``consumed`` marks the point after which
+    its buffer may be overwritten."""
 
     def __init__(self, device):
         self.dev = torch.device(device)
@@ -296,27 +301,40 @@ class _Uploader:
         import os
         self.stream = torch.cuda.Stream(self.dev, priority=int(os.environ.get("I2V_UPLOAD_PRIORITY", "0")))
         self.rings = {}
+        self.enabled = os.environ.get("I2V_UPLOAD_STREAM", "0") == "1"
 
     def upload(self, frames):
+        if not self.enabled:                 # the transfer on the caller's stream, in front of the step (the round-2 form)
+            return frames.to(self.dev, non_blocking=True), None
+        return self._upload(frames)
+
+    def _upload(self, frames):
         # ONE ring of two byte buffers for every shape: upload k+2 waits for the consumer of upload k whatever their shapes, so
         # at most two transfers are ever queued ahead of the step
         nbytes = frames.numel() * frames.element_size()
         ring = self.rings.setdefault("ring", {"i": 0, "buf": [None, None], "free": [None, None]})
         i = ring["i"]
         ring["i"] ^= 1
-        if ring["buf"][i] is None or ring["buf"][i].numel() < nbytes:
-            ring["buf"][i] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=self.dev)
-        dst = ring["buf"][i][:nbytes].view(frames.dtype).view(frames.shape)
+        cur = torch.cuda.current_stream(self.dev)
         if ring["free"][i] is not None:
             self.stream.wait_event(ring["free"][i])          # the copy that last READ this buffer (two uploads ago) is done
         with torch.cuda.stream(self.stream):
+            if ring["buf"][i] is None or ring["buf"][i].numel() < nbytes:
+                # allocated ON the copy stream (the caching allocator hands a block only to work ordered behind its previous
+                # use on the stream it was allocated for) and known to the consumer's stream, so that a release -- growth
+                # here, or the end of the step object -- waits for both
+                ring["buf"][i] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=self.dev)
+            ring["buf"][i].record_stream(cur)
+            dst = ring["buf"][i][:nbytes].view(frames.dtype).view(frames.shape)
             dst.copy_(frames, non_blocking=True)
             done = torch.cuda.Event()
             done.record(self.stream)
-        torch.cuda.current_stream(self.dev).wait_event(done)
+        cur.wait_event(done)
         return dst, (ring, i)
 
     def consumed(self, token):
+        if token is None:
+            return
         ring, i = token
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.dev))
@@ -772,9 +790,10 @@ class SGGEmbStep:
     def invalidate_graphs(self):
         """Drop every captured graph (a learning-rate change -- rates live in the captured kernel arguments --, a capacity
         change, new feature-map buffers).  They are captured again on first use."""
-        dropped = False
+        dropped = any(fs.graph for fs in self.shapes.values())
+        if dropped:
+            torch.cuda.synchronize(self.dev)      # a replay may still be running: its executable graph goes only after it
         for fs in self.shapes.values():
-            dropped |= bool(fs.graph)
             fs.graph = None
         if dropped:
             import gc
@@ -860,7 +879,8 @@ class SGGEmbStep:
             torch.cuda.synchronize(self.dev)
         fs.fitted = True
         live = [f for f in self.shapes.values() if f.graph]
-        if len(live) >= self.max_graphs:                          # least recently used goes
+        if len(live) >= self.max_graphs:                          # least recently used goes (after whatever is still running)
+            torch.cuda.synchronize(self.dev)
             min(live, key=lambda f: f.tick).graph = None
         fmap_key = self._fmap_key
         try:
@@ -1025,7 +1045,8 @@ class InstanceStyleDStep:
         self.opt = FusedSGD(list(net.named_parameters()), lr)
         self.names = ["total", "det", "dloss_s", "dloss_t", "dloss_s_style", "dloss_t_style"] + \
             (["source_adv_cst", "target_adv_cst"] if cr else [])
-        self.losses = {k: torch.zeros((), device=self.dev) for k in self.names}     # static addresses: a captured step writes here
+        self._loss_buf = torch.zeros((len(self.names),), device=self.dev)           # static addresses: a captured step writes here
+        self.losses = {k: self._loss_buf[i] for i, k in enumerate(self.names)}      # (views: one stack + one copy per step)
         self.graph_error = None
 
     # ------------------------------------------------------------------ compatibility views
@@ -1158,8 +1179,7 @@ class InstanceStyleDStep:
                 ops.WGRAD_STREAM = None
             parallel.all_reduce_grads(self.opt.params())
             self.opt.step()
-            for k in self.names:
-                self.losses[k].copy_(vals[k].detach())
+            self._loss_buf.copy_(torch.stack([vals[k].detach().reshape(()) for k in self.names]))
 
     eager_step = _body
 
@@ -1223,8 +1243,7 @@ class InstanceStyleDStep:
         vals["total"] = vals.pop("_src") + vals.pop("_tgt")
         parallel.all_reduce_grads(params)
         self.opt.step()
-        for k in self.names:
-            self.losses[k].copy_(vals[k].detach())
+        self._loss_buf.copy_(torch.stack([vals[k].detach().reshape(()) for k in self.names]))
 
     def _device_sampling(self, on):
         atl = self.net.RCNN_rpn.RPN_anchor_target
@@ -1251,9 +1270,10 @@ class InstanceStyleDStep:
     def invalidate_graphs(self):
         """Drop every captured graph (a learning-rate change: the rates live in the captured kernel arguments); they are
         captured again on first use, into the same memory pool."""
-        dropped = False
+        dropped = any(ds.graph for ds in self.sets.values())
+        if dropped:
+            torch.cuda.synchronize(self.dev)      # a replay may still be running: its executable graph goes only after it
         for ds in self.sets.values():
-            dropped |= bool(ds.graph)
             ds.graph = None
         if dropped:
             import gc
@@ -1297,7 +1317,8 @@ class InstanceStyleDStep:
             if saved is not None:
                 self._restore(saved)
         live = [d for d in self.sets.values() if d.graph]
-        if len(live) >= self.max_graphs:                          # least recently used goes
+        if len(live) >= self.max_graphs:                          # least recently used goes (after whatever is still running)
+            torch.cuda.synchronize(self.dev)
             min(live, key=lambda d: d.tick).graph = None
         try:
             g = torch.cuda.CUDAGraph()
