@@ -97,6 +97,44 @@ def test_varied_synthetic_imdb_feeds_batches_of_several_sizes():
         c.cfg.TRAIN.USE_FLIPPED, c.cfg.TRAIN.SCALES = saved
 
 
+def test_device_prep_loader_items_carry_the_host_items_metadata():
+    """roibatchLoader(device_prep=True): the item is the uint8 frame as decoded + [flipped, canvas_h, canvas_w, scale, target];
+    gt_boxes, num_boxes, paths, the scale and the padded canvas equal what the host form (get_minibatch + the loader's padding,
+    roibatchLoader.py:162-190) returns for the same index and np.random state; the square-trim case is handed back
+    (canvas 0); collate_device_prep keeps the frames a list."""
+    from i2vsgg_amd.model.utils import config as c
+    from i2vsgg_amd.roi_data_layer.roidb import combined_roidb
+    from i2vsgg_amd.roi_data_layer.roibatchLoader import collate_device_prep, roibatchLoader
+    saved = (c.cfg.TRAIN.USE_FLIPPED, c.cfg.TRAIN.SCALES)
+    c.cfg.TRAIN.USE_FLIPPED, c.cfg.TRAIN.SCALES = True, (96,)
+    try:
+        imdb, roidb, rl, ri = combined_roidb("synthetic_10_v")
+        host = roibatchLoader(roidb, rl, ri, 2, imdb.num_classes, training=True, path_return=True)
+        dev = roibatchLoader(roidb, rl, ri, 2, imdb.num_classes, training=True, path_return=True, device_prep=True)
+        trims = flips = 0
+        for i in range(len(roidb)):
+            np.random.seed(i); x = host[i]
+            np.random.seed(i); y = dev[i]
+            assert y[0].dtype == torch.uint8 and y[0].dim() == 3 and y[0].shape[2] == 3
+            e = roidb[int(ri[i])]
+            assert tuple(y[0].shape[:2]) == (e["height"], e["width"]) and bool(y[1][0]) == bool(e["flipped"])
+            flips += int(y[1][0])
+            assert torch.equal(x[2], y[2]) and x[3] == y[3] and x[4] == y[4]
+            assert abs(float(x[1][2]) - float(y[1][3])) < 1e-7 and int(y[1][4]) == 96
+            if int(y[1][1]) == 0:
+                trims += 1
+                continue
+            assert tuple(x[0].shape[1:]) == (int(y[1][1]), int(y[1][2])) == (int(x[1][0]), int(x[1][1]))
+        assert flips == 10 and trims <= 4
+        b = collate_device_prep([dev[0], dev[1]])
+        assert isinstance(b[0], list) and len(b[0]) == 2 and b[1].shape == (2, 5) and b[2].shape == (2, c.cfg.MAX_NUM_GT_BOXES, 5)
+        assert len(b[4]) == 2
+        # flipped copies carry their frame's path: the relation annotations of a frame serve both (imdb.image_path_at semantics)
+        assert {p.split("/")[-1] for p in (e["image"] for e in roidb)} == set(imdb.gt_rels(62))
+    finally:
+        c.cfg.TRAIN.USE_FLIPPED, c.cfg.TRAIN.SCALES = saved
+
+
 def test_rank_sharded_sampler_partitions_the_block_order():
     """One process per GPU: every rank draws the same block order and keeps every world-th block -- disjoint, equally many
     minibatches per rank, blocks still contiguous (one aspect-ratio group per minibatch), a new order every epoch."""
