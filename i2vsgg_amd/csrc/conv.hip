@@ -1032,6 +1032,214 @@ conv_gemm_f32(const ConvP p_in) {
     stamp();
 }
 
+// ---------------------------------------------------------------- persistent form of conv_gemm_f32
+// The same GEMM, staging, LDS image, MFMA order and register epilogue as conv_gemm_f32 (bit-equal results), scheduled as a
+// STREAM OF STAGES: a workgroup owns several tiles (b, b + G, b + 2G, ... of the XCD-aware tile order, G workgroups) and never
+// stops loading -- the operands of the next tile's first stage are requested under the current tile's last stage, and the
+// epilogue's stores drain under the next tile's K loop.  conv_gemm_f32 launches every tile at once: all workgroups of the chip
+// load, then compute, then store IN PHASE; here only the last tile of a workgroup ends in a store burst.
+// A tile queue fed by atomics was tried first and lost by 4x: same-address atomics retire one per ~70 ns at the L2 (8 queues,
+// ~1000 workgroups), and a wave's loads return in order behind its fetch.
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool MASK = false>
+__global__ void __launch_bounds__(THREADS, (TM * TN <= 5 ? 4 : TM * TN <= 6 ? 3 : 2))      // waves per SIMD the register budget is held to
+conv_gemm_pers_f32(const ConvP p) {
+    constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
+    constexpr int A_LD = (BM * 8 + THREADS - 1) / THREADS, B_LD = (BN * 8 + THREADS - 1) / THREADS;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float (*As)[BM * BKS] = reinterpret_cast<float (*)[BM * BKS]>(smem);
+    float (*Bs)[BN * BKS] = reinterpret_cast<float (*)[BN * BKS]>(smem + 2 * BM * BKS);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int T = ((p.M + BM - 1) / BM) * tiles_n;
+    const int kc = tid & 7, kg = kc * 4;
+    const int kend = p.K;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+    constexpr unsigned INV = 0x80000000u;
+
+    // ---- this workgroup's tiles: virtual blocks vb = blockIdx.x + i * gridDim.x (gridDim.x is a multiple of 8, so all of them
+    // sit on this workgroup's XCD) in conv_gemm_f32's XCD-aware order over T virtual blocks
+    auto tile_of = [&](int vb) {
+        const int qq = T >> 3, r = T & 7, x = vb & 7, i = vb >> 3;
+        return (x < r ? x * (qq + 1) : r * (qq + 1) + (x - r) * qq) + i;
+    };
+    unsigned a_vk[A_LD], b_vk[B_LD];
+    auto set_tile = [&](int tile) {               // staging offsets of a tile's rows
+        const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+#pragma unroll
+        for (int qq = 0; qq < A_LD; ++qq) {
+            const int row = (tid >> 3) + qq * (THREADS / 8);
+            const int m = m0 + row;
+            a_vk[qq] = (row < BM && m < p.M) ? ((unsigned)(m * p.K) + (unsigned)kg) * 4u : INV;
+        }
+#pragma unroll
+        for (int qq = 0; qq < B_LD; ++qq) {
+            const int row = (tid >> 3) + qq * (THREADS / 8);
+            const int n = n0 + row;
+            b_vk[qq] = (row < BN && n < p.N) ? ((unsigned)(n * p.K) + (unsigned)kg) * 4u : INV;
+        }
+    };
+    float4 ra[A_LD], rb[B_LD];
+    auto gload = [&](int k0) {
+        const unsigned so = (unsigned)k0 * 4u;
+        const unsigned kinv = ~(unsigned)((k0 + kg - kend) >> 31) & INV;
+#pragma unroll
+        for (int qq = 0; qq < A_LD; ++qq)
+            ra[qq] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, a_vk[qq] | kinv, so, 0));
+#pragma unroll
+        for (int qq = 0; qq < B_LD; ++qq)
+            rb[qq] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, b_vk[qq] | kinv, so, 0));
+    };
+    auto sstore = [&](int S) {
+#pragma unroll
+        for (int qq = 0; qq < A_LD; ++qq) {
+            const int row = (tid >> 3) + qq * (THREADS / 8);
+            if (row < BM) *(float4*)&As[S][row * BKS + ((kc ^ ((row >> 1) & 7)) << 2)] = ra[qq];
+        }
+#pragma unroll
+        for (int qq = 0; qq < B_LD; ++qq) {
+            const int row = (tid >> 3) + qq * (THREADS / 8);
+            if (row < BN) *(float4*)&Bs[S][row * BKS + ((kc ^ ((row >> 1) & 7)) << 2)] = rb[qq];
+        }
+    };
+
+    // operands of the epilogue: always-issued buffer loads (conv_gemm_f32 has the rationale)
+    constexpr bool PREFETCH_RES = TM * TN <= 8;
+    const unsigned n_bytes = (unsigned)p.N * 4u;
+    const __amdgpu_buffer_rsrc_t scr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.scale ? p.scale : p.shift ? p.shift : (const float*)p.x), 0, n_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t shr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.shift ? p.shift : (const float*)p.x), 0, n_bytes, 0x00020000);
+    const unsigned long long y_bytes = (unsigned long long)p.M * p.N * 4ull;
+    const unsigned y_lim = (unsigned)(y_bytes < 0x7FFFFFF0ull ? y_bytes : 0x7FFFFFF0ull);
+    const __amdgpu_buffer_rsrc_t resr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : (const float*)p.x), 0, y_lim, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mskr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.mask ? p.mask : (const float*)p.x), 0, y_lim, 0x00020000);
+    const unsigned sc_inv = (p.flags & I2V_EPI_SCALE) ? 0u : INV;
+    const unsigned sh_inv = ((p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) && p.shift) ? 0u : INV;
+    const unsigned res_inv = (p.flags & I2V_EPI_RESIDUAL) ? 0u : INV;
+    float4 sc[TN], sh[TN], rres[PREFETCH_RES ? TM : 1][PREFETCH_RES ? TN : 1];
+    auto issue_epi = [&](int m0, int n0) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 16 + 4 * fg;
+            const unsigned off = n < p.N ? (unsigned)n * 4u : INV;
+            sc[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(scr, off | sc_inv, 0, 0));
+            sh[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(shr, off | sh_inv, 0, 0));
+        }
+        if constexpr (PREFETCH_RES) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int m = m0 + (wm * TM + i) * 16 + fr, n = n0 + (wn * TN + j) * 16 + 4 * fg;
+                    const unsigned off = (m < p.M && n < p.N) ? (unsigned)(m * p.N + n) * 4u : INV;
+                    rres[i][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(resr, off | res_inv, 0, 2));
+                }
+        }
+    };
+
+    f32x4 acc[TM][TN];
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float4 av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = (wm * TM + i) * 16 + fr;
+                av[i] = *(const float4*)&As[buf][row * BKS + (((h * 4 + fg) ^ ((row >> 1) & 7)) << 2)];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = (wn * TN + j) * 16 + fr;
+                bv[j] = *(const float4*)&Bs[buf][row * BKS + (((h * 4 + fg) ^ ((row >> 1) & 7)) << 2)];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const float a = t == 0 ? av[i].x : t == 1 ? av[i].y : t == 2 ? av[i].z : av[i].w;
+                        const float b = t == 0 ? bv[j].x : t == 1 ? bv[j].y : t == 2 ? bv[j].z : bv[j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, acc[i][j], 0, 0, 0);
+                    }
+        }
+    };
+    auto finish = [&](int m, int n, int j, f32x4 v, float4 rr, float4 mk) {
+        if (m >= p.M || n >= p.N) return;
+        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (p.flags & I2V_EPI_SCALE) { o.x *= sc[j].x; o.y *= sc[j].y; o.z *= sc[j].z; o.w *= sc[j].w; }
+        if ((p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) && p.shift) { o.x += sh[j].x; o.y += sh[j].y; o.z += sh[j].z; o.w += sh[j].w; }
+        if (p.flags & I2V_EPI_RESIDUAL) { o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
+        if (p.flags & I2V_EPI_RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+        if constexpr (MASK) { o.x = mk.x > 0.f ? o.x : 0.f; o.y = mk.y > 0.f ? o.y : 0.f; o.z = mk.z > 0.f ? o.z : 0.f; o.w = mk.w > 0.f ? o.w : 0.f; }
+        *(float4*)(p.y + (long long)m * p.N + n) = o;
+    };
+
+    int vb = blockIdx.x;                       // < T (launch_tile)
+    int cur = tile_of(vb);
+    set_tile(cur);
+    gload(0);
+    int buf = 0;
+    while (cur >= 0) {
+        const int m0 = (cur / tiles_n) * BM, n0 = (cur % tiles_n) * BN;
+        vb += gridDim.x;
+        const int nxt = vb < T ? tile_of(vb) : -1;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        sstore(buf);                                      // stage 0: requested under the previous tile's last stage
+        __syncthreads();
+        int k0 = 0;
+        for (; k0 + 2 * BKS < kend; k0 += BKS) {          // every stage but the last two
+            gload(k0 + BKS);
+            compute(buf);
+            sstore(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+        gload(k0 + BKS);                                  // last stage's operands, then the epilogue's (returns are in order)
+        issue_epi(m0, n0);
+        compute(buf);
+        sstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+        if (nxt >= 0) { set_tile(nxt); gload(0); }        // the next tile's first stage rides under this tile's last
+        compute(buf);
+        buf ^= 1;
+        // epilogue in registers; the stores drain under whatever this workgroup and its neighbours do next
+        float4 mk[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                mk[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (MASK) {
+                    const int m = m0 + (wm * TM + i) * 16 + fr, n = n0 + (wn * TN + j) * 16 + 4 * fg;
+                    const unsigned off = (m < p.M && n < p.N) ? (unsigned)(m * p.N + n) * 4u : INV;
+                    mk[i][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(mskr, off, 0, 0));
+                }
+            }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int m = m0 + (wm * TM + i) * 16 + fr, n = n0 + (wn * TN + j) * 16 + 4 * fg;
+                float4 rr;
+                if constexpr (PREFETCH_RES) rr = rres[PREFETCH_RES ? i : 0][PREFETCH_RES ? j : 0];
+                else {
+                    const unsigned off = (m < p.M && n < p.N) ? (unsigned)(m * p.N + n) * 4u : INV;
+                    rr = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(resr, off | res_inv, 0, 2));
+                }
+                finish(m, n, j, acc[i][j], rr, mk[i][j]);
+            }
+        cur = nxt;
+    }
+}
+
 // epilogue of the split-K path (partials were accumulated with fp32 atomics)
 __global__ void conv_epilogue_kernel(float* __restrict__ y, const float* __restrict__ scale,
                                      const float* __restrict__ shift, const float* __restrict__ res,
@@ -1144,6 +1352,24 @@ void launch_tile(const ConvP& p, bool spec, hipStream_t st) {
         }();
         (void)once_g;
         const size_t lds_g = (size_t)(2 * (BM + BN) * BKS) * sizeof(float);
+        // persistent form (stream of stages): unsplit, unbatched, at least two K stages, at least two tiles per workgroup
+        const int per = g_i2v_tuning[I2V_TUNE_GEMM_PERSIST];
+        if (per > 0 && p.splitk <= 1 && p.nbatch <= 1 && p.K > BKS && !p.clk && !g_i2v_tuning[I2V_TUNE_GEMM_X3] && tiles >= 2 * NUM_CU) {
+            static const int slots = [&] {
+                set_max_lds(conv_gemm_pers_f32<WAVES_M, WAVES_N, TM, TN>);
+                set_max_lds(conv_gemm_pers_f32<WAVES_M, WAVES_N, TM, TN, true>);
+                int n = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_gemm_pers_f32<WAVES_M, WAVES_N, TM, TN>, THREADS, lds_g) != hipSuccess || n < 1) n = 1;
+                return n * NUM_CU;
+            }();
+            // per tiles per workgroup at least (2 by default), as many workgroups as fit at once at most, a multiple of 8
+            int g = (i2v_cdiv(tiles, per < 2 ? 2 : per) + 7) & ~7;
+            if (g > slots) g = slots;
+            if (g > tiles) g = tiles & ~7;
+            if (p.flags & I2V_EPI_MASK) conv_gemm_pers_f32<WAVES_M, WAVES_N, TM, TN, true><<<g, THREADS, lds_g, st>>>(p);
+            else conv_gemm_pers_f32<WAVES_M, WAVES_N, TM, TN><<<g, THREADS, lds_g, st>>>(p);
+            return;
+        }
         if (p.flags & I2V_EPI_MASK) conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true><<<grid, THREADS, lds_g, st>>>(p);
         else if (p.clk) conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, true><<<grid, THREADS, lds_g, st>>>(p);
         else if (g_i2v_tuning[I2V_TUNE_GEMM_X3]) {      // opt-in: 3-term bf16 split on the bf16 matrix pipe

@@ -510,19 +510,22 @@ class SGGEmbStep:
         self.cap_boxes, self.cap_pairs = up(nb, self.cap_boxes), up(npair, self.cap_pairs)
         self.invalidate_graphs()
 
-    def stage(self, frames, info, fields):
+    def stage(self, frames, info, fields, size=None):
         """Hand the NEXT minibatch to the step.  ``frames``: (n,4,H,W) channels_last device tensor (the device front-end's
         blob), or (n,3,H,W) float frames on the device or the host (a roibatchLoader batch; pinned host memory crosses
-        asynchronously).  ``info``: (n,3) im_info rows.  ``fields``: ``sgg_head_inputs`` of the batch.  Ordered on the
+        asynchronously), or -- with ``size`` = (n, H, W) -- a callable that writes the frames into the frame set it is given
+        (``stage_batch_u8``).  ``info``: (n,3) im_info rows.  ``fields``: ``sgg_head_inputs`` of the batch.  Ordered on the
         caller's stream like everything else: it may be called right after ``__call__`` returns, the copies queue behind
         the step that is still running."""
         if fields is None:
             raise ValueError("SGGEmbStep.stage: a minibatch without an annotated relation (the reference loop skips it, "
                              "faster_rcnn_SGG_emb.py:177-183)")
         placer = None
-        if callable(frames):                 # (key, placer): the frames are written into the frame set by the caller
+        if callable(frames):
+            if size is None:
+                raise ValueError("SGGEmbStep.stage: a frame-writing callable needs size=(n, H, W)")
             placer = frames
-            n, H, W = self._pending_key
+            n, H, W = size
         else:
             n, _, H, W = frames.shape
         if int(n) != self.n_frames:
@@ -629,8 +632,7 @@ class SGGEmbStep:
             return False
         if self._uploader is None:
             self._uploader = _Uploader(self.dev)
-        self._pending_key = (len(frames), hc, wc)
-        self.stage(lambda fs: _place_u8(self._uploader, frames, meta, fs.im), info, fields)
+        self.stage(lambda fs: _place_u8(self._uploader, frames, meta, fs.im), info, fields, size=(len(frames), hc, wc))
         return True
 
     def reseed(self, seed):

@@ -773,6 +773,34 @@ def test_pointwise_gemm_kernel_equals_generic_kernel(ops, M, K, N, res):
     np.testing.assert_allclose(out[1].cpu().numpy(), ref.float().cpu().numpy(), rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("M,K,N,res,tile", [(75000, 64, 256, True, 3), (18750, 128, 512, True, 2), (9000, 256, 1024, True, 5),
+                                              (37500, 256, 64, False, 4), (20000, 96, 200, False, 3)])
+def test_persistent_gemm_equals_one_tile_per_workgroup(ops, M, K, N, res, tile):
+    """conv_gemm_pers_f32 (I2V_GEMM_PERSIST: a workgroup streams through several tiles, the next tile's operands requested under
+    the current tile's last stage) is the same arithmetic as conv_gemm_f32: bit-equal outputs, ragged M / N / K included."""
+    from i2vsgg_amd._lib import TUNE, lib
+    rng = np.random.default_rng(M + K + N)
+    x = torch.from_numpy(rng.standard_normal((M, K), dtype=np.float32)).to(DEV)
+    w = torch.from_numpy((rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)).to(DEV)
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, N).astype(np.float32)).to(DEV)
+    sh = torch.from_numpy(rng.uniform(-0.5, 0.5, N).astype(np.float32)).to(DEV)
+    r4 = torch.from_numpy(rng.standard_normal((M, N), dtype=np.float32)).to(DEV).view(M, N, 1, 1) if res else None
+    out = {}
+    try:
+        lib.i2v_conv_set_tile(tile)
+        for mode in (0, 2, 3):
+            assert lib.i2v_set_tuning(TUNE["I2V_GEMM_PERSIST"], mode) == 0
+            out[mode] = ops.conv2d(x.view(M, K, 1, 1), w.view(N, K, 1, 1), sc, sh, r4, 1, 0, relu=True).view(M, N).clone()
+    finally:
+        lib.i2v_set_tuning(TUNE["I2V_GEMM_PERSIST"], 0)
+        lib.i2v_conv_set_tile(-1)
+    assert torch.equal(out[2], out[0]) and torch.equal(out[3], out[0])
+    ref = x.double() @ w.double().t() * sc.double() + sh.double()
+    if res:
+        ref = ref + r4.view(M, N).double()
+    np.testing.assert_allclose(out[2].cpu().numpy(), torch.relu(ref).float().cpu().numpy(), rtol=2e-5, atol=2e-5)
+
+
 def test_pointwise_gemm_kernel_batched_planes(ops):
     """The 36 element-wise planes of a Winograd F(4x4,3x3) layer3 convolution as one batched launch on conv_gemm_f32."""
     from i2vsgg_amd._lib import lib, ptr, stream
