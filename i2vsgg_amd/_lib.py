@@ -84,6 +84,7 @@ SIGNATURES = {
     "i2v_image_prep": (_i, [_p, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p]),
     "i2v_det_postprocess_workspace_bytes": (_z, [_i, _i]),
     "i2v_det_postprocess": (_i, [_p, _p, _p, _i, _p, _p, _f, _f, _f, _i, _i, _f, _f, _i, _p, _p, _p, _z, _p]),
+    "i2v_det_postprocess_info": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _f, _f, _i, _p, _p, _p, _z, _p]),
     "i2v_l2norm_rows_fwd": (_i, [_p, _p, _p, _i, _i, _f, _p]),
     "i2v_l2norm_rows_bwd": (_i, [_p, _p, _p, _p, _i, _i, _f, _p]),
     "i2v_bce_rows_fwd": (_i, [_p, _p, _p, _p, _i, _i, _p]),

@@ -436,10 +436,11 @@ int launch_nms(const float* dets, int n_img, int n, float thresh, int max_keep, 
 // image-wide top-`max_per_image` cut.  The reference does 1 + (n_classes-1) host NMS calls per frame.
 __global__ void det_decode_kernel(const float* __restrict__ rois, const float* __restrict__ prob,
                                   const float* __restrict__ pred, int agnostic, int normalize, float4 stds, float4 means,
-                                  float im_h, float im_w, float scale, int R, int C, float thresh,
-                                  float4* __restrict__ boxes, float* __restrict__ keys, int* __restrict__ n_valid) {
+                                  float im_h, float im_w, float scale, const float* __restrict__ info, int R, int C,
+                                  float thresh, float4* __restrict__ boxes, float* __restrict__ keys, int* __restrict__ n_valid) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (C - 1) * R) return;
+    if (info) { im_h = info[0]; im_w = info[1]; scale = info[2]; }       // the frame's im_info row, on the device (a captured eval step)
     const int seg = idx / R, i = idx % R, j = seg + 1;
     const float* d = pred + (long long)i * (agnostic ? 4 : 4 * C) + (agnostic ? 0 : 4 * j);
     float d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3];
@@ -698,13 +699,13 @@ extern "C" size_t i2v_det_postprocess_workspace_bytes(int32_t R, int32_t C) {
     return det_carve(nullptr, R, C).bytes;
 }
 
-extern "C" int32_t i2v_det_postprocess(const float* rois, const float* cls_prob, const float* bbox_pred,
-                                       int32_t class_agnostic, const float* stds, const float* means, float im_h,
-                                       float im_w, float im_scale, int32_t R, int32_t C, float score_thresh,
-                                       float nms_thresh, int32_t max_per_image, float* dets, int32_t* counts, void* ws,
-                                       size_t ws_bytes, void* stream) {
+static int32_t det_postprocess(const float* rois, const float* cls_prob, const float* bbox_pred,
+                               int32_t class_agnostic, const float* stds, const float* means, float im_h,
+                               float im_w, float im_scale, const float* info, int32_t R, int32_t C, float score_thresh,
+                               float nms_thresh, int32_t max_per_image, float* dets, int32_t* counts, void* ws,
+                               size_t ws_bytes, void* stream) {
     I2V_CHECK_ARG(rois && cls_prob && bbox_pred && dets && counts, "det_postprocess: null pointer");
-    I2V_CHECK_ARG(R > 0 && C > 1 && im_scale > 0.f, "det_postprocess: bad shape");
+    I2V_CHECK_ARG(R > 0 && C > 1 && (info || im_scale > 0.f), "det_postprocess: bad shape");
     I2V_CHECK_ARG((stds == nullptr) == (means == nullptr), "det_postprocess: stds and means go together");
     if (!ws || ws_bytes < i2v_det_postprocess_workspace_bytes(R, C)) {
         i2v_set_error("det_postprocess: workspace too small");
@@ -718,7 +719,7 @@ extern "C" int32_t i2v_det_postprocess(const float* rois, const float* cls_prob,
     const float4 sd = stds ? make_float4(stds[0], stds[1], stds[2], stds[3]) : make_float4(1.f, 1.f, 1.f, 1.f);
     const float4 mn = means ? make_float4(means[0], means[1], means[2], means[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
     det_decode_kernel<<<i2v_cdiv(n, 256), 256, 0, st>>>(rois, cls_prob, bbox_pred, class_agnostic, stds != nullptr, sd, mn,
-                                                        im_h, im_w, im_scale, R, C, score_thresh, w.boxes, w.keys,
+                                                        im_h, im_w, im_scale, info, R, C, score_thresh, w.boxes, w.keys,
                                                         w.n_valid);
     int rc = i2v_sort_desc(w.keys, C - 1, R, w.order, w.sort_ws, w.sort_ws_bytes, stream);
     if (rc) return rc;
@@ -733,6 +734,25 @@ extern "C" int32_t i2v_det_postprocess(const float* rois, const float* cls_prob,
     det_final_kernel<<<C, 256, 0, st>>>(w.tmp, w.cnt, w.total, w.all_scores, w.order2, max_per_image, R, C, dets, counts);
     I2V_CHECK_LAUNCH("det_postprocess");
     return I2V_OK;
+}
+
+extern "C" int32_t i2v_det_postprocess(const float* rois, const float* cls_prob, const float* bbox_pred,
+                                       int32_t class_agnostic, const float* stds, const float* means, float im_h,
+                                       float im_w, float im_scale, int32_t R, int32_t C, float score_thresh,
+                                       float nms_thresh, int32_t max_per_image, float* dets, int32_t* counts, void* ws,
+                                       size_t ws_bytes, void* stream) {
+    return det_postprocess(rois, cls_prob, bbox_pred, class_agnostic, stds, means, im_h, im_w, im_scale, nullptr, R, C,
+                           score_thresh, nms_thresh, max_per_image, dets, counts, ws, ws_bytes, stream);
+}
+
+extern "C" int32_t i2v_det_postprocess_info(const float* rois, const float* cls_prob, const float* bbox_pred,
+                                            int32_t class_agnostic, const float* stds, const float* means,
+                                            const float* im_info, int32_t R, int32_t C, float score_thresh,
+                                            float nms_thresh, int32_t max_per_image, float* dets, int32_t* counts,
+                                            void* ws, size_t ws_bytes, void* stream) {
+    I2V_CHECK_ARG(im_info, "det_postprocess_info: null im_info");
+    return det_postprocess(rois, cls_prob, bbox_pred, class_agnostic, stds, means, 0.f, 0.f, 0.f, im_info, R, C,
+                           score_thresh, nms_thresh, max_per_image, dets, counts, ws, ws_bytes, stream);
 }
 
 extern "C" size_t i2v_relation_topk_workspace_bytes(int32_t n_pairs, int32_t n_rel) {

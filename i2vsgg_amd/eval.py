@@ -7,6 +7,7 @@
                   eval branch of ``forward_relation`` returns; scaling by the box confidences, the ranking over the
                   (pair, predicate) grid and the top-k cut run on the device (``ops.relation_topk``).
 ``relation_frame``  backbone forward + ``forward_relation_eval`` + ``detection_output`` for one frame.
+``DetectStep``    ``detect_frame`` for several frames at a time as one replayable HIP graph (a branch per frame).
 """
 import numpy as np
 import torch
@@ -15,12 +16,172 @@ from . import ops
 from .model.utils.config import cfg
 
 
+class _DetectShape:
+    """What ``DetectStep`` owns for one (frames, H, W): the staged frames, a launch context per frame branch, the graph."""
+
+    def __init__(self, key, device):
+        n, h, w = key
+        self.key = key
+        self.im = torch.zeros((n, 4, h, w), device=device).contiguous(memory_format=torch.channels_last)
+        self.ctx = [ops.LaunchContext(device) for _ in range(n)]
+        self.graph = None             # None: not captured yet; False: capture failed (eager launches for this size)
+        self.tick = 0
+
+
+class DetectStep:
+    """The per-frame body of test_net_instance_styleD_bilinear.py:133-221 (eval forward, de-normalise / decode / clip, per class
+    threshold + sort + NMS 0.3, top-``max_per_image``) for ``frames`` frames at a time as ONE replayable HIP graph with a branch
+    per frame.  The reference evaluates frame by frame (batch_size 1, :95); one frame's kernels leave much of the chip idle
+    (a layer3 GEMM of one frame is 480 workgroups for 1024 slots), so independent frames side by side are the cheap speed-up --
+    every frame is still processed alone: same launches, same arithmetic, same results as ``detect_frame`` (up to the fp32
+    atomics of the split-K GEMMs, as between two calls of ``detect_frame``).
+
+    ``step(im_data, im_info)`` -> list over the frames of the reference's ``all_boxes[j][i]`` lists; ``step.run(batches)``
+    keeps one batch in flight while the host unpacks the previous one.  Frames of one call share a size (the loader pads a
+    minibatch to one size); graphs are kept per size, least recently used first.  The frame's ``im_info`` row is read on the
+    device (``i2v_det_postprocess_info``), so frames of any scale replay the same graph."""
+
+    def __init__(self, net, frames=2, thresh=0.0, max_per_image=100, class_agnostic=False, device="cuda:0", use_graph=True,
+                 max_graphs=8):
+        if net.training:
+            raise RuntimeError("DetectStep: the network must be in eval mode (test_net_...:131 fasterRCNN.eval())")
+        self.net, self.dev, self.frames = net, torch.device(device), int(frames)
+        self.thresh, self.max_per_image, self.class_agnostic = float(thresh), int(max_per_image), bool(class_agnostic)
+        self.use_graph, self.max_graphs = bool(use_graph), int(max_graphs)
+        self.R, self.C = int(cfg.TEST.RPN_POST_NMS_TOP_N), int(net.n_classes)
+        self.info = torch.zeros((self.frames, 3), device=self.dev)
+        self.dets = torch.zeros((self.frames, self.C, self.R, 5), device=self.dev)
+        self.counts = torch.zeros((self.frames, self.C), device=self.dev, dtype=torch.int32)
+        self._host = [(torch.zeros(self.dets.shape).pin_memory(), torch.zeros(self.counts.shape, dtype=torch.int32).pin_memory(),
+                       torch.cuda.Event()) for _ in range(2)]
+        self._slot = 0
+        self._streams = [torch.cuda.Stream(self.dev) for _ in range(self.frames)]
+        self.shapes, self._pool, self._tick, self._staged = {}, None, 0, None
+        self.graph_error = None
+
+    # ------------------------------------------------------------------ one frame, as the reference's loop body runs it
+    def _frame(self, fs, f):
+        with fs.ctx[f]:
+            rois, cls_prob, bbox_pred = self.net.forward_detect(fs.im[f:f + 1], self.info[f:f + 1])
+            stds = means = None
+            agnostic = self.class_agnostic
+            if cfg.TEST.BBOX_REG and cfg.TRAIN.BBOX_NORMALIZE_TARGETS_PRECOMPUTED:
+                stds, means = cfg.TRAIN.BBOX_NORMALIZE_STDS, cfg.TRAIN.BBOX_NORMALIZE_MEANS
+            if not cfg.TEST.BBOX_REG:              # :167-169 "simply repeat the boxes"
+                bbox_pred, agnostic, stds, means = torch.zeros((self.R, 4), device=self.dev), True, None, None
+            ops.detection_postprocess(rois[0], cls_prob[0], bbox_pred.reshape(self.R, -1), 0.0, 0.0, 0.0, agnostic, stds, means,
+                                      self.thresh, cfg.TEST.NMS, self.max_per_image, im_info=self.info[f],
+                                      out=(self.dets[f], self.counts[f]))
+
+    @torch.no_grad()
+    def _body(self, fs):
+        main = torch.cuda.current_stream(self.dev)
+        for f, st in enumerate(self._streams):     # fork from the launching stream itself (a fork inside a fork breaks capture)
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                self._frame(fs, f)
+        for st in self._streams:
+            main.wait_stream(st)
+
+    # ------------------------------------------------------------------ staging, capture, replay
+    def stage(self, im_data, im_info):
+        """``im_data``: (n,3,H,W) float frames (device or pinned host) or the (n,4,H,W) channels_last blob of the device
+        front-end, n <= frames (a short last batch: the other branches re-run what they hold); ``im_info``: (n,3)."""
+        n, c, H, W = im_data.shape
+        if n > self.frames:
+            raise ValueError("DetectStep.stage: %d frames, the step was built for %d" % (n, self.frames))
+        key = (self.frames, int(H), int(W))
+        fs = self.shapes.get(key)
+        if fs is None:
+            fs = self.shapes[key] = _DetectShape(key, self.dev)
+        if c == 4:
+            fs.im[:n].copy_(im_data, non_blocking=True)
+        else:
+            fs.im[:n, :3].copy_(im_data, non_blocking=True)      # NCHW3 -> NHWC4 (channel 3 stays zero)
+        info = torch.as_tensor(im_info, dtype=torch.float32).reshape(-1, 3)
+        self.info[:n].copy_(info, non_blocking=True)
+        if n < self.frames:                                      # idle branches: any valid im_info row (scale > 0) will do
+            self.info[n:].copy_(self.info[:1].expand(self.frames - n, 3))
+        self._staged, self._n = key, int(n)
+        return fs
+
+    def _capture(self, fs):
+        for _ in range(2):                         # eager passes: anchors / transformed filters cached, arenas sized
+            for f in range(self.frames):
+                with torch.no_grad():
+                    self._frame(fs, f)
+                fs.ctx[f].fit()
+        torch.cuda.synchronize(self.dev)
+        if not self.use_graph:
+            fs.graph = False
+            return
+        live = [t for t in self.shapes.values() if t.graph]
+        if len(live) >= self.max_graphs:
+            min(live, key=lambda t: t.tick).graph = None
+        try:
+            g = torch.cuda.CUDAGraph()
+            if self._pool is None:
+                self._pool = torch.cuda.graph_pool_handle()
+            with torch.cuda.graph(g, pool=self._pool):
+                self._body(fs)
+            fs.graph = g
+        except Exception as e:                     # report, keep the eager form for this size
+            fs.graph, self.graph_error = False, repr(e)
+            torch.cuda.synchronize(self.dev)
+
+    def launch(self):
+        """Run the staged batch (asynchronous) and queue the copy of its results into pinned host memory; returns a token
+        for ``collect``."""
+        fs = self.shapes[self._staged]
+        if fs.graph is None:
+            self._capture(fs)
+        self._tick += 1
+        fs.tick = self._tick
+        if fs.graph:
+            fs.graph.replay()
+        else:
+            self._body(fs)
+        dets_h, counts_h, ev = self._host[self._slot]
+        dets_h.copy_(self.dets, non_blocking=True)
+        counts_h.copy_(self.counts, non_blocking=True)
+        ev.record(torch.cuda.current_stream(self.dev))
+        token = (self._slot, self._n)
+        self._slot ^= 1
+        return token
+
+    def collect(self, token):
+        slot, n = token
+        dets_h, counts_h, ev = self._host[slot]
+        ev.synchronize()
+        dets, counts = dets_h.numpy(), counts_h.numpy()
+        return [[np.array(dets[f, j, :counts[f, j]]) for j in range(self.C)] for f in range(n)]
+
+    def __call__(self, im_data, im_info):
+        self.stage(im_data, im_info)
+        return self.collect(self.launch())
+
+    def run(self, batches):
+        """Generator over ``(im_data, im_info)`` batches: yields each batch's result list while the next batch runs."""
+        pending = None
+        for im_data, im_info in batches:
+            self.stage(im_data, im_info)
+            token = self.launch()
+            if pending is not None:
+                yield self.collect(pending)
+            pending = token
+        if pending is not None:
+            yield self.collect(pending)
+
+
 @torch.no_grad()
 def detect_frame(net, im_data, im_info, gt_boxes, num_boxes, thresh=0.0, max_per_image=100, class_agnostic=False):
     """Returns ``all_boxes_i``: list over classes of (n_j, 5) float32 arrays [x1,y1,x2,y2,score] in original-image
     coordinates (entry 0, background, is empty) -- the reference's ``all_boxes[j][i]`` for this frame."""
     assert im_data.shape[0] == 1, "the reference evaluates one frame at a time (test_net_...:95 batch_size 1)"
-    out = net(im_data, im_info, gt_boxes, num_boxes)
+    if hasattr(net, "forward_detect") and not net.training:
+        out = net.forward_detect(im_data, im_info)        # the three outputs read below; the discriminators' are not computed
+    else:
+        out = net(im_data, im_info, gt_boxes, num_boxes)
     rois, cls_prob, bbox_pred = out[0], out[1], out[2]
     info = im_info.reshape(-1).tolist()
     stds = means = None

@@ -104,6 +104,37 @@ class _fasterRCNN(nn.Module):
         return (rois, cls_prob, bbox_pred, rpn_loss_cls.view(-1), rpn_loss_bbox.view(-1), RCNN_loss_cls.view(-1),
                 RCNN_loss_bbox.view(-1), rois_label, d_instance, d_style)
 
+    @torch.no_grad()
+    def forward_detect(self, im_data, im_info):
+        """What the test loop reads of an eval forward (test_net_instance_styleD_bilinear.py:140-149: rois, cls_prob,
+        bbox_pred): the eval branch of ``forward`` without the two discriminator outputs nobody reads there -- netD_style /
+        netD_pixel run only where their context vectors feed the classifier (gc / ic)."""
+        if self.training:
+            raise RuntimeError("forward_detect is the evaluation path: call .eval() first")
+        if self.gc:
+            base_feat, base_feat1 = self.extract_feature(im_data)
+        else:
+            base_feat = self.RCNN_base(im_data)
+        batch_size = base_feat.size(0)
+        rois, _, _ = self.RCNN_rpn(base_feat, im_info, None, None)
+        if cfg.POOLING_MODE == "align":
+            pooled_feat = self.RCNN_roi_align(base_feat, rois.view(-1, 5))
+        elif cfg.POOLING_MODE == "pool":
+            pooled_feat = self.RCNN_roi_pool(base_feat, rois.view(-1, 5))
+        else:
+            raise ValueError("POOLING_MODE %r: 'crop' is dead code in the reference and not provided" % cfg.POOLING_MODE)
+        feat = self._head_to_tail(pooled_feat)
+        if self.gc:
+            _, feat_image = self.netD_style(base_feat1, 1.0)
+            n_prop = feat.size(0) // batch_size
+            feat = torch.cat((feat_image.unsqueeze(1).repeat(1, n_prop, 1).view(-1, feat_image.size(1)), feat), 1)
+        if self.ic:
+            _, feat_instance = self.netD_pixel(pooled_feat, 1.0)
+            feat = torch.cat((feat_instance.view(feat_instance.size(0), -1), feat), 1)
+        bbox_pred = self.RCNN_bbox_pred(feat)
+        cls_prob = F.softmax(self.RCNN_cls_score(feat), 1)
+        return rois, cls_prob.view(batch_size, rois.size(1), -1), bbox_pred.view(batch_size, rois.size(1), -1)
+
     def _init_weights(self):
         def normal_init(m, mean, std):
             m.weight.data.normal_(mean, std)

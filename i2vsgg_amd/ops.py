@@ -1189,11 +1189,13 @@ def dpixel(x_rows, w1, w2, w3, lamb=1.0, pix_per_roi=49, want_feat=False):
 
 
 def detection_postprocess(rois, cls_prob, bbox_pred, im_h, im_w, im_scale, class_agnostic=False, stds=None, means=None,
-                          score_thresh=0.0, nms_thresh=0.3, max_per_image=100):
+                          score_thresh=0.0, nms_thresh=0.3, max_per_image=100, im_info=None, out=None):
     """Per-class detection post-processing of one image on the device (test_net_instance_styleD_bilinear.py:151-221).
 
     rois (R,5) [batch_idx,x1,y1,x2,y2]; cls_prob (R,C); bbox_pred (R,4) or (R,4C).  ``stds`` / ``means``: the
-    TRAIN.BBOX_NORMALIZE_STDS / _MEANS 4-tuples when the deltas are normalised, else None.
+    TRAIN.BBOX_NORMALIZE_STDS / _MEANS 4-tuples when the deltas are normalised, else None.  ``im_info``: the frame's
+    [height, width, scale] as a device tensor of 3 floats, read by the kernel instead of the three host numbers (a
+    captured step: the same launch for every frame); ``out``: (dets, counts) buffers to write into.
     Returns (dets (C,R,5), counts (C,) int32), both on the device: rows ``dets[j, :counts[j]]`` are the reference's
     ``all_boxes[j][i]``."""
     import ctypes
@@ -1205,10 +1207,24 @@ def detection_postprocess(rois, cls_prob, bbox_pred, im_h, im_w, im_scale, class
     if bbox_pred.shape[1] != (4 if class_agnostic else 4 * C):
         raise ValueError("bbox_pred has %d columns, expected %d" % (bbox_pred.shape[1], 4 if class_agnostic else 4 * C))
     dev = rois.device
-    dets = torch.empty((C, R, 5), device=dev, dtype=torch.float32)
-    counts = torch.empty((C,), device=dev, dtype=torch.int32)
+    if out is not None:
+        dets, counts = out
+        if tuple(dets.shape) != (C, R, 5) or tuple(counts.shape) != (C,) or dets.dtype != torch.float32 or \
+                counts.dtype != torch.int32 or not dets.is_contiguous():
+            raise ValueError("detection_postprocess(out=...): needs (%d,%d,5) float32 and (%d,) int32 buffers" % (C, R, C))
+    else:
+        dets = torch.empty((C, R, 5), device=dev, dtype=torch.float32)
+        counts = torch.empty((C,), device=dev, dtype=torch.int32)
     ws = workspace(lib.i2v_det_postprocess_workspace_bytes(R, C), dev, "det")
     f4 = lambda v: (ctypes.c_float * 4)(*[float(t) for t in v]) if v is not None else None
+    if im_info is not None:
+        _need_cuda(im_info)
+        if im_info.dtype != torch.float32 or im_info.numel() != 3 or not im_info.is_contiguous():
+            raise ValueError("detection_postprocess(im_info=...): 3 contiguous floats on the device")
+        check(lib.i2v_det_postprocess_info(ptr(rois), ptr(cls_prob), ptr(bbox_pred), int(bool(class_agnostic)), f4(stds), f4(means),
+                                           ptr(im_info), R, C, float(score_thresh), float(nms_thresh), int(max_per_image),
+                                           ptr(dets), ptr(counts), ptr(ws), ws.numel(), stream()), "det_postprocess_info")
+        return dets, counts
     check(lib.i2v_det_postprocess(ptr(rois), ptr(cls_prob), ptr(bbox_pred), int(bool(class_agnostic)), f4(stds), f4(means),
                                   float(im_h), float(im_w), float(im_scale), R, C, float(score_thresh), float(nms_thresh),
                                   int(max_per_image), ptr(dets), ptr(counts), ptr(ws), ws.numel(), stream()),

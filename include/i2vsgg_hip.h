@@ -169,6 +169,13 @@ int32_t i2v_det_postprocess(const float* rois, const float* cls_prob, const floa
                             const float* stds, const float* means, float im_h, float im_w, float im_scale,
                             int32_t R, int32_t C, float score_thresh, float nms_thresh, int32_t max_per_image,
                             float* dets, int32_t* counts, void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the frame's im_info row [height, width, scale] read from DEVICE memory (3 floats) by the kernel: the
+ * launch arguments are then the same for every frame, so a captured per-frame evaluation step (eval.DetectStep) serves
+ * frames of any scale. */
+int32_t i2v_det_postprocess_info(const float* rois, const float* cls_prob, const float* bbox_pred, int32_t class_agnostic,
+                                 const float* stds, const float* means, const float* im_info,
+                                 int32_t R, int32_t C, float score_thresh, float nms_thresh, int32_t max_per_image,
+                                 float* dets, int32_t* counts, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- relation triplet ranking (eval) -----------------------------------
  * replaces the scoring loop and the argsort of detection_output (lib/utils.py:584-628): cell (i, r) of rel_score

@@ -589,6 +589,44 @@ def test_detect_frame_eval_loop_matches_oracle_postprocess(cfg):
         assert np.array_equal(got[j], want[j]), j
 
 
+def test_detect_step_equals_frame_by_frame_eval(cfg):
+    """eval.DetectStep (several frames per replayed graph, a branch per frame, im_info read on the device) returns what
+    eval.detect_frame returns frame by frame: same boxes, same order, for frames of different scales, a short last batch and the
+    pipelined ``run`` form.  Split-K is switched off for the comparison (its fp32 atomics reorder near-tied scores between any
+    two forwards of the same frame)."""
+    from i2vsgg_amd import eval as ev
+    from i2vsgg_amd._lib import TUNE, lib
+    from i2vsgg_amd.model.faster_rcnn.resnet_instance_styleD_bilinear import resnet
+    torch.manual_seed(1)
+    net = resnet(tuple(range(16)), 50)
+    net.create_architecture()
+    net.to(DEV).eval()
+    ims = [torch.from_numpy(syn.frames(40 + i, 1, 320, 480)[0]).to(DEV) for i in range(3)]
+    infos = [torch.tensor([[320.0, 480.0, sc]], device=DEV) for sc in (1.0, 1.6, 0.8)]
+    z, nb = torch.zeros(1, 1, 5, device=DEV), torch.zeros(1, device=DEV)
+    old = lib.i2v_get_tuning(TUNE["I2V_SPLIT_BELOW"])
+    try:
+        lib.i2v_set_tuning(TUNE["I2V_SPLIT_BELOW"], 0)
+        want = [ev.detect_frame(net, im, info, z, nb, thresh=0.0, max_per_image=100) for im, info in zip(ims, infos)]
+        again = ev.detect_frame(net, ims[0], infos[0], z, nb, thresh=0.0, max_per_image=100)
+        step = ev.DetectStep(net, frames=2, device=DEV)
+        got = step(torch.cat(ims[:2]), torch.cat(infos[:2])) + step(ims[2], infos[2])          # the second call: one frame of two
+        assert step.graph_error is None and step.shapes[step._staged].graph
+        piped = [r for res in step.run([(torch.cat(ims[:2]), torch.cat(infos[:2])), (torch.cat(ims[1:]), torch.cat(infos[1:]))])
+                 for r in res]
+    finally:
+        lib.i2v_set_tuning(TUNE["I2V_SPLIT_BELOW"], old)
+    assert all(np.array_equal(a, b) for a, b in zip(again, want[0]))         # the comparison below is between deterministic runs
+    assert len(got) == 3 and len(piped) == 4
+    assert 0 < sum(len(c) for c in want[0]) <= 100
+    for f, res in list(enumerate(got)) + [(0, piped[0]), (1, piped[1]), (1, piped[2]), (2, piped[3])]:
+        assert len(res) == 16
+        for j in range(16):
+            assert np.array_equal(res[j], want[f][j]), (f, j)
+    # the scale of a frame's im_info row reaches the boxes (:171 pred_boxes /= im_scale)
+    assert max(c[:, :4].max() for c in want[2] if len(c)) > 1.5 * max(c[:, :4].max() for c in want[1] if len(c))
+
+
 def test_relation_eval_branch_and_topk_vs_oracle(cfg):
     """eval branch of forward_relation (faster_rcnn_SGG_emb.py:583-697: all ordered pairs, union
     boxes, dual masks, relation head with softmax) and detection_output (lib/utils.py:584-628: confidence scaling +

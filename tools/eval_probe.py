@@ -44,6 +44,21 @@ def main():
     t_det = timed(lambda i: ev.detect_frame(det, frames[i % 4], info, z, nb, thresh=0.0, max_per_image=100), a.frames)
     print("detect_frame   (TEST %d -> %d proposals): %.2f ms/frame = %.1f frames/s" % (
         cfg.TEST.RPN_PRE_NMS_TOP_N, cfg.TEST.RPN_POST_NMS_TOP_N, 1e3 * t_det, 1 / t_det))
+    for nf in (1, 2, 3, 4):
+        step = ev.DetectStep(det, frames=nf, device=dev)
+        batch = [(torch.cat([frames[(i + j) % 4] for j in range(nf)]), info.expand(nf, 3).contiguous()) for i in range(4)]
+        for b in batch[:2]:
+            step(*b)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        n = 0
+        for _ in step.run(batch[i % 4] for i in range(a.frames)):
+            n += nf
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / n
+        print("DetectStep frames=%d graph=%s: %.2f ms/frame = %.1f frames/s %s" % (nf, bool(step.shapes[step._staged].graph), 1e3 * dt,
+                                                                               1 / dt, step.graph_error or ""))
+        del step
     del det
     torch.cuda.empty_cache()
 

@@ -46,3 +46,14 @@ for name, cin, h, w, cout, k, s, p in shapes:
     print("   median per workgroup: life %.1f us, prologue %.0f cycles, pixel loop %.0f, epilogue %.0f; starts %s ends %s" % (
         med(en - st), med(v[:, 2]), med(v[:, 3]), med(v[:, 4]), " ".join("%.1f" % float(st.quantile(t_)) for t_ in q),
         " ".join("%.1f" % float(en.quantile(t_)) for t_ in q)))
+    # per XCD: do the workgroups of one XCD run longer (cycles) or slower (cycles per us)?
+    xcc = v[:, 6] & 0xF
+    rows = []
+    for xid in sorted(set(xcc.tolist())):
+        sel = xcc == xid
+        life_us = (en - st)[sel]
+        cyc = (v[sel, 2] + v[sel, 3] + v[sel, 4]).double()
+        rows.append("x%d: n %d loop %.0fk end %.1f us %.2f GHz" % (xid, int(sel.sum()), float(v[sel, 3].double().median()) / 1e3,
+                                                                  float(en[sel].median()), float((cyc / life_us).median()) / 1e3))
+    print("   " + " | ".join(rows))
+
