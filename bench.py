@@ -499,6 +499,55 @@ def run_sgg_loader(a, rank, world, dev, frames_per_rank=2, n_batches=8, u8=False
     return line, step, net
 
 
+# ----------------------------------------------------------------------------- the test loops
+def run_eval(a, dev, frames=4, n_iter=24, n_boxes=8):
+    import torch
+    from i2vsgg_amd import eval as ev, synthetic as syn, train
+    ims = [torch.from_numpy(syn.frames(100 + i, 1)[0]).to(dev).contiguous(memory_format=torch.channels_last) for i in range(4)]
+    info = torch.tensor([[600.0, 1000.0, 1.0]], device=dev)
+    z, nb = torch.zeros(1, 1, 5, device=dev), torch.zeros(1, device=dev)
+
+    def per_frame(fn, n):
+        fn(0); fn(1)
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        for i in range(n):
+            fn(2 + i)
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t) / n
+
+    def stepped(step, batches):
+        for b in batches[:2]:
+            step(*b)
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        n = sum(len(r) for r in step.run(batches[i % len(batches)] for i in range(n_iter // frames)))
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t) / n
+
+    out = {"unit": "frames/s", "frames_in_flight": frames, "frame": "600x1000 synthetic, ResNet-%d" % a.layers}
+    det = train.build_instance_styled_net(a.layers, device=dev).eval()
+    t0 = per_frame(lambda i: ev.detect_frame(det, ims[i % 4], info, z, nb), n_iter)
+    step = ev.DetectStep(det, frames=frames, device=dev, use_graph=not a.no_graph)
+    t1 = stepped(step, [(torch.cat([ims[(i + j) % 4] for j in range(frames)]), info.expand(frames, 3).contiguous()) for i in range(4)])
+    out["detect"] = {"loop": "test_net_instance_styleD_bilinear.py:133-221 (TEST: 6000 -> 300 proposals, 16 classes, NMS 0.3, top 100)",
+                     "frame_by_frame": 1.0 / t0, "graph_step": 1.0 / t1, "hip_graph": bool(step.shapes[step._staged].graph),
+                     "graph_error": step.graph_error}
+    del step, det
+    torch.cuda.empty_cache()
+    sgg = train.build_sgg_net(a.layers, device=dev).eval()
+    sgg.vrd.target_gt_rels = {"f%d" % i: syn.relation_annotation(31 + i, n_boxes, n_boxes, 62, 16) for i in range(4)}
+    t0 = per_frame(lambda i: ev.relation_frame(sgg, ims[i % 4], info, "f%d" % (i % 4)), n_iter)
+    step = ev.RelationStep(sgg, frames=frames, device=dev, cap_boxes=n_boxes + 1, use_graph=not a.no_graph)
+    t1 = stepped(step, [(torch.cat([ims[(i + j) % 4] for j in range(frames)]), info.expand(frames, 3).cpu().numpy(),
+                         ["f%d" % ((i + j) % 4) for j in range(frames)]) for i in range(4)])
+    out["relation"] = {"loop": "test_net_SGG_emb.py per frame (%d annotated boxes, %d ordered pairs, top-100 triplets)" % (
+                           n_boxes, n_boxes * (n_boxes - 1)),
+                       "frame_by_frame": 1.0 / t0, "graph_step": 1.0 / t1, "hip_graph": bool(step.shapes[step._staged].graph),
+                       "graph_error": step.graph_error}
+    return out
+
+
 # ----------------------------------------------------------------------------- configs[2]
 def run_instance_styled(a, rank, world, dev, steps, warmup, frames_per_rank=4):
     import numpy as np
@@ -731,12 +780,20 @@ def main():
                 res, s2, n2 = run_instance_styled(a, rank, world, dev, steps=max(4, a.steps // 4), warmup=2)
                 return res
 
+            def eval_loops():
+                # the two TEST loops (test_net_instance_styleD_bilinear.py:133-221, test_net_SGG_emb.py per frame) on 600x1000
+                # frames: frame by frame as the reference evaluates (eval.detect_frame / relation_frame, eager launches) and as
+                # replayed graphs with a branch per frame (eval.DetectStep / RelationStep, 4 frames in flight, host unpacking of
+                # one batch under the next); results are bit-equal (tests/test_gpu_models.py)
+                return run_eval(a, dev)
+
             step.opt.unfuse()
             torch.cuda.empty_cache()
             also("sgg_loader", lambda: loader(False))
             also("sgg_loader_u8", lambda: loader(True))
             also("sgg_gemm_x3", gemm_x3)
             also("instance_styled", isd)
+            also("eval_loops", eval_loops)
     elif a.config == "instance_styled":
         line, step, net = run_instance_styled(a, rank, world, dev, a.steps, a.warmup)
         keep += [step, net]

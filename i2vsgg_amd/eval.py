@@ -8,6 +8,7 @@
                   (pair, predicate) grid and the top-k cut run on the device (``ops.relation_topk``).
 ``relation_frame``  backbone forward + ``forward_relation_eval`` + ``detection_output`` for one frame.
 ``DetectStep``    ``detect_frame`` for several frames at a time as one replayable HIP graph (a branch per frame).
+``RelationStep``  ``relation_frame`` + ``detection_output`` the same way.
 """
 import numpy as np
 import torch
@@ -165,6 +166,183 @@ class DetectStep:
         pending = None
         for im_data, im_info in batches:
             self.stage(im_data, im_info)
+            token = self.launch()
+            if pending is not None:
+                yield self.collect(pending)
+            pending = token
+        if pending is not None:
+            yield self.collect(pending)
+
+
+class RelationStep:
+    """The per-frame body of test_net_SGG_emb.py (backbone, eval branch of forward_relation on the frame's annotated boxes --
+    every ordered pair --, softmax over predicates, ``detection_output`` top-``k`` triplets) for ``frames`` frames at a time as ONE
+    replayable HIP graph with a branch per frame -- ``DetectStep``'s schedule for the relation test loop.
+
+    A frame's boxes and pairs are zero-padded to a capacity (``cap_boxes`` boxes incl. one spare, all their ordered pairs):
+    a pad pair points at the spare box, whose confidence is 0, so its cells score 0 and sort behind every real cell (real
+    cells are products of a softmax and confidences in (0, 1]); the relation head is row-wise in eval mode, so the real rows
+    are what ``relation_frame`` computes.  A frame with more boxes grows the capacity (graphs are captured again).
+
+    ``step(im_data, im_info, im_paths)`` -> list over the frames of ``detection_output``'s five values (five Nones for a frame
+    with fewer than two boxes); ``step.run(batches)`` keeps one batch in flight while the host unpacks the previous one."""
+
+    def __init__(self, net, frames=2, k=100, device="cuda:0", cap_boxes=9, use_graph=True, max_graphs=8):
+        if net.training:
+            raise RuntimeError("RelationStep: the network must be in eval mode")
+        self.net, self.dev, self.frames, self.k = net, torch.device(device), int(frames), int(k)
+        self.use_graph, self.max_graphs = bool(use_graph), int(max_graphs)
+        self.n_rel = int(net.vrd.n_rel)
+        self._streams = [torch.cuda.Stream(self.dev) for _ in range(self.frames)]
+        self.shapes, self._pool, self._tick, self._staged = {}, None, 0, None
+        self.graph_error = None
+        self._slot = 0
+        self._alloc(int(cap_boxes))
+
+    def _alloc(self, cap_boxes):
+        from .train import _Slot
+        F_, cb = self.frames, int(cap_boxes)
+        cp = (cb - 1) * (cb - 2)
+        self.cap_boxes, self.cap_pairs = cb, cp
+        self.kk = min(self.k, cp * self.n_rel)
+        self.inputs = _Slot({"rois": ((F_, cb + cp, 5), torch.float32), "bounds": ((F_, cp, 2, 4), torch.int32),
+                             "ix": ((F_, 2, cp), torch.int64), "conf": ((F_, cb), torch.float32)}, self.dev, host=True)
+        self.out = _Slot({"pair": ((F_, self.kk), torch.int32), "pred": ((F_, self.kk), torch.int32),
+                          "conf": ((F_, self.kk), torch.float32)}, self.dev)
+        self._host = [(torch.zeros(self.out.nbytes, dtype=torch.uint8).pin_memory(), torch.cuda.Event()) for _ in range(2)]
+        for fs in self.shapes.values():
+            fs.graph = None
+        self._pool = None
+
+    def _frame(self, fs, f):
+        from .model.faster_rcnn.faster_rcnn_SGG_emb import rasterize_masks
+        v = self.inputs.views
+        with fs.ctx[f]:
+            fmap = self.net.RCNN_base(fs.im[f:f + 1])
+            rois, ix = v["rois"][f], v["ix"][f]
+            score, _ = self.net.vrd.forward_device(fmap, rois[:self.cap_boxes], None, rasterize_masks(v["bounds"][f], self.dev),
+                                                   ix[0], ix[1], rois=rois)
+            pair, pred, conf = ops.relation_topk(score, v["conf"][f], ix[0], ix[1], self.kk)
+            o = self.out.views
+            o["pair"][f].copy_(pair)
+            o["pred"][f].copy_(pred)
+            o["conf"][f].copy_(conf)
+
+    _body = DetectStep._body
+
+    def stage(self, im_data, im_info, im_paths):
+        """``im_data`` (n,3|4,H,W), n <= frames; ``im_info`` (n,3) on the host; ``im_paths``: the frames' keys into
+        ``net.vrd.target_gt_rels``."""
+        from .model.faster_rcnn.faster_rcnn_SGG_emb import build_eval_pair_tables
+        n, c, H, W = im_data.shape
+        if n > self.frames or len(im_paths) != n:
+            raise ValueError("RelationStep.stage: %d frames / %d paths, the step was built for %d" % (n, len(im_paths), self.frames))
+        info = np.asarray(im_info.cpu() if torch.is_tensor(im_info) else im_info, np.float64).reshape(-1, 3)
+        annos = [self.net.vrd.target_gt_rels[p] for p in im_paths]
+        need = max([len(a["boxes"]) for a in annos] + [1]) + 1
+        if need > self.cap_boxes:
+            torch.cuda.synchronize(self.dev)
+            self._alloc(need)
+        cb, cp = self.cap_boxes, self.cap_pairs
+        rois = np.zeros((self.frames, cb + cp, 5), np.float32)
+        bounds = np.zeros((self.frames, cp, 2, 4), np.int32)
+        ix = np.full((self.frames, 2, cp), cb - 1, np.int64)           # pad pairs point at the spare box (confidence 0)
+        conf = np.zeros((self.frames, cb), np.float32)
+        meta = []
+        for f, a in enumerate(annos):
+            nb = len(a["boxes"])
+            if nb < 2:
+                meta.append(None)
+                continue
+            ih, iw, sc = info[f]
+            boxes = np.array(a["boxes"], np.float64).reshape(-1, 4) * sc
+            union, bnd, ixs, ixo = build_eval_pair_tables(boxes, ih, iw)
+            rois[f, :nb, 1:] = boxes
+            rois[f, cb:cb + len(ixs), 1:] = union
+            bounds[f, :len(ixs)] = bnd
+            ix[f, 0, :len(ixs)], ix[f, 1, :len(ixs)] = ixs, ixo
+            conf[f, :nb] = 1                                            # :608 every annotated box enters with confidence 1
+            meta.append((np.array(a["boxes"], np.float64).reshape(-1, 4), np.asarray(a["box_classes"]), ixs, ixo))
+        key = (self.frames, int(H), int(W))
+        fs = self.shapes.get(key)
+        if fs is None:
+            fs = self.shapes[key] = _DetectShape(key, self.dev)
+        if c == 4:
+            fs.im[:n].copy_(im_data, non_blocking=True)
+        else:
+            fs.im[:n, :3].copy_(im_data, non_blocking=True)
+        self.inputs.write_host({"rois": rois, "bounds": bounds, "ix": ix, "conf": conf})
+        self._staged, self._meta = key, meta
+        return fs
+
+    def _capture(self, fs):
+        for _ in range(2):
+            for f in range(self.frames):
+                with torch.no_grad():
+                    self._frame(fs, f)
+                fs.ctx[f].fit()
+        torch.cuda.synchronize(self.dev)
+        if not self.use_graph:
+            fs.graph = False
+            return
+        live = [t for t in self.shapes.values() if t.graph]
+        if len(live) >= self.max_graphs:
+            min(live, key=lambda t: t.tick).graph = None
+        try:
+            g = torch.cuda.CUDAGraph()
+            if self._pool is None:
+                self._pool = torch.cuda.graph_pool_handle()
+            with torch.cuda.graph(g, pool=self._pool):
+                self._body(fs)
+            fs.graph = g
+        except Exception as e:
+            fs.graph, self.graph_error = False, repr(e)
+            torch.cuda.synchronize(self.dev)
+
+    def launch(self):
+        fs = self.shapes[self._staged]
+        if fs.graph is None:
+            self._capture(fs)
+        self._tick += 1
+        fs.tick = self._tick
+        if fs.graph:
+            fs.graph.replay()
+        else:
+            self._body(fs)
+        hb, ev = self._host[self._slot]
+        hb.copy_(self.out.buf, non_blocking=True)
+        ev.record(torch.cuda.current_stream(self.dev))
+        self._slot ^= 1
+        return (hb, ev, self._meta, self.out.spec, self.kk)          # the buffers travel with the token: a capacity growth replaces them
+
+    def collect(self, token):
+        hb, ev, meta, spec, kk = token
+        ev.synchronize()
+        host = {name: hb[o:o + n].view(dt).view(shape).numpy() for name, o, n, dt, shape in spec}
+        res = []
+        for f, m in enumerate(meta):
+            if m is None:
+                res.append((None,) * 5)
+                continue
+            boxes, classes, ixs, ixo = m
+            pair, pred, tconf = host["pair"][f], host["pred"][f], host["conf"][f]
+            n = int((pair < len(ixs)).sum()) if kk else 0             # real cells are a prefix (pad cells score 0)
+            n = min(n, len(ixs) * self.n_rel)
+            pair, pred, tconf = pair[:n].astype(np.int64), pred[:n], np.array(tconf[:n])
+            rlp, sub, obj = np.zeros((self.k, 3), np.float64), np.zeros((self.k, 4), np.float64), np.zeros((self.k, 4), np.float64)
+            sub[:n], obj[:n] = boxes[ixs[pair]], boxes[ixo[pair]]
+            rlp[:n] = np.stack([classes[ixs[pair]], pred, classes[ixo[pair]]], 1)
+            res.append((rlp, tconf, sub, obj, pair))
+        return res
+
+    def __call__(self, im_data, im_info, im_paths):
+        self.stage(im_data, im_info, im_paths)
+        return self.collect(self.launch())
+
+    def run(self, batches):
+        pending = None
+        for b in batches:
+            self.stage(*b)
             token = self.launch()
             if pending is not None:
                 yield self.collect(pending)

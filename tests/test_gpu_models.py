@@ -685,6 +685,47 @@ def test_relation_eval_branch_and_topk_vs_oracle(cfg):
     assert net.forward_relation_eval(fm, info, "none") == {"bboxes": [], "classes": [], "scores": []}
 
 
+def test_relation_step_equals_frame_by_frame_eval(cfg):
+    """eval.RelationStep (several frames per replayed graph, boxes / pairs padded to a capacity) returns what
+    eval.relation_frame + detection_output return frame by frame: same triplets, same order, same confidences -- for frames
+    with different numbers of boxes, a degenerate frame, a capacity growth and the pipelined ``run`` form.  Split-K off, as in
+    the detector's test."""
+    from i2vsgg_amd import eval as ev
+    from i2vsgg_amd._lib import TUNE, lib
+    from i2vsgg_amd.model.faster_rcnn.resnet_SGG_emb import resnet
+    n_rel, n_cls = 62, 16
+    torch.manual_seed(0)
+    net = resnet(tuple(range(n_cls)), _vrd_args(), 50, obj_vecs=syn.word_vectors(22, n_cls), prd_vecs=syn.word_vectors(21, n_rel))
+    net.create_architecture()
+    _load(net.vrd, syn.vrd_params(13), "vrd.")
+    net.to(DEV).eval()
+    H, W = 320, 480
+    ims = [torch.from_numpy(syn.frames(50 + i, 1, H, W)[0]).to(DEV) for i in range(4)]
+    infos = np.array([[H, W, 1.0], [H, W, 1.25], [H, W, 0.8], [H, W, 1.0]], np.float32)
+    nbox = [5, 3, 1, 9]
+    net.vrd.target_gt_rels = {"f%d" % i: syn.relation_annotation(60 + i, nbox[i], min(nbox[i], nbox[i] * (nbox[i] - 1)), n_rel, n_cls, im_h=int(H / infos[i, 2]),
+                                                                 im_w=int(W / infos[i, 2])) for i in range(4)}
+    old = lib.i2v_get_tuning(TUNE["I2V_SPLIT_BELOW"])
+    try:
+        lib.i2v_set_tuning(TUNE["I2V_SPLIT_BELOW"], 0)
+        want = [ev.relation_frame(net, ims[i], torch.from_numpy(infos[i:i + 1]).to(DEV), "f%d" % i)[1] for i in range(4)]
+        step = ev.RelationStep(net, frames=2, device=DEV, cap_boxes=6)
+        got = step(torch.cat(ims[:2]), infos[:2], ["f0", "f1"])
+        assert step.graph_error is None and step.shapes[step._staged].graph and step.cap_boxes == 6
+        got += step(torch.cat(ims[2:]), infos[2:], ["f2", "f3"])              # 9 boxes: the capacity grows, the graph is captured again
+        assert step.cap_boxes == 10 and step.shapes[step._staged].graph
+        piped = [r for res in step.run([(torch.cat(ims[:2]), infos[:2], ["f0", "f1"]), (ims[3], infos[3:], ["f3"])]) for r in res]
+    finally:
+        lib.i2v_set_tuning(TUNE["I2V_SPLIT_BELOW"], old)
+    assert want[2] == (None,) * 5 and got[2] == (None,) * 5
+    for f, res in list(enumerate(got)) + [(0, piped[0]), (1, piped[1]), (3, piped[2])]:
+        if f == 2:
+            continue
+        for a, b in zip(res, want[f]):
+            assert np.array_equal(np.asarray(a), np.asarray(b)), f
+    assert len(want[1][1]) == 100 and want[1][0][:, 1].max() > 0
+
+
 def test_extract_feature_and_box_classification_vs_oracle(cfg):
     """``_extract_feature`` (faster_rcnn_SGG_emb.py:381-392) and the box classification of the eval branch (:278-291):
     roi_layers.ROIAlign -> layer4 -> mean -> RCNN_cls_score -> softmax with the background column zeroed."""

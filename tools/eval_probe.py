@@ -67,6 +67,22 @@ def main():
     t_rel = timed(lambda i: ev.relation_frame(sgg, frames[i % 4], info, "f%d" % (i % 4)), a.frames)
     print("relation_frame (%d boxes, %d ordered pairs): %.2f ms/frame = %.1f frames/s" % (
         a.boxes, a.boxes * (a.boxes - 1), 1e3 * t_rel, 1 / t_rel))
+    for nf in (1, 2, 3, 4):
+        step = ev.RelationStep(sgg, frames=nf, device=dev, cap_boxes=a.boxes + 1)
+        batch = [(torch.cat([frames[(i + j) % 4] for j in range(nf)]), info.expand(nf, 3).cpu().numpy(),
+                  ["f%d" % ((i + j) % 4) for j in range(nf)]) for i in range(4)]
+        for b in batch[:2]:
+            step(*b)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        n = 0
+        for _ in step.run(batch[i % 4] for i in range(a.frames)):
+            n += nf
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t) / n
+        print("RelationStep frames=%d graph=%s: %.2f ms/frame = %.1f frames/s %s" % (nf, bool(step.shapes[step._staged].graph), 1e3 * dt,
+                                                                                 1 / dt, step.graph_error or ""))
+        del step
 
 
 if __name__ == "__main__":
