@@ -1546,6 +1546,7 @@ struct WgP {
     unsigned x_bytes, gy_bytes;            // buffer descriptor sizes (v2 kernel)
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, M, N, K, m_per_split, lgCin;
     unsigned long long* clk;               // diagnostic (i2v_conv_debug_clock): per-workgroup stamps, CLK instantiation only
+    int prio;                              // I2V_TUNE_WGRAD_PRIO: 0 off, n: wave priority 3 - ((stage >> (n-1)) & 3)
 };
 
 template <int BM, int BN>   // BM over n (Cout), BN over k; 4 waves as 2x2, 64x64 tiles: BM=BN=64 -> wave 32x32
@@ -1901,6 +1902,17 @@ conv_wgrad2_f32(const WgP p_in) {
     int buf = 0;
     for (int ms = mbeg; ms < mend; ms += BKS) {
         const bool more = ms + BKS < mend;
+        if (p.prio) {
+            // experiment (I2V_TUNE_WGRAD_PRIO): issue priority falls with progress, so the co-resident workgroups of a CU stay
+            // together instead of retiring one by one (the arbiter favours the oldest wave: ends spread 84 .. 108 us around a
+            // 93 us median on the layer3 shapes, the last workgroup alone cannot keep the matrix pipe busy)
+            switch (3 - ((((ms - mbeg) / BKS) >> (p.prio - 1)) & 3)) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+            }
+        }
         if (more) gload(ms + BKS);
         compute(buf);
         if (more) sstore(buf ^ 1);
@@ -2196,6 +2208,7 @@ static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st) {
     p.gy_bytes = (unsigned)gb;
     const dim3 grid((unsigned)tiles, splits, p.nbatch > 1 ? p.nbatch : 1);
     p.xcd_remap = ((splits * (p.nbatch > 1 ? p.nbatch : 1)) % 8 == 0 && g_i2v_tuning[I2V_TUNE_WGRAD_XCD]) ? 1 : 0;
+    p.prio = g_i2v_tuning[I2V_TUNE_WGRAD_PRIO];
     if (!v2) conv_wgrad_f32<64, 64><<<grid, THREADS, 0, st>>>(p);
     else if (fused && tm == 128 && tk == 64) conv_wgrad2_f32<4, 2, true><<<grid, THREADS, 0, st>>>(p);
     else if (tm == 128 && tk == 128) conv_wgrad2_f32<4, 4><<<grid, THREADS, 0, st>>>(p);

@@ -318,3 +318,45 @@ def test_training_scripts_run_through_the_data_layer(small_cfg, tmp_path):
     ts.main(["--epochs", "1", "--bs", "2", "--imdb_name", "synthetic_12_v", "--scale", "192", "--disp_interval", "3", "--save_dir",
              str(tmp_path / "u8"), "--device_prep", "--no-save"])
     tv.main(["--epochs", "1", "--device_prep", "--no-save"] + common)
+
+
+def test_test_scripts_equal_their_frame_by_frame_form(small_cfg, tmp_path):
+    """test_instance_styled.py / test_sgg_emb.py (the reference's test loops: combined_roidb(name, False) ->
+    roibatchLoader(training=False) -> DataLoader(batch_size=1)) on a synthetic imdb whose frames differ in size: the graph form
+    (frames grouped by size, 3 per replay, short groups at the end) writes what the frame-by-frame form writes, a checkpoint of
+    the training script loads, ``all_boxes`` has the reference's [class][image] layout."""
+    import pickle
+    import test_instance_styled as td
+    import test_sgg_emb as tr
+    import trainval_instance_styled as tv
+    from i2vsgg_amd._lib import TUNE, lib
+    common = ["--imdbval_name", "synthetic_10_v", "--scale", "192", "--set", "TEST.RPN_POST_NMS_TOP_N", "64"]
+    tv.main(["--epochs", "1", "--bs", "2", "--imdb_name", "synthetic_6_v", "--imdb_name_target", "synthetic_5_v_7", "--scale", "192",
+             "--iters_per_epoch", "2", "--save_dir", str(tmp_path), "--set", "TRAIN.BATCH_SIZE", "16",
+             "TRAIN.RPN_POST_NMS_TOP_N_TARGET", "16"])
+    ck = tmp_path / "res101" / "synthetic" / ("instance_pixel_styleD_bilinear_cr_False_source_synthetic_target_synthetic_t_"
+                                             "session_1_lr_0.0005_epoch_1_bs_2_mscoco.pth")
+    old = lib.i2v_get_tuning(TUNE["I2V_SPLIT_BELOW"])
+    try:
+        lib.i2v_set_tuning(TUNE["I2V_SPLIT_BELOW"], 0)        # no split-K atomics: two forwards of a frame are bit-equal
+        one = td.main(["--frames", "1", "--load_name", str(ck), "--output_dir", str(tmp_path / "o1")] + common)
+        many = td.main(["--frames", "3", "--load_name", str(ck), "--output_dir", str(tmp_path / "o3")] + common)
+        r_one = tr.main(["--frames", "1", "--output_dir", str(tmp_path / "o1"), "--imdbval_name", "synthetic_10_v", "--scale", "192"])
+        r_many = tr.main(["--frames", "3", "--output_dir", str(tmp_path / "o3"), "--imdbval_name", "synthetic_10_v", "--scale", "192"])
+    finally:
+        lib.i2v_set_tuning(TUNE["I2V_SPLIT_BELOW"], old)
+    with open(tmp_path / "o3" / "res101" / "synthetic" / "detections.pkl", "rb") as f:
+        saved = pickle.load(f)
+    assert len(saved) == 16 and len(saved[1]) == 10 and saved[0][0] == []
+    n_det = 0
+    for j in range(1, 16):
+        for i in range(10):
+            assert saved[j][i].shape[1] == 5 and np.array_equal(saved[j][i], one[j][i]) and np.array_equal(many[j][i], one[j][i])
+            n_det += len(saved[j][i])
+    assert n_det > 0
+    assert set(r_one) == set(r_many) and len(r_one) == 10
+    for path, want in r_one.items():
+        for a, b in zip(r_many[path], want):
+            assert np.array_equal(np.asarray(a), np.asarray(b)), path
+    with open(tmp_path / "o3" / "res101" / "synthetic" / "relations.pkl", "rb") as f:
+        assert set(pickle.load(f)) == set(r_one)
