@@ -1547,6 +1547,7 @@ struct WgP {
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, M, N, K, m_per_split, lgCin;
     unsigned long long* clk;               // diagnostic (i2v_conv_debug_clock): per-workgroup stamps, CLK instantiation only
     int prio;                              // I2V_TUNE_WGRAD_PRIO: 0 off, n: wave priority 3 - ((stage >> (n-1)) & 3)
+    int abl;                               // diagnostic instantiation only: ablation bits (i2v_conv_set_tile bits 10-12)
 };
 
 template <int BM, int BN>   // BM over n (Cout), BN over k; 4 waves as 2x2, 64x64 tiles: BM=BN=64 -> wave 32x32
@@ -1669,6 +1670,16 @@ conv_wgrad_f32(const WgP p) {
 // an in-register transpose, four ds_write_b128 -- no scalar LDS traffic, no bank-conflicted transposes.
 // FUSED_SGD: the instantiation that runs the SGD update in its epilogue (prefetches the filter / momentum tiles:
 // +34 VGPRs, four waves per SIMD instead of five -- which the plain gradient kernel should not pay)
+// LDS column swizzle of the filter-gradient kernel.  A fragment read touches 16 consecutive rows of one 16-row group: any
+// bijection of (row >> 1) & 7 keeps it conflict-free, and a term in row >> 4 is constant there.  The transposing stores of a
+// 16-lane group go to rows 4 cg + i (cg = 0..15, four columns per thread): (row >> 1) & 7 alone takes FOUR values there -- a
+// four-way bank conflict on every ds_write_b128; with bit 4 of the row folded in it takes eight (two-way, the best a
+// 4-column block allows: the rows of a group share their parity, which picks the half of the 256-byte bank row).
+__device__ inline int wswz(int row) { return ((row >> 1) & 7) ^ ((row >> 4) & 1); }
+constexpr bool WGRAD_ROWMAJOR = false;     // LDS image of the filter-gradient kernel: the transposed [column][pixel] one (false), or [pixel][column] as the operands
+                                           // arrive (true: no register transposes, conflict-free 16-byte stores, one-float fragment reads merged into
+                                           // ds_read2st64_b32 -- bit-equal, measured 3 % slower on the layer3 shapes: 113.8 vs 110.3 us)
+
 template <int TM, int TN, bool FUSED_SGD = false, bool CLK = false>       // tile = (2*TM*16) filters x (2*TN*16) taps, 4 waves as 2x2
 __global__ void __launch_bounds__(THREADS)
 conv_wgrad2_f32(const WgP p_in) {
@@ -1693,6 +1704,7 @@ conv_wgrad2_f32(const WgP p_in) {
         p.gw += (long long)bz * p.bsw;
     }
     constexpr int BMW = 2 * TM * 16, BNW = 2 * TN * 16;
+    constexpr bool ROWMAJOR = WGRAD_ROWMAJOR;
     constexpr int A_BLK = BMW * 2, B_BLK = BNW * 2;             // (cols/4) * 8 row-groups
     constexpr int NBLK = (A_BLK + B_BLK + THREADS - 1) / THREADS;
     constexpr int STAGE_FLOATS = 2 * (BMW + BNW) * BKS;
@@ -1829,15 +1841,25 @@ conv_wgrad2_f32(const WgP p_in) {
         for (int q = 0; q < NBLK; ++q) {
             if (tid + q * THREADS >= A_BLK + B_BLK) continue;
             float* base = is_a[q] ? As[buf] : Bs[buf];
+            if constexpr (ROWMAJOR) {
+                // [pixel][column] image, as the operands arrive: no transposition, four conflict-free 16-byte stores (the 16 lanes
+                // of a store cover one 256-byte row segment); the 16-column groups of a row are XOR-ed with (pixel >> 2) & 3 so
+                // that the four pixel rows a fragment read touches fall into four different bank quarters
+                const int cols = is_a[q] ? BMW : BNW;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    *(float4*)&base[(4 * m4[q] + t) * cols + ((((cg[q] >> 2) ^ (m4[q] & 3)) << 4) | ((cg[q] & 3) << 2))] = r[q][t];
+                continue;
+            }
             const float4 c0 = make_float4(r[q][0].x, r[q][1].x, r[q][2].x, r[q][3].x);
             const float4 c1 = make_float4(r[q][0].y, r[q][1].y, r[q][2].y, r[q][3].y);
             const float4 c2 = make_float4(r[q][0].z, r[q][1].z, r[q][2].z, r[q][3].z);
             const float4 c3 = make_float4(r[q][0].w, r[q][1].w, r[q][2].w, r[q][3].w);
             const int row = 4 * cg[q];
-            *(float4*)&base[(row + 0) * BKS + ((m4[q] ^ (((row + 0) >> 1) & 7)) << 2)] = c0;
-            *(float4*)&base[(row + 1) * BKS + ((m4[q] ^ (((row + 1) >> 1) & 7)) << 2)] = c1;
-            *(float4*)&base[(row + 2) * BKS + ((m4[q] ^ (((row + 2) >> 1) & 7)) << 2)] = c2;
-            *(float4*)&base[(row + 3) * BKS + ((m4[q] ^ (((row + 3) >> 1) & 7)) << 2)] = c3;
+            *(float4*)&base[(row + 0) * BKS + ((m4[q] ^ wswz(row + 0)) << 2)] = c0;
+            *(float4*)&base[(row + 1) * BKS + ((m4[q] ^ wswz(row + 1)) << 2)] = c1;
+            *(float4*)&base[(row + 2) * BKS + ((m4[q] ^ wswz(row + 2)) << 2)] = c2;
+            *(float4*)&base[(row + 3) * BKS + ((m4[q] ^ wswz(row + 3)) << 2)] = c3;
         }
     };
 
@@ -1848,18 +1870,38 @@ conv_wgrad2_f32(const WgP p_in) {
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fg = lane >> 4;
     auto compute = [&](int buf) {
+        if constexpr (ROWMAJOR) {
+            // the MFMA (s2, t) reduces over the pixels 16 s2 + 4 fg + t (the same sets, in the same order, as the transposed
+            // image's float4 columns): a lane reads ONE float per fragment and MFMA, 16 lanes a 64-byte run of one pixel row
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int m = 16 * s2 + 4 * fg + t;
+                    float a[TM], b[TN];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) a[i] = As[buf][m * BMW + ((((wm * TM + i) ^ fg) << 4) | fr)];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) b[j] = Bs[buf][m * BNW + ((((wn * TN + j) ^ fg) << 4) | fr)];
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
+            return;
+        }
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             float4 av[TM], bv[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int row = (wm * TM + i) * 16 + fr;
-                av[i] = *(const float4*)&As[buf][row * BKS + (((s2 * 4 + fg) ^ ((row >> 1) & 7)) << 2)];
+                av[i] = *(const float4*)&As[buf][row * BKS + (((s2 * 4 + fg) ^ wswz(row)) << 2)];
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int row = (wn * TN + j) * 16 + fr;
-                bv[j] = *(const float4*)&Bs[buf][row * BKS + (((s2 * 4 + fg) ^ ((row >> 1) & 7)) << 2)];
+                bv[j] = *(const float4*)&Bs[buf][row * BKS + (((s2 * 4 + fg) ^ wswz(row)) << 2)];
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -1912,6 +1954,14 @@ conv_wgrad2_f32(const WgP p_in) {
                 case 2: __builtin_amdgcn_s_setprio(2); break;
                 default: __builtin_amdgcn_s_setprio(3); break;
             }
+        }
+        if constexpr (CLK) {        // diagnostic instantiation only (tools/wgrad_phase.py ABL=..): 1 = no staging after the first stage, 2 = no MFMAs
+            if (more && !(p.abl & 1)) gload(ms + BKS);
+            if (!(p.abl & 2)) compute(buf);
+            if (more && !(p.abl & 1)) sstore(buf ^ 1);
+            if (!(p.abl & 4)) __syncthreads();
+            buf ^= (p.abl & 1) ? 0 : 1;
+            continue;
         }
         if (more) gload(ms + BKS);
         compute(buf);
@@ -2214,7 +2264,7 @@ static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st) {
     else if (tm == 128 && tk == 128) conv_wgrad2_f32<4, 4><<<grid, THREADS, 0, st>>>(p);
     else if (tm == 128) conv_wgrad2_f32<4, 2><<<grid, THREADS, 0, st>>>(p);
     else if (fused) conv_wgrad2_f32<2, 2, true><<<grid, THREADS, 0, st>>>(p);
-    else if (g_clk) { p.clk = g_clk; conv_wgrad2_f32<2, 2, false, true><<<grid, THREADS, 0, st>>>(p); }
+    else if (g_clk) { p.clk = g_clk; p.abl = g_ablate; conv_wgrad2_f32<2, 2, false, true><<<grid, THREADS, 0, st>>>(p); }
     else conv_wgrad2_f32<2, 2><<<grid, THREADS, 0, st>>>(p);
     return true;
 }

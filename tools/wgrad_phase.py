@@ -28,7 +28,11 @@ for name, cin, h, w, cout, k, s, p in shapes:
     fl = 2.0 * g.shape[0] * g.shape[2] * g.shape[3] * cout * cin * k * k
     buf = torch.zeros(8 * 65536, dtype=torch.int64, device=dev)
     _lib.lib.i2v_conv_debug_clock(buf.data_ptr())
+    abl = int(os.environ.get("ABL", "0"))     # stamped instantiation only: 1 = no staging after the first stage, 2 = no MFMAs, 4 = no barrier
+    if abl:
+        _lib.lib.i2v_conv_set_tile(0xFF | (abl << 10))
     f()
+    _lib.lib.i2v_conv_set_tile(-1)
     _lib.lib.i2v_conv_debug_clock(None)
     torch.cuda.synchronize()
     v = buf.view(-1, 8).cpu()
