@@ -17,8 +17,8 @@ from . import ops
 from .model.utils.config import cfg
 
 
-class _DetectShape:
-    """What ``DetectStep`` owns for one (frames, H, W): the staged frames, a launch context per frame branch, the graph."""
+class _FrameShape:
+    """What a frame-graph step owns for one (frames, H, W): the staged frames, a launch context per frame branch, the graph."""
 
     def __init__(self, key, device):
         n, h, w = key
@@ -29,7 +29,109 @@ class _DetectShape:
         self.tick = 0
 
 
-class DetectStep:
+class _FrameGraphStep:
+    """Shared machinery of ``DetectStep`` / ``RelationStep``: ``frames`` independent per-frame bodies (``_frame(fs, f)``, written by
+    the subclass against static device buffers) as one HIP graph per frame size with a branch per frame; at most ``max_graphs``
+    sizes are kept (least recently used goes first), their graphs share one memory pool (no two ever run at once)."""
+
+    def __init__(self, net, frames, device, use_graph, max_graphs):
+        if net.training:
+            raise RuntimeError("%s: the network must be in eval mode (test_net_...:131 fasterRCNN.eval())" % type(self).__name__)
+        self.net, self.dev, self.frames = net, torch.device(device), int(frames)
+        self.use_graph, self.max_graphs = bool(use_graph), max(int(max_graphs), 1)
+        self._streams = [torch.cuda.Stream(self.dev) for _ in range(self.frames)]
+        self.shapes, self._pool, self._tick, self._staged = {}, None, 0, None
+        self.graph_error = None
+        self._slot = 0
+
+    @torch.no_grad()
+    def _body(self, fs):
+        main = torch.cuda.current_stream(self.dev)
+        for f, st in enumerate(self._streams):     # fork from the launching stream itself (a fork inside a fork breaks capture)
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                self._frame(fs, f)
+        for st in self._streams:
+            main.wait_stream(st)
+
+    def _shape(self, H, W):
+        key = (self.frames, int(H), int(W))
+        fs = self.shapes.get(key)
+        if fs is None:
+            if len(self.shapes) >= self.max_graphs:           # a new size: the least recently used one goes, once it is idle
+                torch.cuda.synchronize(self.dev)
+                del self.shapes[min(self.shapes, key=lambda k: self.shapes[k].tick)]
+            fs = self.shapes[key] = _FrameShape(key, self.dev)
+        self._staged = key
+        return fs
+
+    def _place(self, fs, im_data):
+        n, c = im_data.shape[:2]
+        if c == 4:
+            fs.im[:n].copy_(im_data, non_blocking=True)
+        else:
+            fs.im[:n, :3].copy_(im_data, non_blocking=True)      # NCHW3 -> NHWC4 (channel 3 stays zero)
+
+    def invalidate_graphs(self):
+        """Drop every captured graph (they are captured again on first use).  Needed after the network's weights change: a
+        graph holds the Winograd-domain filters of the weights it was captured with."""
+        if any(fs.graph for fs in self.shapes.values()):
+            torch.cuda.synchronize(self.dev)
+        for fs in self.shapes.values():
+            fs.graph = None
+        self._pool = None             # the allocator releases a pool with its last graph
+
+    def _capture(self, fs):
+        for _ in range(2):                         # eager passes: anchors / transformed filters cached, arenas sized
+            for f in range(self.frames):
+                with torch.no_grad():
+                    self._frame(fs, f)
+                fs.ctx[f].fit()
+        torch.cuda.synchronize(self.dev)
+        if not self.use_graph:
+            fs.graph = False
+            return
+        try:
+            g = torch.cuda.CUDAGraph()
+            if self._pool is None:
+                self._pool = torch.cuda.graph_pool_handle()
+            with torch.cuda.graph(g, pool=self._pool):
+                self._body(fs)
+            fs.graph = g
+        except Exception as e:                     # report, keep the eager form for this size
+            fs.graph, self.graph_error = False, repr(e)
+            torch.cuda.synchronize(self.dev)
+
+    def _run_staged(self):
+        fs = self.shapes[self._staged]
+        if fs.graph is None:
+            self._capture(fs)
+        self._tick += 1
+        fs.tick = self._tick
+        if fs.graph:
+            fs.graph.replay()
+        else:
+            self._body(fs)
+
+    def run(self, batches):
+        """Generator over batches (the argument tuples of ``stage``): yields each batch's result list while the next batch
+        runs.  (Results sit in two alternating pinned buffers: collect a token before launching twice more.)"""
+        pending = None
+        for b in batches:
+            self.stage(*b)
+            token = self.launch()
+            if pending is not None:
+                yield self.collect(pending)
+            pending = token
+        if pending is not None:
+            yield self.collect(pending)
+
+    def __call__(self, *batch):
+        self.stage(*batch)
+        return self.collect(self.launch())
+
+
+class DetectStep(_FrameGraphStep):
     """The per-frame body of test_net_instance_styleD_bilinear.py:133-221 (eval forward, de-normalise / decode / clip, per class
     threshold + sort + NMS 0.3, top-``max_per_image``) for ``frames`` frames at a time as ONE replayable HIP graph with a branch
     per frame.  The reference evaluates frame by frame (batch_size 1, :95); one frame's kernels leave much of the chip idle
@@ -39,29 +141,22 @@ class DetectStep:
 
     ``step(im_data, im_info)`` -> list over the frames of the reference's ``all_boxes[j][i]`` lists; ``step.run(batches)``
     keeps one batch in flight while the host unpacks the previous one.  Frames of one call share a size (the loader pads a
-    minibatch to one size); graphs are kept per size, least recently used first.  The frame's ``im_info`` row is read on the
-    device (``i2v_det_postprocess_info``), so frames of any scale replay the same graph."""
+    minibatch to one size).  The frame's ``im_info`` row is read on the device (``i2v_det_postprocess_info``), so frames of
+    any scale replay the same graph."""
 
     def __init__(self, net, frames=2, thresh=0.0, max_per_image=100, class_agnostic=False, device="cuda:0", use_graph=True,
                  max_graphs=8):
-        if net.training:
-            raise RuntimeError("DetectStep: the network must be in eval mode (test_net_...:131 fasterRCNN.eval())")
-        self.net, self.dev, self.frames = net, torch.device(device), int(frames)
+        super().__init__(net, frames, device, use_graph, max_graphs)
         self.thresh, self.max_per_image, self.class_agnostic = float(thresh), int(max_per_image), bool(class_agnostic)
-        self.use_graph, self.max_graphs = bool(use_graph), int(max_graphs)
         self.R, self.C = int(cfg.TEST.RPN_POST_NMS_TOP_N), int(net.n_classes)
         self.info = torch.zeros((self.frames, 3), device=self.dev)
         self.dets = torch.zeros((self.frames, self.C, self.R, 5), device=self.dev)
         self.counts = torch.zeros((self.frames, self.C), device=self.dev, dtype=torch.int32)
         self._host = [(torch.zeros(self.dets.shape).pin_memory(), torch.zeros(self.counts.shape, dtype=torch.int32).pin_memory(),
                        torch.cuda.Event()) for _ in range(2)]
-        self._slot = 0
-        self._streams = [torch.cuda.Stream(self.dev) for _ in range(self.frames)]
-        self.shapes, self._pool, self._tick, self._staged = {}, None, 0, None
-        self.graph_error = None
 
-    # ------------------------------------------------------------------ one frame, as the reference's loop body runs it
     def _frame(self, fs, f):
+        """One frame, as the reference's loop body runs it."""
         with fs.ctx[f]:
             rois, cls_prob, bbox_pred = self.net.forward_detect(fs.im[f:f + 1], self.info[f:f + 1])
             stds = means = None
@@ -74,107 +169,39 @@ class DetectStep:
                                       self.thresh, cfg.TEST.NMS, self.max_per_image, im_info=self.info[f],
                                       out=(self.dets[f], self.counts[f]))
 
-    @torch.no_grad()
-    def _body(self, fs):
-        main = torch.cuda.current_stream(self.dev)
-        for f, st in enumerate(self._streams):     # fork from the launching stream itself (a fork inside a fork breaks capture)
-            st.wait_stream(main)
-            with torch.cuda.stream(st):
-                self._frame(fs, f)
-        for st in self._streams:
-            main.wait_stream(st)
-
-    # ------------------------------------------------------------------ staging, capture, replay
     def stage(self, im_data, im_info):
         """``im_data``: (n,3,H,W) float frames (device or pinned host) or the (n,4,H,W) channels_last blob of the device
         front-end, n <= frames (a short last batch: the other branches re-run what they hold); ``im_info``: (n,3)."""
-        n, c, H, W = im_data.shape
+        n, _, H, W = im_data.shape
         if n > self.frames:
             raise ValueError("DetectStep.stage: %d frames, the step was built for %d" % (n, self.frames))
-        key = (self.frames, int(H), int(W))
-        fs = self.shapes.get(key)
-        if fs is None:
-            fs = self.shapes[key] = _DetectShape(key, self.dev)
-        if c == 4:
-            fs.im[:n].copy_(im_data, non_blocking=True)
-        else:
-            fs.im[:n, :3].copy_(im_data, non_blocking=True)      # NCHW3 -> NHWC4 (channel 3 stays zero)
-        info = torch.as_tensor(im_info, dtype=torch.float32).reshape(-1, 3)
-        self.info[:n].copy_(info, non_blocking=True)
+        fs = self._shape(H, W)
+        self._place(fs, im_data)
+        self.info[:n].copy_(torch.as_tensor(im_info, dtype=torch.float32).reshape(-1, 3), non_blocking=True)
         if n < self.frames:                                      # idle branches: any valid im_info row (scale > 0) will do
             self.info[n:].copy_(self.info[:1].expand(self.frames - n, 3))
-        self._staged, self._n = key, int(n)
+        self._n = int(n)
         return fs
-
-    def _capture(self, fs):
-        for _ in range(2):                         # eager passes: anchors / transformed filters cached, arenas sized
-            for f in range(self.frames):
-                with torch.no_grad():
-                    self._frame(fs, f)
-                fs.ctx[f].fit()
-        torch.cuda.synchronize(self.dev)
-        if not self.use_graph:
-            fs.graph = False
-            return
-        live = [t for t in self.shapes.values() if t.graph]
-        if len(live) >= self.max_graphs:
-            min(live, key=lambda t: t.tick).graph = None
-        try:
-            g = torch.cuda.CUDAGraph()
-            if self._pool is None:
-                self._pool = torch.cuda.graph_pool_handle()
-            with torch.cuda.graph(g, pool=self._pool):
-                self._body(fs)
-            fs.graph = g
-        except Exception as e:                     # report, keep the eager form for this size
-            fs.graph, self.graph_error = False, repr(e)
-            torch.cuda.synchronize(self.dev)
 
     def launch(self):
         """Run the staged batch (asynchronous) and queue the copy of its results into pinned host memory; returns a token
         for ``collect``."""
-        fs = self.shapes[self._staged]
-        if fs.graph is None:
-            self._capture(fs)
-        self._tick += 1
-        fs.tick = self._tick
-        if fs.graph:
-            fs.graph.replay()
-        else:
-            self._body(fs)
+        self._run_staged()
         dets_h, counts_h, ev = self._host[self._slot]
         dets_h.copy_(self.dets, non_blocking=True)
         counts_h.copy_(self.counts, non_blocking=True)
         ev.record(torch.cuda.current_stream(self.dev))
-        token = (self._slot, self._n)
         self._slot ^= 1
-        return token
+        return (dets_h, counts_h, ev, self._n)
 
     def collect(self, token):
-        slot, n = token
-        dets_h, counts_h, ev = self._host[slot]
+        dets_h, counts_h, ev, n = token
         ev.synchronize()
         dets, counts = dets_h.numpy(), counts_h.numpy()
         return [[np.array(dets[f, j, :counts[f, j]]) for j in range(self.C)] for f in range(n)]
 
-    def __call__(self, im_data, im_info):
-        self.stage(im_data, im_info)
-        return self.collect(self.launch())
 
-    def run(self, batches):
-        """Generator over ``(im_data, im_info)`` batches: yields each batch's result list while the next batch runs."""
-        pending = None
-        for im_data, im_info in batches:
-            self.stage(im_data, im_info)
-            token = self.launch()
-            if pending is not None:
-                yield self.collect(pending)
-            pending = token
-        if pending is not None:
-            yield self.collect(pending)
-
-
-class RelationStep:
+class RelationStep(_FrameGraphStep):
     """The per-frame body of test_net_SGG_emb.py (backbone, eval branch of forward_relation on the frame's annotated boxes --
     every ordered pair --, softmax over predicates, ``detection_output`` top-``k`` triplets) for ``frames`` frames at a time as ONE
     replayable HIP graph with a branch per frame -- ``DetectStep``'s schedule for the relation test loop.
@@ -188,31 +215,22 @@ class RelationStep:
     with fewer than two boxes); ``step.run(batches)`` keeps one batch in flight while the host unpacks the previous one."""
 
     def __init__(self, net, frames=2, k=100, device="cuda:0", cap_boxes=9, use_graph=True, max_graphs=8):
-        if net.training:
-            raise RuntimeError("RelationStep: the network must be in eval mode")
-        self.net, self.dev, self.frames, self.k = net, torch.device(device), int(frames), int(k)
-        self.use_graph, self.max_graphs = bool(use_graph), int(max_graphs)
-        self.n_rel = int(net.vrd.n_rel)
-        self._streams = [torch.cuda.Stream(self.dev) for _ in range(self.frames)]
-        self.shapes, self._pool, self._tick, self._staged = {}, None, 0, None
-        self.graph_error = None
-        self._slot = 0
+        super().__init__(net, frames, device, use_graph, max_graphs)
+        self.k, self.n_rel = int(k), int(net.vrd.n_rel)
         self._alloc(int(cap_boxes))
 
     def _alloc(self, cap_boxes):
         from .train import _Slot
-        F_, cb = self.frames, int(cap_boxes)
+        F_, cb = self.frames, max(int(cap_boxes), 3)
         cp = (cb - 1) * (cb - 2)
         self.cap_boxes, self.cap_pairs = cb, cp
         self.kk = min(self.k, cp * self.n_rel)
+        self.invalidate_graphs()
         self.inputs = _Slot({"rois": ((F_, cb + cp, 5), torch.float32), "bounds": ((F_, cp, 2, 4), torch.int32),
                              "ix": ((F_, 2, cp), torch.int64), "conf": ((F_, cb), torch.float32)}, self.dev, host=True)
         self.out = _Slot({"pair": ((F_, self.kk), torch.int32), "pred": ((F_, self.kk), torch.int32),
                           "conf": ((F_, self.kk), torch.float32)}, self.dev)
         self._host = [(torch.zeros(self.out.nbytes, dtype=torch.uint8).pin_memory(), torch.cuda.Event()) for _ in range(2)]
-        for fs in self.shapes.values():
-            fs.graph = None
-        self._pool = None
 
     def _frame(self, fs, f):
         from .model.faster_rcnn.faster_rcnn_SGG_emb import rasterize_masks
@@ -228,20 +246,17 @@ class RelationStep:
             o["pred"][f].copy_(pred)
             o["conf"][f].copy_(conf)
 
-    _body = DetectStep._body
-
     def stage(self, im_data, im_info, im_paths):
         """``im_data`` (n,3|4,H,W), n <= frames; ``im_info`` (n,3) on the host; ``im_paths``: the frames' keys into
         ``net.vrd.target_gt_rels``."""
         from .model.faster_rcnn.faster_rcnn_SGG_emb import build_eval_pair_tables
-        n, c, H, W = im_data.shape
+        n, _, H, W = im_data.shape
         if n > self.frames or len(im_paths) != n:
             raise ValueError("RelationStep.stage: %d frames / %d paths, the step was built for %d" % (n, len(im_paths), self.frames))
         info = np.asarray(im_info.cpu() if torch.is_tensor(im_info) else im_info, np.float64).reshape(-1, 3)
         annos = [self.net.vrd.target_gt_rels[p] for p in im_paths]
         need = max([len(a["boxes"]) for a in annos] + [1]) + 1
         if need > self.cap_boxes:
-            torch.cuda.synchronize(self.dev)
             self._alloc(need)
         cb, cp = self.cap_boxes, self.cap_pairs
         rois = np.zeros((self.frames, cb + cp, 5), np.float32)
@@ -263,52 +278,14 @@ class RelationStep:
             ix[f, 0, :len(ixs)], ix[f, 1, :len(ixs)] = ixs, ixo
             conf[f, :nb] = 1                                            # :608 every annotated box enters with confidence 1
             meta.append((np.array(a["boxes"], np.float64).reshape(-1, 4), np.asarray(a["box_classes"]), ixs, ixo))
-        key = (self.frames, int(H), int(W))
-        fs = self.shapes.get(key)
-        if fs is None:
-            fs = self.shapes[key] = _DetectShape(key, self.dev)
-        if c == 4:
-            fs.im[:n].copy_(im_data, non_blocking=True)
-        else:
-            fs.im[:n, :3].copy_(im_data, non_blocking=True)
+        fs = self._shape(H, W)
+        self._place(fs, im_data)
         self.inputs.write_host({"rois": rois, "bounds": bounds, "ix": ix, "conf": conf})
-        self._staged, self._meta = key, meta
+        self._meta = meta
         return fs
 
-    def _capture(self, fs):
-        for _ in range(2):
-            for f in range(self.frames):
-                with torch.no_grad():
-                    self._frame(fs, f)
-                fs.ctx[f].fit()
-        torch.cuda.synchronize(self.dev)
-        if not self.use_graph:
-            fs.graph = False
-            return
-        live = [t for t in self.shapes.values() if t.graph]
-        if len(live) >= self.max_graphs:
-            min(live, key=lambda t: t.tick).graph = None
-        try:
-            g = torch.cuda.CUDAGraph()
-            if self._pool is None:
-                self._pool = torch.cuda.graph_pool_handle()
-            with torch.cuda.graph(g, pool=self._pool):
-                self._body(fs)
-            fs.graph = g
-        except Exception as e:
-            fs.graph, self.graph_error = False, repr(e)
-            torch.cuda.synchronize(self.dev)
-
     def launch(self):
-        fs = self.shapes[self._staged]
-        if fs.graph is None:
-            self._capture(fs)
-        self._tick += 1
-        fs.tick = self._tick
-        if fs.graph:
-            fs.graph.replay()
-        else:
-            self._body(fs)
+        self._run_staged()
         hb, ev = self._host[self._slot]
         hb.copy_(self.out.buf, non_blocking=True)
         ev.record(torch.cuda.current_stream(self.dev))
@@ -326,29 +303,13 @@ class RelationStep:
                 continue
             boxes, classes, ixs, ixo = m
             pair, pred, tconf = host["pair"][f], host["pred"][f], host["conf"][f]
-            n = int((pair < len(ixs)).sum()) if kk else 0             # real cells are a prefix (pad cells score 0)
-            n = min(n, len(ixs) * self.n_rel)
+            n = min(int((pair < len(ixs)).sum()), len(ixs) * self.n_rel)          # real cells are a prefix (pad cells score 0)
             pair, pred, tconf = pair[:n].astype(np.int64), pred[:n], np.array(tconf[:n])
             rlp, sub, obj = np.zeros((self.k, 3), np.float64), np.zeros((self.k, 4), np.float64), np.zeros((self.k, 4), np.float64)
             sub[:n], obj[:n] = boxes[ixs[pair]], boxes[ixo[pair]]
             rlp[:n] = np.stack([classes[ixs[pair]], pred, classes[ixo[pair]]], 1)
             res.append((rlp, tconf, sub, obj, pair))
         return res
-
-    def __call__(self, im_data, im_info, im_paths):
-        self.stage(im_data, im_info, im_paths)
-        return self.collect(self.launch())
-
-    def run(self, batches):
-        pending = None
-        for b in batches:
-            self.stage(*b)
-            token = self.launch()
-            if pending is not None:
-                yield self.collect(pending)
-            pending = token
-        if pending is not None:
-            yield self.collect(pending)
 
 
 @torch.no_grad()
