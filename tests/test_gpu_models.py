@@ -589,6 +589,37 @@ def test_detect_frame_eval_loop_matches_oracle_postprocess(cfg):
         assert np.array_equal(got[j], want[j]), j
 
 
+@pytest.mark.parametrize("ic,gc", [(False, False), (True, True)])
+def test_forward_detect_equals_the_eval_forward(cfg, ic, gc):
+    """``forward_detect`` (what the test loop reads: rois, cls_prob, bbox_pred) == the same three outputs of ``forward`` in eval
+    mode, with and without the context vectors of the two discriminators in the classifier input (split-K off: deterministic)."""
+    from i2vsgg_amd._lib import TUNE, lib
+    from i2vsgg_amd.model.faster_rcnn.resnet_instance_styleD_bilinear import resnet
+    torch.manual_seed(3)
+    net = resnet(tuple(range(16)), 50, ic=ic, gc=gc)
+    net.create_architecture()
+    net.to(DEV).eval()
+    im = torch.from_numpy(syn.frames(77, 1, 320, 480)[0]).to(DEV)
+    info = torch.tensor([[320.0, 480.0, 1.3]], device=DEV)
+    old = lib.i2v_get_tuning(TUNE["I2V_SPLIT_BELOW"])
+    try:
+        lib.i2v_set_tuning(TUNE["I2V_SPLIT_BELOW"], 0)
+        with torch.no_grad():
+            full = net(im, info, torch.zeros(1, 1, 5, device=DEV), torch.zeros(1, device=DEV))
+        fast = net.forward_detect(im, info)
+    finally:
+        lib.i2v_set_tuning(TUNE["I2V_SPLIT_BELOW"], old)
+    assert fast[1].shape == (1, cfg.TEST.RPN_POST_NMS_TOP_N, 16)
+    for a, b in zip(fast, full[:3]):
+        if ic or gc:      # the context vectors are spatial sums accumulated with fp32 atomics: two calls differ in the last bits
+            assert _rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+        else:
+            assert torch.equal(a, b)
+    net.train()
+    with pytest.raises(RuntimeError):
+        net.forward_detect(im, info)
+
+
 def test_detect_step_equals_frame_by_frame_eval(cfg):
     """eval.DetectStep (several frames per replayed graph, a branch per frame, im_info read on the device) returns what
     eval.detect_frame returns frame by frame: same boxes, same order, for frames of different scales, a short last batch and the
