@@ -242,7 +242,7 @@ size_t  i2v_conv_split_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t 
 #define I2V_TUNE_WGRAD_XCD           14   /* 1 (default): a filter-gradient split's tiles share an XCD when the split count is a multiple of 8 */
 #define I2V_TUNE_FC_FOLD             15   /* diagnostic ablation bits of i2v_fc_fold_fwd (0 = the kernel as shipped): 1 no gradient MFMAs, 2 no forward MFMAs, 4 no x loads, 8 no filter / momentum stores, 16 no xp staging */
 #define I2V_TUNE_GEMM_X3             16   /* opt-in (default 0 = fp32 MFMA everywhere): 1 = the pointwise / plain-GEMM kernel multiplies on the bf16 matrix pipe as a three-term split (hi*hi + hi*lo + lo*hi of two 8-bit-mantissa halves; fp32 in, fp32 accumulate, fp32 out) */
-#define I2V_TUNE_GEMM_PERSIST        17   /* 1 = unsplit pointwise / plain GEMMs run on the persistent form of the kernel (tile queue in the split-K workspace, next tile's operands under the current tile's last stage); 0 = one tile per workgroup */
+#define I2V_TUNE_GEMM_PERSIST        17   /* n >= 1: unsplit pointwise / plain GEMMs run on the persistent form of the kernel (a workgroup streams through >= max(n, 2) tiles, the next tile's operands requested under the current tile's last stage); bit-equal, measured slower; 0 (default) = one tile per workgroup */
 #define I2V_TUNE_WGRAD_PRIO          18   /* experiment: n > 0 = the filter-gradient kernel lowers a wave's issue priority as it advances (3 - ((stage >> (n-1)) & 3)); 0 = off */
 #define I2V_TUNE_COUNT               19
 int32_t i2v_set_tuning(int32_t key, int32_t value);

@@ -1205,3 +1205,62 @@ def test_fused_loss_and_target_arithmetic_matches_the_torch_expressions():
     live = z.detach() != 0
     torch.testing.assert_close(ga[live], z.grad[live], rtol=1e-5, atol=0)
     assert float(ga[~live].abs().max()) == 0.0               # aten gives NaN there (inf * 0 through sqrt'); the kernel gives 0
+
+
+KNOBS = [("I2V_CONV_SPEC", 1), ("I2V_CONV_SPEC", 2), ("I2V_SPLIT_TARGET", 3), ("I2V_SPLIT_TARGET_SKINNY", 3), ("I2V_SPLIT_BELOW", 0),
+         ("I2V_SPLIT_BELOW", 2048), ("I2V_SPLIT_ATOMICS", 1), ("I2V_BIG_FC_TILE", -1), ("I2V_WGRAD_V2", 0), ("I2V_WGRAD_V2", 2),
+         ("I2V_WGRAD_V2", 3), ("I2V_WINO_ROWS", 0), ("I2V_WINO_ROWS", 3), ("I2V_ROIPOOL_C128", 0), ("I2V_CONV_GEMM", 0),
+         ("I2V_STAGGER", 4), ("I2V_ROIALIGN_COLS", 0), ("I2V_WGRAD_PER_CU", 2), ("I2V_WGRAD_XCD", 0), ("I2V_GEMM_PERSIST", 2),
+         ("I2V_WGRAD_PRIO", 2), ("I2V_GEMM_X3", 1)]
+
+
+def test_every_tuning_knob_keeps_the_results(ops):
+    """Round-2 review: the I2V_* switches select kernels and launch shapes, and only their defaults ran anywhere.  Every knob at
+    a non-default value (i2v_set_tuning, the call the environment variables are forwarded to): pointwise / strided / 3x3
+    (Winograd) / 5x5 forward, data and filter gradients, the skinny split-K GEMM of the relation head, ROIPool and RoIAlignAvg give
+    what the defaults give -- bit for bit where the knob only moves work around, within fp32 summation-order noise where it changes
+    a split or a tile, within 2^-16 products for the bf16 three-term split."""
+    from i2vsgg_amd._lib import TUNE, lib
+    rng = np.random.default_rng(5)
+    t = lambda *sh: torch.from_numpy(rng.standard_normal(sh, dtype=np.float32)).to(DEV)
+    cl = lambda a: a.contiguous(memory_format=torch.channels_last)
+    x = cl(t(2, 256, 38, 63))
+    w1, w3, w5 = cl(t(128, 256, 1, 1) / 16), cl(t(256, 256, 3, 3) / 48), cl(t(96, 256, 5, 5) / 80)
+    sc, sh = torch.rand(256, device=DEV) + 0.5, torch.rand(256, device=DEV)
+    g1 = cl(t(2, 128, 38, 63))
+    xs, ws = t(128, 8192), t(512, 8192) / 90
+    rois = torch.from_numpy(np.concatenate([rng.integers(0, 2, (48, 1)).astype(np.float32),
+                                            np.sort(rng.uniform(0, 600, (48, 2, 2)).astype(np.float32), 1).reshape(48, 4)[:, [0, 2, 1, 3]]], 1)).to(DEV)
+    xc = cl(t(2, 1024, 38, 63))
+
+    def run():
+        out = {}
+        out["pointwise"] = ops.conv2d(x, w1, sc[:128], sh[:128], None, 1, 0, relu=True)
+        out["strided"] = ops.conv2d(x, w1, sc[:128], sh[:128], None, 2, 0, relu=True)
+        out["winograd"] = ops.conv2d(x, w3, sc, sh, None, 1, 1, relu=True, winograd=True)
+        out["direct3x3"] = ops.conv2d(x, w3, sc, sh, None, 1, 1, relu=True)
+        out["conv5x5s2"] = ops.conv2d(x, w5, None, None, None, 2, 2)
+        out["dgrad"] = ops._conv_dgrad_raw(g1, w1, tuple(x.shape), 1, 0)
+        out["wgrad"] = ops._conv_wgrad_raw(x, g1, (128, 256, 1, 1), 1, 0)
+        out["skinny"] = ops.linear(xs, ws)
+        out["roi_pool"] = ops.roi_pool(xc, rois, 7, 7, 1.0 / 16, out_nchw=False)
+        out["roi_align"] = ops.roi_align(xc, rois, 7, 7, 1.0 / 16)
+        return {k: v.clone() for k, v in out.items()}
+
+    base = run()
+    assert all(torch.isfinite(v).all() for v in base.values())
+    for name, value in KNOBS:
+        key = TUNE[name]
+        old = lib.i2v_get_tuning(key)
+        try:
+            assert lib.i2v_set_tuning(key, value) == 0
+            got = run()
+        finally:
+            lib.i2v_set_tuning(key, old)
+        tol = 2e-4 if name == "I2V_GEMM_X3" else 2e-5
+        for k in base:
+            err = _rel_err(got[k].cpu().numpy(), base[k].cpu().numpy())
+            assert err < tol, (name, value, k, err)
+    again = run()
+    for k in ("pointwise", "strided", "winograd", "roi_pool", "roi_align"):      # the launches without split-K atomics
+        assert torch.equal(again[k], base[k]), k          # the knobs are back at their defaults
