@@ -140,6 +140,31 @@ def test_device_sampling_statistics(fresh_cfg):
     assert all(i < 50 for i in k0[:8]) and len(set(k0[:8])) == 8 and all(i >= 50 for i in k0[8:])
     assert all(0 <= i < 400 for i in keep[1].tolist() + keep[2].tolist())
     assert len(set(keep[2].tolist())) > 16                                                           # spread over the candidates
+    # unbiased: over many draws every candidate of a class is kept equally often (round-2 review: a biased sampler would pass
+    # the size checks above).  z = (count - T p) / sqrt(T p (1 - p)) per candidate: mean z^2 ~ 1, no candidate beyond 5 sigma
+    T = 300
+    cnt_fg = torch.zeros(N, device=DEV)
+    cnt_bg = torch.zeros(N, device=DEV)
+    for _ in range(T):
+        o = _AnchorTargetLayer._subsample_device(lab[:1], 128, 256)[0]
+        cnt_fg += (o == 1)
+        cnt_bg += (o == 0)
+    for cnt, cand, k in ((cnt_fg, lab[0] == 1, 128), (cnt_bg, lab[0] == 0, 128)):
+        n = int(cand.sum())
+        pr = k / n
+        z = (cnt[cand] - T * pr) / (T * pr * (1 - pr)) ** 0.5
+        assert float(cnt[~cand].sum()) == 0 and abs(float(cnt[cand].sum()) - T * k) < 0.5
+        assert 0.75 < float((z * z).mean()) < 1.3 and float(z.abs().max()) < 5.0, (n, float((z * z).mean()), float(z.abs().max()))
+    cnt = torch.zeros(400, device=DEV)
+    for _ in range(T):
+        kp, _n = _ProposalTargetLayer._sample_device(mo[:1], 32, 8)
+        cnt += torch.bincount(kp[0].long(), minlength=400).float()
+    for cand, k in ((slice(0, 50), 8), (slice(50, 400), 24)):
+        n = cand.stop - cand.start
+        pr = k / n
+        z = (cnt[cand] - T * pr) / (T * pr * (1 - pr)) ** 0.5
+        assert abs(float(cnt[cand].sum()) - T * k) < 0.5
+        assert 0.7 < float((z * z).mean()) < 1.4 and float(z.abs().max()) < 5.0, (n, float((z * z).mean()), float(z.abs().max()))
 
 
 def test_res50_yml_full_frame_plumbing(fresh_cfg):
