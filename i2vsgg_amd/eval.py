@@ -48,8 +48,7 @@ class _FrameGraphStep:
     def _body(self, fs):
         main = torch.cuda.current_stream(self.dev)
         for f, st in enumerate(self._streams):     # fork from the launching stream itself (a fork inside a fork breaks capture)
-            st.wait_stream(main)
-            with torch.cuda.stream(st):
+            with ops.branch(st, main):
                 self._frame(fs, f)
         for st in self._streams:
             main.wait_stream(st)

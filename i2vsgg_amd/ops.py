@@ -441,6 +441,35 @@ class LaunchContext:
         return False
 
 
+_BRANCH_DEPTH = 0
+
+
+class branch:
+    """``with ops.branch(stream, origin):`` -- the body runs on ``stream`` as a fork of ``origin`` (stream.wait_stream(origin) first;
+    the caller joins with origin.wait_stream(stream)).  The step objects fork their graph branches through this so that the one
+    capture-time crash the schedule must avoid is an error message instead: a fork made INSIDE a forked branch ends
+    ``hipStreamEndCapture`` in a host segfault on ROCm 7.2 -- every branch forks from the capturing stream itself."""
+
+    def __init__(self, stream, origin):
+        self.stream, self.origin = stream, origin
+
+    def __enter__(self):
+        global _BRANCH_DEPTH
+        if _BRANCH_DEPTH > 0 and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("ops.branch: a fork inside a forked graph branch (hipStreamEndCapture crashes on it): fork every "
+                               "branch from the capturing stream")
+        self.stream.wait_stream(self.origin)
+        self._ctx = torch.cuda.stream(self.stream)
+        self._ctx.__enter__()
+        _BRANCH_DEPTH += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _BRANCH_DEPTH
+        _BRANCH_DEPTH -= 1
+        return self._ctx.__exit__(*exc)
+
+
 def _split_ws(device):
     ws = SPLIT_WS
     if ws is None:

@@ -707,8 +707,7 @@ class SGGEmbStep:
         n = fs.key[0]
         for f in range(n):
             st = self._frame_streams[f]
-            st.wait_stream(main)
-            with torch.cuda.stream(st):
+            with ops.branch(st, main):
                 with fs.ctx[f]:
                     with torch.no_grad():
                         self.net.RCNN_base(fs.im[f:f + 1], out=self._fmap_dst(fs, f))
@@ -772,8 +771,7 @@ class SGGEmbStep:
             for st in self._frame_streams:
                 main.wait_stream(st)
             return
-        self._side.wait_stream(main)
-        with torch.cuda.stream(self._side):
+        with ops.branch(self._side, main):
             self._backbone(fs)              # batch k+1
         self._head()                        # batch k
         main.wait_stream(self._side)
@@ -1198,8 +1196,6 @@ class InstanceStyleDStep:
         self.opt.zero_grad()
         s_src, s_tgt = self._branch_streams
         vals, grads = {}, {}
-        s_src.wait_stream(main)
-        s_tgt.wait_stream(main)
         # Each branch's autograd graph is gone before the other branch's forward starts (only detached values leave the
         # block): a parameter's AccumulateGrad node lives as long as a graph references it and remembers the stream it was
         # made on -- shared between the two branches the engine would synchronise their streams with each other.
@@ -1229,10 +1225,10 @@ class InstanceStyleDStep:
             v["_tgt"] = part
             return {k: t.detach() for k, t in v.items()}, g
 
-        with torch.cuda.stream(s_src), self.ctx_src:
+        with ops.branch(s_src, main), self.ctx_src:
             v, grads["s"] = source()
             vals.update(v)
-        with torch.cuda.stream(s_tgt), self.ctx_tgt:
+        with ops.branch(s_tgt, main), self.ctx_tgt:
             v, grads["t"] = target()
             vals.update(v)
         main.wait_stream(s_src)

@@ -838,3 +838,37 @@ def test_sgg_step_tensor_parallel_fc6_rehearsal_matches_single_graph(cfg, monkey
     for x, y in zip(l0, l1):
         assert abs(x - y) <= 1e-5 * abs(x), (l0, l1)
     assert _rel_err(a1, a0) < 1e-5 and _rel_err(b1, b0) < 1e-5, (_rel_err(a1, a0), _rel_err(b1, b0))
+
+
+def test_fork_inside_a_graph_branch_is_an_error_not_a_crash():
+    """Round-2 review: a fork made inside a forked branch ends hipStreamEndCapture in a host segfault on ROCm 7.2, and the
+    step objects avoided it by construction only.  They fork through ``ops.branch`` now, which refuses the nested fork while a
+    capture is running (and is an ordinary fork / join outside one)."""
+    from i2vsgg_amd import ops
+    s1, s2 = torch.cuda.Stream(DEV), torch.cuda.Stream(DEV)
+    x = torch.ones(1024, device=DEV)
+    torch.cuda.synchronize()
+    g, caught = torch.cuda.CUDAGraph(), []
+    with torch.cuda.graph(g):
+        main = torch.cuda.current_stream()
+        with ops.branch(s1, main):
+            y = x * 2
+            try:
+                with ops.branch(s2, s1):
+                    y = y + 1
+            except RuntimeError as e:
+                caught.append(str(e))
+        main.wait_stream(s1)
+        z = y + 1
+    g.replay()
+    torch.cuda.synchronize()
+    assert caught and "fork inside a forked graph branch" in caught[0]
+    assert float(z[0]) == 3.0
+    main = torch.cuda.current_stream()              # outside a capture nesting is an ordinary (if pointless) fork / join
+    with ops.branch(s1, main):
+        with ops.branch(s2, s1):
+            w = x + 5
+        s1.wait_stream(s2)
+    main.wait_stream(s1)
+    torch.cuda.synchronize()
+    assert float(w[0]) == 6.0
