@@ -565,6 +565,12 @@ def run_instance_styled(a, rank, world, dev, steps, warmup, frames_per_rank=4):
     losses = {k: float(v) for k, v in step.losses.items()}
     n_prof = 2
     rec = profile_eager(step.eager_step if hasattr(step, "eager_step") else step, n_prof, dev)
+    if a.dump_launches and rank == 0:
+        per = len(rec) // n_prof
+        with open(a.dump_launches, "w") as f:
+            for r in rec[-per:]:
+                f.write("%-6s %-52s %8.1f us %7.2f GF %6.1f TF %8.2f MB\n" % (
+                    r["tag"], r["desc"], r["t"] * 1e6, r["flops"] / 1e9, r["flops"] / r["t"] / 1e12, r["bytes"] / 1e6))
     wg = [r for r in rec if r["tag"] == "wgrad"]
     t_wg, f_wg, b_wg = sum(r["t"] for r in wg), sum(r["flops"] for r in wg), sum(r["bytes"] for r in wg)
     # the 3x3 layers' filter gradients run in the Winograd F(4x4,3x3) domain: a quarter of the direct form's MACs are

@@ -1441,6 +1441,13 @@ int run_conv(ConvP p, hipStream_t st, void* split_ws = nullptr, size_t split_ws_
         const double cost = plan(c, sk);
         if (cost < best) { best = cost; cfg = c; splitk = sk; }
     }
+    // HBM-bound pointwise layers (at most four K stages over many rows: the 64 -> 256 / 128 -> 512 expansions of layer1 / layer2 and
+    // their data gradients): the model's MAC count cannot tell the tiles apart (all within 2 %) and picks 128x64; measured, the
+    // 80x64 tile streams best (tools/pers_bench.py, two frames: layer1 conv3 44.0 against 50.7 us, layer2 conv3 33.3 against 37.6)
+    if (g_i2v_tuning[I2V_TUNE_STREAM_TILE] && p.KH == 1 && p.KW == 1 && p.stride == 1 && p.nbatch <= 1 && ksteps <= 4 && p.M >= 16384) {
+        cfg = 3;
+        plan(cfg, splitk);
+    }
     // batched launches with at most four K stages (the Winograd planes of the 64- and 128-channel layers): per-workgroup
     // set-up and epilogue dominate and the model underrates the smallest tile (measured 23.5 vs 27.4 us at 64 channels)
     if (p.nbatch > 1 && ksteps <= 4) { cfg = kNumTiles - 1; plan(cfg, splitk); }

@@ -244,7 +244,8 @@ size_t  i2v_conv_split_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t 
 #define I2V_TUNE_GEMM_X3             16   /* opt-in (default 0 = fp32 MFMA everywhere): 1 = the pointwise / plain-GEMM kernel multiplies on the bf16 matrix pipe as a three-term split (hi*hi + hi*lo + lo*hi of two 8-bit-mantissa halves; fp32 in, fp32 accumulate, fp32 out) */
 #define I2V_TUNE_GEMM_PERSIST        17   /* n >= 1: unsplit pointwise / plain GEMMs run on the persistent form of the kernel (a workgroup streams through >= max(n, 2) tiles, the next tile's operands requested under the current tile's last stage); bit-equal, measured slower; 0 (default) = one tile per workgroup */
 #define I2V_TUNE_WGRAD_PRIO          18   /* experiment: n > 0 = the filter-gradient kernel lowers a wave's issue priority as it advances (3 - ((stage >> (n-1)) & 3)); 0 = off */
-#define I2V_TUNE_COUNT               19
+#define I2V_TUNE_STREAM_TILE         19   /* 1 (default): pointwise layers of at most four K stages over >= 16384 rows (HBM-bound) take the 80x64 tile whatever the cost model says; 0: cost model */
+#define I2V_TUNE_COUNT               20
 int32_t i2v_set_tuning(int32_t key, int32_t value);
 int32_t i2v_get_tuning(int32_t key);
 /* tuning hook: cfg < 0 = cost model; else low byte = tile shape 0..5 (0xFF = cost model),

@@ -1211,7 +1211,7 @@ KNOBS = [("I2V_CONV_SPEC", 1), ("I2V_CONV_SPEC", 2), ("I2V_SPLIT_TARGET", 3), ("
          ("I2V_SPLIT_BELOW", 2048), ("I2V_SPLIT_ATOMICS", 1), ("I2V_BIG_FC_TILE", -1), ("I2V_WGRAD_V2", 0), ("I2V_WGRAD_V2", 2),
          ("I2V_WGRAD_V2", 3), ("I2V_WINO_ROWS", 0), ("I2V_WINO_ROWS", 3), ("I2V_ROIPOOL_C128", 0), ("I2V_CONV_GEMM", 0),
          ("I2V_STAGGER", 4), ("I2V_ROIALIGN_COLS", 0), ("I2V_WGRAD_PER_CU", 2), ("I2V_WGRAD_XCD", 0), ("I2V_GEMM_PERSIST", 2),
-         ("I2V_WGRAD_PRIO", 2), ("I2V_GEMM_X3", 1)]
+         ("I2V_WGRAD_PRIO", 2), ("I2V_STREAM_TILE", 0), ("I2V_GEMM_X3", 1)]
 
 
 def test_every_tuning_knob_keeps_the_results(ops):
@@ -1232,6 +1232,7 @@ def test_every_tuning_knob_keeps_the_results(ops):
     rois = torch.from_numpy(np.concatenate([rng.integers(0, 2, (48, 1)).astype(np.float32),
                                             np.sort(rng.uniform(0, 600, (48, 2, 2)).astype(np.float32), 1).reshape(48, 4)[:, [0, 2, 1, 3]]], 1)).to(DEV)
     xc = cl(t(2, 1024, 38, 63))
+    x2, w2, r2 = cl(t(2, 64, 75, 125)), cl(t(256, 64, 1, 1) / 8), cl(t(2, 256, 75, 125))
 
     def run():
         out = {}
@@ -1243,6 +1244,7 @@ def test_every_tuning_knob_keeps_the_results(ops):
         out["dgrad"] = ops._conv_dgrad_raw(g1, w1, tuple(x.shape), 1, 0)
         out["wgrad"] = ops._conv_wgrad_raw(x, g1, (128, 256, 1, 1), 1, 0)
         out["skinny"] = ops.linear(xs, ws)
+        out["expand"] = ops.conv2d(x2, w2, sc, sh, r2, 1, 0, relu=True)          # K = 64 over 18750 rows: the HBM-bound tile rule
         out["roi_pool"] = ops.roi_pool(xc, rois, 7, 7, 1.0 / 16, out_nchw=False)
         out["roi_align"] = ops.roi_align(xc, rois, 7, 7, 1.0 / 16)
         return {k: v.clone() for k, v in out.items()}
