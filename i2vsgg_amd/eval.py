@@ -71,6 +71,26 @@ class _FrameGraphStep:
         else:
             fs.im[:n, :3].copy_(im_data, non_blocking=True)      # NCHW3 -> NHWC4 (channel 3 stays zero)
 
+    def _place_u8(self, frames_u8, meta):
+        """The device front-end of ``roibatchLoader(training=False, device_prep=True)`` items: uint8 frames as decoded cross PCIe,
+        BGR swap / mean subtraction / resize run in ``i2v_image_prep``.  ``meta`` rows: [flipped, canvas_h, canvas_w, scale,
+        target]; the frames of a call share their canvas.  -> (frame set, the (n,3) im_info rows)."""
+        from .train import _Uploader, _place_u8
+        meta = np.asarray(meta.cpu() if torch.is_tensor(meta) else meta, np.float64).reshape(-1, 5)
+        n = len(frames_u8)
+        if n > self.frames or len(meta) != n:
+            raise ValueError("%s.stage_u8: %d frames / %d meta rows, the step was built for %d" % (type(self).__name__, n, len(meta), self.frames))
+        sizes = {(int(m[1]), int(m[2])) for m in meta}
+        if len(sizes) != 1:
+            raise ValueError("stage_u8: the frames of one call must share their resized size, got %s" % sorted(sizes))
+        (H, W), = sizes
+        fs = self._shape(H, W)
+        if getattr(self, "_uploader", None) is None:
+            self._uploader = _Uploader(self.dev)
+        frames_u8 = [f.reshape(f.shape[-3:]) for f in frames_u8]              # (1,H,W,3) items of a batch_size-1 loader
+        _place_u8(self._uploader, frames_u8, meta, fs.im[:n])
+        return fs, np.array([[m[1], m[2], m[3]] for m in meta], np.float32)
+
     def invalidate_graphs(self):
         """Drop every captured graph (they are captured again on first use).  Needed after the network's weights change: a
         graph holds the Winograd-domain filters of the weights it was captured with."""
@@ -112,12 +132,13 @@ class _FrameGraphStep:
         else:
             self._body(fs)
 
-    def run(self, batches):
-        """Generator over batches (the argument tuples of ``stage``): yields each batch's result list while the next batch
-        runs.  (Results sit in two alternating pinned buffers: collect a token before launching twice more.)"""
+    def run(self, batches, u8=False):
+        """Generator over batches (the argument tuples of ``stage``, or of ``stage_u8`` with ``u8``): yields each batch's result
+        list while the next batch runs.  (Results sit in two alternating pinned buffers: collect a token before launching
+        twice more.)"""
         pending = None
         for b in batches:
-            self.stage(*b)
+            (self.stage_u8 if u8 else self.stage)(*b)
             token = self.launch()
             if pending is not None:
                 yield self.collect(pending)
@@ -176,11 +197,21 @@ class DetectStep(_FrameGraphStep):
             raise ValueError("DetectStep.stage: %d frames, the step was built for %d" % (n, self.frames))
         fs = self._shape(H, W)
         self._place(fs, im_data)
+        self._set_info(im_info, n)
+        return fs
+
+    def stage_u8(self, frames_u8, meta):
+        """The same from ``roibatchLoader(training=False, device_prep=True)`` items: a list of uint8 (H,W,3) frames and their
+        meta rows (``_place_u8``)."""
+        fs, info = self._place_u8(frames_u8, meta)
+        self._set_info(info, len(frames_u8))
+        return fs
+
+    def _set_info(self, im_info, n):
         self.info[:n].copy_(torch.as_tensor(im_info, dtype=torch.float32).reshape(-1, 3), non_blocking=True)
         if n < self.frames:                                      # idle branches: any valid im_info row (scale > 0) will do
             self.info[n:].copy_(self.info[:1].expand(self.frames - n, 3))
         self._n = int(n)
-        return fs
 
     def launch(self):
         """Run the staged batch (asynchronous) and queue the copy of its results into pinned host memory; returns a token
@@ -248,10 +279,25 @@ class RelationStep(_FrameGraphStep):
     def stage(self, im_data, im_info, im_paths):
         """``im_data`` (n,3|4,H,W), n <= frames; ``im_info`` (n,3) on the host; ``im_paths``: the frames' keys into
         ``net.vrd.target_gt_rels``."""
-        from .model.faster_rcnn.faster_rcnn_SGG_emb import build_eval_pair_tables
         n, _, H, W = im_data.shape
         if n > self.frames or len(im_paths) != n:
             raise ValueError("RelationStep.stage: %d frames / %d paths, the step was built for %d" % (n, len(im_paths), self.frames))
+        self._stage_pairs(im_info, im_paths)
+        fs = self._shape(H, W)
+        self._place(fs, im_data)
+        return fs
+
+    def stage_u8(self, frames_u8, meta, im_paths):
+        """The same from ``roibatchLoader(training=False, device_prep=True)`` items (``_place_u8``)."""
+        if len(im_paths) != len(frames_u8):
+            raise ValueError("RelationStep.stage_u8: %d frames / %d paths" % (len(frames_u8), len(im_paths)))
+        m = np.asarray(meta.cpu() if torch.is_tensor(meta) else meta, np.float64).reshape(-1, 5)
+        self._stage_pairs(np.array([[r[1], r[2], r[3]] for r in m], np.float32), im_paths)     # im_info as the host form holds it (fp32); may grow the capacity
+        fs, _ = self._place_u8(frames_u8, meta)
+        return fs
+
+    def _stage_pairs(self, im_info, im_paths):
+        from .model.faster_rcnn.faster_rcnn_SGG_emb import build_eval_pair_tables
         info = np.asarray(im_info.cpu() if torch.is_tensor(im_info) else im_info, np.float64).reshape(-1, 3)
         annos = [self.net.vrd.target_gt_rels[p] for p in im_paths]
         need = max([len(a["boxes"]) for a in annos] + [1]) + 1
@@ -277,11 +323,8 @@ class RelationStep(_FrameGraphStep):
             ix[f, 0, :len(ixs)], ix[f, 1, :len(ixs)] = ixs, ixo
             conf[f, :nb] = 1                                            # :608 every annotated box enters with confidence 1
             meta.append((np.array(a["boxes"], np.float64).reshape(-1, 4), np.asarray(a["box_classes"]), ixs, ixo))
-        fs = self._shape(H, W)
-        self._place(fs, im_data)
         self.inputs.write_host({"rois": rois, "bounds": bounds, "ix": ix, "conf": conf})
         self._meta = meta
-        return fs
 
     def launch(self):
         self._run_staged()

@@ -14,14 +14,16 @@ from .minibatch import get_minibatch
 
 
 class roibatchLoader(data.Dataset):
-    """``device_prep=True`` (training only; not in the reference): the image work of the item -- BGR swap, flip, mean
+    """``device_prep=True`` (not in the reference): the image work of the item -- BGR swap, flip, mean
     subtraction, the resize to the 600-px scale and the placement into the padded batch canvas -- is left to the GPU
     (``i2v_image_prep``).  An item is then (uint8 HWC frame as decoded, meta = [flipped, canvas_h, canvas_w,
     scale], gt_boxes, num_boxes[, path]) with the SAME gt_boxes / im_info contract as the host form (im_info = canvas size +
     scale); use ``collate_device_prep`` as the DataLoader's collate_fn (frames of one minibatch differ in native size) and
     ``Step.stage_batch_u8``.  A quarter of the float blob's bytes cross PCIe and the host resize (~50 ms per frame and core:
     20+ cores to feed one GPU at 430 frames/s) leaves the loader.  Minibatches whose target ratio is exactly 1 (the
-    reference crops those to a square, :182-190) come back with meta[1] = 0: stage them through the host form."""
+    reference crops those to a square, :182-190) come back with meta[1] = 0: stage them through the host form.  In test mode
+    (``training=False``) an item is the frame alone, (uint8 frame, meta, the [1,1,1,1,1] placeholder, 0, path), its canvas the
+    resized frame: ``eval.DetectStep.stage_u8`` / ``eval.RelationStep.stage_u8``."""
 
     def __init__(self, roidb, ratio_list, ratio_index, batch_size, num_classes, training=True, normalize=None,
                  seg_return=False, path_return=False, device_prep=False):
@@ -31,7 +33,7 @@ class roibatchLoader(data.Dataset):
         self.ratio_list, self.ratio_index, self.batch_size = ratio_list, ratio_index, batch_size
         self.data_size = len(ratio_list)
         self.seg_return, self.path_return = seg_return, path_return
-        self.device_prep = bool(device_prep) and training
+        self.device_prep = bool(device_prep)
         # one target aspect ratio per batch so that its images pad to a common shape (:39-54)
         self.ratio_list_batch = torch.zeros(self.data_size)
         for i in range(int(np.ceil(len(ratio_index) / batch_size))):
@@ -56,6 +58,9 @@ class roibatchLoader(data.Dataset):
         H0, W0 = im.shape[:2]
         f = float(target) / float(min(H0, W0))
         ho, wo = int(np.rint(H0 * f)), int(np.rint(W0 * f))                        # cv2's dsize (i2v_image_prep_size)
+        if not self.training:              # test mode (:70-76 of the host form): the frame alone, unpadded; canvas = the resized frame
+            meta = torch.tensor([0.0, ho, wo, f, target], dtype=torch.float64)
+            return (torch.from_numpy(im.astype(np.uint8, copy=False)), meta, torch.FloatTensor([1, 1, 1, 1, 1]), 0, e["image"])
         gt_np = _gt_blob(e, f)
         np.random.shuffle(gt_np)
         gt = torch.from_numpy(gt_np)

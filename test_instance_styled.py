@@ -38,6 +38,8 @@ def parse_args(argv=None):
     p.add_argument("--output_dir", default="output")
     p.add_argument("--max_per_image", type=int, default=100)
     p.add_argument("--thresh", type=float, default=0.0)
+    p.add_argument("--device_prep", action="store_true", help="the loader hands over uint8 frames as decoded; BGR swap, mean "
+                   "subtraction and resize run on the GPU (roibatchLoader(device_prep=True) + stage_u8); needs --frames >= 2")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--set", dest="set_cfgs", nargs=argparse.REMAINDER, default=None)
     return p.parse_args(argv)
@@ -77,7 +79,8 @@ def main(argv=None):
     num_images = len(roidb)
     all_boxes = [[[] for _ in range(num_images)] for _ in range(imdb.num_classes)]          # :115-116
     empty = np.zeros((0, 5), np.float32)
-    dataset = roibatchLoader(roidb, ratio_list, ratio_index, 1, imdb.num_classes, training=False, normalize=False)
+    u8 = a.device_prep and a.frames > 1
+    dataset = roibatchLoader(roidb, ratio_list, ratio_index, 1, imdb.num_classes, training=False, normalize=False, device_prep=u8)
     loader = torch.utils.data.DataLoader(dataset, batch_size=1, shuffle=False, num_workers=a.num_workers, pin_memory=True)
 
     def keep(i, per_class):
@@ -95,21 +98,26 @@ def main(argv=None):
                              device=dev, use_graph=not a.no_graph)
         groups, order = {}, []
 
+        def pack(g):
+            order.append([t[0] for t in g])
+            if u8:                                       # (frames as decoded, their meta rows)
+                return [t[1] for t in g], torch.cat([t[2] for t in g])
+            return torch.cat([t[1] for t in g]), torch.cat([t[2] for t in g])
+
         def batches():
-            # frames of one size travel together; a group leaves when it is full, the rest at the end
+            # frames of one (resized) size travel together; a group leaves when it is full, the rest at the end
             for i, data in enumerate(loader):
-                g = groups.setdefault(tuple(data[0].shape[2:]), [])
+                size = (int(data[1][0][1]), int(data[1][0][2])) if u8 else tuple(data[0].shape[2:])
+                g = groups.setdefault(size, [])
                 g.append((i, data[0], data[1]))
                 if len(g) == a.frames:
-                    order.append([t[0] for t in g])
-                    yield torch.cat([t[1] for t in g]), torch.cat([t[2] for t in g])
+                    yield pack(g)
                     g.clear()
             for g in groups.values():
                 if g:
-                    order.append([t[0] for t in g])
-                    yield torch.cat([t[1] for t in g]), torch.cat([t[2] for t in g])
+                    yield pack(g)
 
-        for k, res in enumerate(step.run(batches())):
+        for k, res in enumerate(step.run(batches(), u8=u8)):
             for i, per_class in zip(order[k], res):
                 keep(i, per_class)
     dt = time.time() - t0

@@ -343,6 +343,10 @@ def test_test_scripts_equal_their_frame_by_frame_form(small_cfg, tmp_path):
         many = td.main(["--frames", "3", "--load_name", str(ck), "--output_dir", str(tmp_path / "o3")] + common)
         r_one = tr.main(["--frames", "1", "--output_dir", str(tmp_path / "o1"), "--imdbval_name", "synthetic_10_v", "--scale", "192"])
         r_many = tr.main(["--frames", "3", "--output_dir", str(tmp_path / "o3"), "--imdbval_name", "synthetic_10_v", "--scale", "192"])
+        # the device front-end in test mode: uint8 frames from the loader, BGR swap / mean subtraction / resize on the GPU
+        many_u8 = td.main(["--frames", "3", "--device_prep", "--load_name", str(ck), "--output_dir", str(tmp_path / "o8")] + common)
+        r_u8 = tr.main(["--frames", "3", "--device_prep", "--output_dir", str(tmp_path / "o8"), "--imdbval_name", "synthetic_10_v",
+                        "--scale", "192"])
     finally:
         lib.i2v_set_tuning(TUNE["I2V_SPLIT_BELOW"], old)
     with open(tmp_path / "o3" / "res101" / "synthetic" / "detections.pkl", "rb") as f:
@@ -352,11 +356,14 @@ def test_test_scripts_equal_their_frame_by_frame_form(small_cfg, tmp_path):
     for j in range(1, 16):
         for i in range(10):
             assert saved[j][i].shape[1] == 5 and np.array_equal(saved[j][i], one[j][i]) and np.array_equal(many[j][i], one[j][i])
+            assert np.array_equal(many_u8[j][i], one[j][i]), (j, i)
             n_det += len(saved[j][i])
     assert n_det > 0
     assert set(r_one) == set(r_many) and len(r_one) == 10
     for path, want in r_one.items():
         for a, b in zip(r_many[path], want):
+            assert np.array_equal(np.asarray(a), np.asarray(b)), path
+        for a, b in zip(r_u8[path], want):
             assert np.array_equal(np.asarray(a), np.asarray(b)), path
     with open(tmp_path / "o3" / "res101" / "synthetic" / "relations.pkl", "rb") as f:
         assert set(pickle.load(f)) == set(r_one)

@@ -135,6 +135,31 @@ def test_device_prep_loader_items_carry_the_host_items_metadata():
         c.cfg.TRAIN.USE_FLIPPED, c.cfg.TRAIN.SCALES = saved
 
 
+def test_device_prep_loader_items_in_test_mode():
+    """roibatchLoader(training=False, device_prep=True): the frame alone -- uint8 as decoded, meta = [0, resized height,
+    resized width, scale, target], the host form's placeholder box, 0, the path -- with the im_info of the host form's item."""
+    from i2vsgg_amd.model.utils import config as c
+    from i2vsgg_amd.roi_data_layer.roidb import combined_roidb
+    from i2vsgg_amd.roi_data_layer.roibatchLoader import roibatchLoader
+    saved = (c.cfg.TRAIN.USE_FLIPPED, c.cfg.TRAIN.SCALES)
+    c.cfg.TRAIN.USE_FLIPPED, c.cfg.TRAIN.SCALES = False, (96,)
+    try:
+        imdb, roidb, rl, ri = combined_roidb("synthetic_6_v", False)
+        host = roibatchLoader(roidb, rl, ri, 1, imdb.num_classes, training=False, normalize=False)
+        dev = roibatchLoader(roidb, rl, ri, 1, imdb.num_classes, training=False, normalize=False, device_prep=True)
+        sizes = set()
+        for i in range(len(roidb)):
+            x, y = host[i], dev[i]
+            assert y[0].dtype == torch.uint8 and tuple(y[0].shape) == (roidb[i]["height"], roidb[i]["width"], 3)
+            assert tuple(x[0].shape[1:]) == (int(y[1][1]), int(y[1][2])) == (int(x[1][0]), int(x[1][1]))
+            assert float(y[1][0]) == 0 and int(y[1][4]) == 96 and np.float32(float(y[1][3])) == np.float32(float(x[1][2]))
+            assert torch.equal(x[2], y[2]) and x[3] == y[3] == 0 and x[4] == y[4]
+            sizes.add(tuple(x[0].shape[1:]))
+        assert len(sizes) >= 2
+    finally:
+        c.cfg.TRAIN.USE_FLIPPED, c.cfg.TRAIN.SCALES = saved
+
+
 def test_rank_sharded_sampler_partitions_the_block_order():
     """One process per GPU: every rank draws the same block order and keeps every world-th block -- disjoint, equally many
     minibatches per rank, blocks still contiguous (one aspect-ratio group per minibatch), a new order every epoch."""
