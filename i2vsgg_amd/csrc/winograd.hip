@@ -548,8 +548,10 @@ static int winograd4_impl(const float* x, const float* U, const float* scale, co
     const long long T = (long long)B * th * tw;
     float* V = v_keep ? v_keep : (float*)ws;        // v_keep: the transformed input outlives the call (the filter gradient reads it)
     float* Mx = (float*)((char*)ws + i2v_align(36 * (size_t)T * Cin * sizeof(float)));
-    // row-split transforms only where the one-thread-per-(tile, channel) launch cannot fill the chip (layer3: 34 vs
-    // 37 us per layer); on layer1/2 their redundant loads cost more than the parallelism buys (79 vs 57 us)
+    // row-split transforms (I2V_TUNE_WINO_ROWS; -1 = by size) pay where the one-thread-per-(tile, channel) launch cannot fill
+    // the chip and runs ALONE (layer3: 34 vs 37 us per layer); on layer1/2 their redundant loads cost more than the parallelism
+    // buys (79 vs 57 us), and inside the step graphs co-running branches fill the chip anyway (headline step 4.59 vs 4.61 ms
+    // without them): the default is the plain form
     const int rows_env = g_i2v_tuning[I2V_TUNE_WINO_ROWS];   // bit 0: input, bit 1: output; -1: by size
     const int rows = rows_env >= 0 ? rows_env : (T * (Cin > Cout ? Cin : Cout) <= 98304 ? 3 : 0);
     if (rows & 1) wino4_input_rows_kernel<<<dim3((unsigned)i2v_cdiv(T * Cin, 256), 6), 256, 0, st>>>(x, V, B, H, W, Cin, th, tw);

@@ -233,7 +233,7 @@ size_t  i2v_conv_split_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t 
 #define I2V_TUNE_BIG_FC_TILE          5   /* tile index for the long skinny GEMMs (rows <= 256, K >= 16384); -1: cost model */
 #define I2V_TUNE_WGRAD_V2             6   /* 0: first-generation wgrad kernel, 1: default, 2/3: larger tiles */
 #define I2V_TUNE_WGRAD_FUSED_TILE     7   /* 128 (default) or 64: filters per workgroup of the fused wgrad+SGD kernel */
-#define I2V_TUNE_WINO_ROWS            8   /* -1 by size; bit 0 / 1: row-split Winograd input / output transform */
+#define I2V_TUNE_WINO_ROWS            8   /* bit 0 / 1: row-split Winograd input / output transform; -1: by size (small launches split); default 0: never -- the split wins for a layer3 launch alone (34 against 37 us) and loses inside the step graphs, whose branches already fill the chip (4.59 against 4.61 ms) */
 #define I2V_TUNE_ROIPOOL_C128         9   /* 1 (default): 128-channel ROIPool forward kernel for NHWC maps */
 #define I2V_TUNE_CONV_GEMM           10   /* 1 (default): pointwise layers / plain GEMMs on the lean conv_gemm_f32 kernel */
 #define I2V_TUNE_STAGGER             11   /* experiment: co-resident conv_gemm_f32 workgroups start this many kcycles apart (0 = off) */
