@@ -2123,6 +2123,41 @@ __global__ void __launch_bounds__(256) sgd_momentum_multi_kernel(const SgdMulti 
     }
 }
 
+// torch.optim.Adam (amsgrad off) for up to SGD_MULTI_MAX tensors per launch, in torch's operation order:
+//   g' = g + wd p;  m += (1 - b1)(g' - m);  v = b2 v + (1 - b2) g' g';  p -= (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// The step count t lives in DEVICE memory (adam_step_kernel increments it once per optimizer step), so a captured training step
+// replays with the right bias corrections.
+struct AdamMulti {
+    float* p[SGD_MULTI_MAX]; const float* g[SGD_MULTI_MAX]; float* m[SGD_MULTI_MAX]; float* v[SGD_MULTI_MAX];
+    long long n[SGD_MULTI_MAX];
+    float lr[SGD_MULTI_MAX], wd[SGD_MULTI_MAX];
+    int first_block[SGD_MULTI_MAX + 1];
+    int count;
+    float b1, b2, eps;
+    const int* step;
+};
+__global__ void adam_step_kernel(int* step) { *step += 1; }
+__global__ void __launch_bounds__(256) adam_multi_kernel(const AdamMulti t) {
+    int k = 0;
+    while (k + 1 < t.count && (int)blockIdx.x >= t.first_block[k + 1]) ++k;
+    const long long base = (long long)(blockIdx.x - t.first_block[k]) * SGD_MULTI_PER_BLOCK;
+    float* p = t.p[k]; const float* g = t.g[k]; float* m = t.m[k]; float* v = t.v[k];
+    const float wd = t.wd[k], b1 = t.b1, b2 = t.b2, eps = t.eps;
+    const float st = (float)*t.step;
+    const float bc1 = 1.0f - powf(b1, st), bc2_sqrt = sqrtf(1.0f - powf(b2, st));
+    const float step_size = t.lr[k] / bc1;
+    for (int j = threadIdx.x; j < SGD_MULTI_PER_BLOCK; j += 256) {
+        const long long i = base + j;
+        if (i >= t.n[k]) break;
+        const float gp = g[i] + wd * p[i];
+        const float mv = m[i] + (1.0f - b1) * (gp - m[i]);
+        const float vv = b2 * v[i] + (1.0f - b2) * gp * gp;
+        m[i] = mv;
+        v[i] = vv;
+        p[i] -= step_size * (mv / (sqrtf(vv) / bc2_sqrt + eps));
+    }
+}
+
 // g_pre = gy * (y > 0); g = g_pre * scale[n]; gbias[n] += sum_m g_pre.  One streaming pass: thread = 4 columns
 // (float4), a workgroup covers rows_per_blk rows x 1024 columns; either output may be NULL.
 __global__ void __launch_bounds__(256)
@@ -2654,6 +2689,42 @@ extern "C" int32_t i2v_sgd_momentum_multi(float* const* p, const float* const* g
         if (blocks == 0) continue;
         sgd_momentum_multi_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(t);
         I2V_CHECK_LAUNCH("sgd_momentum_multi");
+    }
+    return I2V_OK;
+}
+
+extern "C" int32_t i2v_adam_step(int32_t* step_counter, void* stream) {
+    I2V_CHECK_ARG(step_counter, "adam_step: null counter");
+    adam_step_kernel<<<1, 1, 0, (hipStream_t)stream>>>(step_counter);
+    I2V_CHECK_LAUNCH("adam_step");
+    return I2V_OK;
+}
+
+extern "C" int32_t i2v_adam_multi(float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n,
+                                  const float* lr, const float* weight_decay, int32_t count, float beta1, float beta2,
+                                  float eps, const int32_t* step_counter, void* stream) {
+    I2V_CHECK_ARG(count >= 0 && step_counter && (count == 0 || (p && g && m && v && n && lr && weight_decay)), "adam_multi: bad argument");
+    for (int32_t c0 = 0; c0 < count;) {
+        AdamMulti t;
+        t.count = 0;
+        t.b1 = beta1; t.b2 = beta2; t.eps = eps; t.step = step_counter;
+        int blocks = 0;
+        int32_t c = c0;
+        for (; c < count && t.count < SGD_MULTI_MAX; ++c) {
+            I2V_CHECK_ARG(p[c] && g[c] && m[c] && v[c] && n[c] >= 0, "adam_multi: bad tensor");
+            if (n[c] == 0) continue;
+            const long long nb = i2v_cdiv(n[c], (long long)SGD_MULTI_PER_BLOCK);
+            if (t.count && blocks + nb > (1 << 20)) break;        // a very large tensor starts its own launch
+            const int k = t.count++;
+            t.p[k] = p[c]; t.g[k] = g[c]; t.m[k] = m[c]; t.v[k] = v[c]; t.n[k] = n[c]; t.lr[k] = lr[c]; t.wd[k] = weight_decay[c];
+            t.first_block[k] = blocks;
+            blocks += (int)nb;
+        }
+        c0 = c;
+        t.first_block[t.count] = blocks;
+        if (blocks == 0) continue;
+        adam_multi_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(t);
+        I2V_CHECK_LAUNCH("adam_multi");
     }
     return I2V_OK;
 }

@@ -1080,6 +1080,26 @@ def sgd_momentum_multi_(ps, gs, ms, lrs, wds, momentum):
           "sgd_momentum_multi")
 
 
+def adam_multi_(ps, gs, ms, vs, lrs, wds, betas, eps, step_counter):
+    """torch.optim.Adam's update for many tensors (flat, contiguous fp32) in as few launches as the table holds;
+    ``step_counter``: the int32 device scalar ``adam_step_`` increments once per optimizer step."""
+    import ctypes
+    n = len(ps)
+    if n == 0:
+        return
+    _need_cuda(*ps, *gs, *ms, *vs, step_counter)
+    arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
+    arr_n = (ctypes.c_int64 * n)(*[t.numel() for t in ps])
+    arr_lr = (ctypes.c_float * n)(*[float(v) for v in lrs])
+    arr_wd = (ctypes.c_float * n)(*[float(v) for v in wds])
+    check(lib.i2v_adam_multi(arr(ps), arr(gs), arr(ms), arr(vs), arr_n, arr_lr, arr_wd, n, float(betas[0]), float(betas[1]),
+                             float(eps), ptr(step_counter), stream()), "adam_multi")
+
+
+def adam_step_(step_counter):
+    check(lib.i2v_adam_step(ptr(step_counter), stream()), "adam_step")
+
+
 class _DStylePoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x1, x2, dim, rank):

@@ -93,6 +93,10 @@ class FusedSGD:
     def params(self):
         return [it["p"] for it in self.items]
 
+    def state_tensors(self):
+        """Every tensor of the optimizer's own state (a step object snapshots / restores them around warm-up steps)."""
+        return [it["m"] for it in self.items]
+
     @staticmethod
     def bump():
         """The parameters changed (an eager ``step()``, a fused wgrad+SGD epilogue or a graph replay that contains
@@ -166,6 +170,87 @@ class FusedSGD:
             ops.sgd_momentum_multi_([p for p, _, _ in small], [g for _, g, _ in small], [it["m"] for _, _, it in small],
                                     [it["lr"] for _, _, it in small], [it["wd"] for _, _, it in small], self.momentum)
         self.bump()
+
+
+class FusedAdam(FusedSGD):
+    """torch.optim.Adam with the reference's param groups (``--o adam``: trainval_net_instance_styleD_bilinear.py:143-145,
+    trainval_net_SGG_emb.py:146-147) on ``i2v_adam_multi``: same interface as ``FusedSGD`` towards the step objects, no fusion
+    into the filter-gradient kernels (the second-moment update needs the finished gradient).  The step count sits in device
+    memory, so a captured step replays with the right bias corrections; ``state_dict`` is torch.optim.Adam's layout."""
+
+    def __init__(self, named_params, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=None):
+        super().__init__(named_params, lr, momentum=0.0, weight_decay=weight_decay)
+        self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
+        for it in self.items:
+            it["v"] = torch.zeros_like(it["p"])
+        dev = self.items[0]["p"].device if self.items else "cpu"
+        self.t = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def fuse_wgrad(self, min_numel=1 << 24, defer=None):
+        return []
+
+    def state_tensors(self):
+        return [it["m"] for it in self.items] + [it["v"] for it in self.items] + [self.t]
+
+    def state_dict(self):
+        step = float(self.t.item())
+        return {"state": {i: {"step": torch.tensor(step), "exp_avg": it["m"].detach().clone(), "exp_avg_sq": it["v"].detach().clone()}
+                          for i, it in enumerate(self.items)},
+                "param_groups": [{"lr": it["lr"], "betas": self.betas, "eps": self.eps, "weight_decay": it["wd"], "amsgrad": False,
+                                  "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                                  "params": [i], "name": it["name"]} for i, it in enumerate(self.items)]}
+
+    def load_state_dict(self, sd):
+        groups = sd["param_groups"]
+        flat = [pi for g in groups for pi in g["params"]]
+        if len(flat) != len(self.items):
+            raise ValueError("optimizer state holds %d parameters, this optimizer %d" % (len(flat), len(self.items)))
+        by_param = {pi: g for g in groups for pi in g["params"]}
+        step = 0.0
+        for i, it in enumerate(self.items):
+            g = by_param[flat[i]]
+            it["lr"], it["wd"] = float(g["lr"]), float(g.get("weight_decay", it["wd"]))
+            self.betas, self.eps = tuple(float(b) for b in g.get("betas", self.betas)), float(g.get("eps", self.eps))
+            st = sd["state"].get(flat[i], sd["state"].get(str(flat[i])))
+            if st is not None and st.get("exp_avg") is not None:
+                it["m"].copy_(st["exp_avg"].reshape(it["m"].shape))
+                it["v"].copy_(st["exp_avg_sq"].reshape(it["v"].shape))
+                step = max(step, float(st.get("step", 0.0)))
+            else:
+                it["m"].zero_()
+                it["v"].zero_()
+        self.t.fill_(int(step))
+
+    def scale_lr(self, k):
+        for it in self.items:
+            it["lr"] *= k
+
+    @torch.no_grad()
+    def step(self):
+        live = []
+        for it in self.items:
+            p, g = it["p"], it["p"].grad
+            if g is None:                        # torch.optim.Adam skips parameters without a gradient
+                continue
+            if g.stride() != p.stride() and not _same_memory_order(p, g):
+                g = torch.empty_like(p).copy_(g)
+            live.append((p, g, it))
+        if not live:
+            return
+        ops.adam_step_(self.t)
+        ops.adam_multi_([p for p, _, _ in live], [g for _, g, _ in live], [it["m"] for _, _, it in live],
+                        [it["v"] for _, _, it in live], [it["lr"] for _, _, it in live], [it["wd"] for _, _, it in live],
+                        self.betas, self.eps, self.t)
+        self.bump()
+
+
+def make_optimizer(kind, named_params, lr):
+    """``--o sgd | adam`` of the reference loops."""
+    if kind == "sgd":
+        return FusedSGD(named_params, lr)
+    if kind == "adam":
+        return FusedAdam(named_params, lr)
+    raise ValueError("optimizer %r: the reference loops know 'sgd' and 'adam'" % (kind,))
 
 
 def _same_memory_order(p, g):
@@ -401,7 +486,8 @@ class SGGEmbStep:
     """
 
     def __init__(self, net, n_frames, vrd_lr=1e-4, seed=1, device="cuda:0", h=600, w=1000, n_boxes=32, n_pairs=32,
-                 use_graph=True, fuse_sgd=True, zero_arena=True, overlap=None, max_graphs=16, trace_rows=0, stage_synthetic=True):
+                 use_graph=True, fuse_sgd=True, zero_arena=True, overlap=None, max_graphs=16, trace_rows=0, stage_synthetic=True,
+                 optimizer="sgd"):
         import os
         self.net, self.dev, self.n_frames = net, torch.device(device), n_frames
         self.world = parallel.world_size()
@@ -412,7 +498,7 @@ class SGGEmbStep:
             net.vrd.fc6.fc.weight.shape[0] % max(self.world, 1) == 0
         if self.tp and net.vrd.tp is None:
             net.vrd.enable_fc6_tp(parallel.rank(), self.world)
-        self.opt = FusedSGD([(n, p) for n, p in net.named_parameters() if n.startswith("vrd.")], vrd_lr)
+        self.opt = make_optimizer(optimizer, [(n, p) for n, p in net.named_parameters() if n.startswith("vrd.")], vrd_lr)
         self.fused = self.opt.fuse_wgrad() if fuse_sgd else []
         self.loss = torch.zeros((), device=self.dev)
         self._seed = torch.full((), 1.0 / max(self.world, 1), device=self.dev)
@@ -819,7 +905,7 @@ class SGGEmbStep:
 
     def _snapshot(self):
         pend, host = self.opt.pending_state()
-        state = [it["p"].data for it in self.opt.items] + [it["m"] for it in self.opt.items] + pend
+        state = [it["p"].data for it in self.opt.items] + self.opt.state_tensors() + pend
         return (state, [t.clone() for t in state], torch.cuda.get_rng_state(self.dev), host)
 
     def _restore(self, saved):
@@ -1012,7 +1098,7 @@ class InstanceStyleDStep:
     ``max_graphs`` are kept, in one shared memory pool (no two of them ever run at the same time)."""
 
     def __init__(self, net, n_frames, lr=5e-4, eta=0.1, eta_style=0.001, style_lambda=1.0, seed=3, device="cuda:0",
-                 h=600, w=1000, n_gt=8, cr=False, max_graphs=32, stage_synthetic=True):
+                 h=600, w=1000, n_gt=8, cr=False, max_graphs=32, stage_synthetic=True, optimizer="sgd"):
         self.net, self.dev = net, torch.device(device)
         self.cr = cr                  # --cr: consistency regularisation between instance- and image-level D (:299-312)
         self.world = parallel.world_size()
@@ -1042,7 +1128,7 @@ class InstanceStyleDStep:
         self.nb_t = torch.zeros((n_frames,), device=self.dev)
         if stage_synthetic:           # a loop fed by data loaders stages its own first minibatch (``stage_batch``)
             self.reseed(seed)
-        self.opt = FusedSGD(list(net.named_parameters()), lr)
+        self.opt = make_optimizer(optimizer, list(net.named_parameters()), lr)
         self.names = ["total", "det", "dloss_s", "dloss_t", "dloss_s_style", "dloss_t_style"] + \
             (["source_adv_cst", "target_adv_cst"] if cr else [])
         self._loss_buf = torch.zeros((len(self.names),), device=self.dev)           # static addresses: a captured step writes here
@@ -1253,7 +1339,7 @@ class InstanceStyleDStep:
 
     def _snapshot(self):
         pend, host = self.opt.pending_state()
-        state = [it["p"].data for it in self.opt.items] + [it["m"] for it in self.opt.items] + pend
+        state = [it["p"].data for it in self.opt.items] + self.opt.state_tensors() + pend
         return (state, [t.clone() for t in state], torch.cuda.get_rng_state(self.dev), host)
 
     def _restore(self, saved):

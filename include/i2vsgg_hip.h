@@ -469,6 +469,16 @@ int32_t i2v_sgd_momentum_multi(float* const* p, const float* const* g, float* co
                                const float* lr, const float* weight_decay, int32_t count, float momentum,
                                void* stream);
 
+/* torch.optim.Adam (amsgrad off; trainval_net_*.py `--o adam`, :143-145 / :146-147) for `count` tensors, same calling form as
+ * i2v_sgd_momentum_multi: g' = g + wd p; m += (1 - b1)(g' - m); v = b2 v + (1 - b2) g'^2;
+ * p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).  The step count t is an int32 in DEVICE memory that
+ * i2v_adam_step increments (once per optimizer step, before the i2v_adam_multi launches of that step): a captured
+ * training step then replays with the right bias corrections. */
+int32_t i2v_adam_step(int32_t* step_counter, void* stream);
+int32_t i2v_adam_multi(float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n,
+                       const float* lr, const float* weight_decay, int32_t count, float beta1, float beta2, float eps,
+                       const int32_t* step_counter, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

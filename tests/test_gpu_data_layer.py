@@ -314,6 +314,15 @@ def test_training_scripts_run_through_the_data_layer(small_cfg, tmp_path):
     lrs = {round(g["lr"], 10) for g in ck3["optimizer"]["param_groups"]}
     assert lrs == {round(5e-4 * 0.01, 10), round(2 * 5e-4 * 0.01, 10)}        # the decay of the resumed epoch is applied
     assert not torch.equal(ck3["model"]["RCNN_base.6.22.conv3.weight"], ck["model"]["RCNN_base.6.22.conv3.weight"])
+    # ---- --o adam (trainval_net_*.py:143-147): torch.optim.Adam's state layout in the checkpoint, resume from it
+    tv.main(["--epochs", "1", "--o", "adam", "--s", "2"] + common)
+    ck_a = torch.load(str(name).replace("session_1", "session_2").replace("epoch_2", "epoch_1"), map_location="cpu")
+    st = ck_a["optimizer"]["state"][0]
+    assert set(st) == {"step", "exp_avg", "exp_avg_sq"} and float(st["step"]) == 3.0 and ck_a["optimizer"]["param_groups"][0]["betas"] == (0.9, 0.999)
+    assert all(torch.isfinite(v).all() for v in ck_a["model"].values() if v.is_floating_point())
+    tv.main(["--epochs", "2", "--o", "adam", "--s", "2", "--r", "--checksession", "2", "--checkepoch", "1"] + common)
+    ts.main(["--epochs", "1", "--o", "adam", "--bs", "2", "--imdb_name", "synthetic_12_v", "--scale", "192", "--disp_interval", "3",
+             "--save_dir", str(tmp_path / "adam"), "--vrd_lr", "1e-4"])
     # ---- both loops once more with the device front-end (uint8 frames, image work on the GPU)
     ts.main(["--epochs", "1", "--bs", "2", "--imdb_name", "synthetic_12_v", "--scale", "192", "--disp_interval", "3", "--save_dir",
              str(tmp_path / "u8"), "--device_prep", "--no-save"])

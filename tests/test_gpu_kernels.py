@@ -1266,3 +1266,57 @@ def test_every_tuning_knob_keeps_the_results(ops):
     again = run()
     for k in ("pointwise", "strided", "winograd", "roi_pool", "roi_align"):      # the launches without split-K atomics
         assert torch.equal(again[k], base[k]), k          # the knobs are back at their defaults
+
+
+def test_fused_adam_equals_torch_adam():
+    """train.FusedAdam (i2v_adam_multi, step count in device memory) follows torch.optim.Adam on the same param groups for five
+    steps -- tensors below and above a launch table's worth, with and without weight decay, a parameter that never gets a
+    gradient -- and its state_dict loads into torch.optim.Adam (and back) with the trajectories still together."""
+    from i2vsgg_amd import train
+    torch.manual_seed(0)
+    shapes = [(7,), (300, 40), (64, 3, 3, 3), (1100, 1000), (5,)] + [(33,)] * 50
+    ps = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in shapes]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    named = [("w%d.bias" % i if len(s) == 1 else "w%d.weight" % i, p) for i, (s, p) in enumerate(zip(shapes, ps))]
+    opt = train.FusedAdam(named, 3e-3, weight_decay=5e-3)
+    ref = torch.optim.Adam([{"params": [q], "lr": it["lr"], "weight_decay": it["wd"]} for q, it in zip(qs, opt.items)])
+    assert {it["lr"] for it in opt.items} == {3e-3, 6e-3} or not cfg_double_bias()          # biases at twice the rate (DOUBLE_BIAS)
+
+    def one(k):
+        for i, (p, q) in enumerate(zip(ps, qs)):
+            if i == 4:                       # never gets a gradient: both optimizers leave it alone
+                p.grad = q.grad = None
+                continue
+            g = torch.randn(p.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(100 * k + i))
+            p.grad, q.grad = g.clone(), g.clone()
+        opt.step()
+        ref.step()
+
+    for k in range(5):
+        one(k)
+    assert int(opt.t.item()) == 5 and torch.equal(ps[4], qs[4])
+    for p, q in zip(ps, qs):
+        assert _rel_err(p.detach().cpu().numpy(), q.detach().cpu().numpy()) < 2e-6
+    # state_dict: torch.optim.Adam's layout, both ways
+    sd = opt.state_dict()
+    ref2 = torch.optim.Adam([{"params": [q]} for q in qs])
+    ref2.load_state_dict({"state": {i: st for i, st in sd["state"].items() if i != 4},
+                          "param_groups": [{k: v for k, v in g.items() if k != "name"} for g in sd["param_groups"]]})
+    opt2 = train.FusedAdam(named, 1.0)
+    opt2.load_state_dict(ref.state_dict())
+    assert int(opt2.t.item()) == 5 and opt2.items[1]["lr"] == opt.items[1]["lr"]
+    for k in range(5, 8):
+        for i, (p, q) in enumerate(zip(ps, qs)):
+            if i == 4:
+                continue
+            g = torch.randn(p.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(100 * k + i))
+            p.grad, q.grad = g.clone(), g.clone()
+        opt2.step()
+        ref2.step()
+    for p, q in zip(ps, qs):
+        assert _rel_err(p.detach().cpu().numpy(), q.detach().cpu().numpy()) < 3e-6
+
+
+def cfg_double_bias():
+    from i2vsgg_amd.model.utils.config import cfg
+    return bool(cfg.TRAIN.DOUBLE_BIAS)

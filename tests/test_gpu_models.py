@@ -872,3 +872,28 @@ def test_fork_inside_a_graph_branch_is_an_error_not_a_crash():
     main.wait_stream(s1)
     torch.cuda.synchronize()
     assert float(w[0]) == 6.0
+
+
+def test_sgg_step_with_adam_captured_equals_eager(cfg):
+    """``--o adam`` (trainval_net_SGG_emb.py:146-147): the relation step with train.FusedAdam, captured (overlapped graph) against
+    eager launches -- the step count sits in device memory, so every replay applies its own bias corrections."""
+    from i2vsgg_amd import train
+    res = {}
+    for mode in ("eager", "overlap"):
+        net = train.build_sgg_net(layers=50, seed=5, device=DEV)
+        net.vrd.dropout = False
+        step = train.SGGEmbStep(net, 2, seed=3, device=DEV, h=200, w=320, n_boxes=6, n_pairs=5, use_graph=mode != "eager",
+                                overlap=mode == "overlap", optimizer="adam")
+        assert isinstance(step.opt, train.FusedAdam) and step.fused == []
+        assert step.capture(warmup=1, restore=True) == (mode != "eager"), step.graph_error
+        assert int(step.opt.t.item()) == 0                          # the warm-up step was undone, its step count included
+        losses = [float(step().item()) for _ in range(4)]
+        torch.cuda.synchronize()
+        assert int(step.opt.t.item()) == 4                          # one optimizer step per call, in both schedules
+        res[mode] = (losses, net.vrd.fc7.fc.weight.detach().cpu().numpy().copy())
+    l0, w0 = res["eager"]
+    l1, w1 = res["overlap"]
+    assert l0[0] != l0[3]
+    for a, b in zip(l0, l1):
+        assert abs(a - b) <= 1e-5 * abs(a), (l0, l1)
+    assert np.isfinite(w1).all()

@@ -47,7 +47,9 @@ def parse_args(argv=None):
     p.add_argument("--gc", action="store_true", help="image-level (style) context vector")
     p.add_argument("--cr", action="store_true", help="consistency regularisation between the two discriminators")
     p.add_argument("--cag", dest="class_agnostic", action="store_true")
-    p.add_argument("--o", dest="optimizer", default="sgd", choices=["sgd"])
+    p.add_argument("--o", dest="optimizer", default="sgd", choices=["sgd", "adam"],
+                   help="adam: torch.optim.Adam's update on the same param groups (train.FusedAdam); no fusion into the "
+                        "filter-gradient kernels")
     p.add_argument("--cuda", action="store_true", default=True)
     p.add_argument("--disp_interval", type=int, default=5)
     p.add_argument("--scale", type=int, default=0, help="shorter image side (cfg.TRAIN.SCALES; 0: the yml's 600)")
@@ -133,7 +135,7 @@ def main(argv=None):
     net = train.build_instance_styled_net(101 if a.net == "res101" else 50, n_cls=imdb.num_classes, device=dev, ic=a.ic, gc=a.gc,
                                           class_agnostic=a.class_agnostic)
     step = train.InstanceStyleDStep(net, a.batch_size, lr=a.lr, eta=a.eta, eta_style=a.eta_style, style_lambda=a.style_lambda,
-                                    device=dev, cr=a.cr, stage_synthetic=False)
+                                    device=dev, cr=a.cr, stage_synthetic=False, optimizer=a.optimizer)
     start_epoch = a.start_epoch
     if a.resume:
         path = a.load_name or checkpoint_name(a, a.checksession, a.checkepoch)

@@ -38,7 +38,9 @@ def parse_args(argv=None):
     p.add_argument("--vrd_lr", type=float, default=1e-4)
     p.add_argument("--lr_decay_step", type=int, default=1)
     p.add_argument("--lr_decay_gamma", type=float, default=0.9)
-    p.add_argument("--o", dest="optimizer", default="sgd", choices=["sgd"])
+    p.add_argument("--o", dest="optimizer", default="sgd", choices=["sgd", "adam"],
+                   help="adam: torch.optim.Adam's update on the same param groups (train.FusedAdam); no fusion into the "
+                        "filter-gradient kernels")
     p.add_argument("--num_classes", type=int, default=16)
     p.add_argument("--num_relations", type=int, default=62)
     p.add_argument("--vrd_task", default="pre_det")
@@ -104,9 +106,11 @@ def load_checkpoint(path, net, opt):
         rk, world = net.vrd.tp
         for i, g in enumerate(sd["param_groups"]):
             if g.get("name") in ("vrd.fc6.fc.weight", "vrd.fc6.fc.bias"):
-                m = sd["state"][g["params"][0]]["momentum_buffer"]
-                n = m.shape[0] // world
-                sd["state"][g["params"][0]]["momentum_buffer"] = m[rk * n:(rk + 1) * n]
+                st = sd["state"][g["params"][0]]
+                for key in ("momentum_buffer", "exp_avg", "exp_avg_sq"):       # SGD / Adam state of the rows this rank keeps
+                    if st.get(key) is not None:
+                        n = st[key].shape[0] // world
+                        st[key] = st[key][rk * n:(rk + 1) * n]
     opt.load_state_dict(sd)
     opt.bump()
     return int(ck["epoch"])
@@ -153,7 +157,7 @@ def main(argv=None):
     else:
         raise SystemExit("no relation annotations: pass --source_gt_rels_path")
     step = train.SGGEmbStep(net, a.batch_size, vrd_lr=a.vrd_lr, device=dev, use_graph=not a.no_graph and dev.type == "cuda",
-                            stage_synthetic=False)
+                            stage_synthetic=False, optimizer=a.optimizer)
     start_epoch = a.start_epoch
     if a.resume:
         path = a.load_name or checkpoint_name(a, a.checksession, a.checkepoch, iters_per_epoch - 1)
