@@ -5,7 +5,7 @@ Import side effect (before the HIP runtime initialises, which happens at the fir
 legacy default stream that path loses the order between a graph's nodes and the stream's other work while a second
 stream is busy (DESIGN.md section 5 has the bisect and the A/B runs; measured cost of the generic path on the 330-node
 step graph: none).  A value the user has set is left alone, and so is a process whose HIP runtime is already up --
-there ``train._graph_launch_guard`` refuses graph replays on the default stream instead."""
+there ``train.replay_graph`` moves graph replays off the default stream (onto a private stream between event edges) instead."""
 import os
 import sys
 

@@ -128,7 +128,8 @@ class _FrameGraphStep:
         self._tick += 1
         fs.tick = self._tick
         if fs.graph:
-            fs.graph.replay()
+            from .train import replay_graph
+            replay_graph(fs.graph, self.dev)
         else:
             self._body(fs)
 

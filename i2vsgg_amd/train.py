@@ -996,7 +996,7 @@ class SGGEmbStep:
 
     def __call__(self):
         """One step on the caller's current stream (any stream, the legacy default stream included: see
-        ``_graph_launch_guard``).  Returns the device scalar holding the loss of the batch the head just processed.
+        ``replay_graph``).  Returns the device scalar holding the loss of the batch the head just processed.
         Before a successful ``capture()`` a call is the sequential eager step."""
         fs = self.shapes[self._staged]
         if self._graphs_on:
@@ -1005,8 +1005,7 @@ class SGGEmbStep:
             self._tick += 1
             fs.tick = self._tick
             if fs.graph:
-                _graph_launch_guard()
-                fs.graph.replay()
+                replay_graph(fs.graph, self.dev)
                 self._fmap_key = fs.key
             elif self._pipelined:
                 self._body_overlapped(fs)        # this size could not be captured: the same schedule on eager launches
@@ -1022,19 +1021,33 @@ class SGGEmbStep:
         return self()
 
 
-def _graph_launch_guard():
-    """ROCm 7.2's HIP runtime replays a graph through pre-built AQL packet batches (``DEBUG_CLR_GRAPH_PACKET_CAPTURE``,
-    on by default).  On the LEGACY DEFAULT stream that path loses the order between a graph's nodes and the stream's
-    other work while a second stream is busy (losses off by 2e-2 from the second step on, NaN
-    weights; same graphs correct on any created stream, and correct on the default stream with the packet path off).
-    i2vsgg_amd/__init__.py switches the path off before the runtime initialises; if the process had already initialised
-    HIP with it on, replaying on the default stream is refused rather than risked."""
+_REPLAY_STREAMS = {}
+REDIRECT_DEFAULT_STREAM = True      # tools/graph_order_probe.py studies the runtime's default path and switches this off
+
+
+def replay_graph(graph, device=None):
+    """``graph.replay()`` on the caller's current stream -- except in the one case that is not safe.  ROCm 7.2's HIP runtime
+    replays a graph through pre-built AQL packet batches (``DEBUG_CLR_GRAPH_PACKET_CAPTURE``, on by default); on the LEGACY
+    DEFAULT stream that path loses the order between a graph's nodes and the stream's other work while a second stream is busy
+    (losses off by 2e-2 from the second step on, NaN weights; the same graphs are correct on any created
+    stream, and on the default stream with the packet path off).  i2vsgg_amd/__init__.py switches the path off before the runtime
+    initialises.  A process that had already initialised HIP with it on (a script that touched torch.cuda before importing the
+    package) and calls a step on the default stream gets its graph replayed on a private created stream between two event
+    edges instead: the caller's stream order is kept, the replay never runs on the default stream (round 2 refused the call)."""
     import os
-    if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1") != "0" and \
-            torch.cuda.current_stream() == torch.cuda.default_stream():
-        raise RuntimeError("HIP graph replay on the legacy default stream with DEBUG_CLR_GRAPH_PACKET_CAPTURE on: set "
-                           "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before the first HIP call (importing i2vsgg_amd before "
-                           "torch.cuda is initialised does it) or run the step on a stream made with torch.cuda.Stream()")
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    cur = torch.cuda.current_stream(dev)
+    if not REDIRECT_DEFAULT_STREAM or os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1") == "0" or \
+            cur != torch.cuda.default_stream(dev):
+        graph.replay()
+        return
+    s = _REPLAY_STREAMS.get(dev.index)
+    if s is None:
+        s = _REPLAY_STREAMS[dev.index] = torch.cuda.Stream(dev)
+    s.wait_stream(cur)
+    with torch.cuda.stream(s):
+        graph.replay()
+    cur.wait_stream(s)
 
 
 class _SplitBatch(torch.autograd.Function):
@@ -1426,8 +1439,7 @@ class InstanceStyleDStep:
                 # the host-built caches, its effect on the training state is undone, then the step is recorded
                 self._capture_set(ds, 0 if ds.fitted else 1, True)
             if ds.graph:
-                _graph_launch_guard()
-                ds.graph.replay()
+                replay_graph(ds.graph, self.dev)
             else:
                 self._device_sampling(True)
                 (self._body_branches if self.branches else self._body)()

@@ -897,3 +897,17 @@ def test_sgg_step_with_adam_captured_equals_eager(cfg):
     for a, b in zip(l0, l1):
         assert abs(a - b) <= 1e-5 * abs(a), (l0, l1)
     assert np.isfinite(w1).all()
+
+
+def test_steps_work_when_hip_was_up_before_the_package():
+    """Round-2 review: a script that had touched torch.cuda before importing the package (so the runtime's graph packet path
+    stays on) got a RuntimeError from the step on the default stream.  The step now replays its graph on a private stream
+    between event edges there (train.replay_graph): tools/default_stream_probe.py, in a process of its own with the variable
+    unset and HIP initialised first, follows the synchronised trajectory over 20 back-to-back steps at full size."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k != "DEBUG_CLR_GRAPH_PACKET_CAPTURE"}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "default_stream_probe.py")], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "OK:" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

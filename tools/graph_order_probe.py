@@ -21,7 +21,7 @@ import torch  # noqa: E402
 from i2vsgg_amd import train  # noqa: E402
 from i2vsgg_amd.model.utils import config as c  # noqa: E402
 
-train._graph_launch_guard = lambda: None
+train.REDIRECT_DEFAULT_STREAM = False      # replay where the caller stands, the default stream included
 DEV = torch.device("cuda:0")
 N = 23
 
