@@ -4,8 +4,10 @@ Import side effect (before the HIP runtime initialises, which happens at the fir
 ``DEBUG_CLR_GRAPH_PACKET_CAPTURE=0``.  ROCm 7.2's runtime replays HIP graphs through pre-built AQL packet batches; on the
 legacy default stream that path loses the order between a graph's nodes and the stream's other work while a second
 stream is busy (DESIGN.md section 5 has the bisect and the A/B runs; measured cost of the generic path on the 330-node
-step graph: none).  A value the user has set is left alone, and so is a process whose HIP runtime is already up --
-there ``train.replay_graph`` moves graph replays off the default stream (onto a private stream between event edges) instead."""
+step graph: none).  A value the user has set is left alone, and so is a process whose HIP runtime is already up.
+Whether the runtime READ the value cannot be known from here (``torch.cuda.is_available()`` initialises it without torch
+saying so), so ``train.replay_graph`` does not rely on it: a replay asked for on the default stream always runs on a private
+stream between two event edges."""
 import os
 import sys
 

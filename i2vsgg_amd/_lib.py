@@ -22,6 +22,8 @@ _p, _i, _f, _z, _l = C.c_void_p, C.c_int32, C.c_float, C.c_size_t, C.c_int64
 SIGNATURES = {
     "i2v_version": (_i, []),
     "i2v_last_error": (C.c_char_p, []),
+    "i2v_stream_create": (_i, [_i, _i, C.POINTER(C.c_void_p)]),
+    "i2v_stream_destroy": (_i, [_p]),
     "i2v_roi_align_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _p, _i, _p]),
     "i2v_roi_align_bwd": (_i, [_p, _i, _p, _i, _i, _i, _f, _i, _p, _i, _i, _i, _i, _i, _p]),
     "i2v_roi_align_sampled_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _p, _i, _p]),

@@ -1,4 +1,5 @@
 // Error reporting and version of libi2vsgg_hip.so (host-only translation unit).
+#include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include "../../include/i2vsgg_hip.h"
@@ -35,4 +36,47 @@ extern "C" int32_t i2v_set_tuning(int32_t key, int32_t value) {
 
 extern "C" int32_t i2v_get_tuning(int32_t key) {
     return (key < 0 || key >= I2V_TUNE_COUNT) ? I2V_ERR_ARG : g_i2v_tuning[key];
+}
+
+// Streams of the host's own (i2v_stream_create): a step object forks its graph branches onto streams that must not alias
+// each other, the capturing stream or a stream some other component drew from a framework's pool (torch deals 32 pooled
+// streams per device round robin).  A stream created here belongs to the caller alone.
+extern "C" int32_t i2v_stream_create(int32_t device, int32_t priority, void** stream) {
+    if (!stream) {
+        i2v_set_error("stream_create: null output");
+        return I2V_ERR_ARG;
+    }
+    int prev = -1, n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) {
+        i2v_set_error("stream_create: no device %d (%d visible)", device, n);
+        return I2V_ERR_ARG;
+    }
+    hipStream_t s = nullptr;
+    hipError_t e = hipGetDevice(&prev);
+    if (e == hipSuccess && prev != device) e = hipSetDevice(device);
+    if (e == hipSuccess) {
+        int lo = 0, hi = 0;                                   // numerically: hi <= lo, a lower value is a higher priority
+        e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (e == hipSuccess) {
+            int pr = priority < hi ? hi : (priority > lo ? lo : priority);
+            e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, pr);
+        }
+    }
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    if (e != hipSuccess) {
+        i2v_set_error("stream_create: %s", hipGetErrorString(e));
+        return I2V_ERR_LAUNCH;
+    }
+    *stream = (void*)s;
+    return I2V_OK;
+}
+
+extern "C" int32_t i2v_stream_destroy(void* stream) {
+    if (!stream) return I2V_OK;
+    hipError_t e = hipStreamDestroy((hipStream_t)stream);
+    if (e != hipSuccess) {
+        i2v_set_error("stream_destroy: %s", hipGetErrorString(e));
+        return I2V_ERR_LAUNCH;
+    }
+    return I2V_OK;
 }

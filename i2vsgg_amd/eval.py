@@ -39,7 +39,7 @@ class _FrameGraphStep:
             raise RuntimeError("%s: the network must be in eval mode (test_net_...:131 fasterRCNN.eval())" % type(self).__name__)
         self.net, self.dev, self.frames = net, torch.device(device), int(frames)
         self.use_graph, self.max_graphs = bool(use_graph), max(int(max_graphs), 1)
-        self._streams = [torch.cuda.Stream(self.dev) for _ in range(self.frames)]
+        self._streams = [ops.role_stream(self.dev, ("frame", f)) for f in range(self.frames)]
         self.shapes, self._pool, self._tick, self._staged = {}, None, 0, None
         self.graph_error = None
         self._slot = 0
@@ -50,8 +50,7 @@ class _FrameGraphStep:
         for f, st in enumerate(self._streams):     # fork from the launching stream itself (a fork inside a fork breaks capture)
             with ops.branch(st, main):
                 self._frame(fs, f)
-        for st in self._streams:
-            main.wait_stream(st)
+        ops.join(main, *self._streams)
 
     def _shape(self, H, W):
         key = (self.frames, int(H), int(W))
@@ -119,6 +118,7 @@ class _FrameGraphStep:
             fs.graph = g
         except Exception as e:                     # report, keep the eager form for this size
             fs.graph, self.graph_error = False, repr(e)
+            ops.reset_branches()
             torch.cuda.synchronize(self.dev)
 
     def _run_staged(self):

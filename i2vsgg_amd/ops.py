@@ -441,14 +441,57 @@ class LaunchContext:
         return False
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Streams.  ``torch.cuda.Stream()`` does not create a stream: it deals the next of 32 pooled streams per device and priority,
+# round robin -- and torch.cuda.graph's capture stream, ProcessGroupNCCL's streams and every caller's own streams come out of the
+# same pool.  A process that has built a few step objects therefore holds "different" stream objects with the SAME handle, and
+# a fork onto an alias of the forking stream (or of a sibling branch) is no fork at all.  The step objects take their streams
+# from this registry instead: one HIP stream per (device, role), created ONCE per process by the library
+# (``i2v_stream_create``: hipStreamCreateWithPriority, non-blocking), wrapped as a ``torch.cuda.ExternalStream`` and never
+# destroyed.  Such a handle cannot come out of torch's pool, two roles never share one, and step objects built one after the
+# other reuse the same few streams (a stream is an ordered queue: sharing a role between objects that run one after the other
+# costs nothing).
+_ROLE_STREAMS = {}
+STREAM_REQUESTS = []    # every request in order (capped): with torch.cuda.Stream() each of them drew the next pooled handle
+
+
+def role_stream(device, role, priority=0):
+    """The process-wide stream of ``role`` (any hashable: "side", ("frame", 0), "copy", ...) on ``device``."""
+    dev = torch.device(device)
+    index = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (index, role, int(priority))
+    if len(STREAM_REQUESTS) < 4096:
+        STREAM_REQUESTS.append(role)
+    st = _ROLE_STREAMS.get(key)
+    if st is None:
+        import ctypes
+        torch.cuda.init()
+        out = ctypes.c_void_p()
+        check(lib.i2v_stream_create(index, int(priority), ctypes.byref(out)), "i2v_stream_create")
+        taken = {t.cuda_stream for t in _ROLE_STREAMS.values()}
+        if not out.value or out.value in taken:
+            raise _lib.I2VError("role_stream: the runtime handed out stream handle %r twice" % out.value)
+        st = _ROLE_STREAMS[key] = torch.cuda.ExternalStream(out.value, device=torch.device("cuda", index))
+    return st
+
+
+def stream_table():
+    """{(device, role, priority): handle} of every stream the registry has created (tools/stream_handles.py, tests)."""
+    return {k: v.cuda_stream for k, v in _ROLE_STREAMS.items()}
+
+
 _BRANCH_DEPTH = 0
+_FORKED = {}            # handle -> origin handle of every branch forked and not yet joined (ops.join)
 
 
 class branch:
     """``with ops.branch(stream, origin):`` -- the body runs on ``stream`` as a fork of ``origin`` (stream.wait_stream(origin) first;
-    the caller joins with origin.wait_stream(stream)).  The step objects fork their graph branches through this so that the one
-    capture-time crash the schedule must avoid is an error message instead: a fork made INSIDE a forked branch ends
-    ``hipStreamEndCapture`` in a host segfault on ROCm 7.2 -- every branch forks from the capturing stream itself."""
+    the caller joins with ``ops.join(origin, stream, ...)``).  The step objects fork their graph branches through this so that the
+    capture-time failures the schedule must avoid are error messages instead:
+      * a fork made INSIDE a forked branch ends ``hipStreamEndCapture`` in a host segfault on ROCm 7.2 -- every
+        branch forks from the capturing stream itself;
+      * a branch stream whose HANDLE equals the origin's, or that of a sibling branch still open, is not a branch (the work is
+        silently serialised, and events recorded "between" the two are edges of a stream onto itself)."""
 
     def __init__(self, stream, origin):
         self.stream, self.origin = stream, origin
@@ -458,16 +501,39 @@ class branch:
         if _BRANCH_DEPTH > 0 and torch.cuda.is_current_stream_capturing():
             raise RuntimeError("ops.branch: a fork inside a forked graph branch (hipStreamEndCapture crashes on it): fork every "
                                "branch from the capturing stream")
+        h, ho = self.stream.cuda_stream, self.origin.cuda_stream
+        if h == ho:
+            raise RuntimeError("ops.branch: the branch stream IS the forking stream (handle %#x): take branch streams from "
+                               "ops.role_stream, torch.cuda.Stream() deals pooled handles round robin" % h)
+        if h in _FORKED:
+            raise RuntimeError("ops.branch: stream %#x is already an open branch (a sibling's alias?); join it first" % h)
         self.stream.wait_stream(self.origin)
         self._ctx = torch.cuda.stream(self.stream)
         self._ctx.__enter__()
+        _FORKED[h] = ho
         _BRANCH_DEPTH += 1
         return self
 
     def __exit__(self, *exc):
         global _BRANCH_DEPTH
         _BRANCH_DEPTH -= 1
+        if exc and exc[0] is not None:
+            _FORKED.pop(self.stream.cuda_stream, None)       # a failed body: whoever handles the error owns the clean-up
         return self._ctx.__exit__(*exc)
+
+
+def reset_branches():
+    """After a failed capture: forget the branches it left open."""
+    global _BRANCH_DEPTH
+    _FORKED.clear()
+    _BRANCH_DEPTH = 0
+
+
+def join(origin, *streams):
+    """``origin`` waits for every branch in ``streams`` (the join of ``ops.branch``)."""
+    for st in streams:
+        origin.wait_stream(st)
+        _FORKED.pop(st.cuda_stream, None)
 
 
 def _split_ws(device):
@@ -612,6 +678,15 @@ def _conv_wgrad_raw(x, g, w_shape, stride, pad, tag="wgrad", row_scale=None, win
 FUSED_SGD = {}
 
 
+class FusedEntry(tuple):
+    """(momentum buffer, lr, momentum, weight_decay) of one fused filter + the optimizer that registered it (``owner``)."""
+
+    def __new__(cls, m, lr, momentum, wd, owner=None):
+        self = super().__new__(cls, (m, lr, momentum, wd))
+        self.owner = owner
+        return self
+
+
 class DeferredUpdate:
     """Pending SGD update of ONE large linear layer (vrd.fc6 / fc7): the backward of step i leaves (x_i, g_i) here instead of
     running the filter-gradient kernel; the forward of step i+1 applies the update tile by tile while it streams the filter
@@ -622,9 +697,9 @@ class DeferredUpdate:
     ``rows`` are its host twins."""
     ROWS = 128
 
-    def __init__(self, w):
+    def __init__(self, w, owner=None):
         N, K = w.shape[0], w[0].numel()
-        self.w = w
+        self.w, self.owner = w, owner
         self.pend_x = torch.zeros((self.ROWS, K), device=w.device)
         self.pend_g = torch.zeros((self.ROWS, N), device=w.device)
         self.valid = torch.zeros((1,), dtype=torch.int32, device=w.device)
@@ -882,7 +957,10 @@ WGRAD_PENDING = []
 def join_wgrad_branch():
     """Called by the step after backward(): the capturing stream waits for the filter-gradient branch."""
     if WGRAD_STREAM is not None:
-        torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
+        cur = torch.cuda.current_stream()
+        if WGRAD_STREAM.cuda_stream == cur.cuda_stream:
+            raise RuntimeError("join_wgrad_branch: the filter-gradient stream is the current stream")
+        cur.wait_stream(WGRAD_STREAM)
     WGRAD_PENDING.clear()
 
 

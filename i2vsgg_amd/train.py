@@ -52,36 +52,44 @@ class FusedSGD:
             if parallel.exchange_enabled() and not parallel.is_local(p):
                 continue              # its gradient has to cross the ranks first
             if p.dim() >= 2 and p.numel() >= min_numel:
-                ops.FUSED_SGD[p.data_ptr()] = (it["m"], it["lr"], self.momentum, it["wd"])
+                # keyed by storage pointer (what the autograd node sees); ``owner`` says whose entry it is -- a pointer is
+                # reused by the allocator, and an optimizer that is collected late must not remove (or act on) the entry a
+                # newer optimizer made for a new filter at the same address
+                ops.FUSED_SGD[p.data_ptr()] = ops.FusedEntry(it["m"], it["lr"], self.momentum, it["wd"], self)
                 self._fused_keys.append(p.data_ptr())
                 names.append(it["name"])
                 if defer and p.dim() == 2 and p.is_cuda and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0:
-                    ops.DEFERRED_SGD[p.data_ptr()] = ops.DeferredUpdate(p)
+                    ops.DEFERRED_SGD[p.data_ptr()] = ops.DeferredUpdate(p, self)
         return names
+
+    def _mine(self, table, k):
+        ent = table.get(k)
+        return ent if ent is not None and getattr(ent, "owner", None) is self else None
 
     def flush_pending(self):
         """Apply the updates the deferred layers still hold (before anything outside the training step reads their filters:
         checkpoints, evaluation, a learning-rate change)."""
         for k in self._fused_keys:
-            st = ops.DEFERRED_SGD.get(k)
+            st = self._mine(ops.DEFERRED_SGD, k)
             if st is not None:
                 st.flush()
 
     def pending_state(self):
         """Tensors + host state of the pending updates (for a snapshot of the training state)."""
-        sts = [ops.DEFERRED_SGD[k] for k in self._fused_keys if k in ops.DEFERRED_SGD]
+        sts = [ops.DEFERRED_SGD[k] for k in self._fused_keys if self._mine(ops.DEFERRED_SGD, k) is not None]
         return [t for st in sts for t in st.tensors()], [(st.rows, st.armed) for st in sts]
 
     def restore_pending(self, host):
-        sts = [ops.DEFERRED_SGD[k] for k in self._fused_keys if k in ops.DEFERRED_SGD]
+        sts = [ops.DEFERRED_SGD[k] for k in self._fused_keys if self._mine(ops.DEFERRED_SGD, k) is not None]
         for st, (rows, armed) in zip(sts, host):
             st.rows, st.armed = rows, armed
 
     def unfuse(self):
         self.flush_pending()
         for k in self._fused_keys:
-            ops.FUSED_SGD.pop(k, None)
-            ops.DEFERRED_SGD.pop(k, None)
+            for table in (ops.FUSED_SGD, ops.DEFERRED_SGD):
+                if self._mine(table, k) is not None:          # not an entry a newer optimizer made at a reused address
+                    del table[k]
         self._fused_keys = []
 
     def __del__(self):
@@ -129,8 +137,8 @@ class FusedSGD:
                 it["m"].zero_()
         for k in list(self._fused_keys):       # fused entries hold (momentum, lr, ...) by value
             for it in self.items:
-                if it["p"].data_ptr() == k:
-                    ops.FUSED_SGD[k] = (it["m"], it["lr"], self.momentum, it["wd"])
+                if it["p"].data_ptr() == k and self._mine(ops.FUSED_SGD, k) is not None:
+                    ops.FUSED_SGD[k] = ops.FusedEntry(it["m"], it["lr"], self.momentum, it["wd"], self)
 
     def zero_grad(self):
         for it in self.items:
@@ -147,9 +155,9 @@ class FusedSGD:
         self.flush_pending()            # a pending update belongs to the step that computed it: applied at that step's rate
         for it in self.items:
             it["lr"] *= k
-            ent = ops.FUSED_SGD.get(it["p"].data_ptr())
+            ent = self._mine(ops.FUSED_SGD, it["p"].data_ptr())
             if ent is not None:                 # fused entries hold the rate by value (a captured graph holds it too:
-                ops.FUSED_SGD[it["p"].data_ptr()] = (ent[0], it["lr"], ent[2], ent[3])   # re-capture after a decay)
+                ops.FUSED_SGD[it["p"].data_ptr()] = ops.FusedEntry(ent[0], it["lr"], ent[2], ent[3], self)   # re-capture after a decay)
 
     MULTI_BELOW = 1 << 20       # tensors under 1 Mi elements share one launch
 
@@ -384,9 +392,11 @@ class _Uploader:
         # minibatch has one size (4.74 -> 4.86 ms instead of 5.15) but doubles the step (8.7-9.5 ms) as soon as the loop
         # alternates between the graphs of two sizes -- so it is not the default.
         import os
-        self.stream = torch.cuda.Stream(self.dev, priority=int(os.environ.get("I2V_UPLOAD_PRIORITY", "0")))
-        self.rings = {}
         self.enabled = os.environ.get("I2V_UPLOAD_STREAM", "0") == "1"
+        # the copy stream exists only when asked for, and is the process's ONE copy stream (ops.role_stream): a handle of the
+        # library's own, never an alias of a branch / capture / communicator stream out of torch's pool
+        self.stream = ops.role_stream(self.dev, "copy", int(os.environ.get("I2V_UPLOAD_PRIORITY", "0"))) if self.enabled else None
+        self.rings = {}
 
     def upload(self, frames):
         if not self.enabled:                 # the transfer on the caller's stream, in front of the step (the round-2 form)
@@ -511,7 +521,7 @@ class SGGEmbStep:
         self._graphs_on = False
         self.zero_arena = zero_arena
         self.bb_split = os.environ.get("I2V_BB_SPLIT", "1") == "1" and use_graph and n_frames > 1
-        self._frame_streams = [torch.cuda.Stream(self.dev) for _ in range(n_frames)] if self.bb_split else []
+        self._frame_streams = [ops.role_stream(self.dev, ("frame", f)) for f in range(n_frames)] if self.bb_split else []
         self._side = None
         self.ctx_head = ops.LaunchContext(self.dev, arena=zero_arena)      # head branch
         self.ctx_bb = ops.LaunchContext(self.dev, arena=zero_arena)        # eager backbone passes (any size)
@@ -798,8 +808,7 @@ class SGGEmbStep:
                     with torch.no_grad():
                         self.net.RCNN_base(fs.im[f:f + 1], out=self._fmap_dst(fs, f))
         if join:
-            for f in range(n):
-                main.wait_stream(self._frame_streams[f])
+            ops.join(main, *self._frame_streams[:n])
         self._fmap_key = fs.key
 
     TRACE_COLS = ("loss", "features", "scores", "embedding", "rng_canary", "fc7_weight", "fc6_weight_head", "boxes", "labels")
@@ -854,13 +863,12 @@ class SGGEmbStep:
         if self.bb_split:                   # one branch per frame, forked from the capturing stream itself (a fork inside a
             self._backbone_per_frame(fs, join=False)      # forked branch crashes hipStreamEndCapture on ROCm 7.2)
             self._head()
-            for st in self._frame_streams:
-                main.wait_stream(st)
+            ops.join(main, *self._frame_streams[:fs.key[0]])
             return
         with ops.branch(self._side, main):
             self._backbone(fs)              # batch k+1
         self._head()                        # batch k
-        main.wait_stream(self._side)
+        ops.join(main, self._side)
 
     def prime(self):
         """Overlapped schedule only: backbone pass of the batch staged first, so that the first call's head finds its
@@ -925,7 +933,7 @@ class SGGEmbStep:
         fs = self.shapes[self._staged]
         self._measure(fs)
         pipelined, self._pipelined = self._pipelined, False     # the warm-up steps are sequential eager steps
-        s = torch.cuda.Stream(self.dev)
+        s = ops.role_stream(self.dev, "warmup")
         s.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(s):
             for i in range(warmup):
@@ -976,7 +984,7 @@ class SGGEmbStep:
             torch.cuda.synchronize(self.dev)
             if self._pipelined:
                 if self._side is None:
-                    self._side = torch.cuda.Stream(self.dev)
+                    self._side = ops.role_stream(self.dev, "side")
                 with torch.cuda.graph(g, pool=self._pool):
                     self._body_overlapped(fs)
             else:
@@ -989,6 +997,7 @@ class SGGEmbStep:
         except Exception as e:      # report, fall back to eager launches for this size
             fs.graph = False
             self.graph_error = repr(e)
+            ops.reset_branches()
             torch.cuda.synchronize(self.dev)
             return False
         finally:
@@ -1026,24 +1035,23 @@ REDIRECT_DEFAULT_STREAM = True      # tools/graph_order_probe.py studies the run
 
 
 def replay_graph(graph, device=None):
-    """``graph.replay()`` on the caller's current stream -- except in the one case that is not safe.  ROCm 7.2's HIP runtime
-    replays a graph through pre-built AQL packet batches (``DEBUG_CLR_GRAPH_PACKET_CAPTURE``, on by default); on the LEGACY
-    DEFAULT stream that path loses the order between a graph's nodes and the stream's other work while a second stream is busy
-    (losses off by 2e-2 from the second step on, NaN weights; the same graphs are correct on any created
-    stream, and on the default stream with the packet path off).  i2vsgg_amd/__init__.py switches the path off before the runtime
-    initialises.  A process that had already initialised HIP with it on (a script that touched torch.cuda before importing the
-    package) and calls a step on the default stream gets its graph replayed on a private created stream between two event
-    edges instead: the caller's stream order is kept, the replay never runs on the default stream (round 2 refused the call)."""
-    import os
+    """``graph.replay()`` on the caller's current stream -- except on the LEGACY DEFAULT stream, where the replay runs on a
+    private stream between two event edges (the caller's stream order is kept).  ROCm 7.2's HIP runtime replays a graph through
+    pre-built AQL packet batches (``DEBUG_CLR_GRAPH_PACKET_CAPTURE``, on by default); on the legacy default stream that path loses
+    the order between a graph's nodes and the stream's other work while a second stream is busy (losses
+    off by 2e-2 from the second step on, NaN weights; the same graphs are correct on any created stream).
+    i2vsgg_amd/__init__.py switches the path off before the runtime initialises WHEN IT CAN -- but what the runtime actually
+    read cannot be told from os.environ (``torch.cuda.is_available()`` / ``device_count()`` bring the runtime up without setting
+    ``torch.cuda.is_initialized()``; a script may set the variable after its first HIP call), so the variable is not trusted
+    as proof (round-3 advice): every replay asked for on the default stream is redirected.  Cost: two event edges per step."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     cur = torch.cuda.current_stream(dev)
-    if not REDIRECT_DEFAULT_STREAM or os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1") == "0" or \
-            cur != torch.cuda.default_stream(dev):
+    if not REDIRECT_DEFAULT_STREAM or cur.cuda_stream != torch.cuda.default_stream(dev).cuda_stream:
         graph.replay()
         return
     s = _REPLAY_STREAMS.get(dev.index)
     if s is None:
-        s = _REPLAY_STREAMS[dev.index] = torch.cuda.Stream(dev)
+        s = _REPLAY_STREAMS[dev.index] = ops.role_stream(dev, "replay")
     s.wait_stream(cur)
     with torch.cuda.stream(s):
         graph.replay()
@@ -1124,10 +1132,10 @@ class InstanceStyleDStep:
         # (only with the one-pass backbone: a filter met twice in one backward would have its two gradients added on the main
         # stream while the side branch may still be writing the first)
         self.wgrad_branch = os.environ.get("I2V_WGRAD_BRANCH", "0") == "1" and self.dev.type == "cuda" and self.batched
-        self._wgrad_stream = torch.cuda.Stream(self.dev) if self.wgrad_branch else None
+        self._wgrad_stream = ops.role_stream(self.dev, "wgrad") if self.wgrad_branch else None
         # the captured step: source and target as two branches of the graph (_body_branches)
         self.branches = os.environ.get("I2V_ISD_BRANCHES", "1") != "0" and self.dev.type == "cuda" and not self.wgrad_branch
-        self._branch_streams = [torch.cuda.Stream(self.dev) for _ in range(2)] if self.branches else []
+        self._branch_streams = [ops.role_stream(self.dev, ("domain", i)) for i in range(2)] if self.branches else []
         self.sets, self.max_graphs, self._tick, self._pool = {}, int(max_graphs), 0, None
         self._cur = None              # the _DomainSet staged last
         self._uploader = None
@@ -1330,8 +1338,7 @@ class InstanceStyleDStep:
         with ops.branch(s_tgt, main), self.ctx_tgt:
             v, grads["t"] = target()
             vals.update(v)
-        main.wait_stream(s_src)
-        main.wait_stream(s_tgt)
+        ops.join(main, s_src, s_tgt)
         both = [(a, b) for a, b in zip(grads["s"], grads["t"]) if a is not None and b is not None]
         if both:
             torch._foreach_add_([a for a, _ in both], [b for _, b in both])
@@ -1398,7 +1405,7 @@ class InstanceStyleDStep:
         try:
             self._device_sampling(True)
             body = self._body_branches if self.branches else self._body
-            s = torch.cuda.Stream(self.dev)
+            s = ops.role_stream(self.dev, "warmup")
             s.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(s):
                 for i in range(warmup):
@@ -1428,6 +1435,7 @@ class InstanceStyleDStep:
         except Exception as e:
             ds.graph = False
             self.graph_error = repr(e)
+            ops.reset_branches()
             torch.cuda.synchronize(self.dev)
             return False
 

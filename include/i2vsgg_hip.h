@@ -48,6 +48,16 @@ extern "C" {
 int32_t     i2v_version(void);
 const char* i2v_last_error(void);
 
+/* ---- streams of the host's own ---------------------------------------------------
+ * The reference launches on "the current stream" of a global THCState
+ * (roi_align/src/roi_align_cuda.c:5,:31; roi_pooling_cuda.c; nms_cuda.c).  Every entry
+ * point below takes its stream explicitly instead; a host that forks work (the graph
+ * branches of a step) creates the streams it forks onto HERE, so that they cannot
+ * alias a stream a framework deals from a shared pool.  Non-blocking streams;
+ * priority 0 = normal, < 0 = higher (clamped to the device's range). */
+int32_t i2v_stream_create(int32_t device, int32_t priority, void** stream);
+int32_t i2v_stream_destroy(void* stream);
+
 /* ---- ROIAlign (legacy "aligned grid incl. both ends" variant) ------------------
  * replaces roi_align/src/roi_align_cuda.h:1-5 (roi_align_forward_cuda /
  * roi_align_backward_cuda), launchers roi_align_kernel.h:13-27, and -- fused with the

@@ -1,5 +1,7 @@
+import faulthandler
 import os
 import sys
+import time
 
 # before anything initialises the HIP runtime (i2vsgg_amd/__init__.py explains; the package sets it too, this line makes
 # the order independent of which test module imports what first)
@@ -14,9 +16,55 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+_STATE = {"n": 0, "log": None, "t0": time.time()}
+
+
+def _log_dir():
+    d = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        return d
+    except OSError:
+        import tempfile
+        return tempfile.gettempdir()
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # A run that dies (abort, segfault) must still NAME the test it died in.  Round 3's driver run ended in SIGABRT and the
+    # only thing its output tail held was pytest's faulthandler dump, whose ~3 KB "Extension modules" line had pushed the
+    # test name out of view.  So: pytest's own faulthandler plugin is off (pytest.ini), every test announces itself on the
+    # terminal BEFORE it starts (pytest_runtest_logstart below) and in gpurun_out/pytest_progress.log (flushed per test), and
+    # the Python stacks of a fatal signal go to gpurun_out/pytest_fault.log instead of the terminal.
+    d = _log_dir()
+    _STATE["log"] = open(os.path.join(d, "pytest_progress.log"), "a", buffering=1)
+    _STATE["log"].write("==== pytest %s (pid %d)\n" % (" ".join(config.invocation_params.args), os.getpid()))
+    _STATE["fault"] = open(os.path.join(d, "pytest_fault.log"), "a")
+    faulthandler.enable(file=_STATE["fault"], all_threads=True)
+    # The checker's C library is built (gcc, a child process) and loaded HERE, before any test can have initialised the GPU:
+    # a process that has touched the GPU must not start another program on this pool.
+    from oracle import cops
+    cops.lib()
+
+
+def pytest_runtest_logstart(nodeid, location):
+    _STATE["n"] += 1
+    line = "[%d +%.0fs] %s" % (_STATE["n"], time.time() - _STATE["t0"], nodeid)
+    log = _STATE["log"]
+    if log is not None:
+        log.write(line + "\n")
+        log.flush()
+        os.fsync(log.fileno())
+    tr = _STATE.get("tr")
+    if tr is not None:
+        tr.ensure_newline()
+        tr.write(line + " ")
+        tr.flush()
+
+
+@pytest.hookimpl(trylast=True)
+def pytest_sessionstart(session):
+    _STATE["tr"] = session.config.pluginmanager.get_plugin("terminalreporter")
 
 
 def golden(name):

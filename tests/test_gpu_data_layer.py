@@ -76,13 +76,22 @@ def test_roi_pool_with_device_side_extent_equals_the_static_kernel():
         assert float(ops.roi_pool_packed(ops.PackedMaps(buf, 2, C, big), rois_d, 7, 7, 1 / 16.0).abs().max()) == 0.0
 
 
-def test_sgg_captured_step_consumes_loader_batches_of_varying_size(small_cfg):
-    """SGG_emb: 8 loader minibatches of 2 frames in >= 3 sizes, 4-32 boxes and 2-32 pairs per frame, through (a) the eager
+@pytest.mark.parametrize("copy_stream", [False, True])
+def test_sgg_captured_step_consumes_loader_batches_of_varying_size(small_cfg, monkeypatch, copy_stream):
+    """``copy_stream``: the same loop with the frames crossing PCIe on the copy stream (I2V_UPLOAD_STREAM=1).  Round 3 met a host
+    segfault in hipGraphLaunch in exactly this test, in exactly this file order (tests/test_gpu_configs.py first), with the copy
+    stream on, and switched it off by default.  Since then (a) no graph is dropped while a replay of it may still be running
+    (capacity growth in stage() dropped every graph right behind an asynchronous replay -- ``invalidate_graphs`` synchronises
+    first now) and (b) the copy stream is a stream of its own (ops.role_stream) instead of the next of torch's 32 pooled handles.
+    DESIGN.md 5.5 has the analysis.
+
+    SGG_emb: 8 loader minibatches of 2 frames in >= 3 sizes, 4-32 boxes and 2-32 pairs per frame, through (a) the eager
     un-padded step and (b) the captured, overlapped step (capacity-padded head inputs that have to grow once, one graph per
     frame size, extent of the maps read on the device): the same per-batch losses (1e-3; measured ~1e-6) and the same
     weights, with the pipeline's one-call lag."""
     small_cfg()
-    from i2vsgg_amd import train
+    from i2vsgg_amd import ops, train
+    monkeypatch.setenv("I2V_UPLOAD_STREAM", "1" if copy_stream else "0")
     imdb, dl = _loader("synthetic_20_v", 2, seed=3)
     rels = imdb.gt_rels(62)
     batches = [d for d in dl][:8]
@@ -124,6 +133,14 @@ def test_sgg_captured_step_consumes_loader_batches_of_varying_size(small_cfg):
     graphs = sum(1 for fs in step.shapes.values() if fs.graph)
     step.opt.unfuse()
     assert step.graph_error is None, step.graph_error
+    assert (step._uploader.stream is not None) == copy_stream
+    if copy_stream:
+        dev = torch.device(DEV)
+        table = ops.stream_table()
+        assert step._uploader.stream.cuda_stream == table[(dev.index, "copy", 0)]
+        assert len(set(table.values())) == len(table)            # no role shares a handle with another
+        cap = getattr(torch.cuda.graph, "default_capture_stream", None)
+        assert cap is None or cap.cuda_stream not in table.values()
     # one graph per frame size met since the capacity last grew (growing drops every graph)
     assert 2 <= graphs <= len(sizes) and set(k[1:] for k in step.shapes) == sizes
     assert (step.cap_boxes, step.cap_pairs) != cap0          # the capacity grew (and every graph was captured again)
