@@ -340,6 +340,98 @@ def by_kind(rec, n_prof):
             for k, v in agg.items()}
 
 
+# ----------------------------------------------------------------------------- the metric's second half: ROI ops / NMS
+def roi_nms_cases(dev):
+    """The HBM-side ops of the path at the headline sizes, each as (name, launch closure, algorithmic bytes per launch, kernels).
+    Shared with tools/roi_nms_pmc_one.py, so that the PMC passes behind ``traffic`` profile exactly these launches.
+    Algorithmic bytes: SURVEY.md 8(d) -- feature maps read once + output written once (ROIAlign: 9.81 MB + R * 1024 * 49 * 4 B per
+    frame, the backward the same bytes reversed; ROIPool additionally writes its argmax); NMS: the reference algorithm's bytes
+    20 N + 2 * 8 * N * ceil(N / 64) (boxes + the 64-bit suppression mask written, then read)."""
+    import numpy as np
+    import torch
+    from i2vsgg_amd import ops, synthetic as syn
+    cases = []
+    R = 32
+    for B in (1, 4):
+        feat = torch.randn(B, 1024, 38, 63, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+        rois = np.zeros((B * R, 5), np.float32)
+        for b in range(B):
+            rois[b * R:(b + 1) * R, 0] = b
+            rois[b * R:(b + 1) * R, 1:] = syn.boxes(b, R)
+        rt = torch.from_numpy(rois).to(dev)
+        nbytes = B * 1024 * 38 * 63 * 4 + B * R * 1024 * 49 * 4
+        cases.append(("roi_align_avg_fwd_%dx%d" % (B, R), (lambda f=feat, r=rt: ops.roi_align(f.detach(), r, 7, 7, 1 / 16.0, avg=True)),
+                      nbytes, ["roi_align_fwd_nhwc_cols"]))
+        out = ops.roi_align(feat, rt, 7, 7, 1 / 16.0, avg=True)
+        gout = torch.randn_like(out)
+
+        def bwd(f=feat, o=out, g=gout):
+            f.grad = None
+            o.backward(g, retain_graph=True)                # zero-fill of the gradient map + the scatter kernel
+        cases.append(("roi_align_avg_bwd_%dx%d" % (B, R), bwd, nbytes, ["roi_align_bwd_kernel"]))
+    # ROIPool as the captured relation step runs it: 2 packed frames, 32 boxes + 32 union boxes each, NCHW out for vrd.fc6,
+    # extent of the maps read on the device (i2v_roi_pool_fwd_geom)
+    Bp, Rp, C, h, w = 2, 64, 1024, 38, 63
+    buf = torch.randn(Bp * h * w * C, device=dev)
+    maps = ops.PackedMaps(buf, Bp, C, torch.tensor([h, w], dtype=torch.int32, device=dev))
+    rp = np.zeros((Bp * Rp, 5), np.float32)
+    for b in range(Bp):
+        rp[b * Rp:(b + 1) * Rp, 0] = b
+        rp[b * Rp:(b + 1) * Rp, 1:] = syn.boxes(10 + b, Rp)
+    rpt = torch.from_numpy(rp).to(dev)
+    cases.append(("roi_pool_geom_fwd_2x64", lambda: ops.roi_pool_packed(maps, rpt, 7, 7, 1 / 16.0, out_nchw=True),
+                  Bp * C * h * w * 4 + 2 * Bp * Rp * C * 49 * 4, ["roi_pool_fwd"]))
+    for n, keep in ((12000, 2000), (6000, 300)):
+        dets = torch.from_numpy(syn.tie_free_dets(n, n, clustered=True)).to(dev)
+        cases.append(("nms_%d_to_%d" % (n, keep), (lambda d=dets, k=keep: ops.nms_sorted(d, 0.7, k)),
+                      20 * n + 2 * 8 * n * ((n + 63) // 64), ["nms_mask_kernel", "nms_scan"]))
+    return cases
+
+
+def run_roi_nms(dev, reps=20):
+    """``also.roi_nms``: every case of ``roi_nms_cases`` timed with ONE HIP-event pair on the launch stream around ``reps``
+    back-to-back launches, queued behind a ~10 ms blocker GEMM so that the pair brackets device time and not the host's
+    launch latency (the protocol of ``profile_eager``).  ``achieved`` = algorithmic GB/s, ``peak`` 8000 (HBM), ``traffic`` = HBM
+    bytes per launch from the PMC passes of the same launches (profiles/r04_roi_nms_pmc.json, tools/roi_nms_pmc.sh)."""
+    import torch
+    out = {}
+    pmc = {}
+    path = os.path.join(ROOT, "profiles", "r04_roi_nms_pmc.json")
+    if os.path.exists(path):
+        try:
+            with open(path) as f:
+                pmc = json.load(f).get("cases", {})
+        except Exception:
+            pmc = {}
+    blocker = torch.randn(8192, 8192, device=dev)
+    for name, fn, nbytes, kernels in roi_nms_cases(dev):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.mm(blocker, blocker)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(dev)
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        row = {"bound": "hbm", "avg_launch_us": us, "algorithmic_bytes": nbytes, "achieved": nbytes / us / 1e3, "peak": 8000.0,
+               "unit": "GB/s", "frac": nbytes / us / 1e3 / 8000.0, "kernels": kernels, "traffic": None}
+        p = pmc.get(name)
+        if p:
+            row["traffic"] = p.get("hbm_bytes_corrected")
+            row["traffic_over_algorithmic"] = p.get("traffic_over_algorithmic")
+            row["rocprof_avg_us"] = p.get("avg_us")
+            row["traffic_source"] = "profiles/r04_roi_nms_pmc.json"
+        out[name] = row
+    del blocker
+    out["note"] = ("one event pair around %d back-to-back launches behind a blocker GEMM (includes the ~1-2 us between two launches; "
+                   "rocprof_avg_us is the kernels' own time); the backward includes its zero-fill of the gradient map; NMS = mask + "
+                   "scan kernels, bytes of the reference algorithm (the scan is a latency chain, not a stream)" % reps)
+    return out
+
+
 # ----------------------------------------------------------------------------- configs[1] / configs[3]
 def run_sgg(a, rank, world, dev, frames_per_rank=2):
     import torch
@@ -797,7 +889,10 @@ def main():
             torch.cuda.empty_cache()
             also("sgg_loader", lambda: loader(False))
             also("sgg_loader_u8", lambda: loader(True))
-            also("sgg_gemm_x3", gemm_x3)
+            from i2vsgg_amd import _lib as _l2
+            if _l2.EXPERIMENTS:          # an I2V_EXPERIMENTS build only: the default library has no bf16-split kernel
+                also("sgg_gemm_x3", gemm_x3)
+            also("roi_nms", lambda: run_roi_nms(dev))
             also("instance_styled", isd)
             also("eval_loops", eval_loops)
     elif a.config == "instance_styled":

@@ -22,6 +22,7 @@ _p, _i, _f, _z, _l = C.c_void_p, C.c_int32, C.c_float, C.c_size_t, C.c_int64
 SIGNATURES = {
     "i2v_version": (_i, []),
     "i2v_last_error": (C.c_char_p, []),
+    "i2v_build_flags": (_i, []),
     "i2v_stream_create": (_i, [_i, _i, C.POINTER(C.c_void_p)]),
     "i2v_stream_destroy": (_i, [_p]),
     "i2v_roi_align_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _p, _i, _p]),
@@ -133,10 +134,11 @@ lib = _load()
 TUNE = {"I2V_CONV_SPEC": 0, "I2V_SPLIT_TARGET": 1, "I2V_SPLIT_TARGET_SKINNY": 2, "I2V_SPLIT_BELOW": 3, "I2V_SPLIT_ATOMICS": 4,
         "I2V_BIG_FC_TILE": 5, "I2V_WGRAD_V2": 6, "I2V_WGRAD_FUSED_TILE": 7, "I2V_WINO_ROWS": 8, "I2V_ROIPOOL_C128": 9, "I2V_CONV_GEMM": 10, "I2V_STAGGER": 11, "I2V_ROIALIGN_COLS": 12, "I2V_WGRAD_PER_CU": 13, "I2V_WGRAD_XCD": 14, "I2V_FC_FOLD": 15, "I2V_GEMM_X3": 16,
         "I2V_GEMM_PERSIST": 17, "I2V_WGRAD_PRIO": 18, "I2V_STREAM_TILE": 19}
+EXPERIMENTS = bool(lib.i2v_build_flags() & 1)      # built with -DI2V_EXPERIMENTS (I2V_EXPERIMENTS=1 python -m i2vsgg_amd.build)
 for _name, _key in TUNE.items():
     if os.environ.get(_name) not in (None, ""):
         if lib.i2v_set_tuning(_key, int(os.environ[_name])) != 0:
-            raise ImportError("i2vsgg_amd: bad value for %s" % _name)
+            raise ImportError("i2vsgg_amd: %s=%s refused: %s" % (_name, os.environ[_name], lib.i2v_last_error().decode()))
 
 
 def check(rc, what):

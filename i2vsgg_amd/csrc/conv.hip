@@ -792,10 +792,12 @@ conv_gemm_f32(const ConvP p_in) {
             }
         }
     };
+#ifdef I2V_EXPERIMENTS
     if (p.knob > 0) {                     // experiment (I2V_TUNE_STAGGER): co-resident workgroups start ~knob kcycles apart
         const int r = (blockIdx.x >> 8) & 3;
         for (int i = 0; i < r * p.knob; ++i) __builtin_amdgcn_s_sleep(16);
     }
+#endif
     gload(kbeg);                          // first: everything below hides behind this round trip
 
     // Operands of the epilogue.  A lane owns channels n .. n+3 of pixel m for every fragment (i, j):
@@ -1032,6 +1034,7 @@ conv_gemm_f32(const ConvP p_in) {
     stamp();
 }
 
+#ifdef I2V_EXPERIMENTS      // measured slower than one tile per workgroup (profiles/r03_persistent_gemm.txt): not in the default build
 // ---------------------------------------------------------------- persistent form of conv_gemm_f32
 // The same GEMM, staging, LDS image, MFMA order and register epilogue as conv_gemm_f32 (bit-equal results), scheduled as a
 // STREAM OF STAGES: a workgroup owns several tiles (b, b + G, b + 2G, ... of the XCD-aware tile order, G workgroups) and never
@@ -1239,6 +1242,7 @@ conv_gemm_pers_f32(const ConvP p) {
         cur = nxt;
     }
 }
+#endif  // I2V_EXPERIMENTS
 
 // epilogue of the split-K path (partials were accumulated with fp32 atomics)
 __global__ void conv_epilogue_kernel(float* __restrict__ y, const float* __restrict__ scale,
@@ -1326,19 +1330,25 @@ void launch_tile(const ConvP& p, bool spec, hipStream_t st) {
     const size_t epi = (size_t)BM * (BN + 4) * sizeof(float);
     const size_t lds = stage > epi ? stage : epi;
     static bool once = [] {
-        set_max_lds(conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, true>);
         set_max_lds(conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false>);
+#ifdef I2V_EXPERIMENTS
+        set_max_lds(conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, true>);
         if constexpr (WAVES_M == 1) {
             set_max_lds(conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false, 4>);
             set_max_lds(conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false, 12>);
         }
+#endif
         return true;
     }();
     (void)once;
+#ifdef I2V_EXPERIMENTS
     if constexpr (WAVES_M == 1) {      // diagnostic instantiations (tools/conv_ablate.py), 80x64 tile only
         if ((p.ablate & 12) == 4) { conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false, 4><<<dim3(tiles, p.splitk, p.nbatch > 1 ? p.nbatch : 1), THREADS, lds, st>>>(p); return; }
         if ((p.ablate & 12) == 12) { conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false, 12><<<dim3(tiles, p.splitk, p.nbatch > 1 ? p.nbatch : 1), THREADS, lds, st>>>(p); return; }
     }
+#else
+    spec = false;                      // the 8-wave loader / MFMA specialisation is an experiment (I2V_EXPERIMENTS builds only)
+#endif
     const dim3 grid(tiles, p.splitk, p.nbatch > 1 ? p.nbatch : 1);
     // pointwise layers / plain GEMMs whose split-K (if any) is finished in the kernel: the lean specialisation
     const bool pointwise = p.KH == 1 && p.KW == 1 && p.pad == 0 && p.pad_x == 0 && p.stride == 1 && p.ostride == 1 &&
@@ -1352,6 +1362,7 @@ void launch_tile(const ConvP& p, bool spec, hipStream_t st) {
         }();
         (void)once_g;
         const size_t lds_g = (size_t)(2 * (BM + BN) * BKS) * sizeof(float);
+#ifdef I2V_EXPERIMENTS
         // persistent form (stream of stages): unsplit, unbatched, at least two K stages, at least two tiles per workgroup
         const int per = g_i2v_tuning[I2V_TUNE_GEMM_PERSIST];
         if (per > 0 && p.splitk <= 1 && p.nbatch <= 1 && p.K > BKS && !p.clk && !g_i2v_tuning[I2V_TUNE_GEMM_X3] && tiles >= 2 * NUM_CU) {
@@ -1370,17 +1381,23 @@ void launch_tile(const ConvP& p, bool spec, hipStream_t st) {
             else conv_gemm_pers_f32<WAVES_M, WAVES_N, TM, TN><<<g, THREADS, lds_g, st>>>(p);
             return;
         }
+#endif
         if (p.flags & I2V_EPI_MASK) conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true><<<grid, THREADS, lds_g, st>>>(p);
         else if (p.clk) conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, true><<<grid, THREADS, lds_g, st>>>(p);
+#ifdef I2V_EXPERIMENTS
         else if (g_i2v_tuning[I2V_TUNE_GEMM_X3]) {      // opt-in: 3-term bf16 split on the bf16 matrix pipe
             static bool once_x = [] { set_max_lds(conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, false, true>); return true; }();
             (void)once_x;
             conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, false, true><<<grid, THREADS, lds_g, st>>>(p);
-        } else conv_gemm_f32<WAVES_M, WAVES_N, TM, TN><<<grid, THREADS, lds_g, st>>>(p);
+        }
+#endif
+        else conv_gemm_f32<WAVES_M, WAVES_N, TM, TN><<<grid, THREADS, lds_g, st>>>(p);
         return;
     }
-    if (spec) conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, true><<<grid, 2 * THREADS, lds, st>>>(p);
-    else conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false><<<grid, THREADS, lds, st>>>(p);
+#ifdef I2V_EXPERIMENTS
+    if (spec) { conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, true><<<grid, 2 * THREADS, lds, st>>>(p); return; }
+#endif
+    conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false><<<grid, THREADS, lds, st>>>(p);
 }
 
 struct TileCfg { int bm, bn; float eff; };
@@ -1500,6 +1517,7 @@ int run_conv(ConvP p, hipStream_t st, void* split_ws = nullptr, size_t split_ws_
     }
     return I2V_OK;
 }
+
 
 // ---------------------------------------------------------------- dgrad helper
 // wt[c][KH-1-ky][KW-1-kx][n] = w[n][ky][kx][c]: the filter of the transposed conv.
@@ -1951,6 +1969,7 @@ conv_wgrad2_f32(const WgP p_in) {
     int buf = 0;
     for (int ms = mbeg; ms < mend; ms += BKS) {
         const bool more = ms + BKS < mend;
+#ifdef I2V_EXPERIMENTS
         if (p.prio) {
             // experiment (I2V_TUNE_WGRAD_PRIO): issue priority falls with progress, so the co-resident workgroups of a CU stay
             // together instead of retiring one by one (the arbiter favours the oldest wave: ends spread 84 .. 108 us around a
@@ -1962,6 +1981,7 @@ conv_wgrad2_f32(const WgP p_in) {
                 default: __builtin_amdgcn_s_setprio(3); break;
             }
         }
+#endif
         if constexpr (CLK) {        // diagnostic instantiation only (tools/wgrad_phase.py ABL=..): 1 = no staging after the first stage, 2 = no MFMAs
             if (more && !(p.abl & 1)) gload(ms + BKS);
             if (!(p.abl & 2)) compute(buf);
@@ -2341,6 +2361,12 @@ extern "C" int32_t i2v_debug_clock_stamp(void* out2, void* stream) {
 
 extern "C" int32_t i2v_conv_set_tile(int32_t cfg) {
     if (cfg < 0) { g_force_tile = -1; g_spec_mode = -1; g_ablate = 0; return I2V_OK; }
+#ifndef I2V_EXPERIMENTS
+    if (((cfg >> 8) & 3) == 2 || ((cfg >> 10) & 255)) {
+        i2v_set_error("conv_set_tile: the 8-wave specialisation and the ablation bits need a -DI2V_EXPERIMENTS build");
+        return I2V_ERR_UNSUPPORTED;
+    }
+#endif
     g_force_tile = (cfg & 0xFF) == 0xFF ? -1 : (cfg & 0xFF);
     g_spec_mode = ((cfg >> 8) & 3) - 1;
     g_ablate = (cfg >> 10) & 255;

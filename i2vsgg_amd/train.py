@@ -11,7 +11,7 @@ bound otherwise: ~300 small kernels), and all-reduce gradients over RCCL when wo
 import numpy as np
 import torch
 
-from . import ops, parallel
+from . import _lib, ops, parallel
 from . import synthetic as syn
 from .model.utils.config import cfg
 
@@ -46,6 +46,9 @@ class FusedSGD:
         import os
         if defer is None:
             defer = os.environ.get("I2V_DEFER_FC", "0") == "1"
+        if defer and not _lib.EXPERIMENTS:
+            raise RuntimeError("I2V_DEFER_FC / fuse_wgrad(defer=True): the fc fold kernel is an experiment, not in this library "
+                               "(build with I2V_EXPERIMENTS=1 python -m i2vsgg_amd.build)")
         names = []
         for it in self.items:
             p = it["p"]
@@ -376,11 +379,14 @@ class _Uploader:
     """Host frames -> device.  Default: on the caller's stream, in front of the step (a 2 x 3 x 600 x 1000 fp32 minibatch is
     14.4 MB = 0.6 ms at 25 GB/s: bench.py --data loader 5.2 ms per step against 4.6 resident).
     ``I2V_UPLOAD_STREAM=1``: on a COPY stream with two staging buffers and event edges both ways, so that the transfer of
-    minibatch k+1 runs beside the step that is still computing (measured 5.26 -> 5.03 ms).  OFF by default: with it, a
-    process that had created several step objects crashed in hipGraphLaunch (a host segfault, reproducible for one order of the
-    test files, gone with the option off: tests/test_gpu_configs.py followed by tests/test_gpu_data_layer.py) -- torch hands out
-    32 pooled streams per device round robin, so after a few step objects the "copy" stream IS a stream some later capture
-    forks or captures on; the default keeps every transfer on the stream the step replays on.
+    minibatch k+1 runs beside the step that is still computing (measured 5.26 -> 5.03 ms).  Round 3 switched it off after a host
+    segfault in hipGraphLaunch (tests/test_gpu_configs.py followed by tests/test_gpu_data_layer.py) and blamed stream aliasing.
+    Round 4 (profiles/r04_alias_repro.txt): the same order with pooled streams, aliases logged as they happen -- the copy stream
+    WAS a captured branch, the side stream WAS torch's capture stream -- runs clean once no graph is dropped while a replay of
+    it may be in flight (``invalidate_graphs`` synchronises first; stage() grew the head capacity and dropped every graph
+    right behind an asynchronous replay).  The aliases were real but harmless to correctness; they are gone too
+    (ops.role_stream).  The option stays off by default for what it measures, not for safety: the transfer only gets its turn
+    when the step's branches drain (below).  ``tests/test_gpu_data_layer.py`` runs the loader loop with it on.
     ``upload`` returns a device tensor that is valid on the caller's CURRENT stream, ``consumed`` marks the point after which
     its buffer may be overwritten."""
 

@@ -47,6 +47,12 @@ extern "C" {
 
 int32_t     i2v_version(void);
 const char* i2v_last_error(void);
+/* bit set: I2V_BUILD_EXPERIMENTS = compiled with -DI2V_EXPERIMENTS (the measured-and-lost kernel variants of rounds 1-3 and the
+ * diagnostic instantiations: persistent GEMM, bf16 three-term split, 8-wave loader/MFMA specialisation, fc fold, stagger /
+ * priority knobs).  The default build carries none of them; their tuning keys then accept only "off" and their entry
+ * points return I2V_ERR_UNSUPPORTED. */
+#define I2V_BUILD_EXPERIMENTS 1
+int32_t     i2v_build_flags(void);
 
 /* ---- streams of the host's own ---------------------------------------------------
  * The reference launches on "the current stream" of a global THCState
@@ -256,6 +262,8 @@ size_t  i2v_conv_split_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t 
 #define I2V_TUNE_WGRAD_PRIO          18   /* experiment: n > 0 = the filter-gradient kernel lowers a wave's issue priority as it advances (3 - ((stage >> (n-1)) & 3)); 0 = off */
 #define I2V_TUNE_STREAM_TILE         19   /* 1 (default): pointwise layers of at most four K stages over >= 16384 rows (HBM-bound) take the 80x64 tile whatever the cost model says; 0: cost model */
 #define I2V_TUNE_COUNT               20
+/* Keys CONV_SPEC (> 0), STAGGER, FC_FOLD, GEMM_X3, GEMM_PERSIST, WGRAD_PRIO are experiments: I2V_ERR_UNSUPPORTED for any value
+ * but "off" unless the library was built with -DI2V_EXPERIMENTS (i2v_build_flags). */
 int32_t i2v_set_tuning(int32_t key, int32_t value);
 int32_t i2v_get_tuning(int32_t key);
 /* tuning hook: cfg < 0 = cost model; else low byte = tile shape 0..5 (0xFF = cost model),

@@ -303,7 +303,7 @@ def test_training_scripts_run_through_the_data_layer(small_cfg, tmp_path):
     assert all(torch.isfinite(v).all() for v in ck["model"].values() if v.is_floating_point())
     lrs = {round(g["lr"], 12) for g in ck["optimizer"]["param_groups"]}
     assert lrs == {round(1e-4 * 0.5, 12), round(2e-4 * 0.5, 12)}          # one decay (epoch 2); biases at twice the rate
-    ts.main(["--epochs", "3", "--r", "--load_name", str(name)] + common)
+    ts.main(["--epochs", "3", "--resume_train", "--load_name", str(name)] + common)
     ck3 = torch.load(str(name).replace("epoch_2", "epoch_3"), map_location="cpu")
     assert ck3["epoch"] == 4
     lrs = {round(g["lr"], 12) for g in ck3["optimizer"]["param_groups"]}
@@ -344,6 +344,90 @@ def test_training_scripts_run_through_the_data_layer(small_cfg, tmp_path):
     ts.main(["--epochs", "1", "--bs", "2", "--imdb_name", "synthetic_12_v", "--scale", "192", "--disp_interval", "3", "--save_dir",
              str(tmp_path / "u8"), "--device_prep", "--no-save"])
     tv.main(["--epochs", "1", "--device_prep", "--no-save"] + common)
+
+
+def test_stage_chaining_detector_checkpoint_initialises_the_relation_stage(small_cfg, tmp_path):
+    """The method's two stages are chained through checkpoints (scripts/SGG_emb_resnet.sh: ``--r --load_name adapt/instance_pixel_
+    styleD_bilinear_...pth``):
+      * trainval_net_SGG_emb.py:155-173 -- ``--r`` loads every key WITHOUT 'vrd' from the detector file, prints the keys the
+        file lacks, takes its pooling mode; the relation head keeps its initialisation, no optimizer state is read;
+      * trainval_net_instance_styleD_bilinear.py:153-183 -- with 'faster_rcnn' in --load_name the detector is initialised
+        through an allow-list (no netD_pixel / RPN_cls_score / RPN_bbox_pred / RCNN_cls_score / RCNN_bbox_pred), from a file that
+        may lack the discriminators altogether.
+    Here: two steps of trainval_instance_styled.py, its checkpoint into trainval_sgg_emb.py --r; then a plain-detector file (no
+    netD_*) into trainval_instance_styled.py --r."""
+    import trainval_instance_styled as tv
+    import trainval_sgg_emb as ts
+    from i2vsgg_amd import train
+    from i2vsgg_amd.model.utils.config import cfg
+    det_args = ["--net", "res50", "--bs", "2", "--imdb_name", "synthetic_6_v", "--imdb_name_target", "synthetic_5_v_7", "--scale", "192",
+                "--iters_per_epoch", "2", "--disp_interval", "2", "--save_dir", str(tmp_path), "--set", "TRAIN.BATCH_SIZE", "16",
+                "TRAIN.RPN_POST_NMS_TOP_N_TARGET", "16"]
+    tv.main(["--epochs", "1"] + det_args)
+    det = tmp_path / "res50" / "synthetic" / ("instance_pixel_styleD_bilinear_cr_False_source_synthetic_target_synthetic_t_"
+                                              "session_1_lr_0.0005_epoch_1_bs_2_mscoco.pth")
+    ck = torch.load(det, map_location="cpu")
+    fresh = train.build_instance_styled_net(50, n_cls=16, device=DEV).state_dict()
+    assert not torch.equal(ck["model"]["RCNN_base.6.5.conv3.weight"], fresh["RCNN_base.6.5.conv3.weight"].cpu())     # it did train
+
+    # ---- stage 2 from stage 1: the function, then the script
+    net = train.build_sgg_net(50, device=DEV)
+    twin = train.build_sgg_net(50, device=DEV).state_dict()
+    cfg.POOLING_MODE = "pool"
+    said = []
+    loaded, missing = ts.init_from_detector(str(det), net, log=said.append)
+    assert cfg.POOLING_MODE == "align" and not missing and not said
+    sd = net.state_dict()
+    assert loaded and all("vrd" not in k for k in loaded)
+    assert set(loaded) == {k for k in sd if "vrd" not in k}
+    for k, v in sd.items():
+        if "vrd" in k:
+            assert torch.equal(v, twin[k]), k                            # the relation head keeps its initialisation
+        else:
+            assert torch.equal(v.cpu(), ck["model"][k]), k                # RCNN_base / RCNN_rpn / RCNN_top / cls / bbox: the detector's
+    assert not any(k.startswith("netD_") for k in sd)
+    # a file that lacks keys: they are printed and keep their initialisation (:160-163)
+    part = {"model": {k: v for k, v in ck["model"].items() if not k.startswith("RCNN_top.0.")}, "pooling_mode": "align"}
+    torch.save(part, tmp_path / "partial.pth")
+    net2 = train.build_sgg_net(50, device=DEV)
+    said = []
+    _, missing = ts.init_from_detector(str(tmp_path / "partial.pth"), net2, log=said.append)
+    assert missing and said == missing and all(k.startswith("RCNN_top.0.") for k in missing)
+    assert torch.equal(net2.state_dict()["RCNN_top.0.0.conv1.weight"], twin["RCNN_top.0.0.conv1.weight"])
+    sgg_args = ["--net", "res50", "--bs", "2", "--imdb_name", "synthetic_12_v", "--scale", "192", "--iters_per_epoch", "2",
+                "--disp_interval", "2", "--save_dir", str(tmp_path), "--vrd_lr", "1e-4"]
+    ts.main(["--epochs", "1", "--r", "--load_name", str(det)] + sgg_args)
+    out = torch.load(tmp_path / "res50" / "synthetic" / "SGG_emb_p_prior_adap_synthetic_pre_det_session_1_epoch_1_step_1_un.pth",
+                     map_location="cpu")
+    assert out["epoch"] == 2                                              # started at --start_epoch 1, not at the file's epoch
+    for k in ("RCNN_base.0.weight", "RCNN_base.6.5.conv3.weight", "RCNN_rpn.RPN_Conv.weight", "RCNN_top.0.2.conv3.weight",
+              "RCNN_cls_score.weight"):
+        assert torch.equal(out["model"][k], ck["model"][k]), k           # bit-equal to the detector's (frozen in this stage)
+    assert not torch.equal(out["model"]["vrd.fc7.fc.weight"], twin["vrd.fc7.fc.weight"].cpu())      # the head trained
+    lrs = {round(g["lr"], 12) for g in out["optimizer"]["param_groups"]}
+    assert lrs == {1e-4, round(1e-4 * (cfg.TRAIN.DOUBLE_BIAS + 1), 12)}   # a fresh optimizer: nothing of the detector's rates (5e-4)
+    with pytest.raises(SystemExit):
+        ts.main(["--epochs", "1", "--r", "--resume_train", "--load_name", str(det)] + sgg_args)
+
+    # ---- stage 1 from a plain detector file: no discriminators in it, 'faster_rcnn' in its name
+    plain = {"model": {k: v for k, v in ck["model"].items() if not k.startswith("netD_")}, "epoch": 7, "session": 9,
+             "pooling_mode": "pool"}
+    name = tmp_path / "faster_rcnn_1_7_9999.pth"
+    torch.save(plain, name)
+    dnet = train.build_instance_styled_net(50, n_cls=16, device=DEV)
+    init = {k: v.clone() for k, v in dnet.state_dict().items()}
+    cfg.POOLING_MODE = "align"
+    loaded = tv.init_from_detector(str(name), dnet)
+    assert cfg.POOLING_MODE == "align"                                    # :181 looks in the model dict: never taken
+    sd = dnet.state_dict()
+    for k, v in sd.items():
+        dropped = any(t in k for t in tv.WO_PARAMETER)
+        if dropped or k.startswith("netD_"):
+            assert k not in loaded and torch.equal(v, init[k]), k        # keeps its initialisation
+        else:
+            assert k in loaded and torch.equal(v.cpu(), ck["model"][k]), k
+    assert any("RPN_cls_score" in k for k in sd) and any(k.startswith("netD_style") for k in sd)
+    tv.main(["--epochs", "1", "--s", "3", "--r", "--load_name", str(name), "--no-save"] + det_args)     # runs from epoch 1
 
 
 def test_test_scripts_equal_their_frame_by_frame_form(small_cfg, tmp_path):

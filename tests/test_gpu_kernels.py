@@ -473,6 +473,16 @@ def test_dstyle_pool(ops):
     np.testing.assert_allclose(d2.grad.cpu().numpy(), x2.grad.numpy(), rtol=1e-6, atol=1e-6)
 
 
+def _experiments():
+    from i2vsgg_amd import _lib
+    return _lib.EXPERIMENTS
+
+
+needs_experiments = pytest.mark.skipif("not __import__('i2vsgg_amd._lib', fromlist=['EXPERIMENTS']).EXPERIMENTS",
+                                       reason="the default library carries no experiment kernels (I2V_EXPERIMENTS=1 python -m "
+                                              "i2vsgg_amd.build builds them)")
+
+
 def test_cpu_tensor_is_rejected_loudly(ops):
     with pytest.raises(Exception):
         ops.roi_align(torch.zeros(1, 4, 8, 8), torch.zeros(1, 5), 7, 7, 1 / 16.0)
@@ -481,9 +491,11 @@ def test_cpu_tensor_is_rejected_loudly(ops):
 @pytest.mark.parametrize("spec", [1, 2])
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
 def test_conv_every_tile_shape(ops, tile, spec):
-    """Each (BM x BN) instantiation of conv_igemm_f32 -- plain 4-wave (spec=1) and loader/MFMA specialised
-    8-wave (spec=2) -- forced through the tuning hook, incl. ragged M/N/K edges, residual and split-K."""
+    """Each (BM x BN) instantiation of conv_igemm_f32 -- plain 4-wave (spec=1) and, in I2V_EXPERIMENTS builds, loader/MFMA
+    specialised 8-wave (spec=2) -- forced through the tuning hook, incl. ragged M/N/K edges, residual and split-K."""
     from i2vsgg_amd import _lib
+    if spec == 2 and not _lib.EXPERIMENTS:
+        pytest.skip("the 8-wave specialisation is an experiment: not in the default library")
     rng = np.random.default_rng(tile)
     x = rng.standard_normal((2, 72, 13, 17), dtype=np.float32)          # M = 442 (ragged), K = 648 (not /32)
     w = (rng.standard_normal((100, 72, 3, 3), dtype=np.float32) / 25).astype(np.float32)
@@ -775,6 +787,7 @@ def test_pointwise_gemm_kernel_equals_generic_kernel(ops, M, K, N, res):
 
 @pytest.mark.parametrize("M,K,N,res,tile", [(75000, 64, 256, True, 3), (18750, 128, 512, True, 2), (9000, 256, 1024, True, 5),
                                               (37500, 256, 64, False, 4), (20000, 96, 200, False, 3)])
+@needs_experiments
 def test_persistent_gemm_equals_one_tile_per_workgroup(ops, M, K, N, res, tile):
     """conv_gemm_pers_f32 (I2V_GEMM_PERSIST: a workgroup streams through several tiles, the next tile's operands requested under
     the current tile's last stage) is the same arithmetic as conv_gemm_f32: bit-equal outputs, ragged M / N / K included."""
@@ -1000,6 +1013,7 @@ def test_filter_gradient_split_groups_on_one_xcd(B, C, N, H, W, k):
     assert float((on - off).abs().max()) <= 2e-5 * scale          # atomics: summation order differs
 
 
+@needs_experiments
 def test_deferred_fc_update_equals_the_fused_update():
     """i2v_fc_fold_fwd (vrd.fc6 / fc7 in the relation step): the SGD(momentum) update left pending by step i's backward and
     applied inside step i+1's forward GEMM gives the outputs, filters and momenta of the undeferred schedule (forward, then
@@ -1091,6 +1105,7 @@ def test_pair_gather_and_single_workgroup_bce_match_torch():
     assert all(float(ops.bce_rows(z.detach(), t, w)) == float(a) for _ in range(5))
 
 
+@needs_experiments
 def test_gemm_three_term_bf16_split_is_opt_in_and_16_bit_accurate():
     """I2V_TUNE_GEMM_X3 (off by default): the pointwise / plain-GEMM kernel with its products on the bf16 matrix pipe as
     hi*hi + hi*lo + lo*hi.  (1) operands that are exact in bf16 (small integers) give the fp32 kernel's bits -- the layout of
@@ -1207,6 +1222,7 @@ def test_fused_loss_and_target_arithmetic_matches_the_torch_expressions():
     assert float(ga[~live].abs().max()) == 0.0               # aten gives NaN there (inf * 0 through sqrt'); the kernel gives 0
 
 
+EXPERIMENT_KNOBS = {"I2V_CONV_SPEC", "I2V_STAGGER", "I2V_GEMM_PERSIST", "I2V_WGRAD_PRIO", "I2V_GEMM_X3", "I2V_FC_FOLD"}
 KNOBS = [("I2V_CONV_SPEC", 1), ("I2V_CONV_SPEC", 2), ("I2V_SPLIT_TARGET", 3), ("I2V_SPLIT_TARGET_SKINNY", 3), ("I2V_SPLIT_BELOW", 0),
          ("I2V_SPLIT_BELOW", 2048), ("I2V_SPLIT_ATOMICS", 1), ("I2V_BIG_FC_TILE", -1), ("I2V_WGRAD_V2", 0), ("I2V_WGRAD_V2", 2),
          ("I2V_WGRAD_V2", 3), ("I2V_WINO_ROWS", -1), ("I2V_WINO_ROWS", 3), ("I2V_ROIPOOL_C128", 0), ("I2V_CONV_GEMM", 0),
@@ -1249,11 +1265,17 @@ def test_every_tuning_knob_keeps_the_results(ops):
         out["roi_align"] = ops.roi_align(xc, rois, 7, 7, 1.0 / 16)
         return {k: v.clone() for k, v in out.items()}
 
+    from i2vsgg_amd._lib import EXPERIMENTS
     base = run()
     assert all(torch.isfinite(v).all() for v in base.values())
     for name, value in KNOBS:
         key = TUNE[name]
         old = lib.i2v_get_tuning(key)
+        if name in EXPERIMENT_KNOBS and not EXPERIMENTS:
+            # the default library carries no experiment kernels: their knobs accept nothing but "off", loudly
+            assert lib.i2v_set_tuning(key, value) == -4 and b"I2V_EXPERIMENTS" in lib.i2v_last_error()
+            assert lib.i2v_get_tuning(key) == old
+            continue
         try:
             assert lib.i2v_set_tuning(key, value) == 0
             got = run()

@@ -99,6 +99,29 @@ def load_checkpoint(path, net, opt):
     return int(ck["epoch"])
 
 
+WO_PARAMETER = ("netD_pixel", "RPN_cls_score", "RPN_bbox_pred", "RCNN_cls_score", "RCNN_bbox_pred")
+
+
+def init_from_detector(path, net):
+    """trainval_net_instance_styleD_bilinear.py:153-183: initialise from a plain detector checkpoint (the reference takes this
+    branch when 'faster_rcnn' is in --load_name).  Allow-list = the model's own keys that contain none of ``WO_PARAMETER``
+    (:153-161: the instance discriminator and the four class- / anchor-count-dependent output layers keep their
+    initialisation); of the file's ``model`` dict exactly the allow-listed keys are taken (:172), keys the file lacks
+    (netD_style.* of a plain Faster R-CNN) keep their initialisation -- no KeyError.  Session, epoch and optimizer state are
+    not used (:176-180 are commented out), and ``pooling_mode`` is looked up in the MODEL dict (:181, after ``checkpoint`` was
+    rebound to it at :166), i.e. never found: the file's pooling mode is not taken in this mode.  -> loaded keys"""
+    from i2vsgg_amd.model.faster_rcnn.layers import load_reference_state
+    model = torch.load(path, map_location="cpu")["model"]
+    own = net.state_dict()
+    allow = [k for k in own if not any(tag in k for tag in WO_PARAMETER)]
+    loaded = {k: v for k, v in model.items() if k in allow}
+    for k, v in loaded.items():
+        if tuple(v.shape) != tuple(own[k].shape):
+            raise ValueError("init_from_detector: %s is %s in %s, %s here" % (k, tuple(v.shape), path, tuple(own[k].shape)))
+    load_reference_state(net, loaded, strict=False)
+    return sorted(loaded)
+
+
 def main(argv=None):
     a = parse_args(argv)
     from i2vsgg_amd import parallel, train
@@ -137,7 +160,14 @@ def main(argv=None):
     step = train.InstanceStyleDStep(net, a.batch_size, lr=a.lr, eta=a.eta, eta_style=a.eta_style, style_lambda=a.style_lambda,
                                     device=dev, cr=a.cr, stage_synthetic=False, optimizer=a.optimizer)
     start_epoch = a.start_epoch
-    if a.resume:
+    if a.resume and "faster_rcnn" in a.load_name:            # :163: model initialisation with an object-detection checkpoint
+        if rank == 0:
+            print("loading checkpoint %s" % a.load_name)
+        loaded = init_from_detector(a.load_name, net)
+        step.opt.bump()
+        if rank == 0:
+            print("loaded checkpoint %s (%d tensors through the allow-list)" % (a.load_name, len(loaded)))
+    elif a.resume:                                           # :186: resume a run of this script
         path = a.load_name or checkpoint_name(a, a.checksession, a.checkepoch)
         start_epoch = load_checkpoint(path, net, step.opt)
         if rank == 0:

@@ -51,7 +51,15 @@ def parse_args(argv=None):
     p.add_argument("--scale", type=int, default=0, help="shorter image side (cfg.TRAIN.SCALES; 0: the yml's 600)")
     p.add_argument("--save_dir", default="models", help="checkpoints go to <save_dir>/<net>/<dataset> (reference layout)")
     p.add_argument("--s", dest="session", type=int, default=1)
-    p.add_argument("--r", dest="resume", action="store_true", help="resume from --load_name (or --checksession / --checkepoch)")
+    p.add_argument("--r", dest="resume", action="store_true",
+                   help="the reference's --r (trainval_net_SGG_emb.py:155-173): INITIALISE the detector half from the stage-1 "
+                        "checkpoint --load_name (a trainval_instance_styled.py / reference detector file): every key without "
+                        "'vrd' is taken from it, vrd.* keeps its initialisation, training starts at --start_epoch with a fresh "
+                        "optimizer")
+    p.add_argument("--resume_train", action="store_true",
+                   help="continue an interrupted run of THIS script: model, optimizer and epoch from --load_name (or "
+                        "--checksession / --checkepoch).  The reference has no such mode for this script (its --r is the "
+                        "detector hand-off above)")
     p.add_argument("--load_name", default="")
     p.add_argument("--checksession", type=int, default=1)
     p.add_argument("--checkepoch", type=int, default=1)
@@ -116,6 +124,36 @@ def load_checkpoint(path, net, opt):
     return int(ck["epoch"])
 
 
+def init_from_detector(path, net, log=print):
+    """trainval_net_SGG_emb.py:155-173, the stage-1 -> stage-2 hand-off of the method: every key of the model that does not
+    contain 'vrd' is taken from the detector checkpoint's ``model`` dict (a key the file lacks is printed and keeps its
+    initialisation, :160-163), ``vrd.*`` is left alone, ``cfg.POOLING_MODE`` follows the file (:171-172).  Optimizer state,
+    session and epoch of the file are NOT used (":154 resume only for load faster rcnn model, not for other model status").
+    Keys the file holds beyond the model's (netD_pixel.*, netD_style.* of an instance_styleD detector) are ignored, as the
+    reference's loop over ``state_dict.keys()`` ignores them.  -> (loaded keys, missing keys)"""
+    from i2vsgg_amd.model.faster_rcnn.layers import load_reference_state
+    from i2vsgg_amd.model.utils.config import cfg
+    ck = torch.load(path, map_location="cpu")
+    model = ck["model"]
+    own = net.state_dict()
+    loaded, missing = {}, []
+    for k in own:
+        if "vrd" in k:
+            continue
+        if k not in model:
+            log(k)                                            # :161 print(k)
+            missing.append(k)
+            continue
+        if tuple(model[k].shape) != tuple(own[k].shape):
+            raise ValueError("init_from_detector: %s is %s in %s, %s here (other --net / --num_classes?)" % (
+                k, tuple(model[k].shape), path, tuple(own[k].shape)))
+        loaded[k] = model[k]
+    load_reference_state(net, loaded, strict=False)
+    if "pooling_mode" in ck:
+        cfg.POOLING_MODE = ck["pooling_mode"]
+    return sorted(loaded), missing
+
+
 def main(argv=None):
     a = parse_args(argv)
     from i2vsgg_amd import parallel, train
@@ -159,7 +197,18 @@ def main(argv=None):
     step = train.SGGEmbStep(net, a.batch_size, vrd_lr=a.vrd_lr, device=dev, use_graph=not a.no_graph and dev.type == "cuda",
                             stage_synthetic=False, optimizer=a.optimizer)
     start_epoch = a.start_epoch
-    if a.resume:
+    if a.resume and a.resume_train:
+        raise SystemExit("--r initialises from a detector checkpoint, --resume_train continues a run of this script: pick one")
+    if a.resume:                                             # the reference's --r: detector weights in, vrd.* untouched
+        if not a.load_name:
+            raise SystemExit("--r needs --load_name <detector checkpoint> (trainval_net_SGG_emb.py:156)")
+        if rank == 0:
+            print("loading checkpoint %s" % a.load_name)
+        loaded, missing = init_from_detector(a.load_name, net, log=print if rank == 0 else (lambda *_: None))
+        step.opt.bump()                                      # filters changed under every cache derived from them
+        if rank == 0:
+            print("loaded checkpoint %s (%d detector tensors, %d not in the file)" % (a.load_name, len(loaded), len(missing)))
+    if a.resume_train:
         path = a.load_name or checkpoint_name(a, a.checksession, a.checkepoch, iters_per_epoch - 1)
         start_epoch = load_checkpoint(path, net, step.opt)
         if rank == 0:
