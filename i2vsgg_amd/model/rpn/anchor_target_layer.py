@@ -17,6 +17,17 @@ from .bbox_transform import bbox_transform_batch
 from .generate_anchors import generate_anchors, shifted_anchors
 
 
+def record_sample(rec, key, t):
+    """Copy ``t`` into the static tensor ``rec[key]`` (made at first sight, outside any capture: a step's warm-up call)."""
+    buf = rec.get(key)
+    if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+        if torch.cuda.is_available() and t.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("sample_record: no buffer for %r yet -- run one eager step before capturing" % key)
+        rec[key] = t.detach().clone()
+    else:
+        buf.copy_(t)
+
+
 class _AnchorTargetLayer(nn.Module):
     def __init__(self, feat_stride, scales, ratios):
         super().__init__()
@@ -26,6 +37,10 @@ class _AnchorTargetLayer(nn.Module):
         self._allowed_border = 0
         self._cache = {}
         self.device_sampling = False     # True: subsample on the device (capturable), torch's generator
+        # parity instrumentation: ``sample_record`` = {} -> the subsampled labels of every call are copied into it (static
+        # tensors, so a captured step records too); ``sample_replay`` = such a dict -> its labels are used instead of drawing
+        self.sample_record = None
+        self.sample_replay = None
         self.image_size = None           # (h, w) of im_info[0] known on the host: skips the .tolist() synchronisation
 
     def _anchors_for(self, H, W, imh, imw, device):
@@ -59,7 +74,10 @@ class _AnchorTargetLayer(nn.Module):
             labels = torch.where(max_ov < T.RPN_NEGATIVE_OVERLAP, zero, labels)
         num_fg = int(T.RPN_FG_FRACTION * T.RPN_BATCHSIZE)
         assert T.RPN_POSITIVE_WEIGHT < 0, "only the uniform weighting of the reference recipes is supported"
-        if self.device_sampling:
+        if self.sample_replay is not None:
+            labels = self.sample_replay["labels"].to(device=dev, dtype=labels.dtype)
+            w = 1.0 / (labels[B - 1] >= 0).sum().float()
+        elif self.device_sampling:
             labels = self._subsample_device(labels, num_fg, int(T.RPN_BATCHSIZE))
             w = 1.0 / (labels[B - 1] >= 0).sum().float()
         else:
@@ -76,6 +94,8 @@ class _AnchorTargetLayer(nn.Module):
                     lab[i, bg[np.random.permutation(bg.size)[:bg.size - num_bg]]] = -1
             w = 1.0 / float((lab[B - 1] >= 0).sum())
             labels = torch.from_numpy(lab).to(dev)
+        if self.sample_record is not None:
+            record_sample(self.sample_record, "labels", labels)
         gt_sel = torch.gather(gt_boxes[:, :, :4], 1, argmax.long().unsqueeze(2).expand(-1, -1, 4))
         tg = bbox_transform_batch(anc, gt_sel)
         inw = (labels == 1).float() * T.RPN_BBOX_INSIDE_WEIGHTS[0]

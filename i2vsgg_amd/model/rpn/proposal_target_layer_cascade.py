@@ -19,6 +19,8 @@ class _ProposalTargetLayer(nn.Module):
         self.BBOX_NORMALIZE_STDS = torch.FloatTensor(cfg.TRAIN.BBOX_NORMALIZE_STDS)
         self.BBOX_INSIDE_WEIGHTS = torch.FloatTensor(cfg.TRAIN.BBOX_INSIDE_WEIGHTS)
         self.device_sampling = False     # True: sample on the device from torch's generator (capturable; see _sample_device)
+        self.sample_record = None        # parity instrumentation, as in _AnchorTargetLayer: {} -> (keep, nfg) of every call
+        self.sample_replay = None        # such a dict -> used instead of drawing
         self._const = {}                 # device copies of the three constant vectors (an H2D copy cannot be captured)
 
     def _c(self, name, dev):
@@ -37,8 +39,16 @@ class _ProposalTargetLayer(nn.Module):
         R = int(T.BATCH_SIZE)
         fg_per = int(np.round(T.FG_FRACTION * R)) or 1
         _, max_ov, assign = ops.bbox_overlaps(all_rois, gt_boxes)
+        if self.sample_replay is not None:
+            keep, nfg = self.sample_replay["keep"].to(dev), self.sample_replay["nfg"].to(dev)
+            return self._emit(all_rois, gt_boxes, assign, keep, nfg, R)
         if self.device_sampling:
             keep, nfg = self._sample_device(max_ov, R, fg_per)
+            if self.sample_record is not None:
+                from .anchor_target_layer import record_sample
+                record_sample(self.sample_record, "keep", keep)
+                record_sample(self.sample_record, "nfg", nfg)
+                record_sample(self.sample_record, "max_ov", max_ov)
             return self._emit(all_rois, gt_boxes, assign, keep, nfg, R)
         mo = max_ov.cpu().numpy()                                                 # the one D2H (B x (P+G) floats)
         keep_all, nfg_all = [], []

@@ -1156,8 +1156,10 @@ class InstanceStyleDStep:
         if stage_synthetic:           # a loop fed by data loaders stages its own first minibatch (``stage_batch``)
             self.reseed(seed)
         self.opt = make_optimizer(optimizer, list(net.named_parameters()), lr)
+        # total, det = the four detection losses summed, the four discriminator terms (trainval_net_instance...:276-296), then the
+        # four detection losses one by one (rpn_loss_cls, rpn_loss_box, RCNN_loss_cls, RCNN_loss_bbox: :276-279)
         self.names = ["total", "det", "dloss_s", "dloss_t", "dloss_s_style", "dloss_t_style"] + \
-            (["source_adv_cst", "target_adv_cst"] if cr else [])
+            (["source_adv_cst", "target_adv_cst"] if cr else []) + ["rpn_cls", "rpn_box", "rcnn_cls", "rcnn_box"]
         self._loss_buf = torch.zeros((len(self.names),), device=self.dev)           # static addresses: a captured step writes here
         self.losses = {k: self._loss_buf[i] for i, k in enumerate(self.names)}      # (views: one stack + one copy per step)
         self.graph_error = None
@@ -1265,7 +1267,8 @@ class InstanceStyleDStep:
             else:
                 out = net(self.im_s, self.info, self.gt, self.nb, target=False, eta=self.eta, eta_style=self.eta_style)
             _, _, _, l_rpn_cls, l_rpn_box, l_cls, l_box, _, d_inst, d_style = out
-            loss = _mean1(l_rpn_cls) + _mean1(l_rpn_box) + _mean1(l_cls) + _mean1(l_box)
+            parts = dict(rpn_cls=_mean1(l_rpn_cls), rpn_box=_mean1(l_rpn_box), rcnn_cls=_mean1(l_cls), rcnn_box=_mean1(l_box))
+            loss = parts["rpn_cls"] + parts["rpn_box"] + parts["rcnn_cls"] + parts["rcnn_box"]
             dloss_s = ops.half_mse(d_inst)                  # 0.5 * mean(d^2) (:276-277), one kernel each way
             dloss_s_style = ops.half_mse(d_style)
             if batched:
@@ -1277,7 +1280,7 @@ class InstanceStyleDStep:
             dloss_t = ops.half_mse(d_inst_t, 1.0)           # 0.5 * mean((1 - d)^2) (:294-295)
             dloss_t_style = ops.half_mse(d_style_t, 1.0)
             total = loss + dloss_s + dloss_t + self.style_lambda * (dloss_s_style + dloss_t_style)
-            vals = dict(det=loss, dloss_s=dloss_s, dloss_t=dloss_t, dloss_s_style=dloss_s_style, dloss_t_style=dloss_t_style)
+            vals = dict(det=loss, dloss_s=dloss_s, dloss_t=dloss_t, dloss_s_style=dloss_s_style, dloss_t_style=dloss_t_style, **parts)
             if self.cr:
                 cst = consistency_terms(d_inst, d_style, d_inst_t, d_style_t)
                 total = total + cst["source_adv_cst"] + cst["target_adv_cst"]
@@ -1315,8 +1318,9 @@ class InstanceStyleDStep:
         def source():
             out = net(self.im_s, self.info, self.gt, self.nb, target=False, eta=self.eta, eta_style=self.eta_style)
             _, _, _, l_rpn_cls, l_rpn_box, l_cls, l_box, _, d_inst, d_style = out
-            v = {"det": _mean1(l_rpn_cls) + _mean1(l_rpn_box) + _mean1(l_cls) + _mean1(l_box),
-                 "dloss_s": ops.half_mse(d_inst), "dloss_s_style": ops.half_mse(d_style)}
+            v = dict(rpn_cls=_mean1(l_rpn_cls), rpn_box=_mean1(l_rpn_box), rcnn_cls=_mean1(l_cls), rcnn_box=_mean1(l_box))
+            v.update({"det": v["rpn_cls"] + v["rpn_box"] + v["rcnn_cls"] + v["rcnn_box"],
+                      "dloss_s": ops.half_mse(d_inst), "dloss_s_style": ops.half_mse(d_style)})
             part = v["det"] + v["dloss_s"] + self.style_lambda * v["dloss_s_style"]
             if self.cr:
                 v["source_adv_cst"] = _consistency_term(d_inst, d_style)

@@ -650,6 +650,46 @@ def test_detection_postprocess_vs_oracle(ops, oracle, R, C, agnostic, thresh, ma
         assert np.array_equal(dets[j, :counts[j]], want[j]), j
 
 
+@pytest.mark.parametrize("tag", ["c16", "c8_t05", "c16_cag"])
+def test_detection_postprocess_vs_reference_golden(ops, gold, tag):
+    """Row f1 against the reference itself: tests/golden/det_postprocess.npz is the loop of
+    test_net_instance_styleD_bilinear.py:151-221 run with the reference's own bbox_transform_inv / clip_boxes / nms_cpu
+    (tools/gen_golden.py, tier "direct").  The device pass gives the same detections per class in the same order, bit-equal scores,
+    boxes within one ulp of torch's vectorised fp32 exp (the kernel rounds exp once from fp64, as test_rpn_decode documents)."""
+    g = gold("det_postprocess")
+    im_h, im_w, scale, agnostic, thresh, nms_t, maxdet = (float(v) for v in g[tag + "_args"])
+    dets, counts = ops.detection_postprocess(*(torch.from_numpy(g[tag + k]).to(DEV) for k in ("_rois", "_prob", "_pred")), im_h, im_w,
+                                             scale, bool(agnostic), (0.1, 0.1, 0.2, 0.2), (0.0, 0.0, 0.0, 0.0), thresh, nms_t, int(maxdet))
+    counts, dets = counts.cpu().numpy(), dets.cpu().numpy()
+    want_counts = g[tag + "_count"]
+    assert np.array_equal(counts[:len(want_counts)], want_counts) and int(want_counts.sum()) == 100
+    ends = np.cumsum(want_counts)
+    for j in range(1, len(want_counts)):
+        want = g[tag + "_dets"][ends[j] - want_counts[j]:ends[j]]
+        got = dets[j, :counts[j]]
+        assert np.array_equal(got[:, 4], want[:, 4]), j
+        np.testing.assert_allclose(got[:, :4], want[:, :4], rtol=3e-7, atol=1e-4)
+
+
+@pytest.mark.parametrize("tag", ["b9", "b5", "b16", "b1"])
+def test_detection_output_vs_reference_golden(gold, tag):
+    """Row f3 against the reference itself: tests/golden/detection_output.npz is lib/utils.py:584-628 compiled from its own lines
+    and run (tier "extracted").  eval.detection_output (i2v_relation_topk on the device) returns the same top-100 triplets in the
+    same order with bit-equal confidences and boxes; a one-box frame gives five Nones."""
+    from i2vsgg_amd import eval as ev
+    g = gold("detection_output")
+    vrd = {"bboxes": g[tag + "_bboxes"], "classes": g[tag + "_classes"], "scores": g[tag + "_scores"], "ixs": g[tag + "_ixs"],
+           "ixo": g[tag + "_ixo"], "rel_score": torch.from_numpy(g[tag + "_rel_score"]).to(DEV)}
+    got = ev.detection_output(vrd, 100)
+    if tag + "_none" in g.files:
+        assert got == (None,) * 5
+        return
+    rlp, conf, sub, obj, idx = got
+    assert np.array_equal(idx, g[tag + "_idx"]) and np.array_equal(rlp, g[tag + "_rlp"])
+    assert np.array_equal(conf, g[tag + "_conf"])
+    assert np.array_equal(sub, g[tag + "_sub"]) and np.array_equal(obj, g[tag + "_obj"])
+
+
 @pytest.mark.parametrize("H,W,target,flip,rgb", [(375, 500, 600, False, True), (480, 640, 600, True, True),
                                                  (720, 1280, 600, False, False), (500, 375, 600, True, True),
                                                  (33, 47, 20, False, True)])

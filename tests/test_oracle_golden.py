@@ -195,6 +195,51 @@ def test_vrd_head(gold):
     np.testing.assert_allclose(p["vrd.fc6.fc.weight"].grad.numpy()[:4, ::97], g["g_fc6_w"], rtol=1e-3, atol=1e-10)
 
 
+def _split_dets(g, tag):
+    counts = g[tag + "_count"]
+    flat = g[tag + "_dets"]
+    ends = np.cumsum(counts)
+    return [flat[e - c:e] for c, e in zip(counts, ends)]
+
+
+@pytest.mark.parametrize("tag", ["c16", "c8_t05", "c16_cag"])
+def test_detection_loop_vs_reference_pieces(gold, tag):
+    """Row f1: oracle.rpn.detection_postprocess against tests/golden/det_postprocess.npz -- the loop of
+    test_net_instance_styleD_bilinear.py:151-221 executed with the reference's bbox_transform_inv / clip_boxes / nms_cpu
+    (tools/gen_golden.py, tier "direct").  Same detections per class in the same order; scores bit-equal; boxes within one ulp
+    of torch's vectorised fp32 exp (the oracle rounds exp once from fp64, tests/test_oracle_golden.py::test_decode_clip)."""
+    g = gold("det_postprocess")
+    assert str(g["tier"]) == "direct"
+    im_h, im_w, scale, agnostic, thresh, nms_t, maxdet = g[tag + "_args"]
+    got = rpn.detection_postprocess(g[tag + "_rois"], g[tag + "_prob"], g[tag + "_pred"], im_h, im_w, scale, bool(agnostic),
+                                    (0.1, 0.1, 0.2, 0.2), (0.0, 0.0, 0.0, 0.0), thresh, nms_t, int(maxdet))
+    want = _split_dets(g, tag)
+    assert [len(a) for a in got] == [len(a) for a in want]
+    assert sum(len(a) for a in want) == 100
+    for j, (a, b) in enumerate(zip(got, want)):
+        assert np.array_equal(a[:, 4], b[:, 4]), j
+        np.testing.assert_allclose(a[:, :4], b[:, :4], rtol=3e-7, atol=1e-4)
+
+
+@pytest.mark.parametrize("tag", ["b9", "b5", "b16", "b1"])
+def test_detection_output_vs_reference_function(gold, tag):
+    """Row f3: oracle.nets.detection_output against tests/golden/detection_output.npz -- lib/utils.py:584-628 compiled from its
+    own lines and run (tier "extracted": the module has a module-level json.load of an absolute path and cannot be imported;
+    np.float restored for the call).  Tie-free confidences: same triplets, order, confidences (bit-equal) and boxes."""
+    g = gold("detection_output")
+    assert str(g["tier"]) == "extracted"
+    vrd = {"bboxes": g[tag + "_bboxes"], "classes": g[tag + "_classes"], "scores": g[tag + "_scores"], "ixs": g[tag + "_ixs"],
+           "ixo": g[tag + "_ixo"], "rel_score": g[tag + "_rel_score"]}
+    got = nets.detection_output(vrd, 100)
+    if tag + "_none" in g.files:
+        assert got == (None,) * 5
+        return
+    rlp, conf, sub, obj, idx = got
+    assert np.array_equal(rlp, g[tag + "_rlp"]) and np.array_equal(idx, g[tag + "_idx"])
+    assert np.array_equal(conf, g[tag + "_conf"]) and conf.dtype == g[tag + "_conf"].dtype
+    assert np.array_equal(sub, g[tag + "_sub"]) and np.array_equal(obj, g[tag + "_obj"])
+
+
 def test_avgpool_matches_torch():
     x = np.random.default_rng(5).standard_normal((3, 5, 8, 8), dtype=np.float32)
     ref = torch.nn.functional.avg_pool2d(torch.from_numpy(x), 2, 1).numpy()

@@ -9,6 +9,9 @@ regenerate).
 Two tiers, recorded per file in the ``tier`` field:
   "direct"       the reference module imports as shipped (sys.path only):
                  rpn/generate_anchors.py, rpn/bbox_transform.py, nms/nms_cpu.py
+  "extracted"    lib/utils.py:584-628 ``detection_output``: the module cannot be imported (a module-level json.load of an
+                 absolute path), so the function's own lines are compiled from the file and run unmodified, with the
+                 ``np.float`` alias numpy 1.24 removed restored for the call
   "placeholders" the module imports after registering in-process placeholders for
                  three third-party packages absent from this image and for the
                  reference's un-buildable compiled extensions:
@@ -92,6 +95,122 @@ def gen_direct():
                 keep = nms_cpu(torch.from_numpy(dets), th).numpy().astype(np.int32)
                 out["n%d_%s_t%02d" % (n, "c" if clustered else "u", int(th * 10))] = keep
     save("nms_keep", "direct", **out)
+
+
+# ----------------------------------------------------------------------------- the two eval tails
+def gen_eval_tails():
+    """f1: the per-image detection loop of test_net_instance_styleD_bilinear.py:151-221 driven with the reference's own
+    importable pieces (bbox_transform_inv, clip_boxes, nms_cpu -- what model.nms.nms_wrapper.nms always calls) in the loop's
+    order.  The loop itself lives in a script that needs a dataset and a checkpoint, so its control flow is restated here, line
+    by line; every arithmetic step is the reference's function.  Tier "direct".
+    f3: lib/utils.py:584-628 ``detection_output``.  lib/utils.py cannot be imported (a module-level json.load of an absolute
+    path, :34-35), so the function's own source lines are compiled from the file (ast) and run unmodified; it spells the
+    float64 dtype ``np.float``, an alias numpy removed in 1.24 -- restored for the call.  Tier "extracted"."""
+    import ast
+    from model.rpn import bbox_transform as bt
+    from model.nms.nms_cpu import nms_cpu
+
+    def nms(dets, thresh):                                  # nms_wrapper.py:13-20
+        if dets.shape[0] == 0:
+            return []
+        return nms_cpu(dets.cpu(), thresh)
+
+    out = {}
+    for tag, (C, R, thresh, scale, agnostic) in {"c16": (16, 300, 0.0, 1.6, False), "c8_t05": (8, 120, 0.05, 1.0, False),
+                                                 "c16_cag": (16, 300, 0.0, 1.25, True)}.items():
+        rng = np.random.default_rng(900 + C + R)
+        im_h, im_w = 600.0, 1000.0
+        xy = rng.uniform(0, 1, (R, 2)) * [im_w - 120, im_h - 120]
+        wh = rng.uniform(16, 300, (R, 2))
+        rois = np.concatenate([np.zeros((R, 1)), xy, np.minimum(xy + wh, [im_w - 1, im_h - 1])], 1).astype(np.float32)
+        logits = (rng.standard_normal((R, C)) * 2).astype(np.float32)
+        prob = torch.softmax(torch.from_numpy(logits), 1).numpy()
+        assert len(np.unique(prob)) == prob.size                         # tie-free scores
+        pred = (rng.standard_normal((R, 4 if agnostic else 4 * C)) * 0.5).astype(np.float32)
+        stds, means = (0.1, 0.1, 0.2, 0.2), (0.0, 0.0, 0.0, 0.0)         # cfg.TRAIN.BBOX_NORMALIZE_STDS / _MEANS
+        # ---- :151-171
+        scores = torch.from_numpy(prob).view(1, R, C)
+        boxes = torch.from_numpy(rois).view(1, R, 5)[:, :, 1:5]
+        im_info = torch.tensor([[im_h, im_w, scale]])
+        box_deltas = torch.from_numpy(pred).view(1, R, -1)
+        box_deltas = box_deltas.view(-1, 4) * torch.FloatTensor(stds) + torch.FloatTensor(means)
+        box_deltas = box_deltas.view(1, -1, 4) if agnostic else box_deltas.view(1, -1, 4 * C)
+        pred_boxes = bt.bbox_transform_inv(boxes, box_deltas, 1)
+        pred_boxes = bt.clip_boxes(pred_boxes, im_info, 1)
+        pred_boxes /= im_info[0][2].item()
+        scores = scores.squeeze()
+        pred_boxes = pred_boxes.squeeze()
+        # ---- :181-207
+        all_boxes = [np.zeros((0, 5), np.float32)]
+        for j in range(1, C):
+            inds = torch.nonzero(scores[:, j] > thresh).view(-1)
+            if inds.numel() > 0:
+                cls_scores = scores[:, j][inds]
+                _, order = torch.sort(cls_scores, 0, True)
+                cls_boxes = pred_boxes[inds, :] if agnostic else pred_boxes[inds][:, j * 4:(j + 1) * 4]
+                cls_dets = torch.cat((cls_boxes, cls_scores.unsqueeze(1)), 1)
+                cls_dets = cls_dets[order]
+                keep = nms(cls_dets, 0.3)                   # cfg.TEST.NMS
+                cls_dets = cls_dets[keep.view(-1).long()]
+                all_boxes.append(cls_dets.cpu().numpy())
+            else:
+                all_boxes.append(np.zeros((0, 5), np.float32))
+        # ---- :214-221
+        max_per_image = 100
+        image_scores = np.hstack([all_boxes[j][:, -1] for j in range(1, C)])
+        before = len(image_scores)
+        if len(image_scores) > max_per_image:
+            image_thresh = np.sort(image_scores)[-max_per_image]
+            for j in range(1, C):
+                keepj = np.where(all_boxes[j][:, -1] >= image_thresh)[0]
+                all_boxes[j] = all_boxes[j][keepj, :]
+        out[tag + "_rois"], out[tag + "_prob"], out[tag + "_pred"] = rois, prob, pred
+        out[tag + "_args"] = np.array([im_h, im_w, scale, float(agnostic), thresh, 0.3, max_per_image], np.float64)
+        out[tag + "_count"] = np.array([a.shape[0] for a in all_boxes], np.int32)
+        out[tag + "_dets"] = np.concatenate(all_boxes, 0).astype(np.float32)
+        print("    detection loop %-8s %3d rois x %2d classes: %4d detections after NMS, %3d kept" % (
+            tag, R, C, before, out[tag + "_dets"].shape[0]))
+    save("det_postprocess", "direct", **out)
+
+    # ---- f3: detection_output, compiled from its own lines of lib/utils.py
+    path = os.path.join(REF, "lib", "utils.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "detection_output")
+    assert (fn.lineno, fn.end_lineno) == (584, 627), (fn.lineno, fn.end_lineno)      # :628 is the blank line after the return
+    ns = {"np": np}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, "exec"), ns)
+    detection_output = ns["detection_output"]
+    had = hasattr(np, "float")
+    if not had:
+        np.float = float                                    # the alias numpy 1.24 removed (the function's dtype spelling)
+    try:
+        out = {}
+        for tag, (nb, nrel) in {"b9": (9, 26), "b5": (5, 26), "b16": (16, 62), "b1": (1, 26)}.items():
+            rng = np.random.default_rng(77 + nb)
+            xy = rng.uniform(0, 400, (nb, 2))
+            bboxes = np.concatenate([xy, xy + rng.uniform(20, 200, (nb, 2))], 1)
+            classes = rng.integers(1, 16, nb)
+            confs = rng.uniform(0.05, 1.0, nb).astype(np.float32)
+            pairs = [(i, j) for i in range(nb) for j in range(nb) if i != j]        # faster_rcnn_SGG_emb.py:597-606
+            ixs, ixo = np.array([p[0] for p in pairs], np.int64), np.array([p[1] for p in pairs], np.int64)
+            rel = torch.softmax(torch.from_numpy(rng.standard_normal((max(len(pairs), 1), nrel)).astype(np.float32) * 2), 1)
+            vrd_data = {"bboxes": bboxes, "classes": classes, "scores": confs, "ixs": ixs, "ixo": ixo, "rel_score": rel.clone(),
+                        "rel_so_prior": None}
+            res = detection_output(vrd_data)
+            out[tag + "_bboxes"], out[tag + "_classes"], out[tag + "_scores"] = bboxes, classes, confs
+            out[tag + "_ixs"], out[tag + "_ixo"], out[tag + "_rel_score"] = ixs, ixo, rel.numpy()
+            if res[0] is None:
+                out[tag + "_none"] = np.array(1)
+                continue
+            rlp, conf, sub, obj, idx = res
+            assert len(np.unique(conf)) == conf.size        # tie-free ranking
+            out[tag + "_rlp"], out[tag + "_conf"], out[tag + "_sub"], out[tag + "_obj"], out[tag + "_idx"] = rlp, conf, sub, obj, idx
+            print("    detection_output %-4s %2d boxes, %3d pairs x %2d predicates -> %3d triplets, best %.4f" % (
+                tag, nb, len(pairs), nrel, conf.size, conf[0]))
+    finally:
+        if not had:
+            del np.float
+    save("detection_output", "extracted", **out)
 
 
 # ----------------------------------------------------------------------------- placeholders
@@ -447,10 +566,13 @@ def main():
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
-    todo = a.only.split(",") if a.only else ["direct", "rpn", "nets", "full", "ctx", "vrd"]
+    todo = a.only.split(",") if a.only else ["direct", "tails", "rpn", "nets", "full", "ctx", "vrd"]
     if "direct" in todo:
         print("[direct imports]")
         gen_direct()
+    if "tails" in todo:
+        print("[eval tails: direct imports + detection_output compiled from its own lines]")
+        gen_eval_tails()
     if any(t in todo for t in ("rpn", "nets", "full", "vrd", "ctx")):
         print("[imports with placeholders]")
         cfg = install_placeholders()
