@@ -78,7 +78,7 @@ SIGNATURES = {
     "i2v_sgd_momentum": (_i, [_p, _p, _p, _l, _f, _f, _f, _p]),
     "i2v_sgd_momentum_multi": (_i, [_p, _p, _p, _p, _p, _p, _i, _f, _p]),
     "i2v_adam_step": (_i, [_p, _p]),
-    "i2v_adam_multi": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _f, _f, _f, _p, _p]),
+    "i2v_adam_multi": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, C.c_double, C.c_double, C.c_double, _p, _p]),
     "i2v_dstyle_pool_fwd": (_i, [_p, _p, _p, _l, _i, _i, _i, _p]),
     "i2v_dstyle_pool_bwd": (_i, [_p, _p, _p, _p, _p, _l, _i, _i, _i, _p]),
     "i2v_dstyle_fused_workspace_bytes": (_z, [_l, _i, _i, _i]),

@@ -2150,10 +2150,11 @@ __global__ void __launch_bounds__(256) sgd_momentum_multi_kernel(const SgdMulti 
 struct AdamMulti {
     float* p[SGD_MULTI_MAX]; const float* g[SGD_MULTI_MAX]; float* m[SGD_MULTI_MAX]; float* v[SGD_MULTI_MAX];
     long long n[SGD_MULTI_MAX];
-    float lr[SGD_MULTI_MAX], wd[SGD_MULTI_MAX];
+    double lr[SGD_MULTI_MAX];
+    float wd[SGD_MULTI_MAX];
     int first_block[SGD_MULTI_MAX + 1];
     int count;
-    float b1, b2, eps;
+    double b1, b2, eps;          // the betas / eps as the host holds them (Python floats are doubles)
     const int* step;
 };
 __global__ void adam_step_kernel(int* step) { *step += 1; }
@@ -2162,19 +2163,22 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(const AdamMulti t) {
     while (k + 1 < t.count && (int)blockIdx.x >= t.first_block[k + 1]) ++k;
     const long long base = (long long)(blockIdx.x - t.first_block[k]) * SGD_MULTI_PER_BLOCK;
     float* p = t.p[k]; const float* g = t.g[k]; float* m = t.m[k]; float* v = t.v[k];
-    const float wd = t.wd[k], b1 = t.b1, b2 = t.b2, eps = t.eps;
-    const float st = (float)*t.step;
-    const float bc1 = 1.0f - powf(b1, st), bc2_sqrt = sqrtf(1.0f - powf(b2, st));
-    const float step_size = t.lr[k] / bc1;
+    // torch.optim.Adam (_single_tensor_adam) computes the scalars of a step on the host in DOUBLE: bias_correction = 1 - beta ** step,
+    // step_size = lr / bias_correction1, bias_correction2_sqrt = bias_correction2 ** 0.5 -- and hands the tensor kernels their
+    // float roundings.  The same here, once per workgroup (round-3 advice: powf on float betas is off by ~3e-5 at small t).
+    const double st = (double)*t.step;
+    const double bc1 = 1.0 - pow(t.b1, st), bc2 = 1.0 - pow(t.b2, st);
+    const float step_size = (float)(t.lr[k] / bc1), bc2_sqrt = (float)sqrt(bc2);
+    const float w1 = (float)(1.0 - t.b1), b2 = (float)t.b2, w2 = (float)(1.0 - t.b2), eps = (float)t.eps, wd = t.wd[k];
     for (int j = threadIdx.x; j < SGD_MULTI_PER_BLOCK; j += 256) {
         const long long i = base + j;
         if (i >= t.n[k]) break;
-        const float gp = g[i] + wd * p[i];
-        const float mv = m[i] + (1.0f - b1) * (gp - m[i]);
-        const float vv = b2 * v[i] + (1.0f - b2) * gp * gp;
+        const float gp = g[i] + wd * p[i];                    // grad.add(param, alpha=weight_decay)
+        const float mv = m[i] + w1 * (gp - m[i]);             // exp_avg.lerp_(grad, 1 - beta1)
+        const float vv = b2 * v[i] + w2 * gp * gp;            // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value=1 - beta2)
         m[i] = mv;
         v[i] = vv;
-        p[i] -= step_size * (mv / (sqrtf(vv) / bc2_sqrt + eps));
+        p[i] -= step_size * (mv / (sqrtf(vv) / bc2_sqrt + eps));      // param.addcdiv_(exp_avg, denom, value=-step_size)
     }
 }
 
@@ -2579,11 +2583,10 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, const flo
 
 // gw[z] (N x K) = gy[z]^T (M x N) . x[z] (M x K) for z < nbatch: the element-wise planes of a Winograd filter gradient
 // (csrc/winograd.hip).  gw is overwritten; the batches of gw must be contiguous when the reduction is split (one clear).
-static thread_local float g_tn_beta = 0.f;      // i2v_gemm_tn_batched_acc
-
-extern "C" int32_t i2v_gemm_tn_batched(const float* x, const float* gy, float* gw, int32_t M, int32_t N, int32_t K,
-                                       int32_t nbatch, long long stride_x, long long stride_gy, long long stride_gw,
-                                       void* stream) {
+// beta is an explicit argument of the shared implementation (round-3 advice: the accumulating entry point used to pass it
+// through a thread_local global, where an early return could have left it at 1).
+static int32_t gemm_tn_batched_impl(const float* x, const float* gy, float* gw, int32_t M, int32_t N, int32_t K, int32_t nbatch,
+                                    long long stride_x, long long stride_gy, long long stride_gw, float beta, void* stream) {
     I2V_CHECK_ARG(x && gy && gw && M > 0 && N > 0 && K > 0 && nbatch > 0, "gemm_tn_batched: bad argument");
     I2V_CHECK_ARG(N % 4 == 0 && K % 4 == 0, "gemm_tn_batched: N and K must be multiples of 4");
     I2V_CHECK_ARG(nbatch == 1 || stride_gw == (long long)N * K, "gemm_tn_batched: gw batches must be contiguous");
@@ -2598,19 +2601,22 @@ extern "C" int32_t i2v_gemm_tn_batched(const float* x, const float* gy, float* g
         i2v_set_error("gemm_tn_batched: operand larger than 2 GiB per batch");
         return I2V_ERR_UNSUPPORTED;
     }
-    launch_wgrad(p, g_tn_beta, false, (hipStream_t)stream);
+    launch_wgrad(p, beta, false, (hipStream_t)stream);
     I2V_CHECK_LAUNCH("gemm_tn_batched");
     return I2V_OK;
+}
+
+extern "C" int32_t i2v_gemm_tn_batched(const float* x, const float* gy, float* gw, int32_t M, int32_t N, int32_t K,
+                                       int32_t nbatch, long long stride_x, long long stride_gy, long long stride_gw,
+                                       void* stream) {
+    return gemm_tn_batched_impl(x, gy, gw, M, N, K, nbatch, stride_x, stride_gy, stride_gw, 0.f, stream);
 }
 
 // The same accumulating into gw (gw += sum; the caller has cleared or pre-loaded it): no memset node in front.
 extern "C" int32_t i2v_gemm_tn_batched_acc(const float* x, const float* gy, float* gw, int32_t M, int32_t N, int32_t K,
                                            int32_t nbatch, long long stride_x, long long stride_gy, long long stride_gw,
                                            void* stream) {
-    g_tn_beta = 1.f;
-    const int32_t rc = i2v_gemm_tn_batched(x, gy, gw, M, N, K, nbatch, stride_x, stride_gy, stride_gw, stream);
-    g_tn_beta = 0.f;
-    return rc;
+    return gemm_tn_batched_impl(x, gy, gw, M, N, K, nbatch, stride_x, stride_gy, stride_gw, 1.f, stream);
 }
 
 extern "C" int32_t i2v_conv_wgrad(const float* x, const float* gy, float* gw, int32_t B, int32_t H, int32_t W,
@@ -2727,8 +2733,8 @@ extern "C" int32_t i2v_adam_step(int32_t* step_counter, void* stream) {
 }
 
 extern "C" int32_t i2v_adam_multi(float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n,
-                                  const float* lr, const float* weight_decay, int32_t count, float beta1, float beta2,
-                                  float eps, const int32_t* step_counter, void* stream) {
+                                  const double* lr, const float* weight_decay, int32_t count, double beta1, double beta2,
+                                  double eps, const int32_t* step_counter, void* stream) {
     I2V_CHECK_ARG(count >= 0 && step_counter && (count == 0 || (p && g && m && v && n && lr && weight_decay)), "adam_multi: bad argument");
     for (int32_t c0 = 0; c0 < count;) {
         AdamMulti t;

@@ -1168,7 +1168,7 @@ def adam_multi_(ps, gs, ms, vs, lrs, wds, betas, eps, step_counter):
     _need_cuda(*ps, *gs, *ms, *vs, step_counter)
     arr = lambda ts: (ctypes.c_void_p * n)(*[t.data_ptr() for t in ts])
     arr_n = (ctypes.c_int64 * n)(*[t.numel() for t in ps])
-    arr_lr = (ctypes.c_float * n)(*[float(v) for v in lrs])
+    arr_lr = (ctypes.c_double * n)(*[float(v) for v in lrs])
     arr_wd = (ctypes.c_float * n)(*[float(v) for v in wds])
     check(lib.i2v_adam_multi(arr(ps), arr(gs), arr(ms), arr(vs), arr_n, arr_lr, arr_wd, n, float(betas[0]), float(betas[1]),
                              float(eps), ptr(step_counter), stream()), "adam_multi")

@@ -204,9 +204,12 @@ class FusedAdam(FusedSGD):
         return [it["m"] for it in self.items] + [it["v"] for it in self.items] + [self.t]
 
     def state_dict(self):
+        # torch.optim.Adam holds state only for parameters that have received a gradient (round-3 advice); its per-parameter
+        # ``step`` is one shared device counter here -- every trained parameter of the two reference models gets a gradient
+        # every step, so the two agree
         step = float(self.t.item())
         return {"state": {i: {"step": torch.tensor(step), "exp_avg": it["m"].detach().clone(), "exp_avg_sq": it["v"].detach().clone()}
-                          for i, it in enumerate(self.items)},
+                          for i, it in enumerate(self.items) if it.get("seen")},
                 "param_groups": [{"lr": it["lr"], "betas": self.betas, "eps": self.eps, "weight_decay": it["wd"], "amsgrad": False,
                                   "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
                                   "params": [i], "name": it["name"]} for i, it in enumerate(self.items)]}
@@ -227,9 +230,11 @@ class FusedAdam(FusedSGD):
                 it["m"].copy_(st["exp_avg"].reshape(it["m"].shape))
                 it["v"].copy_(st["exp_avg_sq"].reshape(it["v"].shape))
                 step = max(step, float(st.get("step", 0.0)))
+                it["seen"] = True
             else:
                 it["m"].zero_()
                 it["v"].zero_()
+                it["seen"] = False
         self.t.fill_(int(step))
 
     def scale_lr(self, k):
@@ -245,6 +250,7 @@ class FusedAdam(FusedSGD):
                 continue
             if g.stride() != p.stride() and not _same_memory_order(p, g):
                 g = torch.empty_like(p).copy_(g)
+            it["seen"] = True
             live.append((p, g, it))
         if not live:
             return

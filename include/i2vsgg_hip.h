@@ -493,8 +493,10 @@ int32_t i2v_sgd_momentum_multi(float* const* p, const float* const* g, float* co
  * i2v_adam_step increments (once per optimizer step, before the i2v_adam_multi launches of that step): a captured
  * training step then replays with the right bias corrections. */
 int32_t i2v_adam_step(int32_t* step_counter, void* stream);
+/* lr, beta1, beta2, eps are DOUBLES, as torch.optim.Adam holds them: its per-step scalars (1 - beta^t, lr / (1 - beta1^t),
+ * sqrt(1 - beta2^t)) are computed in double and rounded to float once; so are they here. */
 int32_t i2v_adam_multi(float* const* p, const float* const* g, float* const* m, float* const* v, const int64_t* n,
-                       const float* lr, const float* weight_decay, int32_t count, float beta1, float beta2, float eps,
+                       const double* lr, const float* weight_decay, int32_t count, double beta1, double beta2, double eps,
                        const int32_t* step_counter, void* stream);
 
 #ifdef __cplusplus

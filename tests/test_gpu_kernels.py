@@ -1356,11 +1356,14 @@ def test_fused_adam_equals_torch_adam():
 
     for k in range(5):
         one(k)
+        # the early steps are where a float32 bias correction shows (1 - 0.999f^t is off by ~3e-5 at t = 1; round-3 advice): the
+        # scalars of a step are computed in double as torch computes them, so the trajectories agree to rounding from step one
+        for p, q in zip(ps, qs):
+            assert _rel_err(p.detach().cpu().numpy(), q.detach().cpu().numpy()) < 5e-7, k
     assert int(opt.t.item()) == 5 and torch.equal(ps[4], qs[4])
-    for p, q in zip(ps, qs):
-        assert _rel_err(p.detach().cpu().numpy(), q.detach().cpu().numpy()) < 2e-6
-    # state_dict: torch.optim.Adam's layout, both ways
+    # state_dict: torch.optim.Adam's layout, both ways; no state for the parameter that never received a gradient
     sd = opt.state_dict()
+    assert 4 not in sd["state"] and set(sd["state"]) == set(ref.state_dict()["state"])
     ref2 = torch.optim.Adam([{"params": [q]} for q in qs])
     ref2.load_state_dict({"state": {i: st for i, st in sd["state"].items() if i != 4},
                           "param_groups": [{k: v for k, v in g.items() if k != "name"} for g in sd["param_groups"]]})
