@@ -703,8 +703,15 @@ conv_igemm_f32(const ConvP p_in) {
 // 32 k where the fp32 form needs eight 32-cycle ones, so the K loop costs 3/16 of its fp32 time; the dropped a_lo b_lo term is
 // 2^-16 of a product.  Inputs, outputs, accumulators and the epilogue stay fp32; the LDS row (32 k) keeps its 128 bytes
 // (16-byte columns 0-3 = hi of k 8c..8c+7, columns 4-7 = lo), the accumulator layout is that of every 16x16 MFMA.
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool CLK = false, bool MASK = false, bool X3 = false>
-__global__ void __launch_bounds__(THREADS)
+// KG > 1 (round 4): INTRA-WORKGROUP K split.  A GEMM too short in M x N to fill the chip (layer3 conv1 of a frame pair: 240
+// tiles of 80x64 for 1024 slots, K = 1024) used to run as 3 K-splits of 4 waves whose partial tiles crossed the fabric
+// (sc1 write-through + re-read by the last arriver: 14.7 + 9.8 MB per launch beside the layer's own 25.6 MB).  Here ONE
+// workgroup of KG x 4 waves owns the tile: wave group g stages and multiplies k in [g K/KG, (g+1) K/KG) in an LDS region of
+// its own, the groups' partial tiles meet in LDS (register order, conflict-free 16-byte rows) and group 0 adds them IN GROUP
+// ORDER ((p0 + p1) + p2) + p3 -- deterministic -- and runs the one fused epilogue.  Same waves per SIMD as four co-resident
+// split workgroups, no partial ever leaves the CU, no arrival counter.  K must be a multiple of KG x 32 (the host checks).
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool CLK = false, bool MASK = false, bool X3 = false, int KG = 1>
+__global__ void __launch_bounds__(THREADS * KG)
 conv_gemm_f32(const ConvP p_in) {
     ConvP p = p_in;
     // CLK: diagnostic instantiation (i2v_conv_debug_clock): per workgroup {start, end in 100 MHz ticks, prologue / K-loop /
@@ -719,11 +726,36 @@ conv_gemm_f32(const ConvP p_in) {
     constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
     constexpr int A_LD = (BM * 8 + THREADS - 1) / THREADS, B_LD = (BN * 8 + THREADS - 1) / THREADS;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    static_assert(KG == 1 || (!CLK && !X3), "the K-group form has no diagnostic / bf16-split instantiation");
+    // KG > 1: the four waves of a K group synchronise among THEMSELVES between stages (an arrival counter in LDS: release,
+    // add, poll, acquire) -- an s_barrier would march all 16 waves in lock step, every SIMD's four waves staging together and
+    // multiplying together; free-running groups drift apart like co-resident workgroups do, one group's staging under another's
+    // MFMAs.  The counters only grow (4 per barrier), so a fast wave's next arrival cannot release a slow wave early.
+    __shared__ int kcnt[KG > 1 ? KG : 1];
+    int kphase = 0;
+    auto stage_barrier = [&]() {
+        if constexpr (KG == 1) {
+            __syncthreads();
+        } else {
+            kphase += 4;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // my LDS stores have landed
+            if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(&kcnt[threadIdx.x >> 8], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__hip_atomic_load(&kcnt[threadIdx.x >> 8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < kphase)
+                __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    };
+    if constexpr (KG > 1) {
+        if (threadIdx.x < KG) kcnt[threadIdx.x] = 0;
+    }
+    constexpr int GROUP_FLOATS = 2 * (BM + BN) * BKS;          // one K group's two stage buffers
+    extern __shared__ __attribute__((aligned(16))) float smem_all[];
+    const int gid = KG > 1 ? (int)(threadIdx.x >> 8) : 0;      // K group of this wave (4 waves per group)
+    float* smem = smem_all + gid * GROUP_FLOATS;
     float (*As)[BM * BKS] = reinterpret_cast<float (*)[BM * BKS]>(smem);
     float (*Bs)[BN * BKS] = reinterpret_cast<float (*)[BN * BKS]>(smem + 2 * BM * BKS);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = KG > 1 ? (int)(threadIdx.x & (THREADS - 1)) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int fr = lane & 15, fg = lane >> 4;
     const int tiles_n = (p.N + BN - 1) / BN;
@@ -733,12 +765,13 @@ conv_gemm_f32(const ConvP p_in) {
         tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
     }
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-    const int kbeg = blockIdx.y * p.k_per_split;
-    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int kbeg = KG > 1 ? gid * (p.K / KG) : blockIdx.y * p.k_per_split;
+    const int kend = KG > 1 ? kbeg + p.K / KG : min(p.K, kbeg + p.k_per_split);
     const int kc = tid & 7, kg = kc * 4;
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
     constexpr unsigned INV = 0x80000000u;
+    const unsigned g0_inv = gid == 0 ? 0u : INV;               // only K group 0 runs the epilogue: the others fetch no operand of it
     unsigned a_vk[A_LD], b_vk[B_LD];
 #pragma unroll
     for (int q = 0; q < A_LD; ++q) {
@@ -816,9 +849,9 @@ conv_gemm_f32(const ConvP p_in) {
     const unsigned long long y_bytes = (unsigned long long)p.M * p.N * 4ull;
     const __amdgpu_buffer_rsrc_t resr = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.res ? p.res : (const float*)p.x), 0, (unsigned)(y_bytes < 0x7FFFFFF0ull ? y_bytes : 0x7FFFFFF0ull), 0x00020000);
-    const unsigned sc_inv = (p.flags & I2V_EPI_SCALE) ? 0u : INV;
-    const unsigned sh_inv = ((p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) && p.shift) ? 0u : INV;     // scale without shift: the data-gradient epilogue
-    const unsigned res_inv = ((p.flags & I2V_EPI_RESIDUAL) && !split) ? 0u : INV;
+    const unsigned sc_inv = ((p.flags & I2V_EPI_SCALE) ? 0u : INV) | g0_inv;
+    const unsigned sh_inv = (((p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) && p.shift) ? 0u : INV) | g0_inv;     // scale without shift: the data-gradient epilogue
+    const unsigned res_inv = (((p.flags & I2V_EPI_RESIDUAL) && !split) ? 0u : INV) | g0_inv;
     const __amdgpu_buffer_rsrc_t mskr = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(p.mask ? p.mask : (const float*)p.x), 0, (unsigned)(y_bytes < 0x7FFFFFF0ull ? y_bytes : 0x7FFFFFF0ull), 0x00020000);
     float4 sc[TN], sh[TN], rres[PREFETCH_RES ? TM : 1][PREFETCH_RES ? TN : 1];
@@ -899,15 +932,16 @@ conv_gemm_f32(const ConvP p_in) {
                     }
         }
     };
+    if constexpr (KG > 1) __syncthreads();           // the arrival counters are zero (the first stage's loads are in flight)
     sstore(0);
-    __syncthreads();
+    stage_barrier();
     if constexpr (CLK) c_t1 = __builtin_amdgcn_s_memtime();
     int buf = 0, k0 = kbeg;
     for (; k0 + 2 * BKS < kend; k0 += BKS) {          // every stage but the last two
         gload(k0 + BKS);
         compute(buf);
         sstore(buf ^ 1);
-        __syncthreads();
+        stage_barrier();
         buf ^= 1;
     }
     if (k0 + BKS < kend) {                            // two stages left: operands of the last one, then the residual tile
@@ -915,13 +949,38 @@ conv_gemm_f32(const ConvP p_in) {
         issue_res();
         compute(buf);
         sstore(buf ^ 1);
-        __syncthreads();
+        stage_barrier();
         buf ^= 1;
     } else {
         issue_res();
     }
     compute(buf);                                     // last stage (no barrier: nothing is staged after it)
     if constexpr (CLK) c_t2 = __builtin_amdgcn_s_memtime();
+    if constexpr (KG > 1) {
+        // the K groups' partial tiles meet in LDS: every group but the first leaves its accumulators in its own (now idle)
+        // stage region, in register order -- (fragment, wave, lane) x 16 bytes: whole-wave 1-KB rows both ways -- and group 0
+        // adds them in group order
+        static_assert(TM * TN * THREADS * 4 <= GROUP_FLOATS, "a partial tile fits a group's stage buffers");
+        __syncthreads();                              // every wave has read its last stage
+        if (gid > 0) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    *(f32x4*)&smem[(((i * TN + j) * 4 + wave) * 64 + lane) * 4] = acc[i][j];
+        }
+        __syncthreads();
+        if (gid > 0) return;
+#pragma unroll
+        for (int g = 1; g < KG; ++g)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const f32x4 t = *(const f32x4*)&smem_all[g * GROUP_FLOATS + (((i * TN + j) * 4 + wave) * 64 + lane) * 4];
+                    acc[i][j] = (f32x4){acc[i][j][0] + t[0], acc[i][j][1] + t[1], acc[i][j][2] + t[2], acc[i][j][3] + t[3]};
+                }
+    }
     auto stamp = [&]() {
         if constexpr (CLK) {
             __builtin_amdgcn_s_waitcnt(0);
@@ -1322,6 +1381,36 @@ void set_max_lds(K kernel) {
     (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
 }
 
+constexpr int kKGroups = 4;      // wave groups of the intra-workgroup K split (16 waves = 4 per SIMD, one workgroup per CU)
+
+// The intra-workgroup K split (conv_gemm_f32<.., KG = 4>): one workgroup of 16 waves per tile, four stage-buffer sets in LDS.
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+int launch_kgroups(const ConvP& p, hipStream_t st) {
+    constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
+    constexpr int need = kKGroups * 2 * (BM + BN) * BKS * 4;
+    static_assert(need <= 159 * 1024, "four stage-buffer sets fit the CU's LDS");
+    // exactly what the launch asks for: the kernel also has a few bytes of static LDS, and the attribute call fails (leaving
+    // the 64 KB default in force) when dynamic + static would exceed the CU's 160 KB
+    static const hipError_t once_k = [] {
+        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, false, false, kKGroups>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, need);
+        hipError_t e2 = hipFuncSetAttribute((const void*)conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true, false, kKGroups>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, need);
+        return e != hipSuccess ? e : e2;
+    }();
+    if (once_k != hipSuccess) {
+        (void)hipGetLastError();
+        i2v_set_error("conv: %d bytes of LDS refused for the K-group kernel: %s", need, hipGetErrorString(once_k));
+        return I2V_ERR_LAUNCH;
+    }
+    const int tiles = i2v_cdiv(p.M, BM) * i2v_cdiv(p.N, BN);
+    if (p.flags & I2V_EPI_MASK)
+        conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true, false, kKGroups><<<dim3(tiles, 1, 1), THREADS * kKGroups, need, st>>>(p);
+    else
+        conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, false, false, kKGroups><<<dim3(tiles, 1, 1), THREADS * kKGroups, need, st>>>(p);
+    return I2V_OK;
+}
+
 template <int WAVES_M, int WAVES_N, int TM, int TN>
 void launch_tile(const ConvP& p, bool spec, hipStream_t st) {
     constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
@@ -1476,6 +1565,28 @@ int run_conv(ConvP p, hipStream_t st, void* split_ws = nullptr, size_t split_ws_
     p.splitk = splitk;
     p.k_per_split = i2v_cdiv(ksteps, splitk) * BKS;
     p.splitk = i2v_cdiv(p.K, p.k_per_split);
+    // Intra-workgroup K split (conv_gemm_f32<.., KG>): a pointwise GEMM the plan would split over K through memory runs as ONE
+    // 16-wave workgroup per tile whose four wave groups each take a quarter of K and meet in LDS -- same waves per SIMD, no partial
+    // tile leaves the CU.  Its four stage-buffer sets leave room for one workgroup per CU, so it pays when the tiles of ONE round
+    // cover most of the chip: of the tiles 80x64 / 64x64 / 48x64 / 32x64 the smallest (least work per CU) with at most 256 tiles,
+    // if that is at least 180 (70 % of the CUs); otherwise the split across workgroups stays (layer3 conv1: 240 tiles of 80x64 for
+    // a frame pair, 200 of 48x64 for one frame; tools/kgroup_bench.py).  K a multiple of 4 x 32 with >= 2 stages per group.
+    int kg_tile = -1;
+    {
+        const bool pw = p.KH == 1 && p.KW == 1 && p.pad == 0 && p.pad_x == 0 && p.stride == 1 && p.ostride == 1 && p.Ho == p.H &&
+                        p.Wo == p.W && (p.N & 3) == 0 && (p.K & 3) == 0 && g_i2v_tuning[I2V_TUNE_CONV_GEMM] && !p.ablate;
+        if (g_i2v_tuning[I2V_TUNE_KGROUPS] && pw && g_spec_mode <= 0 && !p.clk && p.nbatch <= 1 && p.splitk >= 2 && force < 0 &&
+            p.K % (kKGroups * BKS) == 0 && p.K / kKGroups >= 2 * BKS && !g_i2v_tuning[I2V_TUNE_GEMM_X3] &&
+            (long long)p.M * p.N >= (1 << 18)) {
+            static const int kg_bm[4] = {80, 64, 48, 32};
+            const int nt = i2v_cdiv(p.N, 64);
+            for (int c = 3; c >= 0; --c) {                       // smallest tile first
+                const int t = i2v_cdiv(p.M, kg_bm[c]) * nt;
+                if (t <= NUM_CU) { if (t >= (NUM_CU * 7) / 10) kg_tile = c; break; }
+            }
+            if (kg_tile >= 0) { p.splitk = 1; p.k_per_split = p.K; }
+        }
+    }
     const long long ntiles = (long long)i2v_cdiv(p.M, kTiles[cfg].bm) * i2v_cdiv(p.N, kTiles[cfg].bn);
     p.ws = nullptr;
     p.cnt = nullptr;
@@ -1499,6 +1610,14 @@ int run_conv(ConvP p, hipStream_t st, void* split_ws = nullptr, size_t split_ws_
     const long long nblocks = (long long)i2v_cdiv(p.M, kTiles[cfg].bm) * i2v_cdiv(p.N, kTiles[cfg].bn) * p.splitk;
     // measured neutral on the backbone shapes (l2 c2 +6 %, l3 ds -12 %): off unless forced
     const bool spec = g_spec_mode < 0 ? false : (g_spec_mode == 2 ? nblocks <= 3 * NUM_CU : g_spec_mode != 0);
+    if (kg_tile >= 0) {
+        switch (kg_tile) {
+            case 0: return launch_kgroups<1, 4, 5, 1>(p, st);
+            case 1: return launch_kgroups<2, 2, 2, 2>(p, st);
+            case 2: return launch_kgroups<1, 4, 3, 1>(p, st);
+            default: return launch_kgroups<2, 2, 1, 2>(p, st);
+        }
+    }
     switch (cfg) {
         case 0: launch_tile<2, 2, 4, 4>(p, spec, st); break;
         case 1: launch_tile<2, 2, 4, 2>(p, spec, st); break;

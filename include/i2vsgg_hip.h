@@ -261,7 +261,8 @@ size_t  i2v_conv_split_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t 
 #define I2V_TUNE_GEMM_PERSIST        17   /* n >= 1: unsplit pointwise / plain GEMMs run on the persistent form of the kernel (a workgroup streams through >= max(n, 2) tiles, the next tile's operands requested under the current tile's last stage); bit-equal, measured slower; 0 (default) = one tile per workgroup */
 #define I2V_TUNE_WGRAD_PRIO          18   /* experiment: n > 0 = the filter-gradient kernel lowers a wave's issue priority as it advances (3 - ((stage >> (n-1)) & 3)); 0 = off */
 #define I2V_TUNE_STREAM_TILE         19   /* 1 (default): pointwise layers of at most four K stages over >= 16384 rows (HBM-bound) take the 80x64 tile whatever the cost model says; 0: cost model */
-#define I2V_TUNE_COUNT               20
+#define I2V_TUNE_KGROUPS             20   /* 1: a pointwise GEMM the plan would split over K runs as one 16-wave workgroup per tile whose four wave groups split K and meet in LDS (no partial tile through memory) when one round of such tiles covers >= 70 % of the CUs: 4-10 % faster than the split across workgroups as a kernel on its own, 9 % SLOWER inside the overlapped step (a workgroup that owns a CU's LDS and registers shuts the other branches' workgroups out: profiles/r04_kgroups.txt); 0 (default): split-K across workgroups, partials through the caller's workspace */
+#define I2V_TUNE_COUNT               21
 /* Keys CONV_SPEC (> 0), STAGGER, FC_FOLD, GEMM_X3, GEMM_PERSIST, WGRAD_PRIO are experiments: I2V_ERR_UNSUPPORTED for any value
  * but "off" unless the library was built with -DI2V_EXPERIMENTS (i2v_build_flags). */
 int32_t i2v_set_tuning(int32_t key, int32_t value);

@@ -812,6 +812,7 @@ def test_pointwise_gemm_kernel_equals_generic_kernel(ops, M, K, N, res):
     r4 = r.view(M, N, 1, 1) if res else None
     out = {}
     try:
+        assert lib.i2v_get_tuning(20) == 0       # I2V_KGROUPS off (the default): the split across workgroups shares the generic kernel's K cuts
         for mode in (1, 0):
             assert lib.i2v_set_tuning(10, mode) == 0
             out[mode] = ops.conv2d(x4, w4, sc, sh, r4, 1, 0, relu=True).view(M, N).clone()
@@ -823,6 +824,69 @@ def test_pointwise_gemm_kernel_equals_generic_kernel(ops, M, K, N, res):
         ref = ref + r.double()
     ref = torch.relu(ref)
     np.testing.assert_allclose(out[1].cpu().numpy(), ref.float().cpu().numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("M,K,N,res,mask", [(4788, 1024, 256, True, False), (2394, 1024, 256, False, False), (4788, 1024, 256, True, True),
+                                              (1568, 1024, 512, True, False), (4788, 768, 200, False, False), (6000, 512, 128, True, False)])
+def test_intra_workgroup_k_split_equals_memory_split(ops, M, K, N, res, mask):
+    """Round-3 review item 5 (I2V_KGROUPS=1; off by default, profiles/r04_kgroups.txt): conv_gemm_f32<.., KG = 4> -- a pointwise GEMM the plan would split over K runs as one 16-wave
+    workgroup per tile whose four wave groups take a quarter of K each and meet in LDS (layer3 conv1 of a frame pair: K 1024,
+    N 256; its data-gradient twin with the ReLU mask epilogue) -- against (a) the memory-side split it replaces (I2V_KGROUPS=0:
+    partial tiles through the workspace, summed in split order), (b) the generic kernel conv_igemm_f32 (I2V_CONV_GEMM=0) and
+    (c) float64.  K order: group g sums k in [g K/4, (g+1) K/4) in ascending k, the four partial sums are added
+    ((p0 + p1) + p2) + p3; the split forms cut K elsewhere (3 x 352 / 352 / 320 at K = 1024), so results agree to summation-order
+    rounding (1e-6 of the output scale), not bit for bit.  Deterministic: two launches give the same bits."""
+    from i2vsgg_amd._lib import TUNE, lib
+    rng = np.random.default_rng(M + K + N)
+    x = torch.from_numpy(rng.standard_normal((M, K), dtype=np.float32)).to(DEV)
+    w = torch.from_numpy((rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)).to(DEV)
+    sc = torch.from_numpy(rng.uniform(0.5, 1.5, N).astype(np.float32)).to(DEV)
+    sh = torch.from_numpy(rng.uniform(-0.5, 0.5, N).astype(np.float32)).to(DEV)
+    r4 = torch.from_numpy(rng.standard_normal((M, N), dtype=np.float32)).to(DEV).view(M, N, 1, 1) if res else None
+    mk = torch.from_numpy((rng.uniform(size=(M, N)) < 0.7).astype(np.float32)).to(DEV).view(M, N, 1, 1) if mask else None
+
+    def run():
+        if mask:        # the data-gradient epilogue: gx = mask > 0 ? (g W) * s + res : 0  (i2v_conv_dgrad_fused, pointwise)
+            wt = w.t().contiguous().view(K, N, 1, 1)            # dgrad of a (K <- N) filter is a GEMM with the filter transposed
+            return ops._dgrad_fused(x.view(M, K, 1, 1), wt, (M, N, 1, 1), 0, out_scale=sc, res=r4, mask=mk).reshape(M, N).clone()
+        return ops.conv2d(x.view(M, K, 1, 1), w.view(N, K, 1, 1), sc, sh, r4, 1, 0, relu=True).view(M, N).clone()
+
+    out = {}
+    try:
+        for name, key, val in (("groups", "I2V_KGROUPS", 1), ("memory", "I2V_KGROUPS", 0), ("generic", "I2V_CONV_GEMM", 0)):
+            old = lib.i2v_get_tuning(TUNE[key])
+            assert lib.i2v_set_tuning(TUNE[key], val) == 0
+            try:
+                out[name] = run()
+                if name == "groups":
+                    assert torch.equal(run(), out[name])        # no atomics, fixed order
+            finally:
+                lib.i2v_set_tuning(TUNE[key], old)
+    finally:
+        pass
+    ref = x.double() @ w.double().t()
+    if mask:
+        ref = ref * sc.double() + (r4.view(M, N).double() if res else 0)
+        ref = torch.where(mk.view(M, N) > 0, ref, torch.zeros_like(ref))
+    else:
+        ref = ref * sc.double() + sh.double()
+        if res:
+            ref = ref + r4.view(M, N).double()
+        ref = torch.relu(ref)
+    scale = float(ref.abs().max())
+    for name in ("memory", "generic"):
+        assert float((out["groups"] - out[name]).abs().max()) <= 1e-6 * scale, name
+    assert float((out["groups"].double() - ref).abs().max()) <= 2e-6 * scale
+    # the launch plan: no workspace, no clear -- the partial tiles never leave the CU.  (Tiles per shape: 240 of 80x64, 200 of
+    # 48x64, 240 of 80x64 with the mask epilogue, 200 of 64x64, then two shapes the form does not take -- K = 768 is no multiple
+    # of 128; 6000 x 128 needs > 256 tiles of the smallest tile that would fill the chip -- which keep the split across workgroups.)
+    if K % 128 == 0 and not mask and M < 6000:
+        assert lib.i2v_get_tuning(TUNE["I2V_KGROUPS"]) == 0 and lib.i2v_conv_split_workspace_bytes(1, 1, M, K, N, 1, 1, 1, 0) > 0
+        lib.i2v_set_tuning(TUNE["I2V_KGROUPS"], 1)
+        try:
+            assert lib.i2v_conv_split_workspace_bytes(1, 1, M, K, N, 1, 1, 1, 0) == 0
+        finally:
+            lib.i2v_set_tuning(TUNE["I2V_KGROUPS"], 0)
 
 
 @pytest.mark.parametrize("M,K,N,res,tile", [(75000, 64, 256, True, 3), (18750, 128, 512, True, 2), (9000, 256, 1024, True, 5),
@@ -1267,7 +1331,7 @@ KNOBS = [("I2V_CONV_SPEC", 1), ("I2V_CONV_SPEC", 2), ("I2V_SPLIT_TARGET", 3), ("
          ("I2V_SPLIT_BELOW", 2048), ("I2V_SPLIT_ATOMICS", 1), ("I2V_BIG_FC_TILE", -1), ("I2V_WGRAD_V2", 0), ("I2V_WGRAD_V2", 2),
          ("I2V_WGRAD_V2", 3), ("I2V_WINO_ROWS", -1), ("I2V_WINO_ROWS", 3), ("I2V_ROIPOOL_C128", 0), ("I2V_CONV_GEMM", 0),
          ("I2V_STAGGER", 4), ("I2V_ROIALIGN_COLS", 0), ("I2V_WGRAD_PER_CU", 2), ("I2V_WGRAD_XCD", 0), ("I2V_GEMM_PERSIST", 2),
-         ("I2V_WGRAD_PRIO", 2), ("I2V_STREAM_TILE", 0), ("I2V_GEMM_X3", 1)]
+         ("I2V_WGRAD_PRIO", 2), ("I2V_STREAM_TILE", 0), ("I2V_GEMM_X3", 1), ("I2V_KGROUPS", 1)]
 
 
 def test_every_tuning_knob_keeps_the_results(ops):
