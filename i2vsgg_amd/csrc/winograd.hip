@@ -24,6 +24,27 @@ namespace {
 __device__ inline float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ inline float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
 
+// Loads and stores of the F(4x4,3x3) transforms go through buffer resources, UNCONDITIONALLY: a tap outside the image (or a
+// pixel outside it on the way out) gets the 2 GiB bit OR-ed into its byte offset, the hardware returns 0 for it (drops the
+// store) and no traffic results.  Written as ``inside ? x[..] : 0.f`` every one of a thread's 36 loads sat under a branch of its
+// own (s_cbranch_execz) with an s_waitcnt vmcnt(0) in front of most of them -- six to twelve exposed round trips per thread
+// (round 4, from the ISA; 10.1 -> 5.9 us for the input transform of a layer3 frame pair).  Byte offsets are 32-bit: the
+// launchers refuse tensors of 2 GiB and more.
+constexpr unsigned WINV = 0x80000000u;
+__device__ inline __amdgpu_buffer_rsrc_t wrsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFCu, 0x00020000);
+}
+__device__ inline float wload(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ inline void wstore(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+}
+// 0 when 0 <= iy < H and 0 <= ix < W, else the out-of-range bit
+__device__ inline unsigned outside(int iy, int H, int ix, int W) {
+    return (unsigned)((iy | (H - 1 - iy) | ix | (W - 1 - ix)) >> 31) & WINV;
+}
+
 // one thread per (filter n, channel c): 9 taps -> 16 transform-domain values
 __global__ void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int Cout, int Cin) {
     const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -196,36 +217,43 @@ __global__ void wino4_filter_dgrad_kernel(const float* __restrict__ w, float* __
     }
 }
 
+// One thread per (tile, channel).  All index arithmetic is 32-bit (the launchers refuse tensors of 2 GiB and more; the 64-bit
+// form spent ~660 VALU instructions per thread on addresses); the 36 planes of V / M are reached through the buffer
+// instruction's SCALAR offset (plane * k is uniform), so a plane access costs no vector arithmetic at all.
 __global__ void __launch_bounds__(256)
 wino4_input_kernel(const float* __restrict__ x, float* __restrict__ V, int B, int H, int W, int C, int th, int tw) {
-    const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    const long long T = (long long)B * th * tw;
-    if (idx >= T * C) return;
-    const int c = (int)(idx % C);
-    const long long t = idx / C;
-    const int tx = (int)(t % tw), ty = (int)((t / tw) % th), b = (int)(t / ((long long)tw * th));
-    float m[6][6];
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    const unsigned T = (unsigned)B * th * tw;
+    if (idx >= T * (unsigned)C) return;
+    const unsigned c = idx % (unsigned)C, t = idx / (unsigned)C;
+    const int tx = (int)(t % (unsigned)tw), ty = (int)((t / (unsigned)tw) % (unsigned)th), b = (int)(t / ((unsigned)tw * th));
+    const __amdgpu_buffer_rsrc_t xr = wrsrc(x), vr = wrsrc(V);
+    float d[6][6];                              // d[q][r]: all 36 taps requested before the first is used
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {               // column q of the patch through B^T (rows)
+    for (int q = 0; q < 6; ++q) {
         const int ix = 4 * tx - 1 + q;
-        float d[6], tt[6];
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             const int iy = 4 * ty - 1 + r;
-            d[r] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? x[(((long long)b * H + iy) * W + ix) * C + c] : 0.f;
+            d[q][r] = wload(xr, (unsigned)((((b * H + iy) * W + ix) * C + (int)c) * 4) | outside(iy, H, ix, W));
         }
-        bt6(d, tt);
+    }
+    float m[6][6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {               // column q of the patch through B^T (rows)
+        float tt[6];
+        bt6(d[q], tt);
 #pragma unroll
         for (int r = 0; r < 6; ++r) m[r][q] = tt[r];
     }
-    const long long plane = T * C;
-    float* o = V + t * C + c;
+    const unsigned plane4 = T * (unsigned)C * 4u, o4 = (t * (unsigned)C + c) * 4u;
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
         float v[6];
         bt6(m[r], v);
 #pragma unroll
-        for (int q = 0; q < 6; ++q) o[(long long)(6 * r + q) * plane] = v[q];
+        for (int q = 0; q < 6; ++q)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[q]), vr, o4, plane4 * (unsigned)(6 * r + q), 0);
     }
 }
 
@@ -233,40 +261,52 @@ __global__ void __launch_bounds__(256)
 wino4_output_kernel(const float* __restrict__ Mx, const float* __restrict__ scale, const float* __restrict__ shift,
                     float* __restrict__ y, int B, int H, int W, int N, int th, int tw, int relu,
                     const float* __restrict__ mask = nullptr) {
-    const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-    const long long T = (long long)B * th * tw;
-    if (idx >= T * N) return;
-    const int n = (int)(idx % N);
-    const long long t = idx / N;
-    const int tx = (int)(t % tw), ty = (int)((t / tw) % th), b = (int)(t / ((long long)tw * th));
-    const long long plane = T * N;
-    const float* src = Mx + t * N + n;
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    const unsigned T = (unsigned)B * th * tw;
+    if (idx >= T * (unsigned)N) return;
+    const unsigned n = idx % (unsigned)N, t = idx / (unsigned)N;
+    const int tx = (int)(t % (unsigned)tw), ty = (int)((t / (unsigned)tw) % (unsigned)th), b = (int)(t / ((unsigned)tw * th));
+    const __amdgpu_buffer_rsrc_t sr = wrsrc(Mx), yr = wrsrc(y), mr = wrsrc(mask ? mask : y);
+    const __amdgpu_buffer_rsrc_t scr = wrsrc(scale ? scale : Mx), shr = wrsrc(shift ? shift : Mx);
+    const unsigned plane4 = T * (unsigned)N * 4u, s4 = (t * (unsigned)N + n) * 4u;
+    const unsigned no_mask = mask ? 0u : WINV;
+    // every load of the thread is requested here, before the first use: the mask tile (data gradients; absent: the
+    // out-of-range bit, zeros without traffic), the 36 plane values, scale and shift
+    float mk[4][4], mv[6][6];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int oy = 4 * ty + r, ox = 4 * tx + q;
+            mk[r][q] = wload(mr, (unsigned)((((b * H + oy) * W + ox) * N + (int)n) * 4) | outside(oy, H, ox, W) | no_mask);
+        }
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+            mv[q][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sr, s4, plane4 * (unsigned)(6 * r + q), 0));
+    const float sc_l = wload(scr, (n * 4u) | (scale ? 0u : WINV)), sh_l = wload(shr, (n * 4u) | (shift ? 0u : WINV));
+    const float sc = scale ? sc_l : 1.f, sh = shift ? sh_l : 0.f;
     float s[4][6];
 #pragma unroll
     for (int q = 0; q < 6; ++q) {
-        float m[6], ss[4];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) m[r] = src[(long long)(6 * r + q) * plane];
-        at6(m, ss);
+        float ss[4];
+        at6(mv[q], ss);
 #pragma unroll
         for (int r = 0; r < 4; ++r) s[r][q] = ss[r];
     }
-    const float sc = scale ? scale[n] : 1.f, sh = shift ? shift[n] : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int oy = 4 * ty + r;
         float o[4];
         at6(s[r], o);
-        if (oy >= H) continue;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int ox = 4 * tx + q;
-            if (ox >= W) continue;
             float v = o[q] * sc + sh;
             if (relu) v = fmaxf(v, 0.f);
-            const long long at = (((long long)b * H + oy) * W + ox) * N + n;
-            if (mask && !(mask[at] > 0.f)) v = 0.f;       // data gradient: the ReLU of the tensor it flows into
-            y[at] = v;
+            if (mask && !(mk[r][q] > 0.f)) v = 0.f;       // data gradient: the ReLU of the tensor it flows into
+            wstore(yr, (unsigned)((((b * H + oy) * W + ox) * N + (int)n) * 4) | outside(oy, H, ox, W), v);
         }
     }
 }
@@ -310,7 +350,7 @@ __device__ inline void wino4_input_row(const float* __restrict__ x, float* __res
             d[k] = 0.f;
             if (!bt6_needs<R>(k)) continue;
             const int iy = 4 * ty - 1 + k;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) d[k] = x[(((long long)b * H + iy) * W + ix) * C + c];
+            d[k] = wload(wrsrc(x), (unsigned)((((b * H + iy) * W + ix) * C + c) * 4) | outside(iy, H, ix, W));
         }
         mrow[q] = bt6_row<R>(d);
     }
@@ -375,15 +415,21 @@ wino4_output_rows_kernel(const float* __restrict__ Mx, const float* __restrict__
     float o[4];
     at6(s, o);
     const float sc = scale ? scale[n] : 1.f, sh = shift ? shift[n] : 0.f;
+    const __amdgpu_buffer_rsrc_t yr = wrsrc(y), mr = wrsrc(mask ? mask : y);
+    const unsigned no_mask = mask ? 0u : WINV;
+    float mk[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int ox = 4 * tx + q;
-        if (ox >= W) continue;
+        mk[q] = wload(mr, (unsigned)((((b * H + oy) * W + ox) * N + n) * 4) | outside(oy, H, ox, W) | no_mask);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int ox = 4 * tx + q;
         float v = o[q] * sc + sh;
         if (relu) v = fmaxf(v, 0.f);
-        const long long at = (((long long)b * H + oy) * W + ox) * N + n;
-        if (mask && !(mask[at] > 0.f)) v = 0.f;
-        y[at] = v;
+        if (mask && !(mk[q] > 0.f)) v = 0.f;
+        wstore(yr, (unsigned)((((b * H + oy) * W + ox) * N + n) * 4) | outside(oy, H, ox, W), v);
     }
 }
 
@@ -426,7 +472,7 @@ wino4_gy_kernel(const float* __restrict__ gy, float* __restrict__ Y, int B, int 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int oy = 4 * ty + r;
-            d[r] = (oy < H && ox < W) ? gy[(((long long)b * H + oy) * W + ox) * N + n] : 0.f;
+            d[r] = wload(wrsrc(gy), (unsigned)((((b * H + oy) * W + ox) * N + n) * 4) | outside(oy, H, ox, W));
         }
         a6(d, o);
 #pragma unroll
@@ -539,6 +585,7 @@ static int winograd4_impl(const float* x, const float* U, const float* scale, co
                           int32_t relu, void* ws, size_t ws_bytes, void* stream, float* v_keep = nullptr) {
     I2V_CHECK_ARG(x && U && y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_winograd4_fwd: bad argument");
     I2V_CHECK_ARG(Cin % 4 == 0, "conv3x3_winograd4_fwd: Cin must be a multiple of 4");
+    I2V_CHECK_ARG((long long)B * H * W * (Cin > Cout ? Cin : Cout) * 4 < (1ll << 31), "conv3x3_winograd4_fwd: activation of 2 GiB or more (32-bit byte offsets)");
     if (!ws || ws_bytes < i2v_conv3x3_winograd4_workspace_bytes(B, H, W, Cin, Cout)) {
         i2v_set_error("conv3x3_winograd4_fwd: workspace too small");
         return I2V_ERR_WORKSPACE;
@@ -607,6 +654,7 @@ static int winograd4_wgrad_impl(const float* x, const float* v_in, const float* 
     I2V_CHECK_ARG((x || v_in) && gy && gw && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_winograd4_wgrad: bad argument");
     I2V_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0, "conv3x3_winograd4_wgrad: Cin and Cout must be multiples of 4");
     I2V_CHECK_ARG(beta == 0.f || beta == 1.f, "conv3x3_winograd4_wgrad: beta must be 0 or 1");
+    I2V_CHECK_ARG((long long)B * H * W * (Cin > Cout ? Cin : Cout) * 4 < (1ll << 31), "conv3x3_winograd4_wgrad: activation of 2 GiB or more (32-bit byte offsets)");
     if (!ws || ws_bytes < i2v_conv3x3_winograd4_wgrad_workspace_bytes(B, H, W, Cin, Cout)) {
         i2v_set_error("conv3x3_winograd4_wgrad: workspace too small");
         return I2V_ERR_WORKSPACE;
