@@ -315,11 +315,11 @@ roi_pool_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ ro
 // NHWC map, C % 128 == 0: a workgroup owns 128 channels of one ROI; a 32-lane group takes one bin at a time with four
 // channels per lane (one 16-B load per window cell instead of four 4-B ones), eight bins in flight per workgroup.  Window
 // cells are visited in the same (h, w) order per channel as above: same maxima, same first-maximum argmax.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(512)
 roi_pool_fwd_c128_kernel(const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
                          int* __restrict__ argmax, int C, int H, int W, int PH, int PW, float scale, int out_nchw,
                          const int* __restrict__ geom, long long cap_cells) {
-    extern __shared__ float lds[];
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int P = PH * PW;
     float* sval = lds;
     int* sarg = (int*)(lds + 128 * P);
@@ -336,8 +336,14 @@ roi_pool_fwd_c128_kernel(const float* __restrict__ feat, const float* __restrict
     const int x2 = (int)roundf(roi[3] * scale), y2 = (int)roundf(roi[4] * scale);
     const int rw = max(x2 - x1 + 1, 1), rh = max(y2 - y1 + 1, 1);
     const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
-    const float* fb = feat + (long long)b * H * W * C + c0 + 4 * l32;
-    for (int p = grp; p < P; p += 8) {
+    // Window cells are fetched EIGHT at a time through a buffer resource, unconditionally (a slot beyond the window gets the
+    // out-of-range bit: zeros, no traffic, skipped by the compare): one memory round trip per eight cells instead of one per
+    // cell -- the scan is a dependent chain (first maximum wins), the loads need not be.  Cells are visited in (h, w) order.
+    const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(feat), 0, 0x7FFFFFFCu, 0x00020000);
+    const unsigned lane_off = (unsigned)(c0 + 4 * l32) * 4u, row_bytes = (unsigned)C * 4u;
+    const unsigned img = (unsigned)b * (unsigned)(H * W);
+    const int ngrp = blockDim.x >> 5;            // 16 bins in flight per workgroup (512 threads): 49 bins in four rounds
+    for (int p = grp; p < P; p += ngrp) {
         const int ph = p / PW, pw = p - ph * PW;
         int hs = (int)floorf((float)ph * bh), he = (int)ceilf((float)(ph + 1) * bh);
         hs = min(max(hs + y1, 0), H); he = min(max(he + y1, 0), H);
@@ -346,15 +352,26 @@ roi_pool_fwd_c128_kernel(const float* __restrict__ feat, const float* __restrict
         const bool empty = (he <= hs) || (we <= ws);
         float4 m = empty ? make_float4(0.f, 0.f, 0.f, 0.f) : make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
         int4 mi = make_int4(-1, -1, -1, -1);
-        for (int h = hs; h < he; ++h) {
-            const float* row = fb + (long long)h * W * C;
-            for (int w = ws; w < we; ++w) {
-                const float4 v = *(const float4*)(row + (long long)w * C);
-                const int id = h * W + w;
-                if (v.x > m.x) { m.x = v.x; mi.x = id; }
-                if (v.y > m.y) { m.y = v.y; mi.y = id; }
-                if (v.z > m.z) { m.z = v.z; mi.z = id; }
-                if (v.w > m.w) { m.w = v.w; mi.w = id; }
+        const int nw = we - ws, cells = empty ? 0 : (he - hs) * nw;
+        int h = hs, w = ws;
+        for (int k0 = 0; k0 < cells; k0 += 8) {
+            float4 v[8];
+            int id[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool live = k0 + u < cells;
+                id[u] = live ? h * W + w : -1;
+                v[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                    fr, ((img + (unsigned)(h * W + w)) * row_bytes + lane_off) | (live ? 0u : 0x80000000u), 0, 0));
+                if (++w == we) { w = ws; ++h; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (id[u] < 0) continue;                      // uniform across the 32-lane group
+                if (v[u].x > m.x) { m.x = v[u].x; mi.x = id[u]; }
+                if (v[u].y > m.y) { m.y = v[u].y; mi.y = id[u]; }
+                if (v[u].z > m.z) { m.z = v[u].z; mi.z = id[u]; }
+                if (v[u].w > m.w) { m.w = v[u].w; mi.w = id[u]; }
             }
         }
         const int e = (4 * l32) * P + p;
@@ -362,12 +379,19 @@ roi_pool_fwd_c128_kernel(const float* __restrict__ feat, const float* __restrict
         sarg[e] = mi.x; sarg[e + P] = mi.y; sarg[e + 2 * P] = mi.z; sarg[e + 3 * P] = mi.w;
     }
     __syncthreads();
-    if (out_nchw) {                      // (r, c0..c0+128, :, :) is contiguous
+    if (out_nchw) {                      // (r, c0..c0+128, :, :) is contiguous: 16-byte rows when the chunk's base allows
         float* o = out + (long long)r * C * P + (long long)c0 * P;
         int* a = argmax + (long long)r * C * P + (long long)c0 * P;
-        for (int e = threadIdx.x; e < 128 * P; e += 256) { o[e] = sval[e]; a[e] = sarg[e]; }
+        if ((((long long)r * C + c0) * P) % 4 == 0 && (128 * P) % 4 == 0) {
+            for (int e = threadIdx.x * 4; e < 128 * P; e += 4 * blockDim.x) {
+                *(float4*)(o + e) = *(const float4*)(sval + e);
+                *(int4*)(a + e) = *(const int4*)(sarg + e);
+            }
+        } else {
+            for (int e = threadIdx.x; e < 128 * P; e += blockDim.x) { o[e] = sval[e]; a[e] = sarg[e]; }
+        }
     } else {                             // NHWC: (r, p, c) with c contiguous
-        for (int e = threadIdx.x; e < 128 * P; e += 256) {
+        for (int e = threadIdx.x; e < 128 * P; e += blockDim.x) {
             const int p = e >> 7, ch = e & 127;
             const long long o = (long long)r * P * C + (long long)p * C + c0 + ch;
             out[o] = sval[ch * P + p];
@@ -562,8 +586,9 @@ int32_t roi_pool_fwd_launch(const float* feat, int32_t feat_layout, int32_t B, i
     I2V_CHECK_ARG(PH * PW <= 256, "roi_pool_fwd: pooled grid too large for the LDS stage");
     Strides fs = feat_strides(feat_layout, C, H, W), os = out_strides(out_layout, C, PH, PW);
     const int c128 = g_i2v_tuning[I2V_TUNE_ROIPOOL_C128];
-    if (c128 && feat_layout == I2V_LAYOUT_NHWC && C % 128 == 0 && (size_t)128 * PH * PW * 8 <= 64 * 1024) {
-        roi_pool_fwd_c128_kernel<<<R * (C / 128), 256, (size_t)128 * PH * PW * 8, (hipStream_t)stream>>>(
+    const long long feat_bytes = (long long)B * C * 4 * (geom ? cap_cells : (long long)H * W);       // 32-bit byte offsets in the kernel
+    if (c128 && feat_layout == I2V_LAYOUT_NHWC && C % 128 == 0 && (size_t)128 * PH * PW * 8 <= 64 * 1024 && feat_bytes < (1ll << 31)) {
+        roi_pool_fwd_c128_kernel<<<R * (C / 128), 512, (size_t)128 * PH * PW * 8, (hipStream_t)stream>>>(
             feat, rois, out, argmax, C, H, W, PH, PW, scale, out_layout == I2V_LAYOUT_NCHW, geom, cap_cells);
         I2V_CHECK_LAUNCH("roi_pool_fwd");
         return I2V_OK;
