@@ -1683,7 +1683,8 @@ __global__ void weight_dgrad_sub_layout(const float* __restrict__ w, float* __re
 struct WgP {
     const float* x; const float* gy; float* gw; int direct;
     const float* row_scale;                // gw[n][:] = row_scale[n] * sum (a frozen-BN scale on gy applied where the sum ends), or NULL
-    int xcd_remap;                         // (tile, split) from the dispatch index so that a split's tiles share an XCD (launch_wgrad)
+    int xcd_remap;                         // (tile, split, plane) from the dispatch index so that a split's tiles share an XCD (launch_wgrad)
+    int r_tiles, r_splits, r_total;        // with xcd_remap: the logical grid (tiles x splits x planes = r_total workgroups) behind the 1-D launch
     int nbatch;                            // > 1: blockIdx.z selects one of nbatch independent GEMMs (the planes of a Winograd filter gradient)
     long long bsx, bsg, bsw;               // element strides between the batches of x, gy and gw
     float* sgd_m; float lr, mom, wd;       // sgd_m != NULL: gw is the PARAMETER, updated in place (fused SGD)
@@ -1830,17 +1831,24 @@ conv_wgrad2_f32(const WgP p_in) {
     WgP p = p_in;
     unsigned long long c_rt0 = 0, c_t0 = 0, c_t1 = 0, c_t2 = 0;
     if constexpr (CLK) { c_rt0 = __builtin_amdgcn_s_memrealtime(); c_t0 = __builtin_amdgcn_s_memtime(); }
-    // XCD-aware order (p.xcd_remap: splits x planes is a multiple of 8): workgroups are dealt to the 8 XCDs round robin in
-    // dispatch order, and every XCD has its own L2.  All tiles of one pixel range (one split of one plane) read the same rows
-    // of gy and x; dealt in (tile, split) order they land on all 8 XCDs and every L2 fetches those rows again (PMC: 3.6x the
-    // algorithmic bytes on the layer3 shapes).  Remapped, group s = (split, plane) lives on XCD s % 8 with all of its tiles.
+    // XCD-aware order (p.xcd_remap): workgroups are dealt to the 8 XCDs round robin in dispatch order, and every XCD has its own
+    // L2.  All tiles of one pixel range (one split of one plane: a GROUP) read the same rows of gy and x; dealt in (tile, split)
+    // order they land on all 8 XCDs and every L2 fetches those rows again (PMC: 3.6x the algorithmic bytes on the layer3
+    // shapes).  Round 2 put group s on XCD s % 8 -- possible only when the group count is a multiple of 8, which the
+    // pixel split rarely is (254 splits for layer1's expansion at 8 frames).  Round 4: the launch is 1-D and XCD g owns the
+    // CONTIGUOUS range [g W / 8, (g + 1) W / 8) of the group-major workgroup order (W = tiles x groups): every XCD gets the
+    // same number of workgroups (+-1) whatever the group count, a group lives on one XCD (two where a range boundary cuts
+    // it).  The launch is padded to a multiple of 8; the <= 7 surplus workgroups leave at once.
     int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (p.xcd_remap) {
-        const int L = (bz * (int)gridDim.y + by) * (int)gridDim.x + bx, g = L & 7, r = L >> 3;
-        const int grp = g + 8 * (r / (int)gridDim.x);
-        bx = r % (int)gridDim.x;
-        by = grp % (int)gridDim.y;
-        bz = grp / (int)gridDim.y;
+        const int L = (int)blockIdx.x, g = L & 7, r = L >> 3;
+        const long long W = p.r_total;
+        const int start = (int)((g * W) >> 3), count = (int)(((g + 1) * W) >> 3) - start;
+        if (r >= count) return;
+        const int idx = start + r, grp = idx / p.r_tiles;
+        bx = idx - grp * p.r_tiles;
+        by = grp % p.r_splits;
+        bz = grp / p.r_splits;
     }
     if (p.nbatch > 1) {
         p.x += (long long)bz * p.bsx;
@@ -2441,8 +2449,14 @@ static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st) {
         hipMemsetAsync(p.gw, 0, (p.nbatch > 1 ? (size_t)(p.nbatch - 1) * p.bsw : 0) * sizeof(float) + (size_t)p.N * p.K * sizeof(float), st);
     p.x_bytes = (unsigned)xb;
     p.gy_bytes = (unsigned)gb;
-    const dim3 grid((unsigned)tiles, splits, p.nbatch > 1 ? p.nbatch : 1);
-    p.xcd_remap = ((splits * (p.nbatch > 1 ? p.nbatch : 1)) % 8 == 0 && g_i2v_tuning[I2V_TUNE_WGRAD_XCD]) ? 1 : 0;
+    dim3 grid((unsigned)tiles, splits, p.nbatch > 1 ? p.nbatch : 1);
+    const long long groups = (long long)splits * (p.nbatch > 1 ? p.nbatch : 1), total = tiles * groups;
+    // v2 kernels only (the remap lives there); one group needs no grouping; the 1-D launch must fit an int
+    p.xcd_remap = (v2 && groups >= 2 && total < (1ll << 30) && g_i2v_tuning[I2V_TUNE_WGRAD_XCD]) ? 1 : 0;
+    if (p.xcd_remap) {
+        p.r_tiles = (int)tiles; p.r_splits = splits; p.r_total = (int)total;
+        grid = dim3((unsigned)((total + 7) / 8 * 8), 1, 1);
+    }
     p.prio = g_i2v_tuning[I2V_TUNE_WGRAD_PRIO];
     if (!v2) conv_wgrad_f32<64, 64><<<grid, THREADS, 0, st>>>(p);
     else if (fused && tm == 128 && tk == 64) conv_wgrad2_f32<4, 2, true><<<grid, THREADS, 0, st>>>(p);

@@ -1095,10 +1095,16 @@ def test_winograd_filter_gradient_vs_torch(B, C, N, H, W):
     assert float((got.double() - want * rs.double().view(-1, 1, 1, 1)).abs().max()) <= 2e-4 * 1.5 * scale
 
 
-@pytest.mark.parametrize("B,C,N,H,W,k", [(4, 1024, 256, 38, 63, 1), (4, 256, 1024, 38, 63, 1), (2, 128, 512, 75, 125, 1), (4, 64, 64, 75, 125, 3)])
+@pytest.mark.parametrize("B,C,N,H,W,k", [(4, 1024, 256, 38, 63, 1), (4, 256, 1024, 38, 63, 1), (2, 128, 512, 75, 125, 1), (4, 64, 64, 75, 125, 3),
+                                         (4, 64, 256, 150, 250, 1),     # layer1's expansion at 4 frames: 4 tiles x 254 splits
+                                         (3, 512, 128, 75, 125, 1),     # 16 tiles x 55 splits: an odd group count
+                                         (1, 256, 256, 38, 63, 3),      # Winograd planes: 36 x 16 tiles x 1 split; 18 splits direct
+                                         (1, 192, 64, 20, 33, 1)])      # 3 tiles x 5 splits: fewer groups than XCDs, W % 8 != 0
 def test_filter_gradient_split_groups_on_one_xcd(B, C, N, H, W, k):
-    """Filter gradients whose split count is a multiple of 8 take the dispatch-index remap (a split's tiles share an XCD):
-    same result as with the remap off, and both equal float64 torch."""
+    """Filter gradients take the dispatch-index remap (a split's tiles share an XCD): same result as with the remap off, and
+    both equal float64 torch.  Round 2's remap needed a group count (splits x planes) that is a multiple of 8; round 4 deals
+    every XCD a contiguous range of the group-major order, for ANY group count (odd, fewer than 8, a launch padded by up to 7
+    workgroups that leave at once)."""
     from i2vsgg_amd import _lib, ops
     torch.manual_seed(7)
     cl = lambda t: t.contiguous(memory_format=torch.channels_last)
