@@ -253,7 +253,7 @@ size_t  i2v_conv_split_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t 
 #define I2V_TUNE_ROIPOOL_C128         9   /* 1 (default): 128-channel ROIPool forward kernel for NHWC maps */
 #define I2V_TUNE_CONV_GEMM           10   /* 1 (default): pointwise layers / plain GEMMs on the lean conv_gemm_f32 kernel */
 #define I2V_TUNE_STAGGER             11   /* experiment: co-resident conv_gemm_f32 workgroups start this many kcycles apart (0 = off) */
-#define I2V_TUNE_ROIALIGN_COLS       12   /* 1 (default): ROIAlign forward on column-pair workgroups (one memory round trip) */
+#define I2V_TUNE_ROIALIGN_COLS       12   /* ROIAlign forward, NHWC: 2 (default) = one ROI x 128 channels per workgroup, sample values meet in LDS, each tap through the L2 once (NHWC output, <= 64 sample points; else as 1); 1 = column-pair workgroups (round 2); 0 = one output row per workgroup (round 1) */
 #define I2V_TUNE_WGRAD_PER_CU        13   /* workgroups per CU a split-over-pixels wgrad launch aims for (default 4) */
 #define I2V_TUNE_WGRAD_XCD           14   /* 1 (default): a filter-gradient split's tiles share an XCD when the split count is a multiple of 8 */
 #define I2V_TUNE_FC_FOLD             15   /* diagnostic ablation bits of i2v_fc_fold_fwd (0 = the kernel as shipped): 1 no gradient MFMAs, 2 no forward MFMAs, 4 no x loads, 8 no filter / momentum stores, 16 no xp staging */

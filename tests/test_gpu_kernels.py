@@ -1336,7 +1336,7 @@ EXPERIMENT_KNOBS = {"I2V_CONV_SPEC", "I2V_STAGGER", "I2V_GEMM_PERSIST", "I2V_WGR
 KNOBS = [("I2V_CONV_SPEC", 1), ("I2V_CONV_SPEC", 2), ("I2V_SPLIT_TARGET", 3), ("I2V_SPLIT_TARGET_SKINNY", 3), ("I2V_SPLIT_BELOW", 0),
          ("I2V_SPLIT_BELOW", 2048), ("I2V_SPLIT_ATOMICS", 1), ("I2V_BIG_FC_TILE", -1), ("I2V_WGRAD_V2", 0), ("I2V_WGRAD_V2", 2),
          ("I2V_WGRAD_V2", 3), ("I2V_WINO_ROWS", -1), ("I2V_WINO_ROWS", 3), ("I2V_ROIPOOL_C128", 0), ("I2V_CONV_GEMM", 0),
-         ("I2V_STAGGER", 4), ("I2V_ROIALIGN_COLS", 0), ("I2V_WGRAD_PER_CU", 2), ("I2V_WGRAD_XCD", 0), ("I2V_GEMM_PERSIST", 2),
+         ("I2V_STAGGER", 4), ("I2V_ROIALIGN_COLS", 0), ("I2V_ROIALIGN_COLS", 1), ("I2V_WGRAD_PER_CU", 2), ("I2V_WGRAD_XCD", 0), ("I2V_GEMM_PERSIST", 2),
          ("I2V_WGRAD_PRIO", 2), ("I2V_STREAM_TILE", 0), ("I2V_GEMM_X3", 1), ("I2V_KGROUPS", 1)]
 
 
