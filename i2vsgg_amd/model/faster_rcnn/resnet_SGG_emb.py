@@ -28,9 +28,13 @@ def _load_pickle(path):
 
 
 class vrd(nn.Module):
-    """resnet_SGG_emb.py:65-221.  ``args`` needs num_relations, num_classes, emb_dim, use_obj_visual,
-    spatial_type (only the reference defaults True / 2 are implemented) and may carry
-    the three pickle paths; synthetic runs assign ``source_gt_rels`` directly."""
+    """resnet_SGG_emb.py:65-221.  ``args`` needs num_relations, num_classes, emb_dim, and may carry ``use_obj_visual``
+    (default True: the [subject | object] visual embedding branch ``fc_so``, :96-98 / :166-170), ``spatial_type`` (default 2:
+    the dual-mask conv branch ``conv_lo`` + ``fc_lov = FC(64, 256)``; 1: ``fc_lov = FC(8, 256)`` on the 8-d relative-location
+    feature of ``_getRelativeLoc``, :100-102 / :172-174; anything else: no spatial branch) and the three pickle paths;
+    synthetic runs assign ``source_gt_rels`` directly.  ``fc_fusion`` is FC(256 x branches, 256) as in the reference (:94-123).
+    The reference's scripts only ever run the defaults (its ``type=bool`` flags parse every CLI value to True, SURVEY.md A15);
+    the captured training step (``train.SGGEmbStep``) packs the default form's inputs and says so for the others."""
 
     def __init__(self, args, all_obj_vecs=None, all_prd_vecs=None, bn=False):
         super().__init__()
@@ -46,7 +50,8 @@ class vrd(nn.Module):
             self.source_gt_rels = _load_pickle(args.source_gt_rels_path)
         if getattr(args, "target_gt_rels_path", None):
             self.target_gt_rels = _load_pickle(args.target_gt_rels_path)
-        assert getattr(args, "use_obj_visual", True) and getattr(args, "spatial_type", 2) == 2
+        self.use_obj_visual = bool(getattr(args, "use_obj_visual", True))
+        self.spatial_type = int(getattr(args, "spatial_type", 2))
 
         self.roi_pool = ROIPool((cfg.POOLING_SIZE, cfg.POOLING_SIZE), 1.0 / 16.0)
         self.fc6 = FC(1024 * 7 * 7, 4096)
@@ -54,12 +59,20 @@ class vrd(nn.Module):
         self.so_vis_embeddings = FC(4096, self.emb_dim, relu=False)
         self.fc8 = FC(4096, 256)
         self.criterion = nn.BCEWithLogitsLoss()
-        self.fc_so = FC(300 * 2, 256)
-        self.conv_lo = nn.Sequential(Conv2d(2, 96, 5, same_padding=True, stride=2),
-                                     Conv2d(96, 128, 5, same_padding=True, stride=2),
-                                     Conv2d(128, 64, 8, same_padding=False))
-        self.fc_lov = FC(64, 256)
-        self.fc_fusion = FC(768, 256)
+        n_fusion = 256
+        if self.use_obj_visual:
+            self.fc_so = FC(300 * 2, 256)
+            n_fusion += 256
+        if self.spatial_type == 1:
+            self.fc_lov = FC(8, 256)
+            n_fusion += 256
+        elif self.spatial_type == 2:
+            self.conv_lo = nn.Sequential(Conv2d(2, 96, 5, same_padding=True, stride=2),
+                                         Conv2d(96, 128, 5, same_padding=True, stride=2),
+                                         Conv2d(128, 64, 8, same_padding=False))
+            self.fc_lov = FC(64, 256)
+            n_fusion += 256
+        self.fc_fusion = FC(n_fusion, 256)
         self.fc_rel = FC(256, self.emb_dim, relu=False)
         self.prd_sem_embeddings = nn.Sequential(Linear(300, 1024), nn.LeakyReLU(0.1), Linear(1024, self.emb_dim))
         self.dropout = True          # F.dropout(training=self.training) of the reference (:149-163)
@@ -117,12 +130,16 @@ class vrd(nn.Module):
         h = self.fc7(self._drop(h))
         h = self._drop(h)
         h_box, h_rel = torch.split(h, [nb, h.size(0) - nb])      # one cat in the backward (two slices = 2 fills + 2 copies + add)
-        obj = self.so_vis_embeddings(h_box)
-        x = self.fc8(h_rel)
-        x_so = self.fc_so(ops.pair_gather(obj, ix1, ix2))        # [subject | object] per pair: one kernel each way
-        lo = self.conv_lo(spatial)
-        lo = self.fc_lov(lo.reshape(lo.size(0), -1))
-        x = self.fc_rel(self.fc_fusion(torch.cat((x, x_so, lo), 1)))
+        parts = [self.fc8(h_rel)]
+        if self.use_obj_visual:
+            obj = self.so_vis_embeddings(h_box)
+            parts.append(self.fc_so(ops.pair_gather(obj, ix1, ix2)))       # [subject | object] per pair: one kernel each way
+        if self.spatial_type == 1:
+            parts.append(self.fc_lov(spatial.reshape(spatial.size(0), -1)))
+        elif self.spatial_type == 2:
+            lo = self.conv_lo(spatial)
+            parts.append(self.fc_lov(lo.reshape(lo.size(0), -1)))
+        x = self.fc_rel(self.fc_fusion(torch.cat(parts, 1) if len(parts) > 1 else parts[0]))
         if self._prd_dev is None or self._prd_dev.device != x.device:
             self._prd_dev = torch.from_numpy(np.asarray(self.prd_vecs, np.float32)).to(x.device)
         sem = ops.l2norm_rows(self.prd_sem_embeddings(self._prd_dev))       # F.normalize(p=2, dim=1), one kernel each way
@@ -137,6 +154,15 @@ class vrd(nn.Module):
     def _getUnionBBox(self, aBB, bBB, ih, iw, margin=10):
         return [max(0, min(aBB[0], bBB[0]) - margin), max(0, min(aBB[1], bBB[1]) - margin),
                 min(iw, max(aBB[2], bBB[2]) + margin), min(ih, max(aBB[3], bBB[3]) + margin)]
+
+    def _getRelativeLoc(self, aBB, bBB):
+        """:258-264 (the spatial_type == 1 feature): offsets and log size ratios of the subject and object boxes, float32."""
+        sx1, sy1, sx2, sy2 = np.asarray(aBB).astype(np.float32)
+        ox1, oy1, ox2, oy2 = np.asarray(bBB).astype(np.float32)
+        sw, sh, ow, oh = sx2 - sx1, sy2 - sy1, ox2 - ox1, oy2 - oy1
+        xy = np.array([(sx1 - ox1) / ow, (sy1 - oy1) / oh, (ox1 - sx1) / sw, (oy1 - sy1) / sh])
+        wh = np.log(np.array([sw / ow, sh / oh, ow / sw, oh / sh]))
+        return np.hstack((xy, wh))
 
     def _getDualMask(self, ih, iw, bb):
         rh, rw = 32.0 / ih, 32.0 / iw

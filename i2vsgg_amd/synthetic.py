@@ -138,21 +138,41 @@ VRD_CONVS = (("vrd.conv_lo.0.conv", 96, 2, 5), ("vrd.conv_lo.1.conv", 128, 96, 5
              ("vrd.conv_lo.2.conv", 64, 128, 8))
 
 
-def vrd_params(seed=13, emb_dim=300, device=None, numpy_rng=True, fc6_in=1024 * 7 * 7):
-    """All ``vrd.*`` tensors: 226 480 996 parameters at emb_dim=300 (906 MB fp32)."""
+def vrd_params(seed=13, emb_dim=300, device=None, numpy_rng=True, fc6_in=1024 * 7 * 7, use_obj_visual=True, spatial_type=2):
+    """All ``vrd.*`` tensors: 226 480 996 parameters at emb_dim=300 (906 MB fp32).  ``use_obj_visual`` / ``spatial_type``: the
+    variants of resnet_SGG_emb.py:94-123 (no ``fc_so``; ``fc_lov`` on 8 inputs / no spatial branch; ``fc_fusion`` narrower);
+    the tensors every variant has are the same numbers as the default's (drawn in the same order, the others skipped)."""
     rng = np.random.default_rng(seed) if numpy_rng else None
     gen = None if numpy_rng else torch.Generator(device=device).manual_seed(seed)
     p = {}
+    n_fusion = 256 * (1 + int(bool(use_obj_visual)) + int(spatial_type in (1, 2)))
     for key, cout, cin in VRD_SHAPES:
         cout = emb_dim if cout is None else cout
         cin = fc6_in if key == "vrd.fc6.fc" else cin
+        full = (cout, cin)
+        if key == "vrd.fc_lov.fc" and spatial_type == 1:
+            cin = 8
+        if key == "vrd.fc_fusion.fc":
+            cin = n_fusion
+        if (cout, cin) != full or (key == "vrd.fc_so.fc" and not use_obj_visual) or (key == "vrd.fc_lov.fc" and spatial_type not in (1, 2)):
+            # keep the default's random stream for every other tensor: draw the default-shaped tensor, then a narrower one
+            _normal(rng, full, 1.0 / math.sqrt(full[1]), device, gen)
+            _normal(rng, (full[0],), 1.0 / math.sqrt(full[1]), device, gen)
+            if (key == "vrd.fc_so.fc" and not use_obj_visual) or (key == "vrd.fc_lov.fc" and spatial_type not in (1, 2)):
+                continue
+            r2 = np.random.default_rng(seed + 1000 + cin) if numpy_rng else None
+            bound = 1.0 / math.sqrt(cin)
+            p[key + ".weight"] = _normal(r2, (cout, cin), bound, device, gen)
+            p[key + ".bias"] = _normal(r2, (cout,), bound, device, gen)
+            continue
         bound = 1.0 / math.sqrt(cin)                 # nn.Linear default scale
         p[key + ".weight"] = _normal(rng, (cout, cin), bound, device, gen)
         p[key + ".bias"] = _normal(rng, (cout,), bound, device, gen)
     for key, cout, cin, k in VRD_CONVS:
         bound = 1.0 / math.sqrt(cin * k * k)
-        p[key + ".weight"] = _normal(rng, (cout, cin, k, k), bound, device, gen)
-        p[key + ".bias"] = _normal(rng, (cout,), bound, device, gen)
+        w, b = _normal(rng, (cout, cin, k, k), bound, device, gen), _normal(rng, (cout,), bound, device, gen)
+        if spatial_type == 2:
+            p[key + ".weight"], p[key + ".bias"] = w, b
     return _to(p, device)
 
 

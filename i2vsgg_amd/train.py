@@ -512,6 +512,10 @@ class SGGEmbStep:
                  optimizer="sgd"):
         import os
         self.net, self.dev, self.n_frames = net, torch.device(device), n_frames
+        if not (net.vrd.use_obj_visual and net.vrd.spatial_type == 2):
+            raise ValueError("SGGEmbStep packs the inputs of the reference's default relation head (use_obj_visual=True, "
+                             "spatial_type=2: what every reference script runs); the other vrd variants run through "
+                             "vrd.forward / forward_device")
         self.world = parallel.world_size()
         self.geom = (h, w, n_boxes, n_pairs)
         # data parallelism for everything except vrd.fc6, which is cut by output columns (parallel.py): its 822 MB

@@ -113,10 +113,21 @@ def _convrelu(x, p, k, stride, pad):
     return F.relu(F.conv2d(x, p[k + ".conv.weight"], p[k + ".conv.bias"], stride=stride, padding=pad))
 
 
-def vrd_head(fmap, boxes, rel_boxes, spatial, ix_s, ix_o, prd_vecs, p, training=True):
+def relative_loc(a, b):
+    """vrd._getRelativeLoc (resnet_SGG_emb.py:258-264): the 8-d spatial feature of spatial_type == 1, float32 arithmetic."""
+    sx1, sy1, sx2, sy2 = np.asarray(a).astype(np.float32)
+    ox1, oy1, ox2, oy2 = np.asarray(b).astype(np.float32)
+    sw, sh, ow, oh = sx2 - sx1, sy2 - sy1, ox2 - ox1, oy2 - oy1
+    xy = np.array([(sx1 - ox1) / ow, (sy1 - oy1) / oh, (ox1 - sx1) / sw, (oy1 - sy1) / sh])
+    wh = np.log(np.array([sw / ow, sh / oh, ow / sw, oh / sh]))
+    return np.hstack((xy, wh))
+
+
+def vrd_head(fmap, boxes, rel_boxes, spatial, ix_s, ix_o, prd_vecs, p, training=True, use_obj_visual=True, spatial_type=2):
     """vrd.forward (resnet_SGG_emb.py:128-221), dropout disabled (eval-mode dropout
     for reproducibility, SURVEY.md section 7).  fmap (1,1024,H,W) NCHW numpy/torch;
-    boxes (nb,5), rel_boxes (nr,5), spatial (nr,2,32,32); returns (scores, rel_feat).
+    boxes (nb,5), rel_boxes (nr,5), spatial (nr,2,32,32) -- (nr,8) for spatial_type 1 (:172-174); returns (scores, rel_feat).
+    ``use_obj_visual`` / ``spatial_type``: the branches of :166-180.
     ``training`` only selects whether the final softmax is applied (:216-219)."""
     fmap = torch.as_tensor(fmap, dtype=torch.float32)
     fm = fmap.numpy()
@@ -131,12 +142,16 @@ def vrd_head(fmap, boxes, rel_boxes, spatial, ix_s, ix_o, prd_vecs, p, training=
     obj = _fc(x_so, p, "vrd.so_vis_embeddings", relu=False)
     x_s, x_o = obj.index_select(0, ix_s), obj.index_select(0, ix_o)
     x = _fc(_fc(_fc(pool(rel_boxes), p, "vrd.fc6"), p, "vrd.fc7"), p, "vrd.fc8")
-    x = torch.cat((x, _fc(torch.cat((x_s, x_o), 1), p, "vrd.fc_so")), 1)
-    lo = torch.as_tensor(spatial, dtype=torch.float32)
-    lo = _convrelu(lo, p, "vrd.conv_lo.0", 2, 2)
-    lo = _convrelu(lo, p, "vrd.conv_lo.1", 2, 2)
-    lo = _convrelu(lo, p, "vrd.conv_lo.2", 1, 0)
-    x = torch.cat((x, _fc(lo.reshape(lo.size(0), -1), p, "vrd.fc_lov")), 1)
+    if use_obj_visual:
+        x = torch.cat((x, _fc(torch.cat((x_s, x_o), 1), p, "vrd.fc_so")), 1)
+    lo = torch.as_tensor(np.asarray(spatial), dtype=torch.float32)
+    if spatial_type == 1:
+        x = torch.cat((x, _fc(lo.reshape(lo.size(0), -1), p, "vrd.fc_lov")), 1)
+    elif spatial_type == 2:
+        lo = _convrelu(lo, p, "vrd.conv_lo.0", 2, 2)
+        lo = _convrelu(lo, p, "vrd.conv_lo.1", 2, 2)
+        lo = _convrelu(lo, p, "vrd.conv_lo.2", 1, 0)
+        x = torch.cat((x, _fc(lo.reshape(lo.size(0), -1), p, "vrd.fc_lov")), 1)
     x = _fc(_fc(x, p, "vrd.fc_fusion"), p, "vrd.fc_rel", relu=False)
     sem = torch.as_tensor(prd_vecs, dtype=torch.float32)
     sem = F.linear(sem, p["vrd.prd_sem_embeddings.0.weight"], p["vrd.prd_sem_embeddings.0.bias"])

@@ -195,6 +195,40 @@ def test_vrd_head(gold):
     np.testing.assert_allclose(p["vrd.fc6.fc.weight"].grad.numpy()[:4, ::97], g["g_fc6_w"], rtol=1e-3, atol=1e-10)
 
 
+VRD_VARIANTS = {"nov_s1": (False, 1), "ov_s1": (True, 1), "nov_s2": (False, 2), "ov_s0": (True, 0)}
+
+
+def _variant_inputs(g, tag, n_rel=62, n_cls=16):
+    ov, st = VRD_VARIANTS[tag]
+    anno = syn.relation_annotation(31, 8, 8, n_rel, n_cls)
+    boxes, rel_boxes, spatial, labels, ixs, ixo = nets.build_pairs(anno["boxes"], anno["rels"], 1.0, 600.0, 1000.0, n_rel)
+    if st == 1:
+        spatial = np.array([nets.relative_loc(anno["boxes"][s], anno["boxes"][o]) for s, o in zip(ixs, ixo)])
+        assert np.array_equal(spatial, g[tag + "_spatial"])            # vrd._getRelativeLoc of the reference, bit for bit
+    fmap = np.abs(np.random.default_rng(32).standard_normal((1, 1024, 38, 63), dtype=np.float32))
+    return ov, st, boxes, rel_boxes, spatial, labels, ixs, ixo, fmap
+
+
+@pytest.mark.parametrize("tag", sorted(VRD_VARIANTS))
+def test_vrd_head_variants(gold, tag):
+    """The branches of resnet_SGG_emb.py:94-123 / :166-180 the reference's scripts never select but the class
+    implements: no object-visual branch, the 8-d relative-location feature instead of the dual masks, no spatial branch."""
+    g = gold("vrd_head_variants")
+    ov, st, boxes, rel_boxes, spatial, labels, ixs, ixo, fmap = _variant_inputs(g, tag)
+    p = {k: v.clone().requires_grad_() for k, v in syn.vrd_params(13, use_obj_visual=ov, spatial_type=st).items()}
+    score, feat = nets.vrd_head(fmap, boxes, rel_boxes, spatial, ixs, ixo, syn.word_vectors(21, 62), p, training=True,
+                                use_obj_visual=ov, spatial_type=st)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(score, torch.from_numpy(labels).float())
+    loss.backward()
+    np.testing.assert_allclose(score.detach().numpy(), g[tag + "_scores"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(feat.detach().numpy(), g[tag + "_rel_feat"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(loss.item(), g[tag + "_loss"], rtol=1e-6)
+    np.testing.assert_allclose(p["vrd.fc_fusion.fc.weight"].grad.numpy()[::16], g[tag + "_g_fusion_w"], rtol=1e-3, atol=1e-9)
+    np.testing.assert_allclose(p["vrd.fc7.fc.bias"].grad.numpy(), g[tag + "_g_fc7_b"], rtol=1e-3, atol=1e-9)
+    if st in (1, 2):
+        np.testing.assert_allclose(p["vrd.fc_lov.fc.weight"].grad.numpy()[::4], g[tag + "_g_lov_w"], rtol=1e-3, atol=1e-9)
+
+
 def _split_dets(g, tag):
     counts = g[tag + "_count"]
     flat = g[tag + "_dets"]

@@ -557,6 +557,31 @@ def gen_vrd(cfg):
              g_sem0_b=head.prd_sem_embeddings[0].bias.grad.numpy(),
              g_fc6_w_sum=np.array(head.fc6.fc.weight.grad.numpy().astype(np.float64).sum()),
              g_fc6_w_abs=np.array(np.abs(head.fc6.fc.weight.grad.numpy().astype(np.float64)).sum()))
+        # the variants of resnet_SGG_emb.py:94-123 / :166-180 (the reference's scripts only ever run the defaults: its
+        # type=bool flags parse every CLI value to True -- but the class implements them, so they are pinned too)
+        out = {}
+        for tag, (ov, st) in {"nov_s1": (False, 1), "ov_s1": (True, 1), "nov_s2": (False, 2), "ov_s0": (True, 0)}.items():
+            a2 = argparse.Namespace(**dict(vars(args), use_obj_visual=ov, spatial_type=st))
+            h2 = S.vrd(a2, obj, prd)
+            _load(h2, syn.vrd_params(13, use_obj_visual=ov, spatial_type=st), "vrd.")
+            h2.eval()
+            h2.training = True
+            if st == 1:
+                sp = np.array([h2._getRelativeLoc(np.array(anno["boxes"][s_]), np.array(anno["boxes"][o_])) for s_, o_ in zip(ixs, ixo)])
+                out[tag + "_spatial"] = sp
+            else:
+                sp = spatial
+            sc2, ft2 = h2(fmap, boxes, rel_boxes, sp, classes, ixs, ixo)
+            l2 = h2.criterion(sc2, torch.from_numpy(labels).float())
+            l2.backward()
+            out[tag + "_scores"], out[tag + "_rel_feat"], out[tag + "_loss"] = sc2.detach().numpy(), ft2, l2.detach().numpy()
+            out[tag + "_g_fusion_w"] = h2.fc_fusion.fc.weight.grad.numpy()[::16].copy()
+            out[tag + "_g_fc7_b"] = h2.fc7.fc.bias.grad.numpy()
+            if st in (1, 2):
+                out[tag + "_g_lov_w"] = h2.fc_lov.fc.weight.grad.numpy()[::4].copy()
+            print("    vrd variant %-7s use_obj_visual=%s spatial_type=%d: loss %.6f, fc_fusion %s" % (
+                tag, ov, st, float(l2), tuple(h2.fc_fusion.fc.weight.shape)))
+        save("vrd_head_variants", "placeholders", **out)
     finally:
         S.F.dropout = F_dropout
 
