@@ -317,7 +317,7 @@ def profile_eager(body, n_prof, dev):
     return [dict(t=e0.elapsed_time(e1) * 1e-3, flops=fl, tag=tag, desc=d, bytes=by) for e0, e1, fl, tag, d, by in rec]
 
 
-def pmc_traffic(kernel_key, names=("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json")):
+def pmc_traffic(kernel_key, names=("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json")):
     """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ for this round
     (rocprofv3 cannot run inside the timed process); None when there is no summary."""
     for name in names:
@@ -672,7 +672,7 @@ def run_instance_styled(a, rank, world, dev, steps, warmup, frames_per_rank=4):
     achieved = f_wg_exec / max(t_wg, 1e-12) / 1e12
     # the PMC passes of THIS configuration (tools/profile_bench.sh isd), not the headline's (whose conv_wgrad2_f32 launches
     # are the relation head's skinny GEMMs)
-    traffic, traffic_src = pmc_traffic("conv_wgrad2_f32", ("r03_instance_styled_pmc_summary.json", "r02_instance_styled_pmc_summary.json"))
+    traffic, traffic_src = pmc_traffic("conv_wgrad2_f32", ("r04_instance_styled_pmc_summary.json", "r03_instance_styled_pmc_summary.json", "r02_instance_styled_pmc_summary.json"))
     line = {
         "metric": "frames/sec (600x1000, 32 ROI/frame)", "value": world * 2 * frames_per_rank * steps / elapsed,
         "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
