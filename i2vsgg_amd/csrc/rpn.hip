@@ -266,21 +266,28 @@ nms_scan_pipelined_kernel(const unsigned long long* __restrict__ mask, int n, in
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int limit = max_keep > 0 ? max_keep : n;
     unsigned long long pc[4][SCAN_PIPE_WORDS], pn[4][SCAN_PIPE_WORDS], dc = 0, dn = 0;
+    // A row that is already suppressed when its block is fetched can never be kept, so its mask words are never used: they
+    // are not fetched.  ``removed[rb]`` holds, at that point, the verdict of every block but the one being resolved; with
+    // clustered proposals (12000 -> 2000 kept) most rows are gone by then, and the scan workgroup's ingest -- one CU pulling
+    // 96 KB per block, 18 MB per image, was ~40 % of its time -- shrinks with them.  (Uniform per wave: a row is a wave's.)
     auto fetch = [&](int rb, unsigned long long (&P)[4][SCAN_PIPE_WORDS], unsigned long long& diag) {
+        const unsigned long long gone = removed[rb];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = rb * 64 + wave * 4 + r;
+            const bool live = row < n && !((gone >> (wave * 4 + r)) & 1ull);
 #pragma unroll
             for (int c = 0; c < SCAN_PIPE_WORDS; ++c) {
                 const int j = rb + 1 + lane + 64 * c;
-                P[r][c] = (row < n && j < nblk) ? M[(long long)row * nblk + j] : 0ull;
+                P[r][c] = (live && j < nblk) ? M[(long long)row * nblk + j] : 0ull;
             }
         }
         if (wave == 0) {
             const int row = rb * 64 + lane;
-            diag = row < n ? M[(long long)row * nblk + rb] : 0ull;
+            diag = (row < n && !((gone >> lane) & 1ull)) ? M[(long long)row * nblk + rb] : 0ull;
         }
     };
+    __syncthreads();                                         // ``removed`` is clear (fetch reads it)
     fetch(0, pc, dc);
     __syncthreads();
     for (int rb = 0; rb < nblk; ++rb) {
