@@ -382,17 +382,16 @@ class _Slot:
 
 
 class _Uploader:
-    """Host frames -> device.  Default: on the caller's stream, in front of the step (a 2 x 3 x 600 x 1000 fp32 minibatch is
-    14.4 MB = 0.6 ms at 25 GB/s: bench.py --data loader 5.2 ms per step against 4.6 resident).
-    ``I2V_UPLOAD_STREAM=1``: on a COPY stream with two staging buffers and event edges both ways, so that the transfer of
-    minibatch k+1 runs beside the step that is still computing (measured 5.26 -> 5.03 ms).  Round 3 switched it off after a host
-    segfault in hipGraphLaunch (tests/test_gpu_configs.py followed by tests/test_gpu_data_layer.py) and blamed stream aliasing.
-    Round 4 (profiles/r04_alias_repro.txt): the same order with pooled streams, aliases logged as they happen -- the copy stream
-    WAS a captured branch, the side stream WAS torch's capture stream -- runs clean once no graph is dropped while a replay of
-    it may be in flight (``invalidate_graphs`` synchronises first; stage() grew the head capacity and dropped every graph
-    right behind an asynchronous replay).  The aliases were real but harmless to correctness; they are gone too
-    (ops.role_stream).  The option stays off by default for what it measures, not for safety: the transfer only gets its turn
-    when the step's branches drain (below).  ``tests/test_gpu_data_layer.py`` runs the loader loop with it on.
+    """Host frames -> device on the process's COPY stream (ops.role_stream), two staging buffers and event edges both ways: the
+    transfer of minibatch k+1 runs beside the step that is still computing (a 2 x 3 x 600 x 1000 fp32 minibatch is 14.4 MB;
+    bench.py --data loader over four alternating frame sizes: 5.00 -> 4.82 ms per step, uint8 frames 4.83 -> 4.77).
+    ``I2V_UPLOAD_STREAM=0``: the transfer on the caller's stream, in front of the step (the default of round 3, which had met
+    a host segfault in hipGraphLaunch with the copy stream and blamed stream aliasing).  Round 4
+    (profiles/r04_alias_repro.txt): the same file order with pooled streams and every alias logged -- the copy stream WAS a
+    captured branch, the side stream WAS torch's capture stream -- runs clean once no graph is dropped while a replay of it
+    may be in flight (``invalidate_graphs`` synchronises first; stage() grew the head capacity and dropped every graph right
+    behind an asynchronous replay).  The aliases were real but harmless to correctness; they are gone too (ops.role_stream),
+    and tests/test_gpu_data_layer.py runs the loader loop both ways, in the order that crashed.
     ``upload`` returns a device tensor that is valid on the caller's CURRENT stream, ``consumed`` marks the point after which
     its buffer may be overwritten."""
 
@@ -404,7 +403,7 @@ class _Uploader:
         # minibatch has one size (4.74 -> 4.86 ms instead of 5.15) but doubles the step (8.7-9.5 ms) as soon as the loop
         # alternates between the graphs of two sizes -- so it is not the default.
         import os
-        self.enabled = os.environ.get("I2V_UPLOAD_STREAM", "0") == "1"
+        self.enabled = os.environ.get("I2V_UPLOAD_STREAM", "1") == "1"
         # the copy stream exists only when asked for, and is the process's ONE copy stream (ops.role_stream): a handle of the
         # library's own, never an alias of a branch / capture / communicator stream out of torch's pool
         self.stream = ops.role_stream(self.dev, "copy", int(os.environ.get("I2V_UPLOAD_PRIORITY", "0"))) if self.enabled else None

@@ -78,9 +78,9 @@ def test_roi_pool_with_device_side_extent_equals_the_static_kernel():
 
 @pytest.mark.parametrize("copy_stream", [False, True])
 def test_sgg_captured_step_consumes_loader_batches_of_varying_size(small_cfg, monkeypatch, copy_stream):
-    """``copy_stream``: the same loop with the frames crossing PCIe on the copy stream (I2V_UPLOAD_STREAM=1).  Round 3 met a host
-    segfault in hipGraphLaunch in exactly this test, in exactly this file order (tests/test_gpu_configs.py first), with the copy
-    stream on, and switched it off by default.  Since then (a) no graph is dropped while a replay of it may still be running
+    """``copy_stream``: the loop with the frames crossing PCIe on the copy stream (the default since round 4) / on the caller's
+    stream (I2V_UPLOAD_STREAM=0).  Round 3 met a host segfault in hipGraphLaunch in exactly this test, in exactly this file order
+    (tests/test_gpu_configs.py first), with the copy stream on, and switched it off by default.  Since then (a) no graph is dropped while a replay of it may still be running
     (capacity growth in stage() dropped every graph right behind an asynchronous replay -- ``invalidate_graphs`` synchronises
     first now) and (b) the copy stream is a stream of its own (ops.role_stream) instead of the next of torch's 32 pooled handles.
     DESIGN.md 5.5 has the analysis.
