@@ -367,8 +367,8 @@ def roi_nms_cases(dev):
 
         def bwd(f=feat, o=out, g=gout):
             f.grad = None
-            o.backward(g, retain_graph=True)                # zero-fill of the gradient map + the scatter kernel
-        cases.append(("roi_align_avg_bwd_%dx%d" % (B, R), bwd, nbytes, ["roi_align_bwd_kernel"]))
+            o.backward(g, retain_graph=True)                # the gather form: sample gradients, then every map element written once
+        cases.append(("roi_align_avg_bwd_%dx%d" % (B, R), bwd, nbytes, ["roi_align_bwd_prep_kernel", "roi_align_bwd_gather_kernel"]))
     # ROIPool as the captured relation step runs it: 2 packed frames, 32 boxes + 32 union boxes each, NCHW out for vrd.fc6,
     # extent of the maps read on the device (i2v_roi_pool_fwd_geom)
     Bp, Rp, C, h, w = 2, 64, 1024, 38, 63
@@ -427,7 +427,7 @@ def run_roi_nms(dev, reps=20):
         out[name] = row
     del blocker
     out["note"] = ("one event pair around %d back-to-back launches behind a blocker GEMM (includes the ~1-2 us between two launches; "
-                   "rocprof_avg_us is the kernels' own time); the backward includes its zero-fill of the gradient map; NMS = mask + "
+                   "rocprof_avg_us is the kernels' own time); the backward = sample-gradient kernel + gather kernel (deterministic, no atomics, no zero-fill); NMS = mask + "
                    "scan kernels, bytes of the reference algorithm (the scan is a latency chain, not a stream)" % reps)
     return out
 

@@ -27,6 +27,8 @@ SIGNATURES = {
     "i2v_stream_destroy": (_i, [_p]),
     "i2v_roi_align_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _p, _i, _p]),
     "i2v_roi_align_bwd": (_i, [_p, _i, _p, _i, _i, _i, _f, _i, _p, _i, _i, _i, _i, _i, _p]),
+    "i2v_roi_align_bwd_gather_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
+    "i2v_roi_align_bwd_gather": (_i, [_p, _p, _i, _i, _i, _f, _i, _p, _i, _i, _i, _i, _p, _z, _p]),
     "i2v_roi_align_sampled_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _p, _i, _p]),
     "i2v_roi_align_sampled_bwd": (_i, [_p, _i, _p, _i, _i, _i, _f, _i, _p, _i, _i, _i, _i, _i, _p]),
     "i2v_roi_pool_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _f, _p, _p, _i, _p]),

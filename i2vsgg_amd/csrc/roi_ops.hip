@@ -320,6 +320,207 @@ roi_align_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ r
     }
 }
 
+// ---------------------------------------------------------------- backward as a GATHER (NHWC in and out)
+// The scatter above costs four float atomics per sample and channel: 134 MB of atomically added bytes for 4 frames x 32 ROIs,
+// and the chip adds ~1.3 TB/s of them -- 102 us, 0.07 of the HBM roofline on algorithmic bytes, summation order free.
+// Here every element of the gradient map is written ONCE, by the workgroup that owns it, as the sum of its contributions in
+// the reference's serial order (roi, sample row, sample column ascending -- roi_align_kernel.cu:94-143 run as a loop):
+// deterministic, no atomics, no zero-fill in front.  Two kernels:
+//   prep    per (roi, 128 channels): the sample gradients gs[r][s][c] (the 2x2 mean's backward folded in, same expression as
+//           the scatter kernel) and, once per ROI, the sample geometry table {frame, ok, hs, ws, hr, wr};
+//   gather  per (frame, map row h, 128 channels): the samples of that frame whose taps touch row h (hs == h or hs + 1 == h)
+//           are listed in index order (a deterministic compaction, 2048 samples per pass); wave group g owns the cells
+//           w = g (mod 8) of the row, walks the list and adds its taps -- (float)(g * (1. - hr) * (1 - wr)) ... exactly as the
+//           scatter -- into a 128-channel row buffer in LDS; the row is then stored with 16-byte stores.
+struct AxisGeom { int ok, s; float r; int pad; };        // one axis of ra_sample: in range?, floor (clamped to n - 2), fraction
+
+// ra_sample's arithmetic for one axis (roi_align.c:99-118): the sample grid is separable, a sample row shares hs / hr, a
+// sample column ws / wr, and a sample is inside the map when both are
+__device__ inline AxisGeom ra_axis(float lo, float hi, float scale, int n, int A, int p) {
+    const float a1 = lo * scale, a2 = hi * scale;
+    const float len = fmaxf((float)((double)(a2 - a1) + 1.), 0.f);
+    const float bin = (float)((double)len / (A - 1.));
+    const float v = (float)p * bin + a1;
+    AxisGeom g;
+    g.s = (int)fminf(floorf(v), (float)(n - 2));
+    g.ok = !(v < 0 || v >= n);
+    g.r = v - (float)g.s;
+    g.pad = 0;
+    return g;
+}
+
+// prep: per (roi, 128 channels) the sample gradients gs[r][s][c]; once per ROI the geometry of its AH sample rows
+// (ok = frame index or -1) and AW sample columns
+template <int AVG>
+__global__ void __launch_bounds__(256)
+roi_align_bwd_prep_kernel(const float* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gs,
+                          AxisGeom* __restrict__ rowg, AxisGeom* __restrict__ colg, int R, int C, int H, int W, int PH, int PW,
+                          float scale) {
+    const int nchunk = C >> 7;
+    const int chunk = blockIdx.x % nchunk, r = blockIdx.x / nchunk;
+    const int l = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int AH = PH + AVG, AW = PW + AVG, NS = AH * AW;
+    const float* roi = rois + 5 * (long long)r;
+    if (chunk == 0) {
+        if ((int)threadIdx.x < AH) {
+            AxisGeom q = ra_axis(roi[2], roi[4], scale, H, AH, threadIdx.x);
+            q.ok = q.ok ? (int)roi[0] : -1;
+            rowg[(long long)r * AH + threadIdx.x] = q;
+        } else if ((int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + AW) {
+            colg[(long long)r * AW + (threadIdx.x - 64)] = ra_axis(roi[1], roi[3], scale, W, AW, threadIdx.x - 64);
+        }
+    }
+    // the ROI's PH x PW gradients of this chunk into LDS with every load in flight at once (one round trip), then the samples
+    __shared__ __attribute__((aligned(16))) float4 sg[64 * 32];
+    const float* go = gout + (long long)r * PH * PW * C + (chunk << 7);
+    float* o = gs + ((long long)r * NS) * C + (chunk << 7) + 4 * l;
+    {
+        float4 t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = threadIdx.x + 256 * j;
+            t[j] = (k < PH * PW * 32) ? *(const float4*)(go + (long long)(k >> 5) * C + 4 * (k & 31)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = threadIdx.x + 256 * j;
+            if (k < PH * PW * 32) sg[k] = t[j];
+        }
+    }
+    __syncthreads();
+    for (int s = g; s < NS; s += 8) {
+        const int ah = s / AW, aw = s - ah * AW;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (AVG) {          // avg_pool2d backward: grad / 4 summed over the <= 4 windows holding the sample, raster order
+#pragma unroll
+            for (int dy = -1; dy <= 0; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 0; ++dx) {
+                    const int ph = ah + dy, pw = aw + dx;
+                    if (ph >= 0 && ph < PH && pw >= 0 && pw < PW) {
+                        const float4 t = sg[(ph * PW + pw) * 32 + l];
+                        v.x += t.x / 4.f; v.y += t.y / 4.f; v.z += t.z / 4.f; v.w += t.w / 4.f;
+                    }
+                }
+        } else {
+            v = sg[s * 32 + l];
+        }
+        *(float4*)(o + (long long)s * C) = v;
+    }
+}
+
+constexpr int RAB_SEG = 1024;           // (roi, sample row) pairs examined per list pass
+constexpr int RAB_BATCH = 4;            // listed pairs whose sample gradients are staged in LDS together
+constexpr int RAB_MAXA = 8;             // sample columns per row this kernel takes
+
+// gather: per (frame b, map row h, 128 channels).  The (roi, sample row) pairs of frame b whose taps touch row h (hs == h:
+// the upper taps; hs + 1 == h: the lower taps) are listed in index order -- the reference loop's order -- by a deterministic
+// compaction; the 128-channel gradients of a batch of listed pairs' samples are staged in LDS by all threads at once (one
+// memory round trip per batch), then wave w adds the taps that land on ITS cells (cell % 4 == w) into the row buffer, in list
+// order, two channels per lane.  No two waves touch one cell, so there is nothing to synchronise but the batches.
+__global__ void __launch_bounds__(256)
+roi_align_bwd_gather_kernel(const float* __restrict__ gs, const AxisGeom* __restrict__ rowg, const AxisGeom* __restrict__ colg,
+                            float* __restrict__ gfeat, int n_pairs, int AH, int AW, int C, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float2* rowbuf = (float2*)lds;                                          // [W][64]: 128 channels of every cell, 2 per lane
+    float2* stage = rowbuf + (size_t)W * 64;                                // [RAB_BATCH][RAB_MAXA][64]
+    int* list = (int*)(stage + RAB_BATCH * RAB_MAXA * 64);                  // [RAB_SEG]: pair index * 2 + (hs + 1 == h)
+    __shared__ int s_wave_cnt[4], s_total;
+    __shared__ AxisGeom s_col[RAB_BATCH][RAB_MAXA];
+    __shared__ float s_hr[RAB_BATCH];
+    __shared__ int s_dy[RAB_BATCH];
+    const int nchunk = C >> 7;
+    const int chunk = blockIdx.x % nchunk, h = (blockIdx.x / nchunk) % H, b = blockIdx.x / (nchunk * H);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < W * 64; i += 256) rowbuf[i] = make_float2(0.f, 0.f);
+    for (int base = 0; base < n_pairs; base += RAB_SEG) {
+        if (threadIdx.x == 0) s_total = 0;
+        // ---- the keys of this segment: requested at once (RAB_SEG / 256 = 4 per thread), compacted from registers
+        AxisGeom key[RAB_SEG / 256];
+#pragma unroll
+        for (int k = 0; k < RAB_SEG / 256; ++k) {
+            const int i = base + k * 256 + threadIdx.x;
+            key[k].ok = -1; key[k].s = 0; key[k].r = 0.f;
+            if (i < n_pairs) key[k] = rowg[i];
+        }
+        __syncthreads();
+        const int rounds = (min(RAB_SEG, n_pairs - base) + 255) >> 8;
+#pragma unroll
+        for (int k = 0; k < RAB_SEG / 256; ++k) {
+            if (k >= rounds) break;
+            const int i = base + k * 256 + threadIdx.x;
+            const int dy = key[k].s + 1 == h;
+            const int hit = i < n_pairs && key[k].ok == b && (key[k].s == h || dy);
+            const unsigned long long m = __ballot(hit);
+            if (lane == 0) s_wave_cnt[wave] = __popcll(m);
+            __syncthreads();
+            int off = s_total;
+            for (int w = 0; w < wave; ++w) off += s_wave_cnt[w];
+            if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = 2 * i + dy;
+            __syncthreads();
+            if (threadIdx.x == 0) s_total += s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
+            __syncthreads();
+        }
+        const int n = s_total;
+        for (int e0 = 0; e0 < n; e0 += RAB_BATCH) {
+            const int nb = min(RAB_BATCH, n - e0);
+            {
+                // the 128-channel gradients of the batch's samples, 16 bytes per lane, every load in flight before the first store
+                float4 t[RAB_BATCH * RAB_MAXA * 32 / 256];
+#pragma unroll
+                for (int j = 0; j < RAB_BATCH * RAB_MAXA * 32 / 256; ++j) {
+                    const int k = threadIdx.x + 256 * j;
+                    const int u = k / (RAB_MAXA * 32), aw = (k / 32) % RAB_MAXA, ll = k & 31;
+                    t[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (u < nb && aw < AW) {
+                        const int pair = list[e0 + u] >> 1;
+                        t[j] = *(const float4*)(gs + ((long long)pair * AW + aw) * C + (chunk << 7) + 4 * ll);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < RAB_BATCH * RAB_MAXA * 32 / 256; ++j) ((float4*)stage)[threadIdx.x + 256 * j] = t[j];
+            }
+            if (threadIdx.x < nb * RAB_MAXA) {
+                const int u = threadIdx.x / RAB_MAXA, aw = threadIdx.x % RAB_MAXA;
+                const int pair = list[e0 + u] >> 1, r = pair / AH;
+                AxisGeom q; q.ok = 0; q.s = 0; q.r = 0.f; q.pad = 0;
+                if (aw < AW) q = colg[(long long)r * AW + aw];
+                s_col[u][aw] = q;
+                if (aw == 0) { s_hr[u] = rowg[pair].r; s_dy[u] = list[e0 + u] & 1; }
+            }
+            __syncthreads();
+            // ---- add: pairs in list order, sample columns ascending.  WAVE w owns the cells of its class (cell % 4 == w) with
+            // all 64 lanes (2 channels each): no two waves touch one cell.  The pair's eight column entries and its eight staged
+            // gradients come into registers with one LDS wait each; a tap is then register arithmetic and one read-modify-write
+            // of the row buffer
+            for (int u = 0; u < nb; ++u) {
+                const double fh = s_dy[u] ? (double)s_hr[u] : (1. - s_hr[u]);
+                AxisGeom q[RAB_MAXA];
+                float2 sv[RAB_MAXA];
+#pragma unroll
+                for (int aw = 0; aw < RAB_MAXA; ++aw) q[aw] = s_col[u][aw];
+#pragma unroll
+                for (int aw = 0; aw < RAB_MAXA; ++aw) sv[aw] = stage[(u * RAB_MAXA + aw) * 64 + lane];
+#pragma unroll
+                for (int aw = 0; aw < RAB_MAXA; ++aw) {
+                    if (!q[aw].ok) continue;
+                    const int c0 = q[aw].s;
+                    const int t = ((c0 & 3) == wave) ? 0 : (((c0 + 1) & 3) == wave) ? 1 : -1;      // at most one of the two taps is mine
+                    if (t < 0) continue;
+                    const float wx = t ? q[aw].r : (1 - q[aw].r);          // the scatter kernel's (1 - wr) / wr, in float as there
+                    float2 a = rowbuf[(c0 + t) * 64 + lane];
+                    // the scatter kernel's expressions: g * (1. - hr) * (1 - wr), g * (1. - hr) * wr, g * hr * (1 - wr), g * hr * wr
+                    a.x += (float)(sv[aw].x * fh * wx); a.y += (float)(sv[aw].y * fh * wx);
+                    rowbuf[(c0 + t) * 64 + lane] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    float* o = gfeat + (((long long)b * H + h) * W) * C + (chunk << 7);
+    for (int i = threadIdx.x; i < W * 32; i += 256) *(float4*)(o + (long long)(i >> 5) * C + 4 * (i & 31)) = ((const float4*)rowbuf)[i];
+}
+
 // ---------------------------------------------------------------- ROIPool
 // roi_pooling_kernel.cu:24-93.  One workgroup per (roi, 64-channel chunk); lane = channel, the four
 // waves split the pooled rows (ph % 4).  The PHxPW results of the chunk are staged in LDS so that an
@@ -655,6 +856,43 @@ extern "C" int32_t i2v_roi_align_bwd(const float* gout, int32_t out_layout, cons
     if (avg) roi_align_bwd_kernel<1><<<R * (PH + 1), 256, 0, st>>>(gout, rois, gfeat, C, H, W, PH, PW, scale, fs, os);
     else roi_align_bwd_kernel<0><<<R * PH, 256, 0, st>>>(gout, rois, gfeat, C, H, W, PH, PW, scale, fs, os);
     I2V_CHECK_LAUNCH("roi_align_bwd");
+    return I2V_OK;
+}
+
+extern "C" size_t i2v_roi_align_bwd_gather_workspace_bytes(int32_t R, int32_t C, int32_t PH, int32_t PW, int32_t avg) {
+    const size_t AH = PH + avg, AW = PW + avg;
+    return i2v_align((size_t)R * AH * AW * C * sizeof(float)) + i2v_align((size_t)R * AH * sizeof(AxisGeom)) +
+           i2v_align((size_t)R * AW * sizeof(AxisGeom));
+}
+
+extern "C" int32_t i2v_roi_align_bwd_gather(const float* gout, const float* rois, int32_t R, int32_t PH, int32_t PW, float scale,
+                                            int32_t avg, float* gfeat, int32_t B, int32_t C, int32_t H, int32_t W, void* ws,
+                                            size_t ws_bytes, void* stream) {
+    I2V_CHECK_ARG(gout && rois && gfeat && ws, "roi_align_bwd_gather: null pointer");
+    I2V_CHECK_ARG(B > 0 && C > 0 && H >= 2 && W >= 2 && R > 0 && PH > 0 && PW > 0, "roi_align_bwd_gather: bad shape");
+    I2V_CHECK_ARG(avg == 0 || avg == 1, "roi_align_bwd_gather: avg must be 0/1");
+    I2V_CHECK_ARG(C % 128 == 0, "roi_align_bwd_gather: C must be a multiple of 128 (NHWC in and out)");
+    const size_t AH = PH + avg, AW = PW + avg;
+    I2V_CHECK_ARG(AW <= RAB_MAXA && AH <= 64, "roi_align_bwd_gather: at most 8 sample columns");
+    if (ws_bytes < i2v_roi_align_bwd_gather_workspace_bytes(R, C, PH, PW, avg)) {
+        i2v_set_error("roi_align_bwd_gather: workspace too small");
+        return I2V_ERR_WORKSPACE;
+    }
+    const size_t lds = (size_t)W * 128 * sizeof(float) + (size_t)RAB_BATCH * RAB_MAXA * 128 * sizeof(float) + RAB_SEG * sizeof(int);
+    I2V_CHECK_ARG(lds <= 60 * 1024 && (long long)R * AH < (1ll << 30), "roi_align_bwd_gather: map too wide for the LDS row buffer");
+    hipStream_t st = (hipStream_t)stream;
+    float* gs = (float*)ws;
+    AxisGeom* rowg = (AxisGeom*)((char*)ws + i2v_align((size_t)R * AH * AW * C * sizeof(float)));
+    AxisGeom* colg = (AxisGeom*)((char*)rowg + i2v_align((size_t)R * AH * sizeof(AxisGeom)));
+    if (avg) roi_align_bwd_prep_kernel<1><<<R * (C / 128), 256, 0, st>>>(gout, rois, gs, rowg, colg, R, C, H, W, PH, PW, scale);
+    else roi_align_bwd_prep_kernel<0><<<R * (C / 128), 256, 0, st>>>(gout, rois, gs, rowg, colg, R, C, H, W, PH, PW, scale);
+    static bool once = [] {
+        (void)hipFuncSetAttribute((const void*)roi_align_bwd_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
+        return true;
+    }();
+    (void)once;
+    roi_align_bwd_gather_kernel<<<B * H * (C / 128), 256, lds, st>>>(gs, rowg, colg, gfeat, (int)(R * AH), (int)AH, (int)AW, C, H, W);
+    I2V_CHECK_LAUNCH("roi_align_bwd_gather");
     return I2V_OK;
 }
 

@@ -69,6 +69,9 @@ def _rois_f32(rois):
     return rois.contiguous().float()
 
 
+ROIALIGN_BWD_GATHER = os.environ.get("I2V_ROIALIGN_BWD_GATHER", "1") != "0"     # 0: the atomic scatter (round 1)
+
+
 class _RoIAlignFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, rois, ph, pw, scale, avg, out_nchw):
@@ -94,6 +97,15 @@ class _RoIAlignFn(torch.autograd.Function):
         shape, nhwc, ph, pw, scale, avg, out_nchw = ctx.meta
         B, C, H, W = shape
         gout = gout.contiguous() if out_nchw else gout.contiguous(memory_format=_CL)
+        if ROIALIGN_BWD_GATHER and nhwc and not out_nchw and C % 128 == 0 and W * 512 + 20480 <= 60 * 1024 and pw + avg <= 8 and rois.size(0) > 0:
+            # the gather form: every element of the gradient map written once, in the reference's serial order (deterministic,
+            # no atomics, no zero-fill): 109 -> ~30 us at 4 frames x 32 ROIs
+            gfeat = torch.empty(shape, device=gout.device, dtype=torch.float32, memory_format=_CL)
+            nb = lib.i2v_roi_align_bwd_gather_workspace_bytes(rois.size(0), C, ph, pw, avg)
+            ws = workspace(nb, gout.device, "roi_align_bwd")
+            check(lib.i2v_roi_align_bwd_gather(ptr(gout), ptr(rois), rois.size(0), ph, pw, scale, avg, ptr(gfeat), B, C, H, W,
+                                               ptr(ws), ws.numel(), stream()), "roi_align_bwd_gather")
+            return gfeat, None, None, None, None, None, None
         # the scatter accumulates with atomics into zeros: inside a step they come from the step's pre-zeroed arena (one
         # clear per step for every atomically accumulated output) instead of a fill kernel of their own
         gfeat = ARENA.take(B, C, H, W) if (ARENA is not None and nhwc) else None

@@ -97,6 +97,39 @@ def test_roi_align_bwd(ops, oracle, C, H, W, B, avg):
         np.testing.assert_allclose(feat.grad.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("C,H,W,B,R", [(1024, 38, 63, 4, 32), (128, 19, 32, 2, 9), (256, 50, 67, 1, 40)])
+@pytest.mark.parametrize("avg", [True, False])
+def test_roi_align_bwd_gather_is_deterministic_and_equals_the_scatter(ops, oracle, monkeypatch, C, H, W, B, R, avg):
+    """Round 4: the backward of RoIAlign(Avg) as a gather (i2v_roi_align_bwd_gather: NHWC in and out, C % 128 == 0) -- every
+    element of the gradient map written once, contributions summed in the serial order of roi_align_kernel.cu:94-143 run as a
+    loop (roi, sample row, sample column ascending), no atomics, no zero-fill.  Against the C restatement of that loop, against
+    the atomic scatter it replaces, and twice for the same bits; 4 frames x 32 ROIs at full size (8192 samples: four list
+    passes per workgroup), ROIs of every size incl. sub-cell ones (all 64 samples of a ROI on one map row) and ones outside."""
+    from i2vsgg_amd import ops as O
+    cops, _ = oracle
+    rng = np.random.default_rng(C + H + R)
+    rois = np.concatenate([_rois_cases(rng, B, H, W)] + [np.concatenate([np.full((R, 1), b, np.float32),
+                          syn.boxes(R * 7 + b, R, H * 16, W * 16, 8, min(H, W) * 12)], 1) for b in range(B)]).astype(np.float32)
+    gout = rng.standard_normal((rois.shape[0], C, 7, 7), dtype=np.float32)
+    ref = (cops.roi_align_avg_bwd if avg else cops.roi_align_bwd)(gout, rois, (B, C, H, W), 1.0 / 16.0)
+    rt, gt = torch.from_numpy(rois).to(DEV), torch.from_numpy(gout).to(DEV).contiguous(memory_format=torch.channels_last)
+
+    def run():
+        feat = torch.zeros((B, C, H, W), device=DEV).contiguous(memory_format=torch.channels_last).requires_grad_()
+        O.roi_align(feat, rt, 7, 7, 1.0 / 16.0, avg=avg).backward(gt)
+        return feat.grad
+
+    assert O.ROIALIGN_BWD_GATHER
+    g1, g2 = run(), run()
+    assert torch.equal(g1, g2)                                           # no atomics: the same bits every time
+    monkeypatch.setattr(O, "ROIALIGN_BWD_GATHER", False)
+    sc = run()                                                           # the atomic scatter
+    scale = float(np.abs(ref).max())
+    assert float((g1 - sc).abs().max()) <= 2e-6 * scale
+    np.testing.assert_allclose(g1.cpu().numpy(), ref, rtol=0, atol=2e-6 * scale)
+    assert float(g1.abs().sum()) > 0
+
+
 @pytest.mark.parametrize("C,H,W,B", [(4, 9, 11, 2), (6, 9, 11, 2), (64, 19, 32, 2), (1024, 38, 63, 1)])
 @pytest.mark.parametrize("sampling", [0, 2])
 def test_roi_align_sampled_fwd_bwd(ops, oracle, C, H, W, B, sampling):
