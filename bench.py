@@ -361,7 +361,7 @@ def roi_nms_cases(dev):
         rt = torch.from_numpy(rois).to(dev)
         nbytes = B * 1024 * 38 * 63 * 4 + B * R * 1024 * 49 * 4
         cases.append(("roi_align_avg_fwd_%dx%d" % (B, R), (lambda f=feat, r=rt: ops.roi_align(f.detach(), r, 7, 7, 1 / 16.0, avg=True)),
-                      nbytes, ["roi_align_fwd_nhwc_cols"]))
+                      nbytes, ["roi_align_fwd_roi_kernel"]))
         out = ops.roi_align(feat, rt, 7, 7, 1 / 16.0, avg=True)
         gout = torch.randn_like(out)
 
@@ -380,11 +380,11 @@ def roi_nms_cases(dev):
         rp[b * Rp:(b + 1) * Rp, 1:] = syn.boxes(10 + b, Rp)
     rpt = torch.from_numpy(rp).to(dev)
     cases.append(("roi_pool_geom_fwd_2x64", lambda: ops.roi_pool_packed(maps, rpt, 7, 7, 1 / 16.0, out_nchw=True),
-                  Bp * C * h * w * 4 + 2 * Bp * Rp * C * 49 * 4, ["roi_pool_fwd"]))
+                  Bp * C * h * w * 4 + 2 * Bp * Rp * C * 49 * 4, ["roi_pool_fwd_c128_kernel"]))
     for n, keep in ((12000, 2000), (6000, 300)):
         dets = torch.from_numpy(syn.tie_free_dets(n, n, clustered=True)).to(dev)
         cases.append(("nms_%d_to_%d" % (n, keep), (lambda d=dets, k=keep: ops.nms_sorted(d, 0.7, k)),
-                      20 * n + 2 * 8 * n * ((n + 63) // 64), ["nms_mask_kernel", "nms_scan"]))
+                      20 * n + 2 * 8 * n * ((n + 63) // 64), ["nms_mask_kernel", "nms_scan_pipelined_kernel"]))
     return cases
 
 
