@@ -416,15 +416,22 @@ constexpr int RAB_MAXA = 8;             // sample columns per row this kernel ta
 // gather: per (frame b, map row h, 128 channels).  The (roi, sample row) pairs of frame b whose taps touch row h (hs == h:
 // the upper taps; hs + 1 == h: the lower taps) are listed in index order -- the reference loop's order -- by a deterministic
 // compaction; the 128-channel gradients of a batch of listed pairs' samples are staged in LDS by all threads at once (one
-// memory round trip per batch), then wave w adds the taps that land on ITS cells (cell % 4 == w) into the row buffer, in list
-// order, two channels per lane.  No two waves touch one cell, so there is nothing to synchronise but the batches.
+// memory round trip per batch, requested while the previous batch is added), then WAVE w adds them for ITS 32 channels into the row
+// buffer, in list order: lane = (channel, cell parity) -- of a sample column's two taps (cells ws, ws + 1) one is even and one
+// is odd, so every lane has exactly one tap per column and there is not a branch in the loop; the cells a lane meets along a
+// pair are non-decreasing, a repeated cell (ws + 1 == ws') is forwarded in a register, and the current values of all eight are
+// requested at once.  (Round 4's first form gave wave w the CELLS of class cell % 4 == w: every wave walked every column to
+// find its one tap in four, ~300 instructions and four dependent LDS round trips per pair -- 1.8k cycles, 76 % of the kernel.)
+// No two waves touch one channel, so there is nothing to synchronise but the batches.
 __global__ void __launch_bounds__(256)
 roi_align_bwd_gather_kernel(const float* __restrict__ gs, const AxisGeom* __restrict__ rowg, const AxisGeom* __restrict__ colg,
                             float* __restrict__ gfeat, int n_pairs, int AH, int AW, int C, int H, int W) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float2* rowbuf = (float2*)lds;                                          // [W][64]: 128 channels of every cell, 2 per lane
-    float2* stage = rowbuf + (size_t)W * 64;                                // [RAB_BATCH][RAB_MAXA][64]
-    int* list = (int*)(stage + RAB_BATCH * RAB_MAXA * 64);                  // [RAB_SEG]: pair index * 2 + (hs + 1 == h)
+    float* rowbuf = lds;                                                    // [W + 2][128]: cell x, channel c at x * 128 + (c ^ ((x & 1) << 5))
+                                                                            // (odd cells swap their 32-channel halves: the two half-waves
+                                                                            // of a tap hit different banks); rows W, W + 1: a bin for taps outside the map
+    float* stage = rowbuf + (size_t)(W + 2) * 128;                          // [RAB_BATCH][RAB_MAXA][128]
+    int* list = (int*)(stage + RAB_BATCH * RAB_MAXA * 128);                 // [RAB_SEG]: pair index * 2 + (hs + 1 == h)
     __shared__ int s_wave_cnt[4], s_total;
     __shared__ AxisGeom s_col[RAB_BATCH][RAB_MAXA];
     __shared__ float s_hr[RAB_BATCH];
@@ -432,7 +439,8 @@ roi_align_bwd_gather_kernel(const float* __restrict__ gs, const AxisGeom* __rest
     const int nchunk = C >> 7;
     const int chunk = blockIdx.x % nchunk, h = (blockIdx.x / nchunk) % H, b = blockIdx.x / (nchunk * H);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < W * 64; i += 256) rowbuf[i] = make_float2(0.f, 0.f);
+    const int ch = 32 * wave + (lane & 31), par = lane >> 5, chs = ch ^ (par << 5);
+    for (int i = threadIdx.x; i < (W + 2) * 32; i += 256) ((float4*)rowbuf)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int base = 0; base < n_pairs; base += RAB_SEG) {
         if (threadIdx.x == 0) s_total = 0;
         // ---- the keys of this segment: requested at once (RAB_SEG / 256 = 4 per thread), compacted from registers
@@ -462,33 +470,43 @@ roi_align_bwd_gather_kernel(const float* __restrict__ gs, const AxisGeom* __rest
             __syncthreads();
         }
         const int n = s_total;
-        for (int e0 = 0; e0 < n; e0 += RAB_BATCH) {
+        // the batch's operands travel while the PREVIOUS batch is added: the 128-channel gradients of its samples (16 bytes per
+        // lane, 4 loads per thread) and, on the first threads, the column geometry / row fraction of its pairs
+        constexpr int TL = RAB_BATCH * RAB_MAXA * 32 / 256;
+        float4 t[TL];
+        AxisGeom qn; float hrn = 0.f; int dyn = 0;
+        auto request = [&](int e0) {
             const int nb = min(RAB_BATCH, n - e0);
-            {
-                // the 128-channel gradients of the batch's samples, 16 bytes per lane, every load in flight before the first store
-                float4 t[RAB_BATCH * RAB_MAXA * 32 / 256];
 #pragma unroll
-                for (int j = 0; j < RAB_BATCH * RAB_MAXA * 32 / 256; ++j) {
-                    const int k = threadIdx.x + 256 * j;
-                    const int u = k / (RAB_MAXA * 32), aw = (k / 32) % RAB_MAXA, ll = k & 31;
-                    t[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (u < nb && aw < AW) {
-                        const int pair = list[e0 + u] >> 1;
-                        t[j] = *(const float4*)(gs + ((long long)pair * AW + aw) * C + (chunk << 7) + 4 * ll);
-                    }
+            for (int j = 0; j < TL; ++j) {
+                const int k = threadIdx.x + 256 * j;
+                const int u = k / (RAB_MAXA * 32), aw = (k / 32) % RAB_MAXA, ll = k & 31;
+                t[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (u < nb && aw < AW) {
+                    const int pair = list[e0 + u] >> 1;
+                    t[j] = *(const float4*)(gs + ((long long)pair * AW + aw) * C + (chunk << 7) + 4 * ll);
                 }
-#pragma unroll
-                for (int j = 0; j < RAB_BATCH * RAB_MAXA * 32 / 256; ++j) ((float4*)stage)[threadIdx.x + 256 * j] = t[j];
             }
+            qn.ok = 0; qn.s = 0; qn.r = 0.f; qn.pad = 0;
             if (threadIdx.x < nb * RAB_MAXA) {
                 const int u = threadIdx.x / RAB_MAXA, aw = threadIdx.x % RAB_MAXA;
                 const int pair = list[e0 + u] >> 1, r = pair / AH;
-                AxisGeom q; q.ok = 0; q.s = 0; q.r = 0.f; q.pad = 0;
-                if (aw < AW) q = colg[(long long)r * AW + aw];
-                s_col[u][aw] = q;
-                if (aw == 0) { s_hr[u] = rowg[pair].r; s_dy[u] = list[e0 + u] & 1; }
+                if (aw < AW) qn = colg[(long long)r * AW + aw];
+                if (aw == 0) { hrn = rowg[pair].r; dyn = list[e0 + u] & 1; }
+            }
+        };
+        if (n > 0) request(0);
+        for (int e0 = 0; e0 < n; e0 += RAB_BATCH) {
+            const int nb = min(RAB_BATCH, n - e0);
+#pragma unroll
+            for (int j = 0; j < TL; ++j) ((float4*)stage)[threadIdx.x + 256 * j] = t[j];
+            if (threadIdx.x < nb * RAB_MAXA) {
+                const int u = threadIdx.x / RAB_MAXA, aw = threadIdx.x % RAB_MAXA;
+                s_col[u][aw] = qn;
+                if (aw == 0) { s_hr[u] = hrn; s_dy[u] = dyn; }
             }
             __syncthreads();
+            if (e0 + RAB_BATCH < n) request(e0 + RAB_BATCH);
             // ---- add: pairs in list order, sample columns ascending.  WAVE w owns the cells of its class (cell % 4 == w) with
             // all 64 lanes (2 channels each): no two waves touch one cell.  The pair's eight column entries and its eight staged
             // gradients come into registers with one LDS wait each; a tap is then register arithmetic and one read-modify-write
@@ -496,29 +514,39 @@ roi_align_bwd_gather_kernel(const float* __restrict__ gs, const AxisGeom* __rest
             for (int u = 0; u < nb; ++u) {
                 const double fh = s_dy[u] ? (double)s_hr[u] : (1. - s_hr[u]);
                 AxisGeom q[RAB_MAXA];
-                float2 sv[RAB_MAXA];
+                float sv[RAB_MAXA], pre[RAB_MAXA], wx[RAB_MAXA];
+                int at[RAB_MAXA];
 #pragma unroll
                 for (int aw = 0; aw < RAB_MAXA; ++aw) q[aw] = s_col[u][aw];
 #pragma unroll
-                for (int aw = 0; aw < RAB_MAXA; ++aw) sv[aw] = stage[(u * RAB_MAXA + aw) * 64 + lane];
+                for (int aw = 0; aw < RAB_MAXA; ++aw) sv[aw] = stage[(u * RAB_MAXA + aw) * 128 + ch];
 #pragma unroll
                 for (int aw = 0; aw < RAB_MAXA; ++aw) {
-                    if (!q[aw].ok) continue;
-                    const int c0 = q[aw].s;
-                    const int t = ((c0 & 3) == wave) ? 0 : (((c0 + 1) & 3) == wave) ? 1 : -1;      // at most one of the two taps is mine
-                    if (t < 0) continue;
-                    const float wx = t ? q[aw].r : (1 - q[aw].r);          // the scatter kernel's (1 - wr) / wr, in float as there
-                    float2 a = rowbuf[(c0 + t) * 64 + lane];
+                    const int t = (q[aw].s ^ par) & 1;                        // my tap of this column: the cell of my parity
+                    const int cell = q[aw].ok ? q[aw].s + t : W + par;        // a column outside the map goes to the bin
+                    wx[aw] = t ? q[aw].r : (1 - q[aw].r);                     // the scatter kernel's (1 - wr) / wr, in float as there
+                    at[aw] = cell * 128 + chs;
+                    pre[aw] = rowbuf[at[aw]];
+                }
+                float cur = 0.f;
+                int prev = -1;
+#pragma unroll
+                for (int aw = 0; aw < RAB_MAXA; ++aw) {
+                    const float v = (at[aw] == prev) ? cur : pre[aw];
                     // the scatter kernel's expressions: g * (1. - hr) * (1 - wr), g * (1. - hr) * wr, g * hr * (1 - wr), g * hr * wr
-                    a.x += (float)(sv[aw].x * fh * wx); a.y += (float)(sv[aw].y * fh * wx);
-                    rowbuf[(c0 + t) * 64 + lane] = a;
+                    cur = v + (float)(sv[aw] * fh * wx[aw]);
+                    rowbuf[at[aw]] = cur;
+                    prev = at[aw];
                 }
             }
             __syncthreads();
         }
     }
     float* o = gfeat + (((long long)b * H + h) * W) * C + (chunk << 7);
-    for (int i = threadIdx.x; i < W * 32; i += 256) *(float4*)(o + (long long)(i >> 5) * C + 4 * (i & 31)) = ((const float4*)rowbuf)[i];
+    for (int i = threadIdx.x; i < W * 32; i += 256) {
+        const int x = i >> 5, c4 = i & 31;
+        *(float4*)(o + (long long)x * C + 4 * c4) = ((const float4*)rowbuf)[x * 32 + (c4 ^ ((x & 1) << 3))];
+    }
 }
 
 // ---------------------------------------------------------------- ROIPool
@@ -878,7 +906,7 @@ extern "C" int32_t i2v_roi_align_bwd_gather(const float* gout, const float* rois
         i2v_set_error("roi_align_bwd_gather: workspace too small");
         return I2V_ERR_WORKSPACE;
     }
-    const size_t lds = (size_t)W * 128 * sizeof(float) + (size_t)RAB_BATCH * RAB_MAXA * 128 * sizeof(float) + RAB_SEG * sizeof(int);
+    const size_t lds = (size_t)(W + 2) * 128 * sizeof(float) + (size_t)RAB_BATCH * RAB_MAXA * 128 * sizeof(float) + RAB_SEG * sizeof(int);
     I2V_CHECK_ARG(lds <= 60 * 1024 && (long long)R * AH < (1ll << 30), "roi_align_bwd_gather: map too wide for the LDS row buffer");
     hipStream_t st = (hipStream_t)stream;
     float* gs = (float*)ws;

@@ -97,7 +97,7 @@ class _RoIAlignFn(torch.autograd.Function):
         shape, nhwc, ph, pw, scale, avg, out_nchw = ctx.meta
         B, C, H, W = shape
         gout = gout.contiguous() if out_nchw else gout.contiguous(memory_format=_CL)
-        if ROIALIGN_BWD_GATHER and nhwc and not out_nchw and C % 128 == 0 and W * 512 + 20480 <= 60 * 1024 and pw + avg <= 8 and rois.size(0) > 0:
+        if ROIALIGN_BWD_GATHER and nhwc and not out_nchw and C % 128 == 0 and W * 512 + 21504 <= 60 * 1024 and pw + avg <= 8 and rois.size(0) > 0:
             # the gather form: every element of the gradient map written once, in the reference's serial order (deterministic,
             # no atomics, no zero-fill): 109 -> ~30 us at 4 frames x 32 ROIs
             gfeat = torch.empty(shape, device=gout.device, dtype=torch.float32, memory_format=_CL)
