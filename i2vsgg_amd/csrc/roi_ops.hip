@@ -190,27 +190,30 @@ roi_align_fwd_nhwc_cols(const float* __restrict__ feat, const float* __restrict_
 // them -- each tap crosses the L2 once.  blockIdx % (C / 128) picks the channel chunk: with C = 1024 an XCD (blockIdx % 8)
 // serves ONE 128-channel slice of the maps for every ROI, 1.2 MB per frame, resident in its L2.
 // Same sample geometry (ra_sample), same fp64 tap products (bilinear), same order of the 2 x 2 mean: bit-equal to the kernels above.
-template <int AVG>
+// CH = 64 (launches of fewer than 512 workgroups at 128: one frame's 32 ROIs): twice the workgroups, and the sixteen 16-lane groups
+// fetch all 64 samples in ONE pass instead of two.
+template <int AVG, int CH = 128>
 __global__ void __launch_bounds__(256)
 roi_align_fwd_roi_kernel(const float* __restrict__ feat, const float* __restrict__ rois, float* __restrict__ out,
                          int R, int C, int H, int W, int PH, int PW, float scale) {
-    __shared__ __attribute__((aligned(16))) float4 sv[64 * 32];        // [sample][lane]: 128 channels of up to 64 samples
-    const int nchunk = C >> 7;
+    constexpr int L = CH / 4, G = 256 / L, LG = CH == 128 ? 7 : 6;     // lanes per sample, sample groups, log2(CH)
+    __shared__ __attribute__((aligned(16))) float4 sv[64 * L];         // [sample][lane]: CH channels of up to 64 samples
+    const int nchunk = C >> LG;
     const int chunk = blockIdx.x % nchunk, r = blockIdx.x / nchunk;
     if (r >= R) return;
-    const int l = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int l = threadIdx.x & (L - 1), g = threadIdx.x / L;
     const float* roi = rois + 5 * (long long)r;
     const int b = (int)roi[0];
     const int AH = PH + AVG, AW = PW + AVG, NS = AH * AW;
     const __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(feat), 0, 0x7FFFFFFCu, 0x00020000);
-    const unsigned row = (unsigned)C * 4u, lane_off = (unsigned)((chunk << 7) + 4 * l) * 4u;
+    const unsigned row = (unsigned)C * 4u, lane_off = (unsigned)((chunk << LG) + 4 * l) * 4u;
     const unsigned img = (unsigned)b * (unsigned)(H * W);
-    for (int s0 = g; s0 < NS; s0 += 32) {                // four samples (16 loads) per lane and pass
+    for (int s0 = g; s0 < NS; s0 += 4 * G) {             // four samples (16 loads) per lane and pass
         Sample sm[4];
         float4 t[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int s = s0 + 8 * j;
+            const int s = s0 + G * j;
             const int ph = min(s, NS - 1) / AW, pw = min(s, NS - 1) % AW;
             sm[j] = ra_sample(roi, scale, H, W, AH, AW, ph, pw);
             if (s >= NS) sm[j].ok = 0;
@@ -223,31 +226,31 @@ roi_align_fwd_roi_kernel(const float* __restrict__ feat, const float* __restrict
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int s = s0 + 8 * j;
+            const int s = s0 + G * j;
             if (s >= NS) continue;
             float4 q;
             q.x = bilinear(t[j][0].x, t[j][1].x, t[j][2].x, t[j][3].x, sm[j].hr, sm[j].wr);
             q.y = bilinear(t[j][0].y, t[j][1].y, t[j][2].y, t[j][3].y, sm[j].hr, sm[j].wr);
             q.z = bilinear(t[j][0].z, t[j][1].z, t[j][2].z, t[j][3].z, sm[j].hr, sm[j].wr);
             q.w = bilinear(t[j][0].w, t[j][1].w, t[j][2].w, t[j][3].w, sm[j].hr, sm[j].wr);
-            sv[s * 32 + l] = sm[j].ok ? q : make_float4(0.f, 0.f, 0.f, 0.f);
+            sv[s * L + l] = sm[j].ok ? q : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     __syncthreads();
-    float* ob = out + (long long)r * PH * PW * C + (chunk << 7);
-    for (int o = threadIdx.x; o < PH * PW * 32; o += 256) {
-        const int p = o >> 5, ll = o & 31;
+    float* ob = out + (long long)r * PH * PW * C + (chunk << LG);
+    for (int o = threadIdx.x; o < PH * PW * L; o += 256) {
+        const int p = o / L, ll = o & (L - 1);
         const int ph = p / PW, pw = p - ph * PW;
         float4 v;
         if (AVG) {          // avg_pool2d(2, stride 1): fp32 running sum in window raster order, then /4
-            const float4 a = sv[(ph * AW + pw) * 32 + ll], bb = sv[(ph * AW + pw + 1) * 32 + ll];
-            const float4 c = sv[((ph + 1) * AW + pw) * 32 + ll], d = sv[((ph + 1) * AW + pw + 1) * 32 + ll];
+            const float4 a = sv[(ph * AW + pw) * L + ll], bb = sv[(ph * AW + pw + 1) * L + ll];
+            const float4 c = sv[((ph + 1) * AW + pw) * L + ll], d = sv[((ph + 1) * AW + pw + 1) * L + ll];
             v.x = (((a.x + bb.x) + c.x) + d.x) / 4.f;
             v.y = (((a.y + bb.y) + c.y) + d.y) / 4.f;
             v.z = (((a.z + bb.z) + c.z) + d.z) / 4.f;
             v.w = (((a.w + bb.w) + c.w) + d.w) / 4.f;
         } else {
-            v = sv[p * 32 + ll];
+            v = sv[p * L + ll];
         }
         *(float4*)(ob + (long long)p * C + 4 * ll) = v;
     }
@@ -850,7 +853,10 @@ extern "C" int32_t i2v_roi_align_fwd(const float* feat, int32_t feat_layout, int
         const bool per_roi = g_i2v_tuning[I2V_TUNE_ROIALIGN_COLS] == 2 && out_layout == I2V_LAYOUT_NHWC && (C % 128) == 0 &&
                              (PH + avg) * (PW + avg) <= 64 && (long long)B * H * W * C * 4 < (1ll << 31);
         if (per_roi) {
-            if (avg) roi_align_fwd_roi_kernel<1><<<R * (C / 128), 256, 0, st>>>(feat, rois, out, R, C, H, W, PH, PW, scale);
+            if (R * (C / 128) < 512) {          // a small launch: 64 channels per workgroup, one pass
+                if (avg) roi_align_fwd_roi_kernel<1, 64><<<R * (C / 64), 256, 0, st>>>(feat, rois, out, R, C, H, W, PH, PW, scale);
+                else roi_align_fwd_roi_kernel<0, 64><<<R * (C / 64), 256, 0, st>>>(feat, rois, out, R, C, H, W, PH, PW, scale);
+            } else if (avg) roi_align_fwd_roi_kernel<1><<<R * (C / 128), 256, 0, st>>>(feat, rois, out, R, C, H, W, PH, PW, scale);
             else roi_align_fwd_roi_kernel<0><<<R * (C / 128), 256, 0, st>>>(feat, rois, out, R, C, H, W, PH, PW, scale);
         } else if (!g_i2v_tuning[I2V_TUNE_ROIALIGN_COLS]) {
             if (avg) roi_align_fwd_nhwc<1><<<R * PH, 256, 0, st>>>(feat, rois, out, C, H, W, PH, PW, scale, os);
