@@ -252,6 +252,12 @@ nms_scan_kernel(const unsigned long long* __restrict__ mask, int n, int nblk, in
 // wave 0 plus two workgroup barriers.
 constexpr int SCAN_PIPE_WORDS = 3;      // words per lane: covers nblk - 1 <= 192 columns
 
+// a value every lane holds alike (read from LDS: the compiler must assume otherwise), moved to scalar registers
+__device__ inline unsigned long long uniform64(unsigned long long v) {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+}
+
 __global__ void __launch_bounds__(SCAN_THREADS)
 nms_scan_pipelined_kernel(const unsigned long long* __restrict__ mask, int n, int nblk, int max_keep,
                           int* __restrict__ keep_out, int* __restrict__ num_out) {
@@ -270,35 +276,64 @@ nms_scan_pipelined_kernel(const unsigned long long* __restrict__ mask, int n, in
     // are not fetched.  ``removed[rb]`` holds, at that point, the verdict of every block but the one being resolved; with
     // clustered proposals (12000 -> 2000 kept) most rows are gone by then, and the scan workgroup's ingest -- one CU pulling
     // 96 KB per block, 18 MB per image, was ~40 % of its time -- shrinks with them.  (Uniform per wave: a row is a wave's.)
+    // The fetch itself must be cheap: 16 waves issue 13 loads each per block, and written as ``live ? M[row * nblk + j] : 0`` every
+    // load carried a 64-bit multiply-add, a bounds compare and a branch of its own -- ~400 instructions per wave and block, four
+    // waves per SIMD: the chain per block (2.4k cycles) was instruction ISSUE, not the resolve, the barriers or memory latency
+    // (a deeper prefetch and a one-barrier form both measured slower: they added instructions).  Now: one buffer descriptor over
+    // the image's mask (the launcher keeps it below 2 GiB), byte offsets carried from block to block (+ (64 nblk + 1) * 8), the
+    // three words of a row through the instruction's immediate offset, a word past the end of its row = the 2 GiB bit (zeros, no traffic;
+    // rows past n fall off the descriptor by themselves).
+    const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((void*)M, 0, (unsigned)((long long)n * nblk * 8), 0x00020000);
+    const unsigned ostep = (unsigned)(64 * nblk + 1) * 8u;
+    unsigned noff[4], ndiag = (unsigned)(lane * nblk) * 8u;          // offsets of the NEXT block to fetch
+#pragma unroll
+    for (int r = 0; r < 4; ++r) noff[r] = (unsigned)((wave * 4 + r) * nblk + 1 + lane) * 8u;
     auto fetch = [&](int rb, unsigned long long (&P)[4][SCAN_PIPE_WORDS], unsigned long long& diag) {
         const unsigned long long gone = removed[rb];
+        const int wgone = __builtin_amdgcn_readfirstlane((int)((gone >> (wave * 4)) & 15ull));      // my four rows' verdicts: scalar
+        unsigned past[SCAN_PIPE_WORDS];                                   // a word past the end of its row
+#pragma unroll
+        for (int c = 0; c < SCAN_PIPE_WORDS; ++c) past[c] = (rb + 1 + lane + 64 * c < nblk) ? 0u : 0x80000000u;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int row = rb * 64 + wave * 4 + r;
-            const bool live = row < n && !((gone >> (wave * 4 + r)) & 1ull);
 #pragma unroll
             for (int c = 0; c < SCAN_PIPE_WORDS; ++c) {
-                const int j = rb + 1 + lane + 64 * c;
-                P[r][c] = (live && j < nblk) ? M[(long long)row * nblk + j] : 0ull;
+                P[r][c] = 0ull;
+                // a dead row or a column group past the end of the rows issues NO instruction (scalar branches): one CU's
+                // memory pipe takes these 16 x 13 wave-loads per block one after the other -- issued unconditionally, with
+                // the 2 GiB bit on the dead ones, the scan took 410 us instead of 280
+                if (!((wgone >> r) & 1) && rb + 1 + 64 * c < nblk)
+                    P[r][c] = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(mrs, (noff[r] | past[c]) + 512u * c, 0, 0));
             }
+            noff[r] += ostep;
         }
         if (wave == 0) {
-            const int row = rb * 64 + lane;
-            diag = (row < n && !((gone >> lane) & 1ull)) ? M[(long long)row * nblk + rb] : 0ull;
+            const unsigned dead = ((gone >> lane) & 1ull) ? 0x80000000u : 0u;
+            diag = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(mrs, ndiag | dead, 0, 0));
         }
+        ndiag += ostep;
     };
     __syncthreads();                                         // ``removed`` is clear (fetch reads it)
     fetch(0, pc, dc);
+    // The wait for a block's words is written out, HERE and at the end of every iteration, where the loads have had a whole
+    // iteration to land.  Left to the compiler it sat at the first use of dc / pc in the NEXT iteration -- behind the fetch that
+    // iteration had just issued, and vector loads return in order: vmcnt(0) there waited for the NEW block's words, a full memory
+    // round trip on the serial chain of every block (in-kernel clocks: 950 of a block's 2.5k cycles in wave 0's resolve, for
+    // three kept rows).
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)
     __syncthreads();
     for (int rb = 0; rb < nblk; ++rb) {
         if (rb + 1 < nblk) fetch(rb + 1, pn, dn);            // lands during this iteration
         if (wave == 0) {
             const int row = rb * 64 + lane;
-            unsigned long long cur = removed[rb];
+            // ``removed[rb]`` and ``s_count`` come from LDS: without the readfirstlane the compiler keeps them (and everything
+            // derived: todo, kept, count) in VECTOR registers and runs the loop below under exec masks -- 950 cycles per block
+            // for three kept rows (in-kernel clocks), the largest phase of the chain
+            unsigned long long cur = uniform64(removed[rb]);
             const int valid = min(64, n - rb * 64);
             if (valid < 64) cur |= ~0ull << valid;
             unsigned long long kept = 0;
-            const int count0 = s_count;
+            const int count0 = __builtin_amdgcn_readfirstlane(s_count);
             int count = count0;
             // serial greedy resolve of the 64 rows of this block, entirely in scalar registers: jump
             // to the next unsuppressed row with ffs, fetch its diagonal word with v_readlane
@@ -317,11 +352,11 @@ nms_scan_pipelined_kernel(const unsigned long long* __restrict__ mask, int n, in
             if (lane == 0) { s_kept = kept; s_count = count; }
         }
         __syncthreads();
-        const unsigned long long kept = s_kept;
-        if (s_count >= limit) break;
+        const unsigned long long kept = uniform64(s_kept);
+        if (__builtin_amdgcn_readfirstlane(s_count) >= limit) break;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            if (!((kept >> (wave * 4 + r)) & 1ull)) continue;
+            if (!((kept >> (wave * 4 + r)) & 1ull)) continue;                  // scalar
 #pragma unroll
             for (int c = 0; c < SCAN_PIPE_WORDS; ++c) {
                 const int j = rb + 1 + lane + 64 * c;
@@ -329,6 +364,7 @@ nms_scan_pipelined_kernel(const unsigned long long* __restrict__ mask, int n, in
             }
         }
         __syncthreads();
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): the next block's words, requested an iteration ago
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
