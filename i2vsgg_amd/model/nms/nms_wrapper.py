@@ -3,8 +3,6 @@
 kept row indices in descending-score order.  The work runs on the GPU (device sort + bitmask NMS
 with an on-device suppression scan); the single D2H copy is the returned keep list the reference
 API promises.  Hot paths (``_ProposalLayer``) use ``ops.rpn_proposal`` instead and never sync."""
-import torch
-
 from i2vsgg_amd import ops
 
 

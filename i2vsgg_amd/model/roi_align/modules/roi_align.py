@@ -2,7 +2,6 @@
 (roi_align/modules/roi_align.py:6-42): ``Module(aligned_h, aligned_w, spatial_scale)(features, rois)``
 -> (K, C, h, w); differentiable w.r.t. ``features`` only.  ``RoIAlignAvg`` is ONE fused kernel
 (sample (h+1)x(w+1) points, 2x2 stride-1 mean in registers) instead of align + avg_pool2d."""
-import torch
 from torch.nn.functional import max_pool2d
 from torch.nn.modules.module import Module
 
