@@ -939,6 +939,11 @@ conv_gemm_f32(const ConvP p_in) {
     int buf = 0, k0 = kbeg;
     for (; k0 + 2 * BKS < kend; k0 += BKS) {          // every stage but the last two
         gload(k0 + BKS);
+        // the next stage's loads are REQUESTED here: left alone the scheduler sinks them below 35 of the stage's 40 MFMAs (shorter
+        // live ranges), and a wave then waits out the L2 round trip between its last MFMA and its LDS stores.  With four waves
+        // per SIMD the others cover that (the step did not move: 4.45-4.47 against 4.49-4.53 ms, box noise); pinned, a wave
+        // covers it alone, which is what the source meant
+        __builtin_amdgcn_sched_barrier(0);
         compute(buf);
         sstore(buf ^ 1);
         stage_barrier();
@@ -947,6 +952,7 @@ conv_gemm_f32(const ConvP p_in) {
     if (k0 + BKS < kend) {                            // two stages left: operands of the last one, then the residual tile
         gload(k0 + BKS);
         issue_res();
+        __builtin_amdgcn_sched_barrier(0);
         compute(buf);
         sstore(buf ^ 1);
         stage_barrier();
