@@ -1264,6 +1264,7 @@ conv_gemm_pers_f32(const ConvP p) {
         int k0 = 0;
         for (; k0 + 2 * BKS < kend; k0 += BKS) {          // every stage but the last two
             gload(k0 + BKS);
+            __builtin_amdgcn_sched_barrier(0);            // requested HERE, not where the scheduler would sink them (conv_gemm_f32)
             compute(buf);
             sstore(buf ^ 1);
             __syncthreads();
@@ -1271,11 +1272,13 @@ conv_gemm_pers_f32(const ConvP p) {
         }
         gload(k0 + BKS);                                  // last stage's operands, then the epilogue's (returns are in order)
         issue_epi(m0, n0);
+        __builtin_amdgcn_sched_barrier(0);
         compute(buf);
         sstore(buf ^ 1);
         __syncthreads();
         buf ^= 1;
         if (nxt >= 0) { set_tile(nxt); gload(0); }        // the next tile's first stage rides under this tile's last
+        __builtin_amdgcn_sched_barrier(0);
         compute(buf);
         buf ^= 1;
         // epilogue in registers; the stores drain under whatever this workgroup and its neighbours do next
