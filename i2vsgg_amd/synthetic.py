@@ -250,6 +250,51 @@ def tie_free_dets(seed, n, im_h=600, im_w=1000, clustered=False):
     return np.concatenate([b.astype(np.float32), s[:, None].astype(np.float32)], 1)
 
 
+def roi_cases(seed, B, H, W, scale=16.0, n=24):
+    """(n+6,5) ROIs [b,x1,y1,x2,y2] for a (B,C,H,W) map: n seeded boxes plus a full-image, a sub-pixel, a malformed
+    (x2<x1, y2<y1), a partly outside (negative), a beyond-the-far-edge and a single-point box -- the classes
+    tests/golden/roi_align_fwd.npz (tools/gen_golden.py gen_roi_align) and the ROI kernel tests cover."""
+    rng = np.random.default_rng(seed)
+    bx = boxes(int(rng.integers(1 << 30)), n, H * scale, W * scale, 16, min(H, W) * scale * 0.9)
+    r = np.zeros((n + 6, 5), np.float32)
+    r[:n, 1:] = bx
+    r[:n, 0] = rng.integers(0, B, n)
+    r[n + 0] = [0, 0, 0, W * scale - 1, H * scale - 1]            # full image
+    r[n + 1] = [B - 1, 40.5, 33.25, 41.0, 33.5]                   # sub-pixel
+    r[n + 2] = [0, 120, 90, 60, 30]                               # malformed: x2<x1, y2<y1
+    r[n + 3] = [B - 1, -50, -40, 80, 70]                          # partly outside (negative)
+    r[n + 4] = [0, W * scale - 30, H * scale - 30, W * scale + 90, H * scale + 60]   # beyond the far edge
+    r[n + 5] = [B - 1, 10, 10, 10, 10]                            # single point
+    return r
+
+
+ROI_ALIGN_GOLDEN_CASES = ((4, 9, 11, 2), (64, 19, 32, 2), (1024, 38, 63, 1))          # (C, H, W, B)
+
+
+def roi_align_golden_inputs(C, H, W, B):
+    """The seeded map (B,C,H,W) and rois of one tests/golden/roi_align_fwd.npz case."""
+    feat = np.random.default_rng(9000 + C + H).standard_normal((B, C, H, W), dtype=np.float32)
+    return feat, roi_cases(9100 + C, B, H, W)
+
+
+def instance_styled_step_params(layers=101, n_cls=16):
+    """Seeded weights of the tests/golden/instance_styled_step.npz model (reference state_dict keys)."""
+    p = {}
+    p.update(backbone_params(0, layers, top=True))
+    p.update(rpn_params(10, std=0.02))
+    p.update(det_head_params(11, n_cls))
+    p.update(netd_params(12))
+    return p
+
+
+def instance_styled_step_inputs(B, H, W, n_cls=16):
+    """Source frames + gt, target frames of one instance_styleD step of the golden: (im, info, gt, nb, im_t, info_t)."""
+    im, info = frames(5, B, H, W)
+    gt, nb = gt_boxes(6, B, 6, n_cls, im_h=H, im_w=W)
+    im_t, info_t = frames(8, B, H, W)
+    return im, info, gt, nb, im_t, info_t
+
+
 def context_inputs(B=2, H=320, W=480):
     """Inputs of the ic/gc fixture (tools/gen_golden.py gen_context and tests/test_gpu_models.py): frames, gt, fixed proposals."""
     im, info = frames(5, B, H, W)

@@ -116,3 +116,100 @@ def test_instance_styled_source_and_target_losses_vs_oracle():
     finally:
         cfg.TRAIN.BATCH_SIZE = 128
         cfg.TRAIN.RPN_POST_NMS_TOP_N_TARGET = 128
+
+
+@pytest.mark.parametrize("tag,B,H,W", [("small", 2, 320, 480), ("full", 1, 600, 1000)])
+def test_instance_styled_step_vs_reference_run_golden(gold, tag, B, H, W):
+    """the eight scalars of one D+G step (trainval_net_instance_styleD_bilinear.py:276-296)
+    against the REFERENCE's own ``_fasterRCNN.forward`` run on the same seeded weights and frames
+    (tests/golden/instance_styled_step.npz: its backbone, RPN + nms_cpu, target layers under np.random.seed(3),
+    discriminators and heads; RoIAlignAvg = its own compiled ROIAlignForwardCpu + avg_pool2d).  res101; 2+2 frames of
+    320x480 and 1+1 full 600x1000 frames, 32 ROIs per frame (configs[2]'s shapes).
+
+    Two passes.  (1) The HIP model as shipped: its proposals against the reference's as row sets (a near-tie between two
+    scores may order two boxes differently under another convolution rounding), the two RPN losses and the style terms --
+    which do not depend on the proposals -- within 1e-3.  (2) With the reference's proposals handed to the sampling layer
+    (the RPN still runs: its losses and its share of the np.random stream are the HIP path's own): sampled rois and labels
+    bit-equal, all eight scalars, cls_prob, bbox_pred and the discriminator maps within 1e-3."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU")
+    from i2vsgg_amd.model.faster_rcnn.layers import load_reference_state
+    from i2vsgg_amd.model.faster_rcnn.resnet_instance_styleD_bilinear import resnet
+    from i2vsgg_amd.model.utils import config as c
+    g = gold("instance_styled_step")
+    c.cfg_from_file(c.default_cfg_file("res101"))
+    c.cfg_from_list(["ANCHOR_SCALES", "[8, 16, 32]", "ANCHOR_RATIOS", "[0.5,1,2]", "MAX_NUM_GT_BOXES", "30",
+                     "TRAIN.BATCH_SIZE", "32", "TRAIN.RPN_POST_NMS_TOP_N_TARGET", "32"])
+    cfg = c.cfg
+    try:
+        n_cls = 16
+        net = resnet(tuple(range(n_cls)), 101)
+        net.create_architecture()
+        r = load_reference_state(net, syn.instance_styled_step_params(), strict=False)
+        assert not r.unexpected_keys and all("num_batches" in k for k in r.missing_keys)
+        net.to(DEV).train()
+        im, info, gt, nb, im_t, info_t = syn.instance_styled_step_inputs(B, H, W, n_cls)
+        dev = lambda a: torch.from_numpy(a).to(DEV)  # noqa: E731
+        rpn_forward = net.RCNN_rpn.forward
+        seen, inject = [], {}
+
+        def spy(*a, **k):
+            out = rpn_forward(*a, **k)
+            seen.append(out[0].detach().cpu().numpy())
+            if inject:
+                return (dev(inject.pop("rois")),) + tuple(out[1:])
+            return out
+        net.RCNN_rpn.forward = spy
+
+        def step():
+            np.random.seed(3)
+            with torch.no_grad():
+                o = net(dev(im), dev(info), dev(gt), dev(nb), target=False, eta=0.1, eta_style=0.001)
+                t = net(dev(im_t), dev(info_t), torch.zeros(B, 1, 5, device=DEV), torch.zeros(B, device=DEV), target=True,
+                        eta=0.1, eta_style=0.001)
+            rois, cls_prob, bbox_pred, l_rpn_cls, l_rpn_box, l_cls, l_box, labels, d_inst, d_sty = o
+            losses = np.array([float(v) for v in (
+                l_rpn_cls.mean(), l_rpn_box.mean(), l_cls.mean(), l_box.mean(), 0.5 * torch.mean(d_inst ** 2),
+                0.5 * torch.mean(d_sty ** 2), 0.5 * torch.mean((1 - t[0]) ** 2), 0.5 * torch.mean((1 - t[1]) ** 2))])
+            return losses, o, t
+
+        names = [str(n) for n in g["loss_names"]]
+        want = g[tag + "_losses"]
+
+        # (1) as shipped
+        losses, _, _ = step()
+        for b in range(B):
+            for got, ref in ((seen[0][b], g[tag + "_rpn_rois_src"][b]), (seen[1][b], g[tag + "_rpn_rois_tgt"][b])):
+                a = {tuple(np.round(x, 1)) for x in got if x[1:].any()}
+                o = {tuple(np.round(x, 1)) for x in ref if x[1:].any()}
+                assert len(a & o) >= 0.95 * len(o), (len(a & o), len(o))
+        for i in (0, 1, 5, 7):
+            assert abs(losses[i] - want[i]) <= REL * abs(want[i]), (names[i], losses[i], want[i])
+        as_shipped = losses
+
+        # (2) the reference's proposals in front of the sampling layer
+        del seen[:]
+        inject["rois"] = g[tag + "_rpn_rois_src"]
+        np.random.seed(3)
+        with torch.no_grad():
+            o = net(dev(im), dev(info), dev(gt), dev(nb), target=False, eta=0.1, eta_style=0.001)
+            inject["rois"] = g[tag + "_rpn_rois_tgt"]
+            t = net(dev(im_t), dev(info_t), torch.zeros(B, 1, 5, device=DEV), torch.zeros(B, device=DEV), target=True,
+                    eta=0.1, eta_style=0.001)
+        rois, cls_prob, bbox_pred, l_rpn_cls, l_rpn_box, l_cls, l_box, labels, d_inst, d_sty = o
+        assert np.array_equal(rois.cpu().numpy(), g[tag + "_rois"])
+        assert np.array_equal(labels.cpu().numpy(), g[tag + "_labels"])
+        losses = np.array([float(v) for v in (
+            l_rpn_cls.mean(), l_rpn_box.mean(), l_cls.mean(), l_box.mean(), 0.5 * torch.mean(d_inst ** 2),
+            0.5 * torch.mean(d_sty ** 2), 0.5 * torch.mean((1 - t[0]) ** 2), 0.5 * torch.mean((1 - t[1]) ** 2))])
+        for i, n in enumerate(names):
+            assert abs(losses[i] - want[i]) <= REL * abs(want[i]), (n, losses[i], want[i])
+        for got, key in ((cls_prob, "_cls_prob"), (bbox_pred, "_bbox_pred"), (d_inst, "_d_instance"), (d_sty, "_d_style"),
+                         (t[0], "_d_instance_t"), (t[1], "_d_style_t")):
+            ref = g[tag + key]
+            np.testing.assert_allclose(got.cpu().numpy().reshape(ref.shape), ref, rtol=REL, atol=REL * np.abs(ref).max())
+        print("\n%s: reference %s\n  HIP, reference proposals %s\n  HIP as shipped %s" % (
+            tag, np.round(want, 6), np.round(losses, 6), np.round(as_shipped, 6)))
+    finally:
+        cfg.TRAIN.BATCH_SIZE = 128
+        cfg.TRAIN.RPN_POST_NMS_TOP_N_TARGET = 128

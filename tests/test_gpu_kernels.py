@@ -34,17 +34,55 @@ def _rel_err(a, b):
 
 def _rois_cases(rng, B, H, W, scale=16.0, n=24):
     """ROIs incl. degenerate (x2<x1), sub-pixel, out-of-image and full-image boxes."""
-    bx = syn.boxes(int(rng.integers(1 << 30)), n, H * scale, W * scale, 16, min(H, W) * scale * 0.9)
-    r = np.zeros((n + 6, 5), np.float32)
-    r[:n, 1:] = bx
-    r[:n, 0] = rng.integers(0, B, n)
-    r[n + 0] = [0, 0, 0, W * scale - 1, H * scale - 1]            # full image
-    r[n + 1] = [B - 1, 40.5, 33.25, 41.0, 33.5]                   # sub-pixel
-    r[n + 2] = [0, 120, 90, 60, 30]                               # malformed: x2<x1, y2<y1
-    r[n + 3] = [B - 1, -50, -40, 80, 70]                          # partly outside (negative)
-    r[n + 4] = [0, W * scale - 30, H * scale - 30, W * scale + 90, H * scale + 60]   # beyond the far edge
-    r[n + 5] = [B - 1, 10, 10, 10, 10]                            # single point
-    return r
+    return syn.roi_cases(int(rng.integers(1 << 30)), B, H, W, scale, n)
+
+
+@pytest.mark.parametrize("C,H,W,B", syn.ROI_ALIGN_GOLDEN_CASES)
+def test_roi_align_fwd_bit_equal_to_the_reference_c(ops, gold, C, H, W, B):
+    """The HIP RoIAlign / RoIAlignAvg against outputs of the reference's OWN ``ROIAlignForwardCpu``
+    (roi_align/src/roi_align.c:80-136; tests/golden/roi_align_fwd.npz, tier "extracted") and its
+    ``avg_pool2d(2, 1)`` (modules/roi_align.py:27-29): same bytes for both map layouts and both output layouts, on every
+    ROI class, incl. the full-size 1024-channel map (the ROI-per-workgroup kernel) and the narrow ones (the column kernel)."""
+    from roi_align_pin import check_roi_align_against_golden
+    g = gold("roi_align_fwd")
+    feat, rois = syn.roi_align_golden_inputs(C, H, W, B)
+    ft, rt = torch.from_numpy(feat).to(DEV), torch.from_numpy(rois).to(DEV)
+    for nhwc_in in (True, False):
+        f = ft.contiguous(memory_format=torch.channels_last) if nhwc_in else ft
+        for out_nchw in (True, False):
+            a8 = ops.roi_align(f, rt, 8, 8, 1.0 / 16.0, avg=False, out_nchw=out_nchw)
+            a7 = ops.roi_align(f, rt, 7, 7, 1.0 / 16.0, avg=True, out_nchw=out_nchw)
+            p7 = ops.roi_align(f, rt, 7, 7, 1.0 / 16.0, avg=False, out_nchw=out_nchw)
+            check_roi_align_against_golden(g, C, *(t.contiguous().cpu().numpy() for t in (a8, a7, p7)))
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 128, 9, 11), (1, 256, 19, 32), (2, 8, 9, 11)])
+@pytest.mark.parametrize("avg", [True, False])
+def test_roi_align_bwd_is_the_transpose_of_the_pinned_forward(ops, oracle, monkeypatch, B, C, H, W, avg):
+    """Both HIP backwards (the deterministic gather where it applies: NHWC, C % 128 == 0; and the atomic scatter) against
+    F^T g computed in float64 from the coefficients of the PINNED forward (tests/roi_align_pin.py): the backward has no
+    reference to run (roi_align.c:175), its definition as the forward's transpose is what pins it."""
+    from i2vsgg_amd import ops as O
+    from roi_align_pin import roi_align_matrix, roi_align_bwd_from_matrix
+    cops, _ = oracle
+    rng = np.random.default_rng(B * 100 + H + C)
+    rois = syn.roi_cases(31 + H, B, H, W)
+    k = 8 if avg else 7
+    mats = roi_align_matrix(rois, B, H, W, k, k, 1 / 16.0, cops.roi_align_fwd)
+    gout = rng.standard_normal((rois.shape[0], C, 7, 7), dtype=np.float32)
+    want = roi_align_bwd_from_matrix(mats, cops.avgpool2x2_bwd(gout) if avg else gout, rois, B, C, H, W)
+    scale = np.abs(want).max()
+    rt = torch.from_numpy(rois).to(DEV)
+    for gather in (True, False):
+        monkeypatch.setattr(O, "ROIALIGN_BWD_GATHER", gather)
+        for nhwc in (True, False):
+            feat = torch.zeros((B, C, H, W), device=DEV)
+            feat = (feat.contiguous(memory_format=torch.channels_last) if nhwc else feat).requires_grad_()
+            g = torch.from_numpy(gout).to(DEV)
+            O.roi_align(feat, rt, 7, 7, 1.0 / 16.0, avg=avg, out_nchw=not nhwc).backward(
+                g if not nhwc else g.contiguous(memory_format=torch.channels_last))
+            err = np.abs(feat.grad.cpu().numpy() - want).max()
+            assert err <= 2e-6 * scale, (gather, nhwc, err / scale)
 
 
 @pytest.mark.parametrize("C,H,W,B", [(4, 9, 11, 2), (64, 19, 32, 2), (1024, 38, 63, 1)])

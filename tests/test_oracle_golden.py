@@ -282,3 +282,59 @@ def test_avgpool_matches_torch():
     gy = np.random.default_rng(6).standard_normal((3, 5, 7, 7), dtype=np.float32)
     torch.nn.functional.avg_pool2d(xt, 2, 1).backward(torch.from_numpy(gy))
     np.testing.assert_allclose(cops.avgpool2x2_bwd(gy), xt.grad.numpy(), rtol=1e-6, atol=1e-7)
+
+
+# ----------------------------------------------------------------------------- RoIAlign: pinned by the reference's own C
+from roi_align_pin import check_roi_align_against_golden, roi_align_matrix, roi_align_bwd_from_matrix  # noqa: E402
+
+
+@pytest.mark.parametrize("C,H,W,B", syn.ROI_ALIGN_GOLDEN_CASES)
+def test_roi_align_fwd_bit_equal_to_the_reference_c(gold, C, H, W, B):
+    """roi_align/src/roi_align.c:80-136 ``ROIAlignForwardCpu`` (tier "extracted": oracle/build_ref.py compiles the
+    function's own text) and RoIAlignAvg = avg_pool2d(2, 1) of it (modules/roi_align.py:27-29): the C restatement
+    gives the same bytes on every ROI class."""
+    g = gold("roi_align_fwd")
+    assert str(g["tier"]) == "extracted"
+    feat, rois = syn.roi_align_golden_inputs(C, H, W, B)
+    assert np.array_equal(rois, g["c%d_rois" % C])
+    check_roi_align_against_golden(g, C, cops.roi_align_fwd(feat, rois, 8, 8, 1 / 16.0),
+                                   cops.roi_align_avg_fwd(feat, rois, 7, 7, 1 / 16.0),
+                                   cops.roi_align_fwd(feat, rois, 7, 7, 1 / 16.0))
+
+
+def test_roi_align_fwd_vs_the_reference_library_on_fresh_shapes():
+    """Where oracle/_ref travelled (it is a built artefact: git-ignored, shipped to the GPU box): the restatement against
+    the reference's compiled function on shapes the fixture does not hold, incl. non-square grids and another scale."""
+    from oracle import build_ref
+    if not build_ref.available():
+        pytest.skip("oracle/_ref not built here (python -m oracle.build_ref needs /root/reference)")
+    rng = np.random.default_rng(77)
+    for (B, C, H, W, ah, aw, scale) in ((1, 3, 7, 5, 8, 8, 1 / 16.0), (3, 16, 25, 40, 8, 8, 1 / 16.0), (2, 8, 14, 14, 15, 15, 1 / 16.0),
+                                        (2, 5, 20, 30, 3, 9, 1 / 8.0), (1, 2, 38, 63, 2, 2, 1 / 16.0)):
+        feat = rng.standard_normal((B, C, H, W), dtype=np.float32)
+        rois = syn.roi_cases(int(rng.integers(1 << 20)), B, H, W, scale=1.0 / scale)
+        assert np.array_equal(cops.roi_align_fwd(feat, rois, ah, aw, scale), build_ref.roi_align_fwd(feat, rois, ah, aw, scale))
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 5, 9, 11), (1, 3, 19, 32)])
+def test_roi_align_bwd_is_the_transpose_of_the_pinned_forward(B, C, H, W):
+    """The backward (roi_align_kernel.cu:94-143; the reference has no usable CPU twin, roi_align.c:175 inverts the bounds
+    test) has no reference to run -- but it is by definition the transpose of the forward, and the forward is pinned.
+    Every element of F^T g computed in float64 from the PINNED forward's own coefficients against the restated scatter,
+    and the same with the 2x2 mean of RoIAlignAvg in front; plus the inner-product identity <F x, g> = <x, F^T g>."""
+    rng = np.random.default_rng(B * 100 + H)
+    rois = syn.roi_cases(31 + H, B, H, W)
+    mats = roi_align_matrix(rois, B, H, W, 8, 8, 1 / 16.0, cops.roi_align_fwd)
+    g8 = rng.standard_normal((rois.shape[0], C, 8, 8), dtype=np.float32)
+    want = roi_align_bwd_from_matrix(mats, g8, rois, B, C, H, W)
+    got = cops.roi_align_bwd(g8, rois, (B, C, H, W), 1 / 16.0)
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 2e-6 * scale, np.abs(got - want).max() / scale
+    g7 = rng.standard_normal((rois.shape[0], C, 7, 7), dtype=np.float32)
+    want = roi_align_bwd_from_matrix(mats, cops.avgpool2x2_bwd(g7), rois, B, C, H, W)
+    got = cops.roi_align_avg_bwd(g7, rois, (B, C, H, W), 1 / 16.0)
+    assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+    x = rng.standard_normal((B, C, H, W), dtype=np.float32)
+    lhs = (cops.roi_align_avg_fwd(x, rois, 7, 7, 1 / 16.0).astype(np.float64) * g7).sum()
+    rhs = (x.astype(np.float64) * got).sum()
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0)

@@ -9,7 +9,10 @@ regenerate).
 Two tiers, recorded per file in the ``tier`` field:
   "direct"       the reference module imports as shipped (sys.path only):
                  rpn/generate_anchors.py, rpn/bbox_transform.py, nms/nms_cpu.py
-  "extracted"    lib/utils.py:584-628 ``detection_output``: the module cannot be imported (a module-level json.load of an
+  "extracted"    roi_align/src/roi_align.c:80-136 ``ROIAlignForwardCpu``: the file as a whole needs <TH/TH.h> (its
+                 THFloatTensor wrappers), the function itself only <math.h>; oracle/build_ref.py pipes the function's
+                 own text to gcc unmodified (no stand-in header, nothing of it written to disk but the .so)
+                 lib/utils.py:584-628 ``detection_output``: the module cannot be imported (a module-level json.load of an
                  absolute path), so the function's own lines are compiled from the file and run unmodified, with the
                  ``np.float`` alias numpy 1.24 removed restored for the call
   "placeholders" the module imports after registering in-process placeholders for
@@ -95,6 +98,39 @@ def gen_direct():
                 keep = nms_cpu(torch.from_numpy(dets), th).numpy().astype(np.int32)
                 out["n%d_%s_t%02d" % (n, "c" if clustered else "u", int(th * 10))] = keep
     save("nms_keep", "direct", **out)
+
+
+# ----------------------------------------------------------------------------- RoIAlign: the reference's own C (tier "extracted")
+def gen_roi_align():
+    """``ROIAlignForwardCpu`` (roi_align/src/roi_align.c:80-136) -- the function's own text compiled
+    where it lies by oracle/build_ref.py (self-contained: <math.h> only; the THFloatTensor wrappers at :16-78 are not
+    built) -- on 8x8 grids, and ``RoIAlignAvg``'s ``avg_pool2d(x, kernel_size=2, stride=1)`` of it
+    (roi_align/modules/roi_align.py:27-29) -> 7x7, for C in {4, 64, 1024} over ROIs of every class (seeded, full-image,
+    sub-pixel, malformed, partly outside, beyond the far edge, single point).  Full tensors up to C = 64; the C = 1024 case
+    (7.9 MB) as sha256 of the bytes + sums + a strided sample."""
+    import hashlib
+    from oracle import build_ref
+    build_ref.build()
+    out = {}
+    for C, H, W, B in syn.ROI_ALIGN_GOLDEN_CASES:
+        feat, rois = syn.roi_align_golden_inputs(C, H, W, B)
+        a8 = build_ref.roi_align_fwd(feat, rois, 8, 8, 1.0 / 16.0)
+        a7 = torch.nn.functional.avg_pool2d(torch.from_numpy(a8), kernel_size=2, stride=1).numpy()
+        p7 = build_ref.roi_align_fwd(feat, rois, 7, 7, 1.0 / 16.0)           # RoIAlign(7,7): the un-averaged module
+        tag = "c%d" % C
+        out[tag + "_rois"] = rois
+        for key, v in (("a8", a8), ("avg7", a7), ("p7", p7)):
+            out["%s_%s_shape" % (tag, key)] = np.array(v.shape)
+            out["%s_%s_sha256" % (tag, key)] = np.array(hashlib.sha256(np.ascontiguousarray(v).tobytes()).hexdigest())
+            out["%s_%s_sum" % (tag, key)] = np.array(v.astype(np.float64).sum())
+            out["%s_%s_abs" % (tag, key)] = np.array(np.abs(v.astype(np.float64)).sum())
+            if C <= 64:
+                out["%s_%s" % (tag, key)] = v
+            else:
+                out["%s_%s_sample" % (tag, key)] = v.reshape(-1)[::211].copy()
+        same = np.array_equal(a8, cops.roi_align_fwd(feat, rois, 8, 8, 1.0 / 16.0))
+        print("   C=%4d: 8x8 %s |sum| %.4e   oracle restatement bit-equal: %s" % (C, a8.shape, np.abs(a8).sum(), same))
+    save("roi_align_fwd", "extracted", **out)
 
 
 # ----------------------------------------------------------------------------- the two eval tails (SURVEY.md 8f rows f1 / f3)
@@ -494,6 +530,66 @@ def gen_context(cfg):
         cfg.TRAIN.BATCH_SIZE = 128
 
 
+def gen_step(cfg):
+    """the reference ``_fasterRCNN`` (instance_styleD, ic = gc = False) run as shipped for ONE D+G step's
+    forward passes -- source (faster_rcnn_instance_styleD_bilinear.py:47-182, target=False) then target (target=True) -- and
+    the eight scalars the loop assembles from them (trainval_net_instance_styleD_bilinear.py:276-296).  Its own backbone, own
+    ``_RPN`` (proposal layer with ``nms_cpu``, anchor targets), own ``_ProposalTargetLayer`` under ``np.random.seed(3)``, own
+    discriminators and heads.  The one piece it cannot run here is ``RoIAlignFunction`` (a torch-0.4 legacy Function over an
+    extension that needs TH); the harness's ``RCNN_roi_align`` does what ``RoIAlignAvg.forward`` does
+    (roi_align/modules/roi_align.py:26-29) with the reference's own compiled ``ROIAlignForwardCpu`` (oracle/build_ref.py)
+    in the Function's place: align to 8x8, ``avg_pool2d(x, kernel_size=2, stride=1)``.  Forward only, training mode.
+    Two cases: res101 on 2+2 frames of 320x480, and res101 on 1+1 full 600x1000 frames; 32 ROIs per frame (configs[2])."""
+    import model.faster_rcnn.resnet_instance_styleD_bilinear as R
+    from oracle import build_ref
+    build_ref.build()
+    n_cls = 16
+
+    class RefAlignAvg(torch.nn.Module):
+        def forward(self, features, rois):
+            x = torch.from_numpy(build_ref.roi_align_fwd(features.detach().numpy(), rois.detach().numpy(), 7 + 1, 7 + 1, 1.0 / 16.0))
+            return torch.nn.functional.avg_pool2d(x, kernel_size=2, stride=1)
+
+    cfg.TRAIN.BATCH_SIZE = 32
+    cfg.TRAIN.RPN_POST_NMS_TOP_N_TARGET = 32
+    cfg.TRAIN.RPN_POST_NMS_TOP_N = 2000
+    out = {}
+    try:
+        for tag, B, H, W in (("small", 2, 320, 480), ("full", 1, 600, 1000)):
+            net = R.resnet(tuple(range(n_cls)), 101, pretrained=False, class_agnostic=False)
+            net.create_architecture()
+            p = syn.instance_styled_step_params()
+            miss = net.load_state_dict(p, strict=False)
+            assert not miss.unexpected_keys, miss.unexpected_keys
+            assert all("num_batches" in k for k in miss.missing_keys), miss.missing_keys
+            net.RCNN_roi_align = RefAlignAvg()
+            net.train()
+            im, info, gt, nb, im_t, info_t = syn.instance_styled_step_inputs(B, H, W, n_cls)
+            stash = []
+            net.RCNN_rpn.register_forward_hook(lambda m, i, o: stash.append(o[0].detach().numpy().copy()))
+            np.random.seed(3)
+            with torch.no_grad():
+                (rois, cls_prob, bbox_pred, rpn_loss_cls, rpn_loss_box, RCNN_loss_cls, RCNN_loss_bbox, rois_label, d_inst,
+                 d_sty) = net(torch.from_numpy(im), torch.from_numpy(info), torch.from_numpy(gt), torch.from_numpy(nb),
+                              target=False, eta=0.1, eta_style=0.001)
+                d_inst_t, d_sty_t = net(torch.from_numpy(im_t), torch.from_numpy(info_t), torch.zeros(B, 1, 5), torch.zeros(B),
+                                        target=True, eta=0.1, eta_style=0.001)
+            losses = np.array([rpn_loss_cls.mean(), rpn_loss_box.mean(), RCNN_loss_cls.mean(), RCNN_loss_bbox.mean(),
+                               0.5 * torch.mean(d_inst ** 2), 0.5 * torch.mean(d_sty ** 2),
+                               0.5 * torch.mean((1 - d_inst_t) ** 2), 0.5 * torch.mean((1 - d_sty_t) ** 2)], np.float64)
+            print("   %s: " % tag + " ".join("%.6f" % v for v in losses))
+            out.update({tag + "_losses": losses, tag + "_rpn_rois_src": stash[0], tag + "_rpn_rois_tgt": stash[1],
+                        tag + "_rois": rois.numpy(), tag + "_labels": rois_label.numpy(), tag + "_cls_prob": cls_prob.numpy(),
+                        tag + "_bbox_pred": bbox_pred.numpy(), tag + "_d_instance": d_inst.numpy(), tag + "_d_style": d_sty.numpy(),
+                        tag + "_d_instance_t": d_inst_t.numpy(), tag + "_d_style_t": d_sty_t.numpy()})
+        out["loss_names"] = np.array(["rpn_loss_cls", "rpn_loss_box", "RCNN_loss_cls", "RCNN_loss_bbox", "dloss_s_p",
+                                      "dloss_s_style", "dloss_t_p", "dloss_t_style"])
+        save("instance_styled_step", "placeholders+extracted", **out)
+    finally:
+        cfg.TRAIN.BATCH_SIZE = 128
+        cfg.TRAIN.RPN_POST_NMS_TOP_N_TARGET = 128
+
+
 def gen_vrd(cfg):
     """vrd.forward logits / BCE loss / grads with eval-mode dropout."""
     import pickle
@@ -591,14 +687,17 @@ def main():
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
-    todo = a.only.split(",") if a.only else ["direct", "tails", "rpn", "nets", "full", "ctx", "vrd"]
+    todo = a.only.split(",") if a.only else ["direct", "roialign", "tails", "rpn", "nets", "full", "ctx", "step", "vrd"]
     if "direct" in todo:
         print("[direct imports]")
         gen_direct()
+    if "roialign" in todo:
+        print("[RoIAlign forward: the reference's C function compiled from its own lines]")
+        gen_roi_align()
     if "tails" in todo:
         print("[eval tails: direct imports + detection_output compiled from its own lines]")
         gen_eval_tails()
-    if any(t in todo for t in ("rpn", "nets", "full", "vrd", "ctx")):
+    if any(t in todo for t in ("rpn", "nets", "full", "vrd", "ctx", "step")):
         print("[imports with placeholders]")
         cfg = install_placeholders()
         if "rpn" in todo:
@@ -609,6 +708,8 @@ def main():
             gen_full_frame(cfg)
         if "ctx" in todo:
             gen_context(cfg)
+        if "step" in todo:
+            gen_step(cfg)
         if "vrd" in todo:
             gen_vrd(cfg)
 
