@@ -12,10 +12,13 @@
  *
  * Pinning status:
  *   nms_greedy          pinned  : golden vectors made by the reference nms_cpu.py
- *   roi_align_*         UNPINNED: roi_align/src/roi_align.c needs <TH/TH.h>, absent
- *                       from this image (torch 2.10 ships no TH), and its Python
- *                       wrapper is a torch-0.4 legacy Function; restated line by
- *                       line from roi_align.c:80-136 / roi_align_kernel.cu:94-143.
+ *   roi_align_fwd       pinned  : bit-equal to the reference's own ROIAlignForwardCpu
+ *                       (roi_align/src/roi_align.c:80-136, compiled from its own text by
+ *                       oracle/build_ref.py -> tests/golden/roi_align_fwd.npz, tier "extracted").
+ *   roi_align_bwd       pinned through the forward: restated from roi_align_kernel.cu:94-143
+ *                       (the CPU twin roi_align.c:138-190 inverts its bounds test, :175) and held
+ *                       to the transpose of the pinned forward, element by element
+ *                       (tests/test_oracle_golden.py).
  *   roi_pool_*          UNPINNED: model._C source is absent from the reference tree;
  *                       restated from roi_pooling_kernel.cu:24-93,128-203.
  *   roi_align_sampled_* UNPINNED: model._C (roi_layers/roi_align.py:20,:31) is the csrc of

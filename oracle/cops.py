@@ -61,7 +61,8 @@ def nms_sorted(dets, thresh):
 
 
 def roi_align_fwd(feat, rois, ah, aw, scale):
-    """roi_align.c:80-136; feat NCHW, rois (R,5) -> (R,C,ah,aw).  Parity unpinned."""
+    """roi_align.c:80-136; feat NCHW, rois (R,5) -> (R,C,ah,aw).  Pinned: bit-equal to the reference's compiled function
+    (tests/golden/roi_align_fwd.npz, oracle/build_ref.py)."""
     feat, pf = _f(feat)
     rois, pr = _f(rois)
     B, C, H, W = feat.shape
@@ -73,7 +74,7 @@ def roi_align_fwd(feat, rois, ah, aw, scale):
 
 
 def roi_align_bwd(gout, rois, feat_shape, scale):
-    """roi_align_kernel.cu:94-143 in serial order.  Parity unpinned."""
+    """roi_align_kernel.cu:94-143 in serial order.  Pinned as the transpose of the pinned forward (tests/test_oracle_golden.py)."""
     gout, pg = _f(gout)
     rois, pr = _f(rois)
     B, C, H, W = feat_shape

@@ -183,8 +183,9 @@ def test_instance_styled_step_vs_reference_run_golden(gold, tag, B, H, W):
                 a = {tuple(np.round(x, 1)) for x in got if x[1:].any()}
                 o = {tuple(np.round(x, 1)) for x in ref if x[1:].any()}
                 assert len(a & o) >= 0.95 * len(o), (len(a & o), len(o))
-        for i in (0, 1, 5, 7):
-            assert abs(losses[i] - want[i]) <= REL * abs(want[i]), (names[i], losses[i], want[i])
+        for i in range(8):                                  # the four that depend on which rows were sampled: 1e-2 as shipped
+            tol = REL if i in (0, 1, 5, 7) else 1e-2
+            assert abs(losses[i] - want[i]) <= tol * abs(want[i]), (names[i], losses[i], want[i])
         as_shipped = losses
 
         # (2) the reference's proposals in front of the sampling layer

@@ -491,7 +491,7 @@ def gen_context(cfg):
     context vectors of both discriminators concatenated in front of the layer4 feature
     (faster_rcnn_instance_styleD_bilinear.py:62-67,122-148) -- with the two pieces the reference cannot run here
     supplied by the harness: the RPN (fixed proposals, so that no near-tied score decides the sample) and RoIAlignAvg
-    (legacy autograd.Function over an unbuildable extension -> oracle.cops).  Forward only, training mode."""
+    (legacy autograd.Function over an unbuildable extension -> the reference's compiled ROIAlignForwardCpu, oracle/build_ref.py).  Forward only, training mode."""
     import model.faster_rcnn.resnet_instance_styleD_bilinear as R
     n_cls = 16
     cfg.TRAIN.BATCH_SIZE = 32
@@ -513,7 +513,9 @@ def gen_context(cfg):
 
         class HarnessAlign(torch.nn.Module):
             def forward(self, feat, r):
-                return torch.from_numpy(cops.roi_align_avg_fwd(feat.detach().numpy(), r.detach().numpy(), 7, 7, 1.0 / 16.0))
+                from oracle import build_ref          # the reference's own compiled forward (bit-equal to oracle.cops)
+                x = torch.from_numpy(build_ref.roi_align_fwd(feat.detach().numpy(), r.detach().numpy(), 8, 8, 1.0 / 16.0))
+                return torch.nn.functional.avg_pool2d(x, kernel_size=2, stride=1)
 
         net.RCNN_rpn = FixedRPN()
         net.RCNN_roi_align = HarnessAlign()
