@@ -424,3 +424,81 @@ def test_joint_step_full_size_on_one_gpu(fresh_cfg):
         assert torch.equal(frozen, sgg.RCNN_base[6][22].conv3.weight.detach())      # the relation net's trunk is frozen (:148)
     finally:
         sstep.opt.unfuse()
+
+
+def test_sgg_step_full_size_vs_oracle(fresh_cfg):
+    """configs[1] AT FULL SIZE against the CPU oracle (round-4 review: full-size coverage was self-consistency plus the backbone
+    golden; the oracle comparison of the step ran at 200x320 / res50 / 6 boxes): cfgs/res101.yml, 2 frames of 600x1000,
+    32 boxes + 32 pairs per frame, dropout off.  The eager step's loss, relation logits, ``fc7.bias.grad`` and a strided slice
+    of ``fc6.weight.grad`` within 1e-3 (north_star's tolerance) of ``oracle.nets`` on the same seeded batch
+    (trainval_net_SGG_emb.py:230-255: forward, BCE-with-logits, backward); then the captured / overlapped step -- the form
+    bench.py times -- gives the eager step's loss on the same batch and the same head weights after three steps."""
+    import torch.nn.functional as F
+    from i2vsgg_amd import ops, train
+    from i2vsgg_amd.model.utils import config as c
+    from oracle import nets
+    from test_gpu_models import _weights_close
+    c.cfg_from_file(c.default_cfg_file("res101"))
+    REL = 1e-3
+
+    def make(graph):
+        net = train.build_sgg_net(layers=101, seed=5, device=DEV)
+        net.vrd.dropout = False
+        step = train.SGGEmbStep(net, 2, seed=3, device=DEV, h=600, w=1000, n_boxes=32, n_pairs=32, fuse_sgd=graph,
+                                use_graph=graph)
+        return net, step
+
+    net, step = make(False)
+    assert step.boxes.shape[0] == 64 and step.relb.shape[0] == 64
+    p = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    got_score = {}
+    fwd = net.vrd.forward_device
+
+    def spy(*a, **k):
+        out = fwd(*a, **k)
+        got_score["s"] = out[0].detach().cpu().numpy()
+        return out
+    net.vrd.forward_device = spy
+    loss = float(step())
+    net.vrd.forward_device = fwd
+    g_b7 = net.vrd.fc7.fc.bias.grad.detach().cpu().numpy().copy()
+    g_w6 = net.vrd.fc6.fc.weight.grad.detach().reshape(4096, -1)[::64, ::97].cpu().numpy().copy()
+    g_rel = net.vrd.fc_rel.fc.weight.grad.detach().cpu().numpy().copy()
+
+    # ---------------- oracle: same weights, same batch (CPU, ~10 s)
+    for k in ("vrd.fc6.fc.weight", "vrd.fc7.fc.bias", "vrd.fc_rel.fc.weight"):
+        p[k].requires_grad_(True)
+    with torch.no_grad():
+        fm, _ = nets.extract_feature(step.im[:, :3].contiguous().cpu(), p, blocks=(3, 4, 23))
+    sc, _ = nets.vrd_head(fm, step.boxes.cpu().numpy(), step.relb.cpu().numpy(), step.masks[:, :2].cpu().numpy(),
+                          step.ixs.cpu().numpy(), step.ixo.cpu().numpy(), net.vrd.prd_vecs, p, training=True)
+    labels, wrow = step.labels.cpu(), step.wrow.cpu()
+    ref = (F.binary_cross_entropy_with_logits(sc, labels, reduction="none").mean(1) * wrow).sum()
+    # equal pair counts per frame: the weighted sum IS the reference's plain mean (resnet_SGG_emb.py:93)
+    assert abs(ref.item() - F.binary_cross_entropy_with_logits(sc, labels).item()) < 1e-6
+    ref.backward()
+    assert abs(loss - ref.item()) <= REL * abs(ref.item()), (loss, ref.item())
+    np.testing.assert_allclose(got_score["s"][:64], sc.detach().numpy(), rtol=0, atol=REL)          # cosine logits in [-1, 1]
+
+    def rel(a, b):
+        return np.abs(a - b).max() / np.abs(b).max()
+    assert rel(g_b7, p["vrd.fc7.fc.bias"].grad.numpy()) < REL
+    assert rel(g_w6, p["vrd.fc6.fc.weight"].grad.reshape(4096, -1)[::64, ::97].numpy()) < REL
+    assert rel(g_rel, p["vrd.fc_rel.fc.weight"].grad.numpy()) < REL
+    del p, fm, sc
+
+    # ---------------- the captured / overlapped step on the same batch
+    eager = [loss] + [float(step()) for _ in range(2)]
+    w_eager = net.vrd.fc7.fc.weight.detach().cpu().numpy().copy()
+    step.opt.unfuse()
+    del step, net
+    torch.cuda.empty_cache()
+    net, step = make(True)
+    assert step.capture(warmup=1, restore=True), step.graph_error      # the warm-up step is undone: same start as the eager run
+    cap = [float(step()) for _ in range(3)]
+    step.opt.flush_pending()
+    torch.cuda.synchronize()
+    for a, b in zip(eager, cap):
+        assert abs(a - b) <= 1e-5 * abs(a), (eager, cap)
+    _weights_close(net.vrd.fc7.fc.weight.detach().cpu().numpy(), w_eager, "configs[1] captured vs eager")
+    step.opt.unfuse()
