@@ -341,94 +341,176 @@ def by_kind(rec, n_prof):
 
 
 # ----------------------------------------------------------------------------- the metric's second half: ROI ops / NMS
-def roi_nms_cases(dev):
-    """The HBM-side ops of the path at the headline sizes, each as (name, launch closure, algorithmic bytes per launch, kernels).
-    Shared with tools/roi_nms_pmc_one.py, so that the PMC passes behind ``traffic`` profile exactly these launches.
-    Algorithmic bytes: SURVEY.md 8(d) -- feature maps read once + output written once (ROIAlign: 9.81 MB + R * 1024 * 49 * 4 B per
-    frame, the backward the same bytes reversed; ROIPool additionally writes its argmax); NMS: the reference algorithm's bytes
-    20 N + 2 * 8 * N * ceil(N / 64) (boxes + the 64-bit suppression mask written, then read)."""
+ROI_NMS_CASES = ("roi_align_avg_fwd_1x32", "roi_align_avg_bwd_1x32", "roi_align_avg_fwd_4x32", "roi_align_avg_bwd_4x32",
+                 "roi_pool_geom_fwd_2x64", "nms_12000_to_2000", "nms_6000_to_300")
+ROI_NMS_PMC = "r05_roi_nms_pmc.json"
+COLD_BYTES = 512 << 20          # a rotation's working set: twice the 256 MiB Infinity Cache
+
+
+def roi_nms_case(dev, name, cold=False):
+    """ONE HBM-side op of the path at the headline sizes -> dict(fn, sets, nbytes, kernels).  ``fn(i)`` launches the op once on
+    buffer set ``i % sets`` and returns what must stay alive.  Only this case's buffers are built and nothing of the op is
+    launched here except -- for a backward case -- the one forward per set its autograd node needs (another kernel: it never
+    enters the backward's rows).  Shared with tools/roi_nms_pmc_one.py, so that the PMC passes profile exactly these launches.
+
+    Two cache states: warm (``cold=False``: one set, launched back to back -- maps and outputs come out of the 256 MiB Infinity
+    Cache, which is how the op runs inside a step, right behind the layer that wrote its map) and cold (a rotation over enough
+    distinct maps AND outputs to exceed twice the Infinity Cache: every byte comes from / goes to HBM).
+
+    ``kernels``: kernel name -> launches per op (exactly).  Algorithmic bytes: SURVEY.md 8(d) -- feature maps read once + output
+    written once (ROIAlign: 9.81 MB + R * 1024 * 49 * 4 B per frame, the backward the same bytes reversed; ROIPool additionally
+    writes its argmax); NMS: the reference algorithm's bytes 20 N + 2 * 8 * N * ceil(N / 64) (boxes + the 64-bit suppression
+    mask written, then read)."""
     import numpy as np
     import torch
     from i2vsgg_amd import ops, synthetic as syn
-    cases = []
     R = 32
-    for B in (1, 4):
-        feat = torch.randn(B, 1024, 38, 63, device=dev).contiguous(memory_format=torch.channels_last).requires_grad_()
+
+    def n_sets(per_set):
+        return max(2, -(-COLD_BYTES // per_set)) if cold else 1
+
+    if name.startswith("roi_align_avg_"):
+        B = int(name.rsplit("_", 1)[1].split("x")[0])
+        bwd = "_bwd_" in name
+        nbytes = B * 1024 * 38 * 63 * 4 + B * R * 1024 * 49 * 4
         rois = np.zeros((B * R, 5), np.float32)
         for b in range(B):
             rois[b * R:(b + 1) * R, 0] = b
             rois[b * R:(b + 1) * R, 1:] = syn.boxes(b, R)
         rt = torch.from_numpy(rois).to(dev)
-        nbytes = B * 1024 * 38 * 63 * 4 + B * R * 1024 * 49 * 4
-        cases.append(("roi_align_avg_fwd_%dx%d" % (B, R), (lambda f=feat, r=rt: ops.roi_align(f.detach(), r, 7, 7, 1 / 16.0, avg=True)),
-                      nbytes, ["roi_align_fwd_roi_kernel"]))
-        out = ops.roi_align(feat, rt, 7, 7, 1 / 16.0, avg=True)
-        gout = torch.randn_like(out)
+        sets = n_sets(nbytes)
+        feats = [torch.randn(B, 1024, 38, 63, device=dev).contiguous(memory_format=torch.channels_last) for _ in range(sets)]
+        if not bwd:
+            return dict(fn=lambda i: ops.roi_align(feats[i % sets], rt, 7, 7, 1 / 16.0, avg=True), sets=sets, nbytes=nbytes,
+                        kernels={"roi_align_fwd_roi_kernel": 1})
+        for f in feats:
+            f.requires_grad_()
+        outs = [ops.roi_align(f, rt, 7, 7, 1 / 16.0, avg=True) for f in feats]
+        gouts = [torch.randn_like(o) for o in outs]
 
-        def bwd(f=feat, o=out, g=gout):
-            f.grad = None
-            o.backward(g, retain_graph=True)                # the gather form: sample gradients, then every map element written once
-        cases.append(("roi_align_avg_bwd_%dx%d" % (B, R), bwd, nbytes, ["roi_align_bwd_prep_kernel", "roi_align_bwd_gather_kernel"]))
-    # ROIPool as the captured relation step runs it: 2 packed frames, 32 boxes + 32 union boxes each, NCHW out for vrd.fc6,
-    # extent of the maps read on the device (i2v_roi_pool_fwd_geom)
-    Bp, Rp, C, h, w = 2, 64, 1024, 38, 63
-    buf = torch.randn(Bp * h * w * C, device=dev)
-    maps = ops.PackedMaps(buf, Bp, C, torch.tensor([h, w], dtype=torch.int32, device=dev))
-    rp = np.zeros((Bp * Rp, 5), np.float32)
-    for b in range(Bp):
-        rp[b * Rp:(b + 1) * Rp, 0] = b
-        rp[b * Rp:(b + 1) * Rp, 1:] = syn.boxes(10 + b, Rp)
-    rpt = torch.from_numpy(rp).to(dev)
-    cases.append(("roi_pool_geom_fwd_2x64", lambda: ops.roi_pool_packed(maps, rpt, 7, 7, 1 / 16.0, out_nchw=True),
-                  Bp * C * h * w * 4 + 2 * Bp * Rp * C * 49 * 4, ["roi_pool_fwd_c128_kernel"]))
-    for n, keep in ((12000, 2000), (6000, 300)):
-        dets = torch.from_numpy(syn.tie_free_dets(n, n, clustered=True)).to(dev)
-        cases.append(("nms_%d_to_%d" % (n, keep), (lambda d=dets, k=keep: ops.nms_sorted(d, 0.7, k)),
-                      20 * n + 2 * 8 * n * ((n + 63) // 64), ["nms_mask_kernel", "nms_scan_pipelined_kernel"]))
-    return cases
+        def run(i):
+            f = feats[i % sets]
+            f.grad = None                                   # the gradient map is written, not accumulated: a fresh block per set
+            outs[i % sets].backward(gouts[i % sets], retain_graph=True)
+            return f.grad
+        return dict(fn=run, sets=sets, nbytes=nbytes, kernels=dict(ops.ROIALIGN_BWD_KERNELS))
+    if name == "roi_pool_geom_fwd_2x64":
+        # ROIPool as the captured relation step runs it: 2 packed frames, 32 boxes + 32 union boxes each, NCHW out for vrd.fc6,
+        # extent of the maps read on the device (i2v_roi_pool_fwd_geom)
+        Bp, Rp, C, h, w = 2, 64, 1024, 38, 63
+        nbytes = Bp * C * h * w * 4 + 2 * Bp * Rp * C * 49 * 4
+        sets = n_sets(nbytes)
+        ext = torch.tensor([h, w], dtype=torch.int32, device=dev)
+        maps = [ops.PackedMaps(torch.randn(Bp * h * w * C, device=dev), Bp, C, ext) for _ in range(sets)]
+        rp = np.zeros((Bp * Rp, 5), np.float32)
+        for b in range(Bp):
+            rp[b * Rp:(b + 1) * Rp, 0] = b
+            rp[b * Rp:(b + 1) * Rp, 1:] = syn.boxes(10 + b, Rp)
+        rpt = torch.from_numpy(rp).to(dev)
+        return dict(fn=lambda i: ops.roi_pool_packed(maps[i % sets], rpt, 7, 7, 1 / 16.0, out_nchw=True), sets=sets, nbytes=nbytes,
+                    kernels={"roi_pool_fwd_c128_kernel": 1})
+    if name.startswith("nms_"):
+        n, keep = int(name.split("_")[1]), int(name.split("_")[3])
+        nbytes = 20 * n + 2 * 8 * n * ((n + 63) // 64)
+        sets = n_sets(nbytes)
+        base = syn.tie_free_dets(n, n, clustered=True)
+        dets = [torch.from_numpy(base).to(dev) for _ in range(sets)]
+        # cold: the op's 18 MB mask lives in a per-stream workspace, written and read back inside the op -- the rotation can
+        # only renew the boxes; the mask round trip stays where the hardware keeps it (stated in the line)
+        return dict(fn=lambda i: ops.nms_sorted(dets[i % sets], 0.7, keep), sets=sets, nbytes=nbytes, kernels=dict(ops.NMS_KERNELS))
+    raise KeyError(name)
 
 
-def run_roi_nms(dev, reps=20):
-    """``also.roi_nms``: every case of ``roi_nms_cases`` timed with ONE HIP-event pair on the launch stream around ``reps``
-    back-to-back launches, queued behind a ~10 ms blocker GEMM so that the pair brackets device time and not the host's
-    launch latency (the protocol of ``profile_eager``).  ``achieved`` = algorithmic GB/s, ``peak`` 8000 (HBM), ``traffic`` = HBM
-    bytes per launch from the PMC passes of the same launches (profiles/r04_roi_nms_pmc.json, tools/roi_nms_pmc.sh)."""
+def time_roi_nms_case(dev, case, blocker, reps=20):
+    """us per op: ONE HIP-event pair on the launch stream around back-to-back launches (whole rotations in the cold state),
+    queued behind a ~10 ms blocker GEMM so that the pair brackets device time and not the host's launch latency."""
     import torch
-    out = {}
+    sets = case["sets"]
+    reps = max(reps, sets) // sets * sets
+    ring = [None] * sets
+    for i in range(max(3, sets)):
+        ring[i % sets] = case["fn"](i)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.mm(blocker, blocker)
+    e0.record()
+    for i in range(reps):
+        ring[i % sets] = case["fn"](i)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) * 1e3 / reps, reps
+
+
+def run_roi_nms(dev, reps=20, only=None):
+    """``also.roi_nms`` and the top-level ``roofline_hbm``: every case of ROI_NMS_CASES in both cache states.  Per state:
+    ``events_us`` (live, this run), and from the committed rocprofv3 passes of the SAME launches (profiles/r05_roi_nms_pmc.json,
+    tools/roi_nms_pmc.sh: >= 100 launches per pass, the first 5 dropped) ``rocprof_us``, ``traffic`` (HBM bytes per op from the
+    FETCH_SIZE / WRITE_SIZE passes, corrected as the guide prescribes) and ``frac`` = algorithmic bytes / rocprof_us / 8 TB/s
+    (``frac_events`` beside it; where no rocprof record exists ``frac`` falls back to the event time and ``source`` says so)."""
+    import torch
     pmc = {}
-    path = os.path.join(ROOT, "profiles", "r04_roi_nms_pmc.json")
+    path = os.path.join(ROOT, "profiles", ROI_NMS_PMC)
     if os.path.exists(path):
         try:
             with open(path) as f:
                 pmc = json.load(f).get("cases", {})
         except Exception:
             pmc = {}
+    out = {}
     blocker = torch.randn(8192, 8192, device=dev)
-    for name, fn, nbytes, kernels in roi_nms_cases(dev):
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.mm(blocker, blocker)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize(dev)
-        us = e0.elapsed_time(e1) * 1e3 / reps
-        row = {"bound": "hbm", "avg_launch_us": us, "algorithmic_bytes": nbytes, "achieved": nbytes / us / 1e3, "peak": 8000.0,
-               "unit": "GB/s", "frac": nbytes / us / 1e3 / 8000.0, "kernels": kernels, "traffic": None}
-        p = pmc.get(name)
-        if p:
-            row["traffic"] = p.get("hbm_bytes_corrected")
-            row["traffic_over_algorithmic"] = p.get("traffic_over_algorithmic")
-            row["rocprof_avg_us"] = p.get("avg_us")
-            row["traffic_source"] = "profiles/r04_roi_nms_pmc.json"
+    for name in ROI_NMS_CASES:
+        if only and only not in name:
+            continue
+        row = {"bound": "hbm", "peak": 8000.0, "unit": "GB/s"}
+        for state in ("warm", "cold"):
+            case = roi_nms_case(dev, name, cold=state == "cold")
+            us, n = time_roi_nms_case(dev, case, blocker, reps)
+            nbytes = case["nbytes"]
+            st = {"events_us": us, "frac_events": nbytes / us / 1e3 / 8000.0, "sets": case["sets"], "launches_timed": n}
+            p = pmc.get(name, {}).get(state)
+            if p:
+                st.update(rocprof_us=p["avg_us"], achieved=nbytes / p["avg_us"] / 1e3, frac=nbytes / p["avg_us"] / 1e3 / 8000.0,
+                          traffic=p["hbm_bytes_corrected"], traffic_over_algorithmic=p["traffic_over_algorithmic"],
+                          source="profiles/" + ROI_NMS_PMC)
+            else:
+                st.update(rocprof_us=None, achieved=nbytes / us / 1e3, frac=st["frac_events"], traffic=None,
+                          source="HIP events of this run (no rocprofv3 record for this case)")
+            row[state] = st
+            row["algorithmic_bytes"] = nbytes
+            row["kernels"] = sorted(case["kernels"])
+            del case
+            torch.cuda.synchronize(dev)
+            torch.cuda.empty_cache()
         out[name] = row
     del blocker
-    out["note"] = ("one event pair around %d back-to-back launches behind a blocker GEMM (includes the ~1-2 us between two launches; "
-                   "rocprof_avg_us is the kernels' own time); the backward = sample-gradient kernel + gather kernel (deterministic, no atomics, no zero-fill); NMS = mask + "
-                   "scan kernels, bytes of the reference algorithm (the scan is a latency chain, not a stream)" % reps)
+    out["note"] = ("warm = one buffer set launched back to back (maps and outputs in the 256 MiB Infinity Cache: the op's state "
+                   "inside a step); cold = a rotation over >= 512 MiB of distinct maps and outputs; events_us = one event pair "
+                   "around the launches behind a blocker GEMM (includes the ~1-2 us between two launches), rocprof_us = the "
+                   "kernels' own durations; NMS = mask + scan kernels on the reference algorithm's bytes (the scan is a latency "
+                   "chain, not a stream)")
+    return out
+
+
+def roofline_hbm(roi_nms):
+    """The metric's second half as a top-level object next to ``roofline`` (the driver's record keeps top-level keys only):
+    the RoIAlignAvg forward at configs[2]'s size (4 frames x 32 ROIs) from HBM (cold state), with the other HBM-side ops of
+    the path as numeric rows."""
+    main = roi_nms.get("roi_align_avg_fwd_4x32")
+    if not main or "cold" not in main:
+        return None
+    c = main["cold"]
+    out = {"bound": "hbm", "kernel": "roi_align_fwd_roi_kernel", "case": "RoIAlignAvg forward, 4 frames x 32 ROIs, 1024 channels, cold "
+           "(maps and outputs rotate over >= 512 MiB)", "achieved": c["achieved"], "peak": 8000.0, "unit": "GB/s", "frac": c["frac"],
+           "traffic": c["traffic"], "algorithmic_bytes": main["algorithmic_bytes"], "rocprof_us": c["rocprof_us"],
+           "events_us": c["events_us"], "frac_events": c["frac_events"], "source": c["source"], "cases": {}}
+    for name, row in roi_nms.items():
+        if not isinstance(row, dict) or "warm" not in row:
+            continue
+        for state in ("warm", "cold"):
+            st = row[state]
+            out["cases"]["%s.%s" % (name, state)] = {"us": st["rocprof_us"] if st["rocprof_us"] is not None else st["events_us"],
+                                                     "events_us": st["events_us"], "achieved": st["achieved"], "frac": st["frac"],
+                                                     "traffic": st["traffic"], "algorithmic_bytes": row["algorithmic_bytes"]}
     return out
 
 
@@ -893,6 +975,8 @@ def main():
             if _l2.EXPERIMENTS:          # an I2V_EXPERIMENTS build only: the default library has no bf16-split kernel
                 also("sgg_gemm_x3", gemm_x3)
             also("roi_nms", lambda: run_roi_nms(dev))
+            if "error" not in line["also"]["roi_nms"]:
+                line["roofline_hbm"] = roofline_hbm(line["also"]["roi_nms"])
             also("instance_styled", isd)
             also("eval_loops", eval_loops)
     elif a.config == "instance_styled":

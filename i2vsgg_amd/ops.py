@@ -70,6 +70,9 @@ def _rois_f32(rois):
 
 
 ROIALIGN_BWD_GATHER = os.environ.get("I2V_ROIALIGN_BWD_GATHER", "1") != "0"     # 0: the atomic scatter (round 1)
+# kernel name -> launches per op, for the profiling tools (bench.py roi_nms_case, tools/roi_nms_pmc_summary.py)
+ROIALIGN_BWD_KERNELS = {"roi_align_bwd_prep_kernel": 1, "roi_align_bwd_gather_kernel": 1}
+NMS_KERNELS = {"nms_mask_kernel": 1, "nms_scan_pipelined_kernel": 1}
 
 
 class _RoIAlignFn(torch.autograd.Function):

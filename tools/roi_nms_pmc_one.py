@@ -1,24 +1,29 @@
 #!/usr/bin/env python3
-"""ONE case of bench.py's ``roi_nms_cases`` (the launches behind ``also.roi_nms``), N launches, for the rocprofv3 passes of
-tools/roi_nms_pmc.sh (kernel trace, --pmc FETCH_SIZE, --pmc WRITE_SIZE: three separate runs per case).
+"""ONE case of bench.py's ROI_NMS_CASES (the launches behind ``roofline_hbm`` / ``also.roi_nms``) in ONE cache state, for the
+rocprofv3 passes of tools/roi_nms_pmc.sh (kernel trace, --pmc FETCH_SIZE, --pmc WRITE_SIZE: three separate runs per case
+and state).  N + 5 ops are launched; the summary drops each kernel's first 5 ops (cold start, first-touch of the buffers).
 
-usage: roi_nms_pmc_one.py CASE      (no argument: list the case names)
-Prints one JSON line: the case, its launches and its algorithmic bytes per launch."""
+usage: roi_nms_pmc_one.py CASE warm|cold      (no argument: list the case names)
+Prints one JSON line: the case, its ops, the kernels with their launches per op and the algorithmic bytes per op."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 import torch
 import bench
 
-N = 10
-dev = torch.device("cuda:0")
-cases = bench.roi_nms_cases(dev)
-if len(sys.argv) < 2:
-    print(" ".join(c[0] for c in cases))
+N, DROP = 100, 5
+if len(sys.argv) < 3:
+    print(" ".join(bench.ROI_NMS_CASES))
     sys.exit(0)
-name, fn, nbytes, kernels = next(c for c in cases if c[0] == sys.argv[1])
+name, state = sys.argv[1], sys.argv[2]
+dev = torch.device("cuda:0")
+case = bench.roi_nms_case(dev, name, cold=state == "cold")
+sets = case["sets"]
+n = -(-N // sets) * sets                      # whole rotations
+ring = [None] * sets
 torch.cuda.synchronize()
-for _ in range(N):
-    fn()
+for i in range(DROP + n):
+    ring[i % sets] = case["fn"](i)
 torch.cuda.synchronize()
-print(json.dumps({"case": name, "launches": N, "algorithmic_bytes": nbytes, "kernels": kernels}))
+print(json.dumps({"case": name, "state": state, "ops": n, "dropped": DROP, "sets": sets, "algorithmic_bytes": case["nbytes"],
+                  "kernels": case["kernels"]}))
