@@ -328,13 +328,18 @@ roi_align_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ r
 // and the chip adds ~1.3 TB/s of them -- 102 us, 0.07 of the HBM roofline on algorithmic bytes, summation order free.
 // Here every element of the gradient map is written ONCE, by the workgroup that owns it, as the sum of its contributions in
 // the reference's serial order (roi, sample row, sample column ascending -- roi_align_kernel.cu:94-143 run as a loop):
-// deterministic, no atomics, no zero-fill in front.  Two kernels:
-//   prep    per (roi, 128 channels): the sample gradients gs[r][s][c] (the 2x2 mean's backward folded in, same expression as
-//           the scatter kernel) and, once per ROI, the sample geometry table {frame, ok, hs, ws, hr, wr};
-//   gather  per (frame, map row h, 128 channels): the samples of that frame whose taps touch row h (hs == h or hs + 1 == h)
-//           are listed in index order (a deterministic compaction, 2048 samples per pass); wave group g owns the cells
-//           w = g (mod 8) of the row, walks the list and adds its taps -- (float)(g * (1. - hr) * (1 - wr)) ... exactly as the
-//           scatter -- into a 128-channel row buffer in LDS; the row is then stored with 16-byte stores.
+// deterministic, no atomics, no zero-fill in front.  ONE kernel (round 5; round 4 ran a second kernel in front that wrote
+// the sample gradients and the sample geometry to a workspace -- 2.0x the algorithmic bytes): per (frame, map row h,
+// 128 channels)
+//   list    the (roi, sample row) pairs of the frame whose taps touch row h (hs == h: the upper taps; hs + 1 == h: the lower
+//           taps), in index order, by a deterministic ballot compaction; the row geometry is computed from the roi table on
+//           the spot (a thread looks at the frame index first: only the frame's own pairs cost the fp64 arithmetic);
+//   stage   per batch of listed pairs: the 128-channel sample gradients straight from grad_out -- the 2x2 mean's backward
+//           (avg_pool2d: grad / 4 summed over the <= 4 windows holding the sample, raster order) folded into the load -- and
+//           one tap record per (pair, sample column, cell parity): the cell of the row buffer the tap goes to and its weight;
+//   add     wave w adds them for ITS 32 channels into the row buffer in list order; the row is then stored with 16-byte stores.
+// A tap's weight is (1 - hr | hr) * (1 - wr | wr) rounded to fp32 once per (pair, column) instead of the scatter's
+// double-promoted product per element (roi_align_kernel.cu:137-140): a tap differs from the scatter's by <= 1 ulp.
 struct AxisGeom { int ok, s; float r; int pad; };        // one axis of ra_sample: in range?, floor (clamped to n - 2), fraction
 
 // ra_sample's arithmetic for one axis (roi_align.c:99-118): the sample grid is separable, a sample row shares hs / hr, a
@@ -352,199 +357,214 @@ __device__ inline AxisGeom ra_axis(float lo, float hi, float scale, int n, int A
     return g;
 }
 
-// prep: per (roi, 128 channels) the sample gradients gs[r][s][c]; once per ROI the geometry of its AH sample rows
-// (ok = frame index or -1) and AW sample columns
-template <int AVG>
-__global__ void __launch_bounds__(256)
-roi_align_bwd_prep_kernel(const float* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gs,
-                          AxisGeom* __restrict__ rowg, AxisGeom* __restrict__ colg, int R, int C, int H, int W, int PH, int PW,
-                          float scale) {
-    const int nchunk = C >> 7;
-    const int chunk = blockIdx.x % nchunk, r = blockIdx.x / nchunk;
-    const int l = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int AH = PH + AVG, AW = PW + AVG, NS = AH * AW;
-    const float* roi = rois + 5 * (long long)r;
-    if (chunk == 0) {
-        if ((int)threadIdx.x < AH) {
-            AxisGeom q = ra_axis(roi[2], roi[4], scale, H, AH, threadIdx.x);
-            q.ok = q.ok ? (int)roi[0] : -1;
-            rowg[(long long)r * AH + threadIdx.x] = q;
-        } else if ((int)threadIdx.x >= 64 && (int)threadIdx.x < 64 + AW) {
-            colg[(long long)r * AW + (threadIdx.x - 64)] = ra_axis(roi[1], roi[3], scale, W, AW, threadIdx.x - 64);
-        }
-    }
-    // the ROI's PH x PW gradients of this chunk into LDS with every load in flight at once (one round trip), then the samples
-    __shared__ __attribute__((aligned(16))) float4 sg[64 * 32];
-    const float* go = gout + (long long)r * PH * PW * C + (chunk << 7);
-    float* o = gs + ((long long)r * NS) * C + (chunk << 7) + 4 * l;
-    {
-        float4 t[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = threadIdx.x + 256 * j;
-            t[j] = (k < PH * PW * 32) ? *(const float4*)(go + (long long)(k >> 5) * C + 4 * (k & 31)) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = threadIdx.x + 256 * j;
-            if (k < PH * PW * 32) sg[k] = t[j];
-        }
-    }
-    __syncthreads();
-    for (int s = g; s < NS; s += 8) {
-        const int ah = s / AW, aw = s - ah * AW;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (AVG) {          // avg_pool2d backward: grad / 4 summed over the <= 4 windows holding the sample, raster order
-#pragma unroll
-            for (int dy = -1; dy <= 0; ++dy)
-#pragma unroll
-                for (int dx = -1; dx <= 0; ++dx) {
-                    const int ph = ah + dy, pw = aw + dx;
-                    if (ph >= 0 && ph < PH && pw >= 0 && pw < PW) {
-                        const float4 t = sg[(ph * PW + pw) * 32 + l];
-                        v.x += t.x / 4.f; v.y += t.y / 4.f; v.z += t.z / 4.f; v.w += t.w / 4.f;
-                    }
-                }
-        } else {
-            v = sg[s * 32 + l];
-        }
-        *(float4*)(o + (long long)s * C) = v;
-    }
-}
-
-constexpr int RAB_SEG = 1024;           // (roi, sample row) pairs examined per list pass
-constexpr int RAB_BATCH = 4;            // listed pairs whose sample gradients are staged in LDS together
+constexpr int RAB_SEG = 1024;           // (roi, sample row) pairs examined per list pass: 256 per wave
+constexpr int RAB_BATCH = 4;            // listed pairs whose sample gradients are staged in LDS together (one per wave's record lanes)
 constexpr int RAB_MAXA = 8;             // sample columns per row this kernel takes
 
-// gather: per (frame b, map row h, 128 channels).  The (roi, sample row) pairs of frame b whose taps touch row h (hs == h:
-// the upper taps; hs + 1 == h: the lower taps) are listed in index order -- the reference loop's order -- by a deterministic
-// compaction; the 128-channel gradients of a batch of listed pairs' samples are staged in LDS by all threads at once (one
-// memory round trip per batch, requested while the previous batch is added), then WAVE w adds them for ITS 32 channels into the row
-// buffer, in list order: lane = (channel, cell parity) -- of a sample column's two taps (cells ws, ws + 1) one is even and one
-// is odd, so every lane has exactly one tap per column and there is not a branch in the loop; the cells a lane meets along a
-// pair are non-decreasing, a repeated cell (ws + 1 == ws') is forwarded in a register, and the current values of all eight are
-// requested at once.  (Round 4's first form gave wave w the CELLS of class cell % 4 == w: every wave walked every column to
-// find its one tap in four, ~300 instructions and four dependent LDS round trips per pair -- 1.8k cycles, 76 % of the kernel.)
-// No two waves touch one channel, so there is nothing to synchronise but the batches.
-__global__ void __launch_bounds__(256)
-roi_align_bwd_gather_kernel(const float* __restrict__ gs, const AxisGeom* __restrict__ rowg, const AxisGeom* __restrict__ colg,
-                            float* __restrict__ gfeat, int n_pairs, int AH, int AW, int C, int H, int W) {
+struct TapRec { int cell0; float w0; int cell1; float w1; };    // a sample column's tap on the even / odd cell: row-buffer cell, weight
+
+#ifdef RAB_CLOCKS           // tools/micro/rab_clock.hip only: per-workgroup phase stamps (s_memtime), never in the library
+__device__ unsigned long long g_rab_clk[8192][6];
+#define RAB_T(x) const unsigned long long x = __builtin_amdgcn_s_memtime()
+#define RAB_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define RAB_T(x)
+#define RAB_ADD(acc, a, b)
+#endif
+
+// lane = (channel, cell parity) -- of a sample column's two taps (cells ws, ws + 1) one is even and one is odd, so every lane
+// has exactly one tap per column and there is not a branch in the add loop; the cells a lane meets along a pair are
+// non-decreasing, a repeated cell (ws + 1 == ws') is forwarded in a register, and the current values of all eight are requested
+// at once.  No two waves touch one channel, so there is nothing to synchronise but the batches.
+// P7: pooled grid 7 x 7 (the path's own: RoIAlignAvg(7, 7) -> 8 x 8 samples) with the grid sizes as constants.
+template <int AVG, int P7>
+__global__ void __launch_bounds__(256, 3)           // three workgroups per CU (LDS allows three): <= 168 VGPRs
+roi_align_bwd_row_kernel(const float* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gfeat, int R, int PH_,
+                         int PW_, float scale, int B, int C, int H, int W) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* rowbuf = lds;                                                    // [W + 2][128]: cell x, channel c at x * 128 + (c ^ ((x & 1) << 5))
                                                                             // (odd cells swap their 32-channel halves: the two half-waves
                                                                             // of a tap hit different banks); rows W, W + 1: a bin for taps outside the map
     float* stage = rowbuf + (size_t)(W + 2) * 128;                          // [RAB_BATCH][RAB_MAXA][128]
-    int* list = (int*)(stage + RAB_BATCH * RAB_MAXA * 128);                 // [RAB_SEG]: pair index * 2 + (hs + 1 == h)
-    __shared__ int s_wave_cnt[4], s_total;
-    __shared__ AxisGeom s_col[RAB_BATCH][RAB_MAXA];
-    __shared__ float s_hr[RAB_BATCH];
-    __shared__ int s_dy[RAB_BATCH];
+    unsigned short* list = (unsigned short*)(stage + RAB_BATCH * RAB_MAXA * 128);   // [4][256]: wave w's hits among ITS 256 candidates,
+                                                                            // (index in the segment) * 2 + (hs + 1 == h); the list = the four in wave order
+    __shared__ int s_cnt[4];
+    __shared__ TapRec s_rec[RAB_BATCH][RAB_MAXA];
+    const int PH = P7 ? 7 : PH_, PW = P7 ? 7 : PW_;
+    const int AH = PH + AVG, AW = PW + AVG;
+    const int n_pairs = R * AH;
     const int nchunk = C >> 7;
-    const int chunk = blockIdx.x % nchunk, h = (blockIdx.x / nchunk) % H, b = blockIdx.x / (nchunk * H);
+    // rows are dealt from the middle of the map outwards, all frames of a row together: boxes crowd the middle, so the rows
+    // with the longest lists start first and the launch ends on short ones
+    const int chunk = blockIdx.x % nchunk, b = (blockIdx.x / nchunk) % B, hk = blockIdx.x / (nchunk * B);
+    const int h = (hk & 1) ? H / 2 - 1 - (hk >> 1) : H / 2 + (hk >> 1);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int ch = 32 * wave + (lane & 31), par = lane >> 5, chs = ch ^ (par << 5);
+#ifdef RAB_CLOCKS
+    unsigned long long c_list = 0, c_stage = 0, c_add = 0, c_req = 0, c_n = 0;
+#endif
+    RAB_T(c_begin);
     for (int i = threadIdx.x; i < (W + 2) * 32; i += 256) ((float4*)rowbuf)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int base = 0; base < n_pairs; base += RAB_SEG) {
-        if (threadIdx.x == 0) s_total = 0;
-        // ---- the keys of this segment: requested at once (RAB_SEG / 256 = 4 per thread), compacted from registers
-        AxisGeom key[RAB_SEG / 256];
+        RAB_T(c_l0);
+        // ---- the list of this segment.  Wave w looks at candidates [256 w, 256 w + 256) in four rounds and appends its hits to
+        // its own quarter of the list (a ballot and a running count: no barrier); a pair of another frame is dismissed on its
+        // frame index before any arithmetic.  One barrier, then every thread knows the four counts.  No load sits under a
+        // condition (a candidate past the end re-reads the last roi and is masked).
+        {
+            int cnt = 0;
+            float f0[4], y1[4], y2[4];
 #pragma unroll
-        for (int k = 0; k < RAB_SEG / 256; ++k) {
-            const int i = base + k * 256 + threadIdx.x;
-            key[k].ok = -1; key[k].s = 0; key[k].r = 0.f;
-            if (i < n_pairs) key[k] = rowg[i];
+            for (int k = 0; k < 4; ++k) {
+                const int i = min(base + 256 * wave + 64 * k + lane, n_pairs - 1);
+                const float* roi = rois + 5 * (long long)(i / AH);
+                f0[k] = roi[0]; y1[k] = roi[2]; y2[k] = roi[4];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int il = 256 * wave + 64 * k + lane, i = base + il;
+                int hit = 0, dy = 0;
+                if (i < n_pairs && (int)f0[k] == b) {
+                    const AxisGeom q = ra_axis(y1[k], y2[k], scale, H, AH, i % AH);
+                    dy = q.s + 1 == h;
+                    hit = q.ok && (q.s == h || dy);
+                }
+                const unsigned long long m = __ballot(hit);
+                if (hit) list[256 * wave + cnt + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(2 * il + dy);
+                cnt += __popcll(m);
+            }
+            if (lane == 0) s_cnt[wave] = cnt;
         }
         __syncthreads();
-        const int rounds = (min(RAB_SEG, n_pairs - base) + 255) >> 8;
-#pragma unroll
-        for (int k = 0; k < RAB_SEG / 256; ++k) {
-            if (k >= rounds) break;
-            const int i = base + k * 256 + threadIdx.x;
-            const int dy = key[k].s + 1 == h;
-            const int hit = i < n_pairs && key[k].ok == b && (key[k].s == h || dy);
-            const unsigned long long m = __ballot(hit);
-            if (lane == 0) s_wave_cnt[wave] = __popcll(m);
-            __syncthreads();
-            int off = s_total;
-            for (int w = 0; w < wave; ++w) off += s_wave_cnt[w];
-            if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = 2 * i + dy;
-            __syncthreads();
-            if (threadIdx.x == 0) s_total += s_wave_cnt[0] + s_wave_cnt[1] + s_wave_cnt[2] + s_wave_cnt[3];
-            __syncthreads();
-        }
-        const int n = s_total;
-        // the batch's operands travel while the PREVIOUS batch is added: the 128-channel gradients of its samples (16 bytes per
-        // lane, 4 loads per thread) and, on the first threads, the column geometry / row fraction of its pairs
+        const int p1 = s_cnt[0], p2 = p1 + s_cnt[1], p3 = p2 + s_cnt[2], n = p3 + s_cnt[3];
+        auto entry = [&](int e) {           // the e-th listed pair: global pair index * 2 + dy
+            const int w = (e >= p1) + (e >= p2) + (e >= p3);
+            const int off = w == 0 ? 0 : (w == 1 ? p1 : (w == 2 ? p2 : p3));
+            return 2 * base + (int)list[256 * w + e - off];
+        };
+        RAB_T(c_l1);
+        RAB_ADD(c_list, c_l0, c_l1);
+#ifdef RAB_CLOCKS
+        c_n += n;
+#endif
+        // the batch's operands travel while the PREVIOUS batch is added: the grad_out rows its samples are made of (16 bytes per
+        // lane; with the 2x2 mean four loads per sample) and, on eight lanes of every wave, the roi of one pair -- requested here
+        // through a buffer resource, none under a condition (a sample / window cell that does not exist gets the out-of-range
+        // bit: zeros, no traffic), first used when the batch is staged.  The tap records are made from the roi AFTER the previous
+        // batch's chain, when the loads have long landed.
         constexpr int TL = RAB_BATCH * RAB_MAXA * 32 / 256;
-        float4 t[TL];
-        AxisGeom qn; float hrn = 0.f; int dyn = 0;
+        constexpr int NQ = AVG ? 4 : 1;
+        const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gout), 0, 0x7FFFFFFCu, 0x00020000);
+        float4 q4[TL][NQ];
+        float rq[4];
+        int rcode = 0;
+        TapRec recn;
         auto request = [&](int e0) {
             const int nb = min(RAB_BATCH, n - e0);
 #pragma unroll
             for (int j = 0; j < TL; ++j) {
                 const int k = threadIdx.x + 256 * j;
                 const int u = k / (RAB_MAXA * 32), aw = (k / 32) % RAB_MAXA, ll = k & 31;
-                t[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (u < nb && aw < AW) {
-                    const int pair = list[e0 + u] >> 1;
-                    t[j] = *(const float4*)(gs + ((long long)pair * AW + aw) * C + (chunk << 7) + 4 * ll);
+                const int live = u < nb && aw < AW;
+                const int pair = entry(e0 + min(u, nb - 1)) >> 1;
+                const int r = pair / AH, ah = pair - r * AH;
+                const unsigned at = (unsigned)(r * PH * PW) * (unsigned)C + (unsigned)((chunk << 7) + 4 * ll);
+                if (AVG) {              // the (<= 4) pooled cells whose 2x2 window holds the sample, raster order
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const int ph = ah - 1 + (d >> 1), pw = aw - 1 + (d & 1);
+                        const unsigned dead = (live && ph >= 0 && ph < PH && pw >= 0 && pw < PW) ? 0u : 0x80000000u;
+                        q4[j][d] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                            gr, ((at + (unsigned)((ph * PW + pw) * C)) * 4u) | dead, 0, 0));
+                    }
+                } else {
+                    q4[j][0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                        gr, ((at + (unsigned)((ah * PW + aw) * C)) * 4u) | (live ? 0u : 0x80000000u), 0, 0));
                 }
             }
-            qn.ok = 0; qn.s = 0; qn.r = 0.f; qn.pad = 0;
-            if (threadIdx.x < nb * RAB_MAXA) {
-                const int u = threadIdx.x / RAB_MAXA, aw = threadIdx.x % RAB_MAXA;
-                const int pair = list[e0 + u] >> 1, r = pair / AH;
-                if (aw < AW) qn = colg[(long long)r * AW + aw];
-                if (aw == 0) { hrn = rowg[pair].r; dyn = list[e0 + u] & 1; }
+            rcode = entry(e0 + min(wave, nb - 1));
+            const float* roi = rois + 5 * (long long)((rcode >> 1) / AH);
+            rq[0] = roi[1]; rq[1] = roi[2]; rq[2] = roi[3]; rq[3] = roi[4];
+            if (wave >= nb) rcode = -1;
+        };
+        auto make_rec = [&]() {
+            recn.cell0 = W; recn.cell1 = W + 1; recn.w0 = 0.f; recn.w1 = 0.f;
+            if (lane < RAB_MAXA && lane < AW && rcode >= 0) {
+                const AxisGeom qr = ra_axis(rq[1], rq[3], scale, H, AH, (rcode >> 1) % AH);
+                const AxisGeom qc = ra_axis(rq[0], rq[2], scale, W, AW, lane);
+                if (qc.ok) {
+                    const float fh = (rcode & 1) ? qr.r : (1 - qr.r);
+                    const float wl = fh * (1 - qc.r), wr = fh * qc.r;     // taps on cells ws, ws + 1
+                    const int odd = qc.s & 1;                            // the even cell is ws (odd == 0) or ws + 1
+                    recn.cell0 = qc.s + odd;      recn.w0 = odd ? wr : wl;
+                    recn.cell1 = qc.s + 1 - odd;  recn.w1 = odd ? wl : wr;
+                }
             }
         };
-        if (n > 0) request(0);
+        if (n > 0) { request(0); make_rec(); }
         for (int e0 = 0; e0 < n; e0 += RAB_BATCH) {
             const int nb = min(RAB_BATCH, n - e0);
+            RAB_T(c_s0);
 #pragma unroll
-            for (int j = 0; j < TL; ++j) ((float4*)stage)[threadIdx.x + 256 * j] = t[j];
-            if (threadIdx.x < nb * RAB_MAXA) {
-                const int u = threadIdx.x / RAB_MAXA, aw = threadIdx.x % RAB_MAXA;
-                s_col[u][aw] = qn;
-                if (aw == 0) { s_hr[u] = hrn; s_dy[u] = dyn; }
+            for (int j = 0; j < TL; ++j) {
+                float4 v = q4[j][0];
+                if (AVG) {              // avg_pool2d backward: grad / 4 summed over the windows, raster order
+                    v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        v.x += q4[j][d].x / 4.f; v.y += q4[j][d].y / 4.f; v.z += q4[j][d].z / 4.f; v.w += q4[j][d].w / 4.f;
+                    }
+                }
+                ((float4*)stage)[threadIdx.x + 256 * j] = v;
             }
+            if (lane < RAB_MAXA) s_rec[wave][lane] = recn;
             __syncthreads();
+            RAB_T(c_s1);
             if (e0 + RAB_BATCH < n) request(e0 + RAB_BATCH);
-            // ---- add: pairs in list order, sample columns ascending.  WAVE w owns the cells of its class (cell % 4 == w) with
-            // all 64 lanes (2 channels each): no two waves touch one cell.  The pair's eight column entries and its eight staged
-            // gradients come into registers with one LDS wait each; a tap is then register arithmetic and one read-modify-write
-            // of the row buffer
-            for (int u = 0; u < nb; ++u) {
-                const double fh = s_dy[u] ? (double)s_hr[u] : (1. - s_hr[u]);
-                AxisGeom q[RAB_MAXA];
-                float sv[RAB_MAXA], pre[RAB_MAXA], wx[RAB_MAXA];
-                int at[RAB_MAXA];
-#pragma unroll
-                for (int aw = 0; aw < RAB_MAXA; ++aw) q[aw] = s_col[u][aw];
-#pragma unroll
-                for (int aw = 0; aw < RAB_MAXA; ++aw) sv[aw] = stage[(u * RAB_MAXA + aw) * 128 + ch];
+            RAB_T(c_s2);
+            // ---- add: pairs in list order, sample columns ascending; a pair's eight tap records, staged gradients and current
+            // cell values come into registers with one LDS wait each, a tap is then a multiply-add and one store.  The next
+            // pair's records and gradients are read under this pair's chain.
+            float sv[RAB_MAXA], wt[RAB_MAXA];
+            int at[RAB_MAXA];
+            auto fetch = [&](int u) {
 #pragma unroll
                 for (int aw = 0; aw < RAB_MAXA; ++aw) {
-                    const int t = (q[aw].s ^ par) & 1;                        // my tap of this column: the cell of my parity
-                    const int cell = q[aw].ok ? q[aw].s + t : W + par;        // a column outside the map goes to the bin
-                    wx[aw] = t ? q[aw].r : (1 - q[aw].r);                     // the scatter kernel's (1 - wr) / wr, in float as there
-                    at[aw] = cell * 128 + chs;
-                    pre[aw] = rowbuf[at[aw]];
+                    const int2 q = *(const int2*)((const char*)&s_rec[u][aw] + 8 * par);
+                    at[aw] = q.x * 128 + chs;
+                    wt[aw] = __int_as_float(q.y);
+                    sv[aw] = stage[(u * RAB_MAXA + aw) * 128 + ch];
                 }
+            };
+            fetch(0);
+            for (int u = 0; u < nb; ++u) {
+                float pre[RAB_MAXA], tap[RAB_MAXA];
+                int a[RAB_MAXA];
+#pragma unroll
+                for (int aw = 0; aw < RAB_MAXA; ++aw) { a[aw] = at[aw]; pre[aw] = rowbuf[a[aw]]; tap[aw] = sv[aw] * wt[aw]; }
+                if (u + 1 < nb) fetch(u + 1);
                 float cur = 0.f;
                 int prev = -1;
 #pragma unroll
                 for (int aw = 0; aw < RAB_MAXA; ++aw) {
-                    const float v = (at[aw] == prev) ? cur : pre[aw];
-                    // the scatter kernel's expressions: g * (1. - hr) * (1 - wr), g * (1. - hr) * wr, g * hr * (1 - wr), g * hr * wr
-                    cur = v + (float)(sv[aw] * fh * wx[aw]);
-                    rowbuf[at[aw]] = cur;
-                    prev = at[aw];
+                    const float v = (a[aw] == prev) ? cur : pre[aw];
+                    cur = v + tap[aw];
+                    rowbuf[a[aw]] = cur;
+                    prev = a[aw];
                 }
             }
+            if (e0 + RAB_BATCH < n) make_rec();
             __syncthreads();
+            RAB_T(c_s3);
+            RAB_ADD(c_stage, c_s0, c_s1); RAB_ADD(c_req, c_s1, c_s2); RAB_ADD(c_add, c_s2, c_s3);
         }
     }
+#ifdef RAB_CLOCKS
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        unsigned long long* o6 = g_rab_clk[blockIdx.x];
+        o6[0] = __builtin_amdgcn_s_memtime() - c_begin; o6[1] = c_list; o6[2] = c_stage; o6[3] = c_req; o6[4] = c_add; o6[5] = c_n;
+    }
+#endif
     float* o = gfeat + (((long long)b * H + h) * W) * C + (chunk << 7);
     for (int i = threadIdx.x; i < W * 32; i += 256) {
         const int x = i >> 5, c4 = i & 31;
@@ -894,38 +914,36 @@ extern "C" int32_t i2v_roi_align_bwd(const float* gout, int32_t out_layout, cons
 }
 
 extern "C" size_t i2v_roi_align_bwd_gather_workspace_bytes(int32_t R, int32_t C, int32_t PH, int32_t PW, int32_t avg) {
-    const size_t AH = PH + avg, AW = PW + avg;
-    return i2v_align((size_t)R * AH * AW * C * sizeof(float)) + i2v_align((size_t)R * AH * sizeof(AxisGeom)) +
-           i2v_align((size_t)R * AW * sizeof(AxisGeom));
+    (void)R; (void)C; (void)PH; (void)PW; (void)avg;
+    return 0;                           // round 5: one kernel, nothing staged in global memory (the entry stays for its callers)
 }
 
 extern "C" int32_t i2v_roi_align_bwd_gather(const float* gout, const float* rois, int32_t R, int32_t PH, int32_t PW, float scale,
                                             int32_t avg, float* gfeat, int32_t B, int32_t C, int32_t H, int32_t W, void* ws,
                                             size_t ws_bytes, void* stream) {
-    I2V_CHECK_ARG(gout && rois && gfeat && ws, "roi_align_bwd_gather: null pointer");
+    (void)ws; (void)ws_bytes;
+    I2V_CHECK_ARG(gout && rois && gfeat, "roi_align_bwd_gather: null pointer");
     I2V_CHECK_ARG(B > 0 && C > 0 && H >= 2 && W >= 2 && R > 0 && PH > 0 && PW > 0, "roi_align_bwd_gather: bad shape");
     I2V_CHECK_ARG(avg == 0 || avg == 1, "roi_align_bwd_gather: avg must be 0/1");
     I2V_CHECK_ARG(C % 128 == 0, "roi_align_bwd_gather: C must be a multiple of 128 (NHWC in and out)");
     const size_t AH = PH + avg, AW = PW + avg;
-    I2V_CHECK_ARG(AW <= RAB_MAXA && AH <= 64, "roi_align_bwd_gather: at most 8 sample columns");
-    if (ws_bytes < i2v_roi_align_bwd_gather_workspace_bytes(R, C, PH, PW, avg)) {
-        i2v_set_error("roi_align_bwd_gather: workspace too small");
-        return I2V_ERR_WORKSPACE;
-    }
-    const size_t lds = (size_t)(W + 2) * 128 * sizeof(float) + (size_t)RAB_BATCH * RAB_MAXA * 128 * sizeof(float) + RAB_SEG * sizeof(int);
-    I2V_CHECK_ARG(lds <= 60 * 1024 && (long long)R * AH < (1ll << 30), "roi_align_bwd_gather: map too wide for the LDS row buffer");
+    I2V_CHECK_ARG(AW <= RAB_MAXA, "roi_align_bwd_gather: at most 8 sample columns (pooled_w + avg <= 8)");
+    const size_t lds = (size_t)(W + 2) * 128 * sizeof(float) + (size_t)RAB_BATCH * RAB_MAXA * 128 * sizeof(float) + RAB_SEG * sizeof(unsigned short);
+    I2V_CHECK_ARG(lds <= 60 * 1024 && (long long)R * AH < (1ll << 29), "roi_align_bwd_gather: map too wide for the LDS row buffer");
+    I2V_CHECK_ARG((long long)B * H * (C / 128) < (1ll << 31), "roi_align_bwd_gather: grid too large");
+    I2V_CHECK_ARG((long long)R * PH * PW * C * 4 < (1ll << 31), "roi_align_bwd_gather: grad_out beyond the 2 GiB a 32-bit buffer offset reaches");
     hipStream_t st = (hipStream_t)stream;
-    float* gs = (float*)ws;
-    AxisGeom* rowg = (AxisGeom*)((char*)ws + i2v_align((size_t)R * AH * AW * C * sizeof(float)));
-    AxisGeom* colg = (AxisGeom*)((char*)rowg + i2v_align((size_t)R * AH * sizeof(AxisGeom)));
-    if (avg) roi_align_bwd_prep_kernel<1><<<R * (C / 128), 256, 0, st>>>(gout, rois, gs, rowg, colg, R, C, H, W, PH, PW, scale);
-    else roi_align_bwd_prep_kernel<0><<<R * (C / 128), 256, 0, st>>>(gout, rois, gs, rowg, colg, R, C, H, W, PH, PW, scale);
     static bool once = [] {
-        (void)hipFuncSetAttribute((const void*)roi_align_bwd_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
+        (void)hipFuncSetAttribute((const void*)roi_align_bwd_row_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
+        (void)hipFuncSetAttribute((const void*)roi_align_bwd_row_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
+        (void)hipFuncSetAttribute((const void*)roi_align_bwd_row_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
         return true;
     }();
     (void)once;
-    roi_align_bwd_gather_kernel<<<B * H * (C / 128), 256, lds, st>>>(gs, rowg, colg, gfeat, (int)(R * AH), (int)AH, (int)AW, C, H, W);
+    const dim3 grid(B * H * (C / 128));
+    if (avg && PH == 7 && PW == 7) roi_align_bwd_row_kernel<1, 1><<<grid, 256, lds, st>>>(gout, rois, gfeat, R, PH, PW, scale, B, C, H, W);
+    else if (avg) roi_align_bwd_row_kernel<1, 0><<<grid, 256, lds, st>>>(gout, rois, gfeat, R, PH, PW, scale, B, C, H, W);
+    else roi_align_bwd_row_kernel<0, 0><<<grid, 256, lds, st>>>(gout, rois, gfeat, R, PH, PW, scale, B, C, H, W);
     I2V_CHECK_LAUNCH("roi_align_bwd_gather");
     return I2V_OK;
 }

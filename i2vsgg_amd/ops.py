@@ -71,7 +71,7 @@ def _rois_f32(rois):
 
 ROIALIGN_BWD_GATHER = os.environ.get("I2V_ROIALIGN_BWD_GATHER", "1") != "0"     # 0: the atomic scatter (round 1)
 # kernel name -> launches per op, for the profiling tools (bench.py roi_nms_case, tools/roi_nms_pmc_summary.py)
-ROIALIGN_BWD_KERNELS = {"roi_align_bwd_prep_kernel": 1, "roi_align_bwd_gather_kernel": 1}
+ROIALIGN_BWD_KERNELS = {"roi_align_bwd_row_kernel": 1}
 NMS_KERNELS = {"nms_mask_kernel": 1, "nms_scan_pipelined_kernel": 1}
 
 
@@ -102,12 +102,10 @@ class _RoIAlignFn(torch.autograd.Function):
         gout = gout.contiguous() if out_nchw else gout.contiguous(memory_format=_CL)
         if ROIALIGN_BWD_GATHER and nhwc and not out_nchw and C % 128 == 0 and W * 512 + 21504 <= 60 * 1024 and pw + avg <= 8 and rois.size(0) > 0:
             # the gather form: every element of the gradient map written once, in the reference's serial order (deterministic,
-            # no atomics, no zero-fill): 109 -> ~30 us at 4 frames x 32 ROIs
+            # no atomics, no zero-fill, no workspace: one kernel since round 5)
             gfeat = torch.empty(shape, device=gout.device, dtype=torch.float32, memory_format=_CL)
-            nb = lib.i2v_roi_align_bwd_gather_workspace_bytes(rois.size(0), C, ph, pw, avg)
-            ws = workspace(nb, gout.device, "roi_align_bwd")
             check(lib.i2v_roi_align_bwd_gather(ptr(gout), ptr(rois), rois.size(0), ph, pw, scale, avg, ptr(gfeat), B, C, H, W,
-                                               ptr(ws), ws.numel(), stream()), "roi_align_bwd_gather")
+                                               None, 0, stream()), "roi_align_bwd_gather")
             return gfeat, None, None, None, None, None, None
         # the scatter accumulates with atomics into zeros: inside a step they come from the step's pre-zeroed arena (one
         # clear per step for every atomically accumulated output) instead of a fill kernel of their own

@@ -82,8 +82,9 @@ int32_t i2v_roi_align_bwd(const float* grad_out, int32_t out_layout, const float
 
 /* The same backward as a GATHER (NHWC grad_out (R,PH,PW,C) and NHWC grad_feat, C % 128 == 0): every element of grad_feat is
  * WRITTEN once (no zero-fill by the caller, no atomics) as the sum of its contributions in the serial order of
- * roi_align_kernel.cu:94-143 (roi, sample row, sample column ascending): deterministic.  Workspace: the sample gradients
- * (R x (PH+avg)(PW+avg) x C floats) + a geometry table. */
+ * roi_align_kernel.cu:94-143 (roi, sample row, sample column ascending): deterministic.  pooled_w + avg <= 8, any pooled_h.
+ * One kernel since round 5: no workspace is needed (the query returns 0; ``workspace`` may be NULL -- both stay in the
+ * signature for callers built against round 4). */
 size_t  i2v_roi_align_bwd_gather_workspace_bytes(int32_t R, int32_t C, int32_t pooled_h, int32_t pooled_w, int32_t avg);
 int32_t i2v_roi_align_bwd_gather(const float* grad_out, const float* rois, int32_t R, int32_t pooled_h, int32_t pooled_w,
                                  float spatial_scale, int32_t avg, float* grad_feat, int32_t B, int32_t C, int32_t H, int32_t W,

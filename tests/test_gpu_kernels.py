@@ -56,9 +56,10 @@ def test_roi_align_fwd_bit_equal_to_the_reference_c(ops, gold, C, H, W, B):
             check_roi_align_against_golden(g, C, *(t.contiguous().cpu().numpy() for t in (a8, a7, p7)))
 
 
-@pytest.mark.parametrize("B,C,H,W", [(2, 128, 9, 11), (1, 256, 19, 32), (2, 8, 9, 11)])
+@pytest.mark.parametrize("B,C,H,W,PH,PW", [(2, 128, 9, 11, 7, 7), (1, 256, 19, 32, 7, 7), (2, 8, 9, 11, 7, 7), (2, 128, 19, 32, 14, 7),
+                                           (1, 128, 9, 11, 3, 5)])
 @pytest.mark.parametrize("avg", [True, False])
-def test_roi_align_bwd_is_the_transpose_of_the_pinned_forward(ops, oracle, monkeypatch, B, C, H, W, avg):
+def test_roi_align_bwd_is_the_transpose_of_the_pinned_forward(ops, oracle, monkeypatch, B, C, H, W, PH, PW, avg):
     """Both HIP backwards (the deterministic gather where it applies: NHWC, C % 128 == 0; and the atomic scatter) against
     F^T g computed in float64 from the coefficients of the PINNED forward (tests/roi_align_pin.py): the backward has no
     reference to run (roi_align.c:175), its definition as the forward's transpose is what pins it."""
@@ -67,9 +68,8 @@ def test_roi_align_bwd_is_the_transpose_of_the_pinned_forward(ops, oracle, monke
     cops, _ = oracle
     rng = np.random.default_rng(B * 100 + H + C)
     rois = syn.roi_cases(31 + H, B, H, W)
-    k = 8 if avg else 7
-    mats = roi_align_matrix(rois, B, H, W, k, k, 1 / 16.0, cops.roi_align_fwd)
-    gout = rng.standard_normal((rois.shape[0], C, 7, 7), dtype=np.float32)
+    mats = roi_align_matrix(rois, B, H, W, PH + int(avg), PW + int(avg), 1 / 16.0, cops.roi_align_fwd)
+    gout = rng.standard_normal((rois.shape[0], C, PH, PW), dtype=np.float32)      # non-square grids too (14 x 7: 15 sample rows)
     want = roi_align_bwd_from_matrix(mats, cops.avgpool2x2_bwd(gout) if avg else gout, rois, B, C, H, W)
     scale = np.abs(want).max()
     rt = torch.from_numpy(rois).to(DEV)
@@ -79,7 +79,7 @@ def test_roi_align_bwd_is_the_transpose_of_the_pinned_forward(ops, oracle, monke
             feat = torch.zeros((B, C, H, W), device=DEV)
             feat = (feat.contiguous(memory_format=torch.channels_last) if nhwc else feat).requires_grad_()
             g = torch.from_numpy(gout).to(DEV)
-            O.roi_align(feat, rt, 7, 7, 1.0 / 16.0, avg=avg, out_nchw=not nhwc).backward(
+            O.roi_align(feat, rt, PH, PW, 1.0 / 16.0, avg=avg, out_nchw=not nhwc).backward(
                 g if not nhwc else g.contiguous(memory_format=torch.channels_last))
             err = np.abs(feat.grad.cpu().numpy() - want).max()
             assert err <= 2e-6 * scale, (gather, nhwc, err / scale)
