@@ -386,11 +386,12 @@ class _Uploader:
     transfer of minibatch k+1 runs beside the step that is still computing (a 2 x 3 x 600 x 1000 fp32 minibatch is 14.4 MB;
     bench.py --data loader over four alternating frame sizes: 5.00 -> 4.82 ms per step, uint8 frames 4.83 -> 4.77).
     ``I2V_UPLOAD_STREAM=0``: the transfer on the caller's stream, in front of the step (the default of round 3, which had met
-    a host segfault in hipGraphLaunch with the copy stream and blamed stream aliasing).  Round 4
-    (profiles/r04_alias_repro.txt): the same file order with pooled streams and every alias logged -- the copy stream WAS a
-    captured branch, the side stream WAS torch's capture stream -- runs clean once no graph is dropped while a replay of it
-    may be in flight (``invalidate_graphs`` synchronises first; stage() grew the head capacity and dropped every graph right
-    behind an asynchronous replay).  The aliases were real but harmless to correctness; they are gone too (ops.role_stream),
+    a host segfault in hipGraphLaunch with the copy stream and blamed stream aliasing).  The same file order with pooled
+    streams and every alias logged -- the copy stream WAS a captured branch, the side stream WAS torch's capture stream --
+    neither crashes (profiles/r04_alias_repro.txt; that record stopped on a bookkeeping KeyError of the test before the numeric
+    comparison) nor changes a loss or a weight (profiles/r05_alias_repro.txt: run to the end, 18 passed) once no graph is
+    dropped while a replay of it may be in flight (``invalidate_graphs`` synchronises first; stage() grew the head capacity
+    and dropped every graph right behind an asynchronous replay).  The aliases cost the overlap, not correctness; they are gone too (ops.role_stream),
     and tests/test_gpu_data_layer.py runs the loader loop both ways, in the order that crashed.
     ``upload`` returns a device tensor that is valid on the caller's CURRENT stream, ``consumed`` marks the point after which
     its buffer may be overwritten."""

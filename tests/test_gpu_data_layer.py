@@ -134,7 +134,7 @@ def test_sgg_captured_step_consumes_loader_batches_of_varying_size(small_cfg, mo
     step.opt.unfuse()
     assert step.graph_error is None, step.graph_error
     assert (step._uploader.stream is not None) == copy_stream
-    if copy_stream:
+    if copy_stream and os.environ.get("I2V_ALIAS_REPRO") != "1":       # tools/alias_repro.py undoes the role streams on purpose
         dev = torch.device(DEV)
         table = ops.stream_table()
         assert step._uploader.stream.cuda_stream == table[(dev.index, "copy", 0)]

@@ -14,6 +14,7 @@ import sys
 
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 os.environ["I2V_UPLOAD_STREAM"] = "1"
+os.environ["I2V_ALIAS_REPRO"] = "1"          # the test skips its role-table bookkeeping (there is no table here) and goes on to its loss / weight comparison
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import pytest  # noqa: E402
@@ -22,7 +23,7 @@ import torch  # noqa: E402
 from i2vsgg_amd import ops  # noqa: E402
 
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-LOG = open(os.path.join(ROOT, "gpurun_out", "r04_alias_repro.txt"), "w", buffering=1)
+LOG = open(os.path.join(ROOT, "gpurun_out", "r05_alias_repro.txt"), "w", buffering=1)
 DRAWS = []
 
 
