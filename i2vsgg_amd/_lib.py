@@ -75,7 +75,7 @@ SIGNATURES = {
     "i2v_conv_wgrad_sgd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _p]),
     "i2v_fc_fold_supported": (_i, [_i, _i, _i, _i]),
     "i2v_fc_fold_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _p]),
-    "i2v_epilogue_bwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _p]),
+    "i2v_epilogue_bwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _p, _z, _p]),
     "i2v_maxpool3x3s2_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "i2v_sgd_momentum": (_i, [_p, _p, _p, _l, _f, _f, _f, _p]),
     "i2v_sgd_momentum_multi": (_i, [_p, _p, _p, _p, _p, _p, _i, _f, _p]),

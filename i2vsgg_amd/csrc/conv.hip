@@ -558,21 +558,42 @@ conv_igemm_f32(const ConvP p_in) {
         constexpr int FIN_CH = C_LD < 6 ? C_LD : 6;
         const bool vec = (p.N & 3) == 0;
         for (int it0 = 0; it0 < C_LD; it0 += FIN_CH) {
-            float4 u[FIN_CH][kSplitInKernelMax], rr[FIN_CH];
+            float4 u[FIN_CH][kSplitInKernelMax], rr[FIN_CH], acc4[FIN_CH] = {};
+            // rounds of kSplitInKernelMax splits, summed in split order: ((((p0 + p1) + p2) + p3) + p4) + ... -- one round for
+            // the backbone's splits (<= 4), more for the long skinny GEMMs of the relation head (round 5: they took the
+            // atomic finish before, whose sum depends on arrival order)
+            for (int s0 = 0; s0 < nsplit; s0 += kSplitInKernelMax) {
 #pragma unroll
-            for (int c = 0; c < FIN_CH; ++c) {
-                const int e = gtid + (it0 + c) * NT;
-                const int row = e / (BN / 4), col = (e % (BN / 4)) * 4;
-                const int m = m0 + row, n = n0 + col;
-                const bool ok = e < BM * (BN / 4) && m < p.M && n < p.N;
-                const unsigned off = (unsigned)(row * BN + col) * 4u;
+                for (int c = 0; c < FIN_CH; ++c) {
+                    const int e = gtid + (it0 + c) * NT;
+                    const int row = e / (BN / 4), col = (e % (BN / 4)) * 4;
+                    const int m = m0 + row, n = n0 + col;
+                    const bool ok = e < BM * (BN / 4) && m < p.M && n < p.N;
+                    const unsigned off = (unsigned)(row * BN + col) * 4u;
 #pragma unroll
-                for (int sp = 0; sp < kSplitInKernelMax; ++sp)
-                    u[c][sp] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-                        wsr, (ok && sp < nsplit && sp != my) ? off + (unsigned)(sp * split_stride * sizeof(float)) : 0xFFFFFFF0u,
-                        0, SC01));
-                rr[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok && vec && (p.flags & I2V_EPI_RESIDUAL)) rr[c] = __builtin_bit_cast(float4, __builtin_nontemporal_load((const f32x4*)(p.res + (long long)m * p.N + n)));
+                    for (int sp = 0; sp < kSplitInKernelMax; ++sp)
+                        u[c][sp] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                            wsr, (ok && s0 + sp < nsplit && s0 + sp != my) ? off + (unsigned)((s0 + sp) * split_stride * sizeof(float)) : 0xFFFFFFF0u,
+                            0, SC01));
+                    if (s0 == 0) {
+                        rr[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (ok && vec && (p.flags & I2V_EPI_RESIDUAL)) rr[c] = __builtin_bit_cast(float4, __builtin_nontemporal_load((const f32x4*)(p.res + (long long)m * p.N + n)));
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < FIN_CH; ++c) {
+                    const int e = gtid + (it0 + c) * NT;
+                    const int row = e / (BN / 4), col = (e % (BN / 4)) * 4;
+                    const float4 mine4 = (e < BM * (BN / 4)) ? *(const float4*)&smem[row * CROW + col] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    float4 v = acc4[c];
+#pragma unroll
+                    for (int sp = 0; sp < kSplitInKernelMax; ++sp) {   // slots >= nsplit were read out of range: zeros
+                        const float4 t = s0 + sp == my ? mine4 : u[c][sp];
+                        if (s0 == 0 && sp == 0) v = t;
+                        else { v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                    }
+                    acc4[c] = v;
+                }
             }
 #pragma unroll
             for (int c = 0; c < FIN_CH; ++c) {
@@ -580,13 +601,7 @@ conv_igemm_f32(const ConvP p_in) {
                 const int row = e / (BN / 4), col = (e % (BN / 4)) * 4;
                 const int m = m0 + row, n = n0 + col;
                 if (e >= BM * (BN / 4) || m >= p.M || n >= p.N) continue;
-                const float4 mine4 = *(const float4*)&smem[row * CROW + col];
-                float4 v = my == 0 ? mine4 : u[c][0];
-#pragma unroll
-                for (int sp = 1; sp < kSplitInKernelMax; ++sp) {   // slots >= nsplit were read out of range: zeros
-                    const float4 t = sp == my ? mine4 : u[c][sp];
-                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-                }
+                const float4 v = acc4[c];
                 const long long o = (long long)m * p.N + n;      // split-K only runs with ostride == 1
                 float vv[4] = {v.x, v.y, v.z, v.w};
                 if (vec) {
@@ -1073,28 +1088,37 @@ conv_gemm_f32(const ConvP p_in) {
     const int nsplit = gridDim.y, my = blockIdx.y;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-        float4 u[TN][kSplitInKernelMax], rr[TN], mk[TN];
+        float4 u[TN][kSplitInKernelMax], rr[TN], mk[TN], v4[TN] = {};
+        // rounds of kSplitInKernelMax splits, summed in split order (conv_igemm_f32 has the rationale): one round for the
+        // backbone's splits, more for the relation head's skinny GEMMs
+        for (int s0 = 0; s0 < nsplit; s0 += kSplitInKernelMax) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+            for (int j = 0; j < TN; ++j) {
 #pragma unroll
-            for (int sp = 0; sp < kSplitInKernelMax; ++sp)
-                u[j][sp] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-                    wsr, (sp < nsplit && sp != my) ? slot(i, j) + (unsigned)(sp * split_stride * sizeof(float)) : 0xFFFFFFF0u, 0, SC01));
-            rr[j] = res_at(i, j);
-            if constexpr (MASK) mk[j] = mask_at(i, j);
-            else mk[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const float4 m4 = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-            float4 v = my == 0 ? m4 : u[j][0];
-#pragma unroll
-            for (int sp = 1; sp < kSplitInKernelMax; ++sp) {      // slots >= nsplit were read out of range: zeros
-                const float4 t = sp == my ? m4 : u[j][sp];
-                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                for (int sp = 0; sp < kSplitInKernelMax; ++sp)
+                    u[j][sp] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                        wsr, (s0 + sp < nsplit && s0 + sp != my) ? slot(i, j) + (unsigned)((s0 + sp) * split_stride * sizeof(float)) : 0xFFFFFFF0u, 0, SC01));
+                if (s0 == 0) {
+                    rr[j] = res_at(i, j);
+                    if constexpr (MASK) mk[j] = mask_at(i, j);
+                    else mk[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
-            finish(i, j, (f32x4){v.x, v.y, v.z, v.w}, rr[j], mk[j]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float4 m4 = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                float4 v = v4[j];
+#pragma unroll
+                for (int sp = 0; sp < kSplitInKernelMax; ++sp) {      // slots >= nsplit were read out of range: zeros
+                    const float4 t = s0 + sp == my ? m4 : u[j][sp];
+                    if (s0 == 0 && sp == 0) v = t;
+                    else { v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                }
+                v4[j] = v;
+            }
         }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) finish(i, j, (f32x4){v4[j].x, v4[j].y, v4[j].z, v4[j].w}, rr[j], mk[j]);
     }
     stamp();
 }
@@ -1602,8 +1626,12 @@ int run_conv(ConvP p, hipStream_t st, void* split_ws = nullptr, size_t split_ws_
     const size_t ws_need = (size_t)p.splitk * ntiles * kTiles[cfg].bm * kTiles[cfg].bn * sizeof(float);
     // in-kernel finish pays where the output is large (atomics and the extra epilogue pass scale with it);
     // for the small FC outputs of the vrd head the atomics are cheap and a serial sum of many splits is not
-    const bool wants_ws = p.splitk > 1 && !g_split_atomics && p.splitk <= kSplitInKernelMax &&
-                          (long long)p.M * p.N >= (1 << 18) && ntiles <= kSplitCounters;
+    // round 5: the ordered finish takes ANY number of splits (rounds of kSplitInKernelMax) and any output size, so that no
+    // forward or data-gradient GEMM depends on arrival order (SPLIT_ATOMICS = 2 restores round 4's rule: atomics beyond four
+    // splits and for outputs under 2^18 elements; 1: atomics always)
+    const bool r4_rule = g_split_atomics == 2;
+    const bool wants_ws = p.splitk > 1 && g_split_atomics != 1 && (!r4_rule || (p.splitk <= kSplitInKernelMax && (long long)p.M * p.N >= (1 << 18))) &&
+                          ntiles <= kSplitCounters && ws_need < (1ull << 31) - (64u << 20);
     // dry == 2: the workspace this shape would use (0: none)
     if (p.dry == 2) return wants_ws ? (int)std::min<size_t>(kSplitCounterBytes + ws_need, 0x7FFFFFFF) : 0;
     const bool in_kernel = wants_ws && split_ws && kSplitCounterBytes + ws_need <= split_ws_bytes;
@@ -1702,6 +1730,10 @@ struct WgP {
     unsigned long long* clk;               // diagnostic (i2v_conv_debug_clock): per-workgroup stamps, CLK instantiation only
     int prio;                              // I2V_TUNE_WGRAD_PRIO: 0 off, n: wave priority 3 - ((stage >> (n-1)) & 3)
     int abl;                               // diagnostic instantiation only: ablation bits (i2v_conv_set_tile bits 10-12)
+    // ordered finish of a split over pixels (round 5): partial tiles through the caller's split workspace, summed in split
+    // order by the last workgroup to arrive at the tile's counter (the protocol of conv_igemm_f32's split-K finish): the sum
+    // does not depend on arrival order, no clear of gw in front.  ord_ws == NULL: fp32 atomics into a cleared gw.
+    float* ord_ws; int* ord_cnt; int ord_splits, ord_tiles, ord_acc;      // ord_acc: gw += sum (beta = 1) instead of gw = sum
 };
 
 template <int BM, int BN>   // BM over n (Cout), BN over k; 4 waves as 2x2, 64x64 tiles: BM=BN=64 -> wave 32x32
@@ -2181,6 +2213,56 @@ conv_wgrad2_f32(const WgP p_in) {
                 *(float4*)(p.gw + o) = g;
             }
         }
+    } else if (p.ord_ws) {
+        // ---- ordered finish: my partial tile to the workspace (sc1: coherent across the XCDs without fences), arrival count,
+        // the last workgroup of the tile sums the partials in split order -- four in flight per round -- and writes gw
+        constexpr int SC01 = 16;
+        const int tile_lin = bz * p.ord_tiles + bx, nsplit = p.ord_splits, my = by;
+        const size_t split_stride = (size_t)p.ord_tiles * (p.nbatch > 1 ? p.nbatch : 1) * (BMW * BNW);      // floats between splits
+        const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.ord_ws + (size_t)tile_lin * (BMW * BNW)), 0, 0x7FFFFFF0, 0x00020000);
+        for (int e = tid; e < BMW * (BNW / 4); e += THREADS) {
+            const int row = e / (BNW / 4), col = (e % (BNW / 4)) * 4;
+            const float4 v = *(const float4*)&smem[row * CROW + col];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), wsr,
+                                                   (unsigned)(my * split_stride * sizeof(float)) + (unsigned)(row * BNW + col) * 4u, 0, SC01);
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        __shared__ int ord_last;
+        if (tid == 0) {
+            const int arrived = __hip_atomic_fetch_add(p.ord_cnt + tile_lin, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = arrived == nsplit - 1;
+            if (last) __hip_atomic_store(p.ord_cnt + tile_lin, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // next launch
+            ord_last = last;
+        }
+        __syncthreads();
+        if (ord_last) {
+            for (int e = tid; e < BMW * (BNW / 4); e += THREADS) {
+                const int row = e / (BNW / 4), col = (e % (BNW / 4)) * 4;
+                const int n = n0 + row, k = k0 + col;
+                if (n >= p.N || k >= p.K) continue;                     // K % 4 == 0
+                const long long o = (long long)n * p.K + k;
+                const unsigned off = (unsigned)(row * BNW + col) * 4u;
+                const float4 mine4 = *(const float4*)&smem[row * CROW + col];
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.ord_acc) v = *(const float4*)(p.gw + o);
+                for (int s0 = 0; s0 < nsplit; s0 += 4) {
+                    float4 u[4];
+#pragma unroll
+                    for (int sp = 0; sp < 4; ++sp)
+                        u[sp] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                            wsr, (s0 + sp < nsplit && s0 + sp != my) ? off + (unsigned)((s0 + sp) * split_stride * sizeof(float)) : 0xFFFFFFF0u, 0, SC01));
+#pragma unroll
+                    for (int sp = 0; sp < 4; ++sp) {                    // slots >= nsplit were read out of range: zeros
+                        const float4 t = s0 + sp == my ? mine4 : u[sp];
+                        if (s0 == 0 && sp == 0 && !p.ord_acc) v = t;
+                        else { v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+                    }
+                }
+                *(float4*)(p.gw + o) = v;
+            }
+        }
     } else {
         for (int e = tid; e < BMW * BNW; e += THREADS) {
             const int row = e / BNW, col = e % BNW;
@@ -2318,18 +2400,63 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(const AdamMulti t) {
     }
 }
 
+// Ordered finish of per-workgroup column sums (round 5): ``s`` = this workgroup's sum of four columns n..n+3 over ITS rows.
+// With a workspace the sums of one column block (blockIdx.y) meet there: every workgroup stores its row of partials (sc1),
+// counts its arrival, and the LAST one adds the gridDim.x partials of every column in block order -- eight in flight per round --
+// onto gbias: bit-reproducible where fp32 atomics (the workspace-free form) add in arrival order.  Every thread of the
+// workgroup must call it (barriers inside); ``live`` = the thread owns four columns.
+__device__ inline void colsum_finish4(float4 s, int n, int N, bool live, float* __restrict__ gbias, float* part, int* cnt) {
+    if (!part) {
+        if (live) {
+            atomicAdd(gbias + n, s.x); atomicAdd(gbias + n + 1, s.y);
+            atomicAdd(gbias + n + 2, s.z); atomicAdd(gbias + n + 3, s.w);
+        }
+        return;
+    }
+    constexpr int SC01 = 16;
+    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void*)part, 0, 0x7FFFFFF0, 0x00020000);
+    const unsigned rowb = (unsigned)N * 4u, off = (unsigned)n * 4u;
+    if (live) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s), pr, blockIdx.x * rowb + off, 0, SC01);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    __shared__ int cs_last;
+    if (threadIdx.x == 0) {
+        const int arrived = __hip_atomic_fetch_add(cnt + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = arrived == (int)gridDim.x - 1;
+        if (last) __hip_atomic_store(cnt + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cs_last = last;
+    }
+    __syncthreads();
+    if (!cs_last || !live) return;
+    float4 t = *(const float4*)(gbias + n);
+    const int nb = gridDim.x, my = blockIdx.x;
+    for (int b0 = 0; b0 < nb; b0 += 8) {
+        float4 u[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            u[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                pr, (b0 + k < nb && b0 + k != my) ? (unsigned)(b0 + k) * rowb + off : 0xFFFFFFF0u, 0, SC01));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float4 v = b0 + k == my ? s : u[k];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+    }
+    *(float4*)(gbias + n) = t;
+}
+
 // g_pre = gy * (y > 0); g = g_pre * scale[n]; gbias[n] += sum_m g_pre.  One streaming pass: thread = 4 columns
 // (float4), a workgroup covers rows_per_blk rows x 1024 columns; either output may be NULL.
 __global__ void __launch_bounds__(256)
 epilogue_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ scale,
                     float* __restrict__ g, float* __restrict__ gpre, float* __restrict__ gbias, long long M, int N,
-                    int relu, int rows_per_blk, float* __restrict__ g_t) {
+                    int relu, int rows_per_blk, float* __restrict__ g_t, float* part, int* cnt) {
     const int n = (blockIdx.y * 256 + threadIdx.x) * 4;
-    if (n >= N) return;
+    const bool live = n < N;
     const long long r0 = (long long)blockIdx.x * rows_per_blk;
-    const long long r1 = r0 + rows_per_blk < M ? r0 + rows_per_blk : M;
+    const long long r1 = !live ? r0 : (r0 + rows_per_blk < M ? r0 + rows_per_blk : M);
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (scale) sc = *(const float4*)(scale + n);
+    if (scale && live) sc = *(const float4*)(scale + n);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
     for (long long r = r0; r < r1; ++r) {
@@ -2347,10 +2474,7 @@ epilogue_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, c
             g_t[(long long)(n + 2) * M + r] = v.z * sc.z; g_t[(long long)(n + 3) * M + r] = v.w * sc.w;
         }
     }
-    if (gbias) {
-        atomicAdd(gbias + n, s.x); atomicAdd(gbias + n + 1, s.y);
-        atomicAdd(gbias + n + 2, s.z); atomicAdd(gbias + n + 3, s.w);
-    }
+    if (gbias) colsum_finish4(s, n, N, live, gbias, part, cnt);
 }
 
 // Narrow tensors (N <= 1024 columns, tall M: the conv_lo feature maps of the relation head are 16384 x 96):
@@ -2360,7 +2484,7 @@ epilogue_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y, c
 __global__ void __launch_bounds__(256)
 epilogue_bwd_narrow_kernel(const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ scale,
                            float* __restrict__ g, float* __restrict__ gpre, float* __restrict__ gbias, long long M,
-                           int N, int relu, int rows_per_blk) {
+                           int N, int relu, int rows_per_blk, float* part, int* cnt) {
     __shared__ float red[256 * 4];
     const int cg = N >> 2;                       // column groups (<= 256)
     const int lanes = 256 / cg;                  // row lanes (>= 1)
@@ -2388,15 +2512,14 @@ epilogue_bwd_narrow_kernel(const float* __restrict__ gy, const float* __restrict
     if (!gbias) return;
     *(float4*)&red[threadIdx.x * 4] = s;
     __syncthreads();
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
     if (threadIdx.x < cg) {
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int l = 0; l < lanes; ++l) {
             const float4 u = *(const float4*)&red[(l * cg + threadIdx.x) * 4];
             t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
         }
-        atomicAdd(gbias + n, t.x); atomicAdd(gbias + n + 1, t.y);
-        atomicAdd(gbias + n + 2, t.z); atomicAdd(gbias + n + 3, t.w);
     }
+    colsum_finish4(t, (int)(threadIdx.x % cg) * 4, N, threadIdx.x < cg, gbias, part, cnt);
 }
 
 __global__ void __launch_bounds__(256)
@@ -2424,7 +2547,9 @@ epilogue_bwd_scalar_kernel(const float* __restrict__ gy, const float* __restrict
 
 
 // picks the kernel + pixel split for one wgrad problem; returns false when v2 cannot be used
-static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st) {
+constexpr int kWgradOrderedMax = 16;     // most splits the ordered finish of a filter gradient sums (one workgroup reads them all)
+
+static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st, void* split_ws = nullptr, size_t split_ws_bytes = 0) {
     const long long xb = (long long)p.B * p.H * p.W * p.Cin * 4, gb = (long long)p.M * p.N * 4;
     const bool v2 = (p.N % 4 == 0) && xb < (1ll << 31) && gb < (1ll << 31) && g_wgrad_v2;
     if (p.row_scale && !v2) { i2v_set_error("conv_wgrad_scaled: shape outside the v2 kernel (Cout % 4, 2 GiB operands)"); return false; }
@@ -2451,10 +2576,30 @@ static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st) {
         if (splits > msteps / 4) splits = msteps / 4;
         if (splits < 1) splits = 1;
     }
+    // Ordered finish (round 5; a caller that passes its split workspace): a split of up to kWgradOrderedMax parts is summed in
+    // split order by the tile's last workgroup instead of with atomics -- bit-reproducible, and no clear of gw.  A SMALL
+    // problem (under 2 GFLOP: the relation head's conv_lo filters, its linear layers' data gradients) that would split
+    // further is capped there; a large one (the instance_styleD backbone: up to 254 splits to fill the chip) keeps the atomics.
+    const int planes = p.nbatch > 1 ? p.nbatch : 1;
+    bool ordered = false;
+    if (v2 && !fused && split_ws && splits > 1 && g_i2v_tuning[I2V_TUNE_SPLIT_ATOMICS] == 0) {
+        if (splits > kWgradOrderedMax && 2.0 * p.M * p.N * p.K * planes < 2e9) splits = kWgradOrderedMax;
+        const size_t need = kSplitCounterBytes + (size_t)splits * tiles * planes * (size_t)(tm * tk) * sizeof(float);
+        ordered = splits <= kWgradOrderedMax && tiles * planes <= kSplitCounters && need <= split_ws_bytes && need < (1ull << 31);
+    }
+    // the first-generation kernel (Cout % 4 != 0: a 62-row linear layer's data gradient run on this kernel with the roles
+    // swapped) has no ordered finish: a small problem whose caller asks for reproducible sums is not split at all
+    if (!v2 && !fused && split_ws && splits > 1 && g_i2v_tuning[I2V_TUNE_SPLIT_ATOMICS] == 0 && 2.0 * p.M * p.N * p.K * planes < 2e9)
+        splits = 1;
     p.m_per_split = i2v_cdiv(msteps, splits) * rs;
     splits = i2v_cdiv(p.M, p.m_per_split);
     p.direct = (splits == 1 && beta == 0.f) || fused;
-    if (beta == 0.f && !p.direct)
+    if (ordered && splits > 1) {
+        p.ord_cnt = reinterpret_cast<int*>(split_ws);
+        p.ord_ws = reinterpret_cast<float*>(static_cast<char*>(split_ws) + kSplitCounterBytes);
+        p.ord_splits = splits; p.ord_tiles = (int)tiles; p.ord_acc = beta != 0.f;
+    }
+    if (beta == 0.f && !p.direct && !p.ord_ws)
         hipMemsetAsync(p.gw, 0, (p.nbatch > 1 ? (size_t)(p.nbatch - 1) * p.bsw : 0) * sizeof(float) + (size_t)p.N * p.K * sizeof(float), st);
     p.x_bytes = (unsigned)xb;
     p.gy_bytes = (unsigned)gb;
@@ -2706,7 +2851,7 @@ extern "C" int32_t i2v_conv_dgrad_fused(const float* gy, const float* w, const f
 
 static int conv_wgrad_impl(const float* x, const float* gy, float* gw, const float* row_scale, int32_t B, int32_t H,
                            int32_t W, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
-                           float beta, void* stream) {
+                           float beta, void* stream, void* split_ws = nullptr, size_t split_ws_bytes = 0) {
     int rc = check_conv("conv_wgrad", x, gy, gw, B, H, W, Cin, Cout, KH, KW, stride, pad);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -2718,7 +2863,7 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, const flo
     p.M = B * p.Ho * p.Wo; p.N = Cout; p.K = KH * KW * Cin;
     p.lgCin = ilog2_exact(Cin);
     I2V_CHECK_ARG(beta == 0.f || beta == 1.f, "conv_wgrad: beta must be 0 or 1");
-    if (!launch_wgrad(p, beta, false, st)) return I2V_ERR_UNSUPPORTED;
+    if (!launch_wgrad(p, beta, false, st, split_ws, split_ws_bytes)) return I2V_ERR_UNSUPPORTED;
     I2V_CHECK_LAUNCH("conv_wgrad");
     return I2V_OK;
 }
@@ -2764,8 +2909,8 @@ extern "C" int32_t i2v_gemm_tn_batched_acc(const float* x, const float* gy, floa
 extern "C" int32_t i2v_conv_wgrad(const float* x, const float* gy, float* gw, int32_t B, int32_t H, int32_t W,
                                   int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                                   float beta, void* ws, size_t ws_bytes, void* stream) {
-    (void)ws; (void)ws_bytes;
-    return conv_wgrad_impl(x, gy, gw, nullptr, B, H, W, Cin, Cout, KH, KW, stride, pad, beta, stream);
+    // ws: the caller's split workspace (i2v_conv_fwd's: zeroed counters + slab; NULL: splits are summed with fp32 atomics)
+    return conv_wgrad_impl(x, gy, gw, nullptr, B, H, W, Cin, Cout, KH, KW, stride, pad, beta, stream, ws, ws_bytes);
 }
 
 extern "C" int32_t i2v_conv_wgrad_scaled(const float* x, const float* gy, const float* row_scale, float* gw, int32_t B,
@@ -2801,12 +2946,24 @@ extern "C" int32_t i2v_conv_wgrad_sgd(const float* x, const float* gy, float* w,
 }
 
 extern "C" int32_t i2v_epilogue_bwd(const float* gy, const float* y, const float* scale, float* g, float* gpre,
-                                    float* gbias, int64_t M, int32_t N, int32_t relu, float* g_t, void* stream) {
+                                    float* gbias, int64_t M, int32_t N, int32_t relu, float* g_t, void* split_ws,
+                                    size_t split_ws_bytes, void* stream) {
     I2V_CHECK_ARG(gy && M >= 0 && N > 0, "epilogue_bwd: bad argument");
     I2V_CHECK_ARG(!relu || y, "epilogue_bwd: relu needs y");
     if (M == 0) return I2V_OK;
     const bool vec = (N & 3) == 0;
     const int cols = vec ? 1024 : 256;
+    // ordered column sums (round 5): with the caller's split workspace (i2v_conv_fwd's: zeroed counters + slab) the row
+    // blocks' partial sums are added in block order by the last block to arrive -- few blocks then, the finisher reads them all
+    const bool want_ord = gbias && vec && split_ws && g_i2v_tuning[I2V_TUNE_SPLIT_ATOMICS] == 0;
+    auto ordered = [&](long long nblk, int ncolblk, float*& part, int*& cnt) {
+        part = nullptr; cnt = nullptr;
+        const size_t need = kSplitCounterBytes + (size_t)nblk * N * sizeof(float);
+        if (!want_ord || nblk < 2 || ncolblk > kSplitCounters || need > split_ws_bytes || need >= (1ull << 31)) return;
+        cnt = reinterpret_cast<int*>(split_ws);
+        part = reinterpret_cast<float*>(static_cast<char*>(split_ws) + kSplitCounterBytes);
+    };
+    float* part; int* cnt;
     // enough workgroups to cover the chip even for the 64..128-row tensors of the relation head
     int rows = 64;
     while (rows > 4 && (long long)i2v_cdiv(M, rows) * i2v_cdiv(N, cols) < 2 * NUM_CU) rows >>= 1;
@@ -2816,13 +2973,17 @@ extern "C" int32_t i2v_epilogue_bwd(const float* gy, const float* y, const float
         // few workgroups: same-address atomics retire one per ~150 ns, so 256 contenders cost more than the rows
         int rpb = lanes * 64;
         while (rpb > lanes && i2v_cdiv(M, rpb) < 48) rpb >>= 1;
+        if (want_ord) while (i2v_cdiv(M, rpb) > 64) rpb <<= 1;           // the finisher sums at most 64 partials per column
+        ordered(i2v_cdiv(M, rpb), 1, part, cnt);
         epilogue_bwd_narrow_kernel<<<(unsigned)i2v_cdiv(M, rpb), 256, 0, (hipStream_t)stream>>>(gy, y, scale, g, gpre,
-                                                                                              gbias, M, N, relu, rpb);
+                                                                                              gbias, M, N, relu, rpb, part, cnt);
         I2V_CHECK_LAUNCH("epilogue_bwd");
         return I2V_OK;
     }
+    if (want_ord && vec) while (i2v_cdiv(M, rows) > 32 && rows < 1024) rows <<= 1;   // at most 32 row blocks to sum
     dim3 grid(i2v_cdiv(M, rows), i2v_cdiv(N, cols));
-    if (vec) epilogue_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(gy, y, scale, g, gpre, gbias, M, N, relu, rows, g_t);
+    ordered(grid.x, (int)grid.y, part, cnt);
+    if (vec) epilogue_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(gy, y, scale, g, gpre, gbias, M, N, relu, rows, g_t, part, cnt);
     else epilogue_bwd_scalar_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(gy, y, scale, g, gpre, gbias, M, N, relu, rows, g_t);
     I2V_CHECK_LAUNCH("epilogue_bwd");
     return I2V_OK;

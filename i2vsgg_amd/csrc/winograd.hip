@@ -585,7 +585,11 @@ static int winograd4_impl(const float* x, const float* U, const float* scale, co
                           int32_t relu, void* ws, size_t ws_bytes, void* stream, float* v_keep = nullptr) {
     I2V_CHECK_ARG(x && U && y && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_winograd4_fwd: bad argument");
     I2V_CHECK_ARG(Cin % 4 == 0, "conv3x3_winograd4_fwd: Cin must be a multiple of 4");
-    I2V_CHECK_ARG((long long)B * H * W * (Cin > Cout ? Cin : Cout) * 4 < (1ll << 31), "conv3x3_winograd4_fwd: activation of 2 GiB or more (32-bit byte offsets)");
+    // the transform kernels reach the 36 planes of V / M with 32-bit byte offsets (plane (6 r + q) at (6 r + q) * T * C * 4, through a
+    // 0x7FFFFFFC-byte descriptor): the WORKSPACE side is ~2.25x the padded activation and is what must stay below 2 GiB
+    I2V_CHECK_ARG((long long)B * H * W * (Cin > Cout ? Cin : Cout) * 4 < (1ll << 31) &&
+                  36ll * B * ((H + 3) / 4) * ((W + 3) / 4) * (Cin > Cout ? Cin : Cout) * 4 < (1ll << 31),
+                  "conv3x3_winograd4_fwd: the 36-plane transform workspace (or the activation) reaches 2 GiB (32-bit byte offsets)");
     if (!ws || ws_bytes < i2v_conv3x3_winograd4_workspace_bytes(B, H, W, Cin, Cout)) {
         i2v_set_error("conv3x3_winograd4_fwd: workspace too small");
         return I2V_ERR_WORKSPACE;
@@ -654,7 +658,9 @@ static int winograd4_wgrad_impl(const float* x, const float* v_in, const float* 
     I2V_CHECK_ARG((x || v_in) && gy && gw && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "conv3x3_winograd4_wgrad: bad argument");
     I2V_CHECK_ARG(Cin % 4 == 0 && Cout % 4 == 0, "conv3x3_winograd4_wgrad: Cin and Cout must be multiples of 4");
     I2V_CHECK_ARG(beta == 0.f || beta == 1.f, "conv3x3_winograd4_wgrad: beta must be 0 or 1");
-    I2V_CHECK_ARG((long long)B * H * W * (Cin > Cout ? Cin : Cout) * 4 < (1ll << 31), "conv3x3_winograd4_wgrad: activation of 2 GiB or more (32-bit byte offsets)");
+    I2V_CHECK_ARG((long long)B * H * W * (Cin > Cout ? Cin : Cout) * 4 < (1ll << 31) &&
+                  36ll * B * ((H + 3) / 4) * ((W + 3) / 4) * (Cin > Cout ? Cin : Cout) * 4 < (1ll << 31),
+                  "conv3x3_winograd4_wgrad: the 36-plane transform workspace (or the activation) reaches 2 GiB (32-bit byte offsets)");
     if (!ws || ws_bytes < i2v_conv3x3_winograd4_wgrad_workspace_bytes(B, H, W, Cin, Cout)) {
         i2v_set_error("conv3x3_winograd4_wgrad: workspace too small");
         return I2V_ERR_WORKSPACE;

@@ -549,6 +549,13 @@ def join(origin, *streams):
         _FORKED.pop(st.cuda_stream, None)
 
 
+def _sws_args(device=None):
+    """(pointer, bytes) of the split workspace in force: what the ordered cross-workgroup sums of round 5 (bias column sums,
+    split filter gradients) need next to the split-K GEMMs."""
+    t = _split_ws(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    return ptr(t), t.numel()
+
+
 def _split_ws(device):
     ws = SPLIT_WS
     if ws is None:
@@ -681,7 +688,8 @@ def _conv_wgrad_raw(x, g, w_shape, stride, pad, tag="wgrad", row_scale=None, win
             check(lib.i2v_conv_wgrad_scaled(ptr(x), ptr(g), ptr(row_scale), ptr(gw), B, H, W, Cin, Cout, KH, KW, stride, pad,
                                             beta, stream()), "conv_wgrad_scaled")
         else:
-            check(lib.i2v_conv_wgrad(ptr(x), ptr(g), ptr(gw), B, H, W, Cin, Cout, KH, KW, stride, pad, beta, None, 0,
+            sws = _split_ws(x.device)       # ordered sum of a split reduction (bit-reproducible; no atomics, no clear)
+            check(lib.i2v_conv_wgrad(ptr(x), ptr(g), ptr(gw), B, H, W, Cin, Cout, KH, KW, stride, pad, beta, ptr(sws), sws.numel(),
                                      stream()), "conv_wgrad")
     return gw
 
@@ -790,7 +798,7 @@ class _LinearDeferredFn(torch.autograd.Function):
         g_t = torch.empty((N, M, 1, 1), device=gy.device, dtype=torch.float32) if as_wgrad else None
         # one pass over gy: g = gy * (y > 0) straight into the pending buffer, the bias column sums, g^T for the data gradient
         check(lib.i2v_epilogue_bwd(ptr(gy), ptr(y) if ctx.relu else None, None, ptr(g), None, ptr(gbias), M, N, int(ctx.relu),
-                                   ptr(g_t), stream()), "epilogue_bwd")
+                                   ptr(g_t), *_sws_args(), stream()), "epilogue_bwd")
         gx = None
         if need_gx:      # with THIS step's filter: the pending update is only applied by the next forward
             w4 = w.view(N, K, 1, 1)
@@ -888,7 +896,7 @@ class _ConvFn(torch.autograd.Function):
             if ctx.needs_input_grad[0] and not ctx.wino_dgrad and _linear_dgrad_as_wgrad(x.shape, w.shape, stride, pad):
                 g_t = torch.empty((N, M, 1, 1), device=gy.device, dtype=torch.float32)
             check(lib.i2v_epilogue_bwd(ptr(gy), ptr(y), ptr(scale) if has_scale else None, ptr(g), ptr(gpre), ptr(gbias),
-                                       M, N, int(relu), ptr(g_t), stream()), "epilogue_bwd")
+                                       M, N, int(relu), ptr(g_t), *_sws_args(), stream()), "epilogue_bwd")
             if g is None:
                 g = gy
             if need_res:
@@ -1029,7 +1037,7 @@ class _BottleneckFn(torch.autograd.Function):
         else:       # the consumers of ``out`` know nothing of its ReLU: one masking pass
             gpre = torch.empty_like(g)
             M, N = g.shape[0] * g.shape[2] * g.shape[3], g.shape[1]
-            check(lib.i2v_epilogue_bwd(ptr(g), ptr(out), None, ptr(gpre), None, None, M, N, 1, None, stream()), "epilogue_bwd")
+            check(lib.i2v_epilogue_bwd(ptr(g), ptr(out), None, ptr(gpre), None, None, M, N, 1, None, *_sws_args(), stream()), "epilogue_bwd")
         st = ctx.stride
         # ---- data gradients (the chain the rest of the backward waits for)
         g2 = _dgrad_fused(gpre, w3, a2.shape, 0, gy_scale=s3, out_scale=s2, mask=a2)         # gradient at conv2's raw output
@@ -1261,7 +1269,7 @@ class _DStyleFusedFn(torch.autograd.Function):
                 gb = ARENA.take_flat(N) if ARENA is not None else None
                 if gb is None:
                     gb = torch.zeros((N,), device=g.device, dtype=torch.float32)
-                check(lib.i2v_epilogue_bwd(ptr(g), None, None, None, None, ptr(gb), M, N, 0, None, stream()), "epilogue_bwd")
+                check(lib.i2v_epilogue_bwd(ptr(g), None, None, None, None, ptr(gb), M, N, 0, None, *_sws_args(), stream()), "epilogue_bwd")
             gw = _conv_wgrad_raw(rows4, g4, (N, K, 1, 1), 1, 0).view(N, K) if need_w else None
             gx = _conv_dgrad_raw(g4, w.view(N, K, 1, 1), (M, K, 1, 1), 1, 0).view(M, K) if ctx.needs_input_grad[0] else None
             outs.append((gx, gw, gb))

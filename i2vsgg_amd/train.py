@@ -1024,20 +1024,26 @@ class SGGEmbStep:
         ``replay_graph``).  Returns the device scalar holding the loss of the batch the head just processed.
         Before a successful ``capture()`` a call is the sequential eager step."""
         fs = self.shapes[self._staged]
-        if self._graphs_on:
-            if fs.graph is None:
-                self._capture_frames(fs)         # first sight of this frame size (or the graphs were invalidated)
-            self._tick += 1
-            fs.tick = self._tick
-            if fs.graph:
-                replay_graph(fs.graph, self.dev)
-                self._fmap_key = fs.key
-            elif self._pipelined:
-                self._body_overlapped(fs)        # this size could not be captured: the same schedule on eager launches
+        try:
+            if self._graphs_on:
+                if fs.graph is None:
+                    self._capture_frames(fs)         # first sight of this frame size (or the graphs were invalidated)
+                self._tick += 1
+                fs.tick = self._tick
+                if fs.graph:
+                    replay_graph(fs.graph, self.dev)
+                    self._fmap_key = fs.key
+                elif self._pipelined:
+                    self._body_overlapped(fs)        # this size could not be captured: the same schedule on eager launches
+                else:
+                    self._body()
             else:
                 self._body()
-        else:
-            self._body()
+        except BaseException:
+            # an eager body that raised between a branch and its join leaves process-wide role streams marked open
+            # (ops._FORKED): every later step object on this device would be refused its branches
+            ops.reset_branches()
+            raise
         self.opt.bump()
         return self.loss
 
@@ -1461,22 +1467,26 @@ class InstanceStyleDStep:
 
     def __call__(self):
         ds = self._cur
-        if self._graphs_on:
-            if ds.graph is None:
-                # first sight of this pair of sizes (or the graphs were invalidated): one eager step sizes its arenas and fills
-                # the host-built caches, its effect on the training state is undone, then the step is recorded
-                self._capture_set(ds, 0 if ds.fitted else 1, True)
-            if ds.graph:
-                replay_graph(ds.graph, self.dev)
+        try:
+            if self._graphs_on:
+                if ds.graph is None:
+                    # first sight of this pair of sizes (or the graphs were invalidated): one eager step sizes its arenas and
+                    # fills the host-built caches, its effect on the training state is undone, then the step is recorded
+                    self._capture_set(ds, 0 if ds.fitted else 1, True)
+                if ds.graph:
+                    replay_graph(ds.graph, self.dev)
+                else:
+                    self._device_sampling(True)
+                    (self._body_branches if self.branches else self._body)()
+                self.opt.bump()
             else:
-                self._device_sampling(True)
-                (self._body_branches if self.branches else self._body)()
-            self.opt.bump()
-        else:
-            self._body()
-            if not ds.fitted:               # eager use: size the arena of atomically accumulated outputs after the first step
-                ds.ctx.fit()
-                ds.fitted = True
+                self._body()
+                if not ds.fitted:           # eager use: size the arena of atomically accumulated outputs after the first step
+                    ds.ctx.fit()
+                    ds.fitted = True
+        except BaseException:
+            ops.reset_branches()            # a body that raised between a branch and its join: see SGGEmbStep.__call__
+            raise
         return self.losses["total"]
 
 

@@ -255,7 +255,7 @@ size_t  i2v_conv_split_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t 
 #define I2V_TUNE_SPLIT_TARGET         1   /* workgroups per CU a split-K launch aims for (default 2) */
 #define I2V_TUNE_SPLIT_TARGET_SKINNY  2   /* the same for GEMMs of <= 256 rows (-1: as SPLIT_TARGET) */
 #define I2V_TUNE_SPLIT_BELOW          3   /* split K only when the unsplit grid has fewer tiles than this (default 256) */
-#define I2V_TUNE_SPLIT_ATOMICS        4   /* 1: always finish split-K with atomics */
+#define I2V_TUNE_SPLIT_ATOMICS        4   /* 0 (default): split-K partials through the caller's workspace, summed in split order by the last workgroup to arrive -- any number of splits, any output size: bit-reproducible; 2: round 4's rule (fp32 atomics beyond four splits and for outputs under 2^18 elements); 1: always atomics */
 #define I2V_TUNE_BIG_FC_TILE          5   /* tile index for the long skinny GEMMs (rows <= 256, K >= 16384); -1: cost model */
 #define I2V_TUNE_WGRAD_V2             6   /* 0: first-generation wgrad kernel, 1: default, 2/3: larger tiles */
 #define I2V_TUNE_WGRAD_FUSED_TILE     7   /* 128 (default) or 64: filters per workgroup of the fused wgrad+SGD kernel */
@@ -338,6 +338,9 @@ int32_t i2v_conv_dgrad(const float* gy, const float* w, float* gx, int32_t B, in
                        void* stream);
 size_t  i2v_conv_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                                        int32_t KH, int32_t KW, int32_t stride, int32_t pad);
+/* i2v_conv_wgrad's workspace (round 5) is the caller's SPLIT workspace (i2v_conv_fwd's: counters zero between launches + slab): a
+ * reduction over the pixels that is split across workgroups (up to 16 parts; small problems are capped there) is then summed in split
+ * order by the tile's last workgroup -- bit-reproducible, no clear of gw in front.  NULL: fp32 atomics into a cleared gw. */
 int32_t i2v_conv_wgrad(const float* x, const float* gy, float* gw, int32_t B, int32_t H, int32_t W,
                        int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                        float beta, void* workspace, size_t workspace_bytes, void* stream);
@@ -393,9 +396,11 @@ int32_t i2v_fc_fold_fwd(const float* x, const float* x_pending, const float* g_p
 /* epilogue backward, one streaming pass: g_pre = gy * (y>0) [relu]; g = g_pre * scale[n] (scale may be NULL);
  * gbias[n] += column sums of g_pre.  g, gpre and gbias may each be NULL; in-place (g == gy or gpre == gy) allowed.
  * g_t (may be NULL): g once more, column-major (N x M) -- the operand a linear layer's data gradient reads when it
- * runs on the filter-gradient kernel with the roles swapped (saves the separate transpose of the small gradient). */
+ * runs on the filter-gradient kernel with the roles swapped (saves the separate transpose of the small gradient).
+ * split_ws / split_ws_bytes: the caller's split workspace (i2v_conv_fwd's: counters zero between launches + slab).  With it
+ * the row blocks' column sums are added in block order by the last block to arrive (bit-reproducible); NULL: fp32 atomics. */
 int32_t i2v_epilogue_bwd(const float* gy, const float* y, const float* scale, float* g, float* gpre, float* gbias,
-                         int64_t M, int32_t N, int32_t relu, float* g_t, void* stream);
+                         int64_t M, int32_t N, int32_t relu, float* g_t, void* split_ws, size_t split_ws_bytes, void* stream);
 
 /* 3x3 / stride 2 / pad 0 / ceil_mode max pool of the stem (resnet_instance...:228), NHWC */
 int32_t i2v_maxpool3x3s2_fwd(const float* x, float* y, int32_t* argmax, int32_t B, int32_t H, int32_t W, int32_t C,
