@@ -598,6 +598,18 @@ def run_sgg(a, rank, world, dev, frames_per_rank=2):
                                   "gflop_algorithmic_per_step": f_alg / n_prof / 1e9},
                      "by_kind": by_kind(rec, n_prof)},
     }
+    # the whole step against the matrix pipe: every GEMM-shaped launch of a step (backbone, head forward, data and filter
+    # gradients, fused updates), executed MACs (Winograd F(4x4,3x3) runs 1/4 of the direct count) / the TIMED ms per step
+    wf = lambda r: 0.25 if "winograd F4" in r["desc"] else 4.0 / 9.0 if "winograd" in r["desc"] else 1.0   # noqa: E731
+    g_exec = sum(r["flops"] * wf(r) for r in rec) / n_prof / 1e9
+    g_alg = sum(r["flops"] for r in rec) / n_prof / 1e9
+    ms = 1e3 * elapsed / a.steps
+    line["roofline"]["step"] = {"gflop_executed_per_step": g_exec, "gflop_algorithmic_per_step": g_alg, "ms_per_step": ms,
+                                "executed_tflops": g_exec / ms, "frac": g_exec / ms / MFMA_F32_PEAK_TFLOPS,
+                                "algorithmic_frac": g_alg / ms / MFMA_F32_PEAK_TFLOPS,
+                                "note": "every GEMM-shaped launch of one step / the timed ms per step of the replayed graph; the "
+                                        "fc6 path (forward 0.43 ms + fused update 0.79 ms of kernel time for 4.1 GB) is HBM-bound, "
+                                        "not MFMA-bound: profiles/r05_step_budget.txt has the per-kind budget"}
     return line, step, net
 
 

@@ -135,7 +135,7 @@ lib = _load()
 # The library reads no environment variable; the documented I2V_* tuning switches are forwarded here, once, at import.
 TUNE = {"I2V_CONV_SPEC": 0, "I2V_SPLIT_TARGET": 1, "I2V_SPLIT_TARGET_SKINNY": 2, "I2V_SPLIT_BELOW": 3, "I2V_SPLIT_ATOMICS": 4,
         "I2V_BIG_FC_TILE": 5, "I2V_WGRAD_V2": 6, "I2V_WGRAD_FUSED_TILE": 7, "I2V_WINO_ROWS": 8, "I2V_ROIPOOL_C128": 9, "I2V_CONV_GEMM": 10, "I2V_STAGGER": 11, "I2V_ROIALIGN_COLS": 12, "I2V_WGRAD_PER_CU": 13, "I2V_WGRAD_XCD": 14, "I2V_FC_FOLD": 15, "I2V_GEMM_X3": 16,
-        "I2V_GEMM_PERSIST": 17, "I2V_WGRAD_PRIO": 18, "I2V_STREAM_TILE": 19, "I2V_KGROUPS": 20}
+        "I2V_GEMM_PERSIST": 17, "I2V_WGRAD_PRIO": 18, "I2V_STREAM_TILE": 19, "I2V_KGROUPS": 20, "I2V_WGRAD_ORDERED_GFLOP": 21}
 EXPERIMENTS = bool(lib.i2v_build_flags() & 1)      # built with -DI2V_EXPERIMENTS (I2V_EXPERIMENTS=1 python -m i2vsgg_amd.build)
 for _name, _key in TUNE.items():
     if os.environ.get(_name) not in (None, ""):

@@ -19,11 +19,11 @@ extern "C" const char* i2v_last_error(void) { return g_err; }
 // Tuning table (i2v_set_tuning): the library reads no environment variable; a host that wants the knobs sets them
 // explicitly (i2vsgg_amd/_lib.py forwards the documented I2V_* variables once at import).
 int g_i2v_tuning[I2V_TUNE_COUNT] = {
-    /* CONV_SPEC */ -1, /* SPLIT_TARGET */ 2, /* SPLIT_TARGET_SKINNY */ -1, /* SPLIT_BELOW */ 256, /* SPLIT_ATOMICS */ 0,
+    /* CONV_SPEC */ -1, /* SPLIT_TARGET */ 2, /* SPLIT_TARGET_SKINNY */ -1, /* SPLIT_BELOW */ 256, /* SPLIT_ATOMICS */ 2,
     /* BIG_FC_TILE */ 1, /* WGRAD_V2 */ 1, /* WGRAD_FUSED_TILE */ 128, /* WINO_ROWS */ 0, /* ROIPOOL_C128 */ 1,
     /* CONV_GEMM */ 1, /* STAGGER */ 0, /* ROIALIGN_COLS */ 2, /* WGRAD_PER_CU */ 4, /* WGRAD_XCD */ 1,
     /* FC_FOLD */ 0, /* GEMM_X3 */ 0, /* GEMM_PERSIST */ 0, /* WGRAD_PRIO */ 0, /* STREAM_TILE */ 1,
-    /* KGROUPS */ 0,
+    /* KGROUPS */ 0, /* WGRAD_ORDERED_GFLOP */ 8,
 };
 
 extern "C" int32_t i2v_build_flags(void) {

@@ -1627,10 +1627,13 @@ int run_conv(ConvP p, hipStream_t st, void* split_ws = nullptr, size_t split_ws_
     // in-kernel finish pays where the output is large (atomics and the extra epilogue pass scale with it);
     // for the small FC outputs of the vrd head the atomics are cheap and a serial sum of many splits is not
     // round 5: the ordered finish takes ANY number of splits (rounds of kSplitInKernelMax) and any output size, so that no
-    // forward or data-gradient GEMM depends on arrival order (SPLIT_ATOMICS = 2 restores round 4's rule: atomics beyond four
-    // splits and for outputs under 2^18 elements; 1: atomics always)
-    const bool r4_rule = g_split_atomics == 2;
-    const bool wants_ws = p.splitk > 1 && g_split_atomics != 1 && (!r4_rule || (p.splitk <= kSplitInKernelMax && (long long)p.M * p.N >= (1 << 18))) &&
+    // forward or data-gradient GEMM of the relation head depends on arrival order (SPLIT_ATOMICS = 2 restores round 4's rule
+    // everywhere: atomics beyond four splits and for outputs under 2^18 elements; 1: atomics always)
+    // SPLIT_ATOMICS == 0 (what the relation step's head context selects, ops.LaunchContext(ordered=True)): ordered for every
+    // shape.  The process default is 2, round 4's rule: measured on configs[2], ordering every reduction of the step -- its
+    // 8-16-way filter-gradient splits, the bias sums of netD_style's 37500-row projections -- costs 46.2 -> 48.1 ms.
+    const bool r4_ok = p.splitk <= kSplitInKernelMax && (long long)p.M * p.N >= (1 << 18);
+    const bool wants_ws = p.splitk > 1 && g_split_atomics != 1 && (r4_ok || g_split_atomics == 0) &&
                           ntiles <= kSplitCounters && ws_need < (1ull << 31) - (64u << 20);
     // dry == 2: the workspace this shape would use (0: none)
     if (p.dry == 2) return wants_ws ? (int)std::min<size_t>(kSplitCounterBytes + ws_need, 0x7FFFFFFF) : 0;
@@ -2576,20 +2579,25 @@ static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st, void* s
         if (splits > msteps / 4) splits = msteps / 4;
         if (splits < 1) splits = 1;
     }
-    // Ordered finish (round 5; a caller that passes its split workspace): a split of up to kWgradOrderedMax parts is summed in
-    // split order by the tile's last workgroup instead of with atomics -- bit-reproducible, and no clear of gw.  A SMALL
-    // problem (under 2 GFLOP: the relation head's conv_lo filters, its linear layers' data gradients) that would split
-    // further is capped there; a large one (the instance_styleD backbone: up to 254 splits to fill the chip) keeps the atomics.
+    // Ordered finish (round 5; a caller that passes its split workspace): the split of a SMALL problem (under I2V_TUNE_WGRAD_ORDERED_GFLOP = 8 GFLOP: the
+    // relation head's conv_lo filters, its linear layers' data gradients), capped at kWgradOrderedMax parts, is summed in split
+    // order by the tile's last workgroup instead of with atomics -- bit-reproducible, and no clear of gw.  A large one (the
+    // instance_styleD backbone: up to 254 splits to fill the chip) keeps the atomics.
     const int planes = p.nbatch > 1 ? p.nbatch : 1;
     bool ordered = false;
-    if (v2 && !fused && split_ws && splits > 1 && g_i2v_tuning[I2V_TUNE_SPLIT_ATOMICS] == 0) {
-        if (splits > kWgradOrderedMax && 2.0 * p.M * p.N * p.K * planes < 2e9) splits = kWgradOrderedMax;
+    // (measured: with the backbone's 8-16-way splits ordered too, configs[2] went 46.1 -> 48.4 ms -- the finisher's serial reads
+    // are a tail on every one of ~200 launches -- so only small problems take the ordered finish)
+    const double ord_flops = 1e9 * g_i2v_tuning[I2V_TUNE_WGRAD_ORDERED_GFLOP], flops = 2.0 * p.M * p.N * p.K * planes;
+    if (v2 && !fused && split_ws && splits > 1 && g_i2v_tuning[I2V_TUNE_SPLIT_ATOMICS] == 0 && flops < ord_flops) {
+        // a split beyond kWgradOrderedMax parts is capped only where that costs nothing (under 1 GFLOP: conv_lo.0's 128-way
+        // split of a 0.3 GFLOP problem); a larger problem that wants more parts to fill the chip keeps them and the atomics
+        if (splits > kWgradOrderedMax && flops < 1e9) splits = kWgradOrderedMax;
         const size_t need = kSplitCounterBytes + (size_t)splits * tiles * planes * (size_t)(tm * tk) * sizeof(float);
         ordered = splits <= kWgradOrderedMax && tiles * planes <= kSplitCounters && need <= split_ws_bytes && need < (1ull << 31);
     }
     // the first-generation kernel (Cout % 4 != 0: a 62-row linear layer's data gradient run on this kernel with the roles
     // swapped) has no ordered finish: a small problem whose caller asks for reproducible sums is not split at all
-    if (!v2 && !fused && split_ws && splits > 1 && g_i2v_tuning[I2V_TUNE_SPLIT_ATOMICS] == 0 && 2.0 * p.M * p.N * p.K * planes < 2e9)
+    if (!v2 && !fused && split_ws && splits > 1 && g_i2v_tuning[I2V_TUNE_SPLIT_ATOMICS] == 0 && flops < ord_flops)
         splits = 1;
     p.m_per_split = i2v_cdiv(msteps, splits) * rs;
     splits = i2v_cdiv(p.M, p.m_per_split);
@@ -2955,7 +2963,10 @@ extern "C" int32_t i2v_epilogue_bwd(const float* gy, const float* y, const float
     const int cols = vec ? 1024 : 256;
     // ordered column sums (round 5): with the caller's split workspace (i2v_conv_fwd's: zeroed counters + slab) the row
     // blocks' partial sums are added in block order by the last block to arrive -- few blocks then, the finisher reads them all
-    const bool want_ord = gbias && vec && split_ws && g_i2v_tuning[I2V_TUNE_SPLIT_ATOMICS] == 0;
+    // ... and small tensors only (at most 2^21 elements: the relation head's layers): a large one (netD_style's 37500 x 2560
+    // projections) needs its hundreds of row blocks to stream at full rate (measured: configs[2] 46.3 -> 48.1 ms with every
+    // tensor held to <= 32 row blocks), so it keeps the atomics
+    const bool want_ord = gbias && vec && split_ws && g_i2v_tuning[I2V_TUNE_SPLIT_ATOMICS] == 0 && M * (long long)N <= (1ll << 21);
     auto ordered = [&](long long nblk, int ncolblk, float*& part, int*& cnt) {
         part = nullptr; cnt = nullptr;
         const size_t need = kSplitCounterBytes + (size_t)nblk * N * sizeof(float);

@@ -420,6 +420,8 @@ class SplitWorkspace:
 
 
 SPLIT_WS = None     # set like ARENA; None -> one workspace per launch stream
+_TUNE_SPLIT_ATOMICS = 4                 # include/i2vsgg_hip.h I2V_TUNE_SPLIT_ATOMICS
+ORDERED_SUMS = os.environ.get("I2V_ORDERED_SUMS", "1") != "0"     # 0: LaunchContext(ordered=True) is ignored (A/B of its cost)
 _split_ws_by_stream = {}
 
 
@@ -428,11 +430,16 @@ class LaunchContext:
     atomically accumulated outputs, its split-K workspace and its tagged scratch buffers.  ``with ctx:`` installs them
     for the calls made inside (forward AND the autograd backward triggered inside the block)."""
 
-    def __init__(self, device, arena=True):
+    def __init__(self, device, arena=True, ordered=False):
         self.device = torch.device(device)
         self.arena = ZeroArena(1024, self.device) if arena else None      # sized after the first eager step (fit())
         self.split = SplitWorkspace(self.device)
         self.scratch = {}
+        # ordered: every reduction the launches of this context split across workgroups -- split-K GEMMs of any split count,
+        # small filter gradients, bias column sums -- is summed in a fixed order through ``split`` (I2V_TUNE_SPLIT_ATOMICS = 0
+        # while the context is entered): bit-reproducible results.  The relation step's head asks for it (free there); the
+        # instance_styleD step does not (+4 % of its step: DESIGN.md 5.10)
+        self.ordered = bool(ordered)
 
     def fit(self):
         """After an eager step: re-size the arena to what the step asked for."""
@@ -444,6 +451,11 @@ class LaunchContext:
         global ARENA, SPLIT_WS, SCRATCH
         self._saved = (ARENA, SPLIT_WS, SCRATCH)
         ARENA, SPLIT_WS, SCRATCH = self.arena, self.split, self.scratch
+        self._tune = None
+        if self.ordered and ORDERED_SUMS:
+            self._tune = lib.i2v_get_tuning(_TUNE_SPLIT_ATOMICS)
+            if self._tune == 2:             # an explicit I2V_SPLIT_ATOMICS=1 (always atomics) is the user's to keep
+                lib.i2v_set_tuning(_TUNE_SPLIT_ATOMICS, 0)
         if self.arena is not None:
             self.arena.reset()          # one clear for every atomically accumulated output of this piece of work
         return self
@@ -451,6 +463,8 @@ class LaunchContext:
     def __exit__(self, *exc):
         global ARENA, SPLIT_WS, SCRATCH
         ARENA, SPLIT_WS, SCRATCH = self._saved
+        if self._tune == 2:
+            lib.i2v_set_tuning(_TUNE_SPLIT_ATOMICS, 2)
         return False
 
 
@@ -688,9 +702,14 @@ def _conv_wgrad_raw(x, g, w_shape, stride, pad, tag="wgrad", row_scale=None, win
             check(lib.i2v_conv_wgrad_scaled(ptr(x), ptr(g), ptr(row_scale), ptr(gw), B, H, W, Cin, Cout, KH, KW, stride, pad,
                                             beta, stream()), "conv_wgrad_scaled")
         else:
-            sws = _split_ws(x.device)       # ordered sum of a split reduction (bit-reproducible; no atomics, no clear)
-            check(lib.i2v_conv_wgrad(ptr(x), ptr(g), ptr(gw), B, H, W, Cin, Cout, KH, KW, stride, pad, beta, ptr(sws), sws.numel(),
-                                     stream()), "conv_wgrad")
+            # ordered sum of a split reduction (bit-reproducible; no atomics, no clear) through the split workspace in force --
+            # unless this call runs on the filter-gradient side branch (I2V_WGRAD_BRANCH), beside the main chain's GEMMs that
+            # own that workspace: launches sharing one must be ordered on the device, so there the sum stays atomic
+            side = WGRAD_STREAM is not None and torch.cuda.current_stream().cuda_stream == WGRAD_STREAM.cuda_stream
+            sws = None if side else _split_ws(x.device)
+            check(lib.i2v_conv_wgrad(ptr(x), ptr(g), ptr(gw), B, H, W, Cin, Cout, KH, KW, stride, pad, beta,
+                                     ptr(sws) if sws is not None else None, sws.numel() if sws is not None else 0, stream()),
+                  "conv_wgrad")
     return gw
 
 

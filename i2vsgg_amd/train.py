@@ -539,7 +539,7 @@ class SGGEmbStep:
         self.bb_split = os.environ.get("I2V_BB_SPLIT", "1") == "1" and use_graph and n_frames > 1
         self._frame_streams = [ops.role_stream(self.dev, ("frame", f)) for f in range(n_frames)] if self.bb_split else []
         self._side = None
-        self.ctx_head = ops.LaunchContext(self.dev, arena=zero_arena)      # head branch
+        self.ctx_head = ops.LaunchContext(self.dev, arena=zero_arena, ordered=True)      # head branch: bit-reproducible sums
         self.ctx_bb = ops.LaunchContext(self.dev, arena=zero_arena)        # eager backbone passes (any size)
         self.shapes, self.max_graphs, self._tick, self._pool = {}, int(max_graphs), 0, None
         self.cap_boxes, self.cap_pairs = n_frames * n_boxes, n_frames * n_pairs      # rows of the padded head inputs

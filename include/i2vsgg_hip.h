@@ -255,7 +255,7 @@ size_t  i2v_conv_split_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t 
 #define I2V_TUNE_SPLIT_TARGET         1   /* workgroups per CU a split-K launch aims for (default 2) */
 #define I2V_TUNE_SPLIT_TARGET_SKINNY  2   /* the same for GEMMs of <= 256 rows (-1: as SPLIT_TARGET) */
 #define I2V_TUNE_SPLIT_BELOW          3   /* split K only when the unsplit grid has fewer tiles than this (default 256) */
-#define I2V_TUNE_SPLIT_ATOMICS        4   /* 0 (default): split-K partials through the caller's workspace, summed in split order by the last workgroup to arrive -- any number of splits, any output size: bit-reproducible; 2: round 4's rule (fp32 atomics beyond four splits and for outputs under 2^18 elements); 1: always atomics */
+#define I2V_TUNE_SPLIT_ATOMICS        4   /* how reductions that are split across workgroups are finished.  2 (process default, round 4's rule): split-K GEMMs of up to four parts and outputs of >= 2^18 elements through the caller's workspace, summed in split order by the last workgroup to arrive; everything else (more parts, small outputs, split filter gradients, bias column sums) with fp32 atomics.  0: EVERY such reduction ordered -- any number of split-K parts, filter gradients (up to 16 parts, I2V_TUNE_WGRAD_ORDERED_GFLOP), bias column sums of tensors up to 2^21 elements: bit-reproducible; what the relation step selects for its head (measured: free there, +4 % on the instance_styleD step, whose launches are larger).  1: always atomics */
 #define I2V_TUNE_BIG_FC_TILE          5   /* tile index for the long skinny GEMMs (rows <= 256, K >= 16384); -1: cost model */
 #define I2V_TUNE_WGRAD_V2             6   /* 0: first-generation wgrad kernel, 1: default, 2/3: larger tiles */
 #define I2V_TUNE_WGRAD_FUSED_TILE     7   /* 128 (default) or 64: filters per workgroup of the fused wgrad+SGD kernel */
@@ -272,7 +272,8 @@ size_t  i2v_conv_split_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t 
 #define I2V_TUNE_WGRAD_PRIO          18   /* experiment: n > 0 = the filter-gradient kernel lowers a wave's issue priority as it advances (3 - ((stage >> (n-1)) & 3)); 0 = off */
 #define I2V_TUNE_STREAM_TILE         19   /* 1 (default): pointwise layers of at most four K stages over >= 16384 rows (HBM-bound) take the 80x64 tile whatever the cost model says; 0: cost model */
 #define I2V_TUNE_KGROUPS             20   /* 1: a pointwise GEMM the plan would split over K runs as one 16-wave workgroup per tile whose four wave groups split K and meet in LDS (no partial tile through memory) when one round of such tiles covers >= 70 % of the CUs: 4-10 % faster than the split across workgroups as a kernel on its own, 9 % SLOWER inside the overlapped step (a workgroup that owns a CU's LDS and registers shuts the other branches' workgroups out: profiles/r04_kgroups.txt); 0 (default): split-K across workgroups, partials through the caller's workspace */
-#define I2V_TUNE_COUNT               21
+#define I2V_TUNE_WGRAD_ORDERED_GFLOP 21   /* a filter gradient (or a linear layer's data gradient run on that kernel) whose reduction is split takes the ORDERED finish -- partials through the caller's split workspace, summed in split order, at most 16 splits -- when the problem is below this many GFLOP (default 8: the relation head's layers; 0: never; the instance_styleD backbone's larger ones keep fp32 atomics) */
+#define I2V_TUNE_COUNT               22
 /* Keys CONV_SPEC (> 0), STAGGER, FC_FOLD, GEMM_X3, GEMM_PERSIST, WGRAD_PRIO are experiments: I2V_ERR_UNSUPPORTED for any value
  * but "off" unless the library was built with -DI2V_EXPERIMENTS (i2v_build_flags). */
 int32_t i2v_set_tuning(int32_t key, int32_t value);

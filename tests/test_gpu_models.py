@@ -961,6 +961,72 @@ def test_sgg_step_tensor_parallel_fc6_rehearsal_matches_single_graph(cfg, monkey
     _weights_close(b1, b0, "fc7, column-parallel rehearsal vs single graph")
 
 
+@pytest.mark.parametrize("which", ["sgg_plain_dp", "instance_styled"])
+def test_rccl_rehearsal_of_the_plain_data_parallel_exchanges(cfg, monkeypatch, which):
+    """Round-4 review item 8: the two RCCL-in-graph paths that had never run on a GPU.  One rank, a 1-rank ``nccl`` group,
+    I2V_FORCE_EXCHANGE=1:
+      * ``sgg_plain_dp``: SGGEmbStep with I2V_TP_FC6=0 -- north_star's literal partitioning, ONE sum all-reduce of every
+        ``vrd.*`` gradient (906 MB, the 822 MB fc6 gradient first) captured in the head branch of the step graph;
+      * ``instance_styled``: InstanceStyleDStep captured with its 202 MB all-reduce (train.py ``_body_branches``: after the
+        join of the source / target branches, before the update).
+    Same losses and weights as the single-GPU captured step from the same seeds; the graphs are dropped before the
+    communicator.  (World size 1: the reduction is the identity -- what is rehearsed is the capture of the collectives, the
+    bucket packing and the schedule; the 2-rank numerics run on CPU under gloo.  Multi-GPU: unmeasured on hardware.)"""
+    import gc
+    import torch.distributed as dist
+    from i2vsgg_amd import parallel, train
+    res = []
+    for forced in (False, True):
+        if forced:
+            monkeypatch.setenv("I2V_FORCE_EXCHANGE", "1")
+            monkeypatch.setenv("I2V_TP_FC6", "0")
+            monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+            monkeypatch.setenv("MASTER_PORT", str(29900 + os.getpid() % 90))
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+        step = net = None
+        try:
+            torch.manual_seed(0)
+            np.random.seed(3)
+            assert parallel.exchange_enabled() == forced
+            if which == "sgg_plain_dp":
+                net = train.build_sgg_net(layers=50, seed=5, device=DEV)
+                net.vrd.dropout = False
+                step = train.SGGEmbStep(net, 1, seed=3, device=DEV, h=200, w=320, n_boxes=6, n_pairs=5)
+                assert not step.tp and net.vrd.tp is None
+                # an exchanged gradient cannot be consumed by a fused update: fc6 is fused only where its gradient stays local
+                assert ("vrd.fc6.fc.weight" in step.fused) == (not forced)
+                assert step.capture(warmup=1) and step.overlap, step.graph_error
+                losses = [float(step().item()) for _ in range(3)]
+                step.opt.flush_pending()
+                watch = [net.vrd.fc6.fc.weight, net.vrd.fc7.fc.weight, net.vrd.fc_rel.fc.bias]
+            else:
+                net = train.build_instance_styled_net(50, device=DEV)
+                step = train.InstanceStyleDStep(net, 1, seed=3, device=DEV, h=256, w=320)
+                assert step.capture(warmup=1), step.graph_error
+                losses = []
+                for _ in range(3):
+                    step()
+                    losses.append(float(step.losses["total"]))
+                p = dict(net.named_parameters())
+                watch = [p["RCNN_base.6.5.conv3.weight"], p["RCNN_rpn.RPN_Conv.weight"], p["netD_style.fc_1.weight"],
+                         p["RCNN_bbox_pred.bias"]]
+            torch.cuda.synchronize()
+            res.append((losses, [w.detach().cpu().numpy().copy() for w in watch]))
+            step.opt.unfuse()
+        finally:
+            step = net = watch = None                # the graphs that captured RCCL kernels go before the communicator
+            gc.collect()
+            torch.cuda.synchronize()
+            if forced:
+                dist.destroy_process_group()
+    (l0, w0), (l1, w1) = res
+    assert l0[0] != l0[2] and all(np.isfinite(l0)) and all(np.isfinite(l1))
+    for x, y in zip(l0, l1):
+        assert abs(x - y) <= 1e-5 * abs(x), (l0, l1)
+    for i, (a, b) in enumerate(zip(w0, w1)):
+        _weights_close(b, a, "%s rehearsal vs single graph, tensor %d" % (which, i))
+
+
 def test_fork_inside_a_graph_branch_is_an_error_not_a_crash():
     """Round-2 review: a fork made inside a forked branch ends hipStreamEndCapture in a host segfault on ROCm 7.2, and the
     step objects avoided it by construction only.  They fork through ``ops.branch`` now, which refuses the nested fork while a

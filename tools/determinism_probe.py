@@ -45,18 +45,6 @@ def eager_once():
     return loss, got, grads
 
 
-print("== eager step, unfused update: run A vs run B")
-for rep in range(2):
-    la, ga, gra = eager_once()
-    lb, gb, grb = eager_once()
-    print(" rep %d: loss equal %s | score equal %s | rel_feat equal %s" % (rep, torch.equal(la, lb), torch.equal(ga["score"], gb["score"]),
-                                                                           torch.equal(ga["feat"], gb["feat"])))
-    for n in gra:
-        if not torch.equal(gra[n], grb[n]):
-            d = (gra[n] - grb[n]).abs().max().item() / max(gra[n].abs().max().item(), 1e-30)
-            print("   grad differs: %-40s %s rel %.2e" % (n, tuple(gra[n].shape), d))
-
-
 def trajectory(graph, overlap, fuse, n=5):
     net = train.build_sgg_net(layers=layers, seed=5, device=DEV)
     net.vrd.dropout = False
@@ -71,13 +59,17 @@ def trajectory(graph, overlap, fuse, n=5):
     return torch.stack(losses), w
 
 
-for name, (graph, overlap, fuse) in (("eager, unfused update", (False, False, False)), ("eager, fused update", (False, False, True)),
-                                     ("sequential graph, fused", (True, False, True)), ("overlapped graph, fused", (True, True, True)),
-                                     ("overlapped graph, unfused", (True, True, False))):
-    print("== %s, 5 steps: run A vs run B" % name)
-    for rep in range(2):
-        la, wa = trajectory(graph, overlap, fuse)
-        lb, wb = trajectory(graph, overlap, fuse)
+MODES = {"eu": ("eager, unfused update", (False, False, False)), "ef": ("eager, fused update", (False, False, True)),
+         "sf": ("sequential graph, fused", (True, False, True)), "of": ("overlapped graph, fused", (True, True, True)),
+         "ou": ("overlapped graph, unfused", (True, True, False))}
+order = sys.argv[2].split(",") if len(sys.argv) > 2 else ["eu", "ef", "sf", "of", "ou"]
+nsteps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+for key in order:
+    name, (graph, overlap, fuse) = MODES[key]
+    print("== %s, %d steps: runs A, B, C" % (name, nsteps))
+    runs = [trajectory(graph, overlap, fuse, nsteps) for _ in range(3)]
+    for a, b in ((0, 1), (1, 2), (0, 2)):
+        (la, wa), (lb, wb) = runs[a], runs[b]
         bad = [(n, (wa[n] - wb[n]).abs().max().item() / max(wa[n].abs().max().item(), 1e-30)) for n in wa if not torch.equal(wa[n], wb[n])]
-        print(" rep %d: losses equal %s; %d of %d tensors differ %s" % (rep, torch.equal(la, lb), len(bad), len(wa),
-                                                                     " ".join("%s:%.1e" % (n.replace("vrd.", ""), d) for n, d in bad)))
+        print(" %s vs %s: losses equal %s; %d of %d tensors differ %s" % ("ABC"[a], "ABC"[b], torch.equal(la, lb), len(bad), len(wa),
+                                                                       " ".join("%s:%.1e" % (n.replace("vrd.", ""), d) for n, d in bad[:8])))
