@@ -1416,18 +1416,20 @@ void set_max_lds(K kernel) {
 
 constexpr int kKGroups = 4;      // wave groups of the intra-workgroup K split (16 waves = 4 per SIMD, one workgroup per CU)
 
-// The intra-workgroup K split (conv_gemm_f32<.., KG = 4>): one workgroup of 16 waves per tile, four stage-buffer sets in LDS.
-template <int WAVES_M, int WAVES_N, int TM, int TN>
+// The intra-workgroup K split (conv_gemm_f32<.., KG>): one workgroup of KG x 4 waves per tile, KG stage-buffer sets in LDS.
+// KG = 4 (round 4): 16 waves, 115-156 KB -- the workgroup owns its CU.  KG = 2 (round 5): 8 waves, 58-78 KB -- two of them, or
+// one and the 4-wave workgroups of the step's other branches, share a CU.
+template <int WAVES_M, int WAVES_N, int TM, int TN, int KG = kKGroups>
 int launch_kgroups(const ConvP& p, hipStream_t st) {
     constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
-    constexpr int need = kKGroups * 2 * (BM + BN) * BKS * 4;
-    static_assert(need <= 159 * 1024, "four stage-buffer sets fit the CU's LDS");
+    constexpr int need = KG * 2 * (BM + BN) * BKS * 4;
+    static_assert(need <= 159 * 1024, "the stage-buffer sets fit the CU's LDS");
     // exactly what the launch asks for: the kernel also has a few bytes of static LDS, and the attribute call fails (leaving
     // the 64 KB default in force) when dynamic + static would exceed the CU's 160 KB
     static const hipError_t once_k = [] {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, false, false, kKGroups>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, false, false, KG>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, need);
-        hipError_t e2 = hipFuncSetAttribute((const void*)conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true, false, kKGroups>,
+        hipError_t e2 = hipFuncSetAttribute((const void*)conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true, false, KG>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, need);
         return e != hipSuccess ? e : e2;
     }();
@@ -1438,9 +1440,9 @@ int launch_kgroups(const ConvP& p, hipStream_t st) {
     }
     const int tiles = i2v_cdiv(p.M, BM) * i2v_cdiv(p.N, BN);
     if (p.flags & I2V_EPI_MASK)
-        conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true, false, kKGroups><<<dim3(tiles, 1, 1), THREADS * kKGroups, need, st>>>(p);
+        conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true, false, KG><<<dim3(tiles, 1, 1), THREADS * KG, need, st>>>(p);
     else
-        conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, false, false, kKGroups><<<dim3(tiles, 1, 1), THREADS * kKGroups, need, st>>>(p);
+        conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, false, false, KG><<<dim3(tiles, 1, 1), THREADS * KG, need, st>>>(p);
     return I2V_OK;
 }
 
@@ -1608,8 +1610,9 @@ int run_conv(ConvP p, hipStream_t st, void* split_ws = nullptr, size_t split_ws_
     {
         const bool pw = p.KH == 1 && p.KW == 1 && p.pad == 0 && p.pad_x == 0 && p.stride == 1 && p.ostride == 1 && p.Ho == p.H &&
                         p.Wo == p.W && (p.N & 3) == 0 && (p.K & 3) == 0 && g_i2v_tuning[I2V_TUNE_CONV_GEMM] && !p.ablate;
+        const int kgn = g_i2v_tuning[I2V_TUNE_KGROUPS] == 2 ? 2 : kKGroups;       // wave groups: 2 (round 5), or 4 (1 / 4)
         if (g_i2v_tuning[I2V_TUNE_KGROUPS] && pw && g_spec_mode <= 0 && !p.clk && p.nbatch <= 1 && p.splitk >= 2 && force < 0 &&
-            p.K % (kKGroups * BKS) == 0 && p.K / kKGroups >= 2 * BKS && !g_i2v_tuning[I2V_TUNE_GEMM_X3] &&
+            p.K % (kgn * BKS) == 0 && p.K / kgn >= 2 * BKS && !g_i2v_tuning[I2V_TUNE_GEMM_X3] &&
             (long long)p.M * p.N >= (1 << 18)) {
             static const int kg_bm[4] = {80, 64, 48, 32};
             const int nt = i2v_cdiv(p.N, 64);
@@ -1650,6 +1653,14 @@ int run_conv(ConvP p, hipStream_t st, void* split_ws = nullptr, size_t split_ws_
     const long long nblocks = (long long)i2v_cdiv(p.M, kTiles[cfg].bm) * i2v_cdiv(p.N, kTiles[cfg].bn) * p.splitk;
     // measured neutral on the backbone shapes (l2 c2 +6 %, l3 ds -12 %): off unless forced
     const bool spec = g_spec_mode < 0 ? false : (g_spec_mode == 2 ? nblocks <= 3 * NUM_CU : g_spec_mode != 0);
+    if (kg_tile >= 0 && g_i2v_tuning[I2V_TUNE_KGROUPS] == 2) {
+        switch (kg_tile) {
+            case 0: return launch_kgroups<1, 4, 5, 1, 2>(p, st);
+            case 1: return launch_kgroups<2, 2, 2, 2, 2>(p, st);
+            case 2: return launch_kgroups<1, 4, 3, 1, 2>(p, st);
+            default: return launch_kgroups<2, 2, 1, 2, 2>(p, st);
+        }
+    }
     if (kg_tile >= 0) {
         switch (kg_tile) {
             case 0: return launch_kgroups<1, 4, 5, 1>(p, st);

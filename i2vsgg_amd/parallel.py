@@ -31,6 +31,27 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def capture_kwargs():
+    """Extra arguments for ``torch.cuda.graph`` while a process group exists.  ProcessGroupNCCL's watchdog thread polls the
+    events of collectives still on its list (those of the eager warm-up steps) with hipEventQuery; under the default GLOBAL
+    capture mode a query from ANY thread while a capture is running is an error, the watchdog thread throws, nothing catches it
+    and the process aborts (round 5: the 1-rank RCCL rehearsal of the instance_styleD step died so, SIGABRT inside its capture;
+    the relation step had been getting away with it on timing).  THREAD_LOCAL confines the check to the capturing thread.
+    ``wait_for_collectives`` below empties the watchdog's list first, which is the other half."""
+    if dist.is_available() and dist.is_initialized():
+        return {"capture_error_mode": "thread_local"}
+    return {}
+
+
+def wait_for_collectives(device):
+    """Before a capture: every collective launched so far has finished AND has left the watchdog's work list (it drops a
+    finished work on its next pass, every ~100 ms)."""
+    if dist.is_available() and dist.is_initialized() and device.type == "cuda":
+        import time
+        torch.cuda.synchronize(device)
+        time.sleep(0.3)
+
+
 def init_from_env(backend=None):
     """Initialise from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torchrun).  Returns (rank, world, device)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))

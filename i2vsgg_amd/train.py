@@ -998,13 +998,14 @@ class SGGEmbStep:
             if self._pool is None:
                 self._pool = torch.cuda.graph_pool_handle()
             torch.cuda.synchronize(self.dev)
+            parallel.wait_for_collectives(self.dev)
             if self._pipelined:
                 if self._side is None:
                     self._side = ops.role_stream(self.dev, "side")
-                with torch.cuda.graph(g, pool=self._pool):
+                with torch.cuda.graph(g, pool=self._pool, **parallel.capture_kwargs()):
                     self._body_overlapped(fs)
             else:
-                with torch.cuda.graph(g, pool=self._pool):
+                with torch.cuda.graph(g, pool=self._pool, **parallel.capture_kwargs()):
                     self._rotate()
                     self._backbone(fs)
                     self._head()
@@ -1454,7 +1455,8 @@ class InstanceStyleDStep:
             g = torch.cuda.CUDAGraph()
             if self._pool is None:
                 self._pool = torch.cuda.graph_pool_handle()
-            with torch.cuda.graph(g, pool=self._pool):
+            parallel.wait_for_collectives(self.dev)
+            with torch.cuda.graph(g, pool=self._pool, **parallel.capture_kwargs()):
                 body()
             ds.graph = g
             return True

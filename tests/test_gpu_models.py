@@ -1023,8 +1023,10 @@ def test_rccl_rehearsal_of_the_plain_data_parallel_exchanges(cfg, monkeypatch, w
     assert l0[0] != l0[2] and all(np.isfinite(l0)) and all(np.isfinite(l1))
     for x, y in zip(l0, l1):
         assert abs(x - y) <= 1e-5 * abs(x), (l0, l1)
+    # the relation step's sums are ordered (bit-reproducible); the instance_styleD step keeps round 4's rule (fp32 atomics in its
+    # many-way split reductions: ordering them costs 4 % of its step), so two of ITS runs agree to rounding, not to the bit
     for i, (a, b) in enumerate(zip(w0, w1)):
-        _weights_close(b, a, "%s rehearsal vs single graph, tensor %d" % (which, i))
+        _weights_close(b, a, "%s rehearsal vs single graph, tensor %d" % (which, i), peak=1e-5 if which == "sgg_plain_dp" else 1e-4)
 
 
 def test_fork_inside_a_graph_branch_is_an_error_not_a_crash():

@@ -38,13 +38,15 @@ for name, M, K, N, res in cases:
     w = torch.randn(N, K, 1, 1, device=DEV) / K ** 0.5
     sc, sh = torch.rand(N, device=DEV) + 0.5, torch.rand(N, device=DEV)
     r = torch.randn(M, N, 1, 1, device=DEV) if res else None
-    row = []
-    for kg in (1, 0):
+    row, outs = [], []
+    for kg in (4, 2, 0):
         lib.i2v_set_tuning(TUNE["I2V_KGROUPS"], kg)
         us = timeit(lambda: ops.conv2d(x, w, sc, sh, r, 1, 0, relu=True))
+        outs.append(ops.conv2d(x, w, sc, sh, r, 1, 0, relu=True).clone())
         ws = lib.i2v_conv_split_workspace_bytes(1, 1, M, K, N, 1, 1, 1, 0)
         row.append((us, ws))
-    lib.i2v_set_tuning(TUNE["I2V_KGROUPS"], 1)
+    lib.i2v_set_tuning(TUNE["I2V_KGROUPS"], 0)
     fl = 2.0 * M * N * K
-    print("%-36s M %5d K %4d N %4d: K groups %6.1f us (%5.1f TF, ws %5.1f MB) | memory split %6.1f us (%5.1f TF, ws %5.1f MB)" % (
-        name, M, K, N, row[0][0], fl / row[0][0] / 1e6, row[0][1] / 1e6, row[1][0], fl / row[1][0] / 1e6, row[1][1] / 1e6))
+    err = max(float((o - outs[2]).abs().max()) for o in outs[:2]) / float(outs[2].abs().max())
+    print("%-36s M %5d K %4d N %4d: 4 K groups %6.1f us (%5.1f TF) | 2 K groups %6.1f us (%5.1f TF) | memory split %6.1f us (%5.1f TF, ws %5.1f MB)  max dev %.1e" % (
+        name, M, K, N, row[0][0], fl / row[0][0] / 1e6, row[1][0], fl / row[1][0] / 1e6, row[2][0], fl / row[2][0] / 1e6, row[2][1] / 1e6, err))
