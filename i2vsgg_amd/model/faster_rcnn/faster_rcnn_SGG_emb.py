@@ -190,8 +190,15 @@ class _fasterRCNN(nn.Module):
         if not counts:
             return {"boxes": [], "classes": [], "confs": []}
         t = lambda a, dt=torch.float32: torch.from_numpy(np.concatenate(a)).to(dev, dt)
-        score, _ = self.vrd.forward_device(fmap, t(boxes), t(rel_boxes), rasterize_masks(np.concatenate(bounds), dev),
-                                           t(ixs, torch.long), t(ixo, torch.long))
+        if self.vrd.spatial_type == 1:
+            # the 8-d relative-location feature (resnet_SGG_emb.py:258-264).  The reference's loop never builds it (the call is
+            # commented out at :229 and its ``type=bool`` flag cannot select the branch); here the flag works
+            b_all, s_all, o_all = np.concatenate(boxes)[:, 1:], np.concatenate(ixs), np.concatenate(ixo)
+            spatial = torch.from_numpy(np.stack([self.vrd._getRelativeLoc(b_all[i], b_all[j]) for i, j in zip(s_all, o_all)])
+                                       .astype(np.float32)).to(dev)
+        else:
+            spatial = rasterize_masks(np.concatenate(bounds), dev)
+        score, _ = self.vrd.forward_device(fmap, t(boxes), t(rel_boxes), spatial, t(ixs, torch.long), t(ixo, torch.long))
         target = t(labels)
         # mean over frames of the per-frame BCE mean (== reference run per frame, averaged)
         w = torch.cat([torch.full((c,), 1.0 / (c * len(counts))) for c in counts]).to(dev)

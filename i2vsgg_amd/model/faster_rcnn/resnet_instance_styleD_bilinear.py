@@ -15,7 +15,7 @@ from .layers import C4Base, ConvParams, load_reference_state, make_layer
 from .utils import Linear, _LinearParams
 
 RESNET_BLOCKS = {50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
-FUSED_STYLE = os.environ.get("I2V_FUSED_STYLE", "1") != "0"      # 0: two GEMM launches + a pooling pass (the round-1 form)
+FUSED_STYLE = True      # False (a test sets it): two GEMM launches + a pooling pass (the round-1 form)
 
 
 class netD_pixel(nn.Module):

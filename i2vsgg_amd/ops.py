@@ -69,7 +69,7 @@ def _rois_f32(rois):
     return rois.contiguous().float()
 
 
-ROIALIGN_BWD_GATHER = os.environ.get("I2V_ROIALIGN_BWD_GATHER", "1") != "0"     # 0: the atomic scatter (round 1)
+ROIALIGN_BWD_GATHER = True     # False (tests set it): the atomic scatter of round 1, which still serves NCHW / narrow maps
 # kernel name -> launches per op, for the profiling tools (bench.py roi_nms_case, tools/roi_nms_pmc_summary.py)
 ROIALIGN_BWD_KERNELS = {"roi_align_bwd_row_kernel": 1}
 NMS_KERNELS = {"nms_mask_kernel": 1, "nms_scan_pipelined_kernel": 1}
@@ -618,7 +618,7 @@ def _conv_fwd_raw(x, w, scale, shift, res, stride, pad, flags, out=None):
     return y
 
 
-LINEAR_DGRAD_AS_WGRAD = int(os.environ.get("I2V_LINEAR_DGRAD_AS_WGRAD", "0"))     # filter elements from which a linear layer's dgrad goes through the wgrad kernel
+LINEAR_DGRAD_AS_WGRAD = 0     # filter elements from which a linear layer's dgrad goes through the wgrad kernel
 
 
 def _linear_dgrad_as_wgrad(in_shape, w_shape, stride, pad):
@@ -657,7 +657,7 @@ def _conv_dgrad_raw(g, w, in_shape, stride, pad):
 
 # I2V_WINOGRAD_WGRAD=0: the filter gradient of a trained 3x3 layer stays on the direct kernel (its forward and data gradient
 # are Winograd F(4x4,3x3) with WINOGRAD_TRAIN)
-WINOGRAD_WGRAD = os.environ.get("I2V_WINOGRAD_WGRAD", "1") != "0"
+WINOGRAD_WGRAD = True
 
 
 def _winograd_wgrad_ok(x, w_shape, stride, pad):
@@ -842,7 +842,7 @@ def _conv_wgrad_sgd_raw(x, g, w, cfg, stride, pad):
 
 
 # I2V_WINOGRAD_TRAIN=0: direct kernels for trained 3x3 layers too (fp32 error 1e-6 instead of 1e-5 per layer)
-WINOGRAD_TRAIN = os.environ.get("I2V_WINOGRAD_TRAIN", "1") != "0"
+WINOGRAD_TRAIN = True
 WINOGRAD_TRAIN_MIN_C = 64
 
 
@@ -945,7 +945,7 @@ class _ConvFn(torch.autograd.Function):
 # ---------------------------------------------------------------- a trained bottleneck as ONE autograd node
 # I2V_BLOCK_FUSED=0: every conv of a trained bottleneck is its own autograd node again (one streaming pass over the
 # activation gradient per conv for the BN scale / ReLU mask, the skip connection's gradient added by autograd)
-BLOCK_FUSED = os.environ.get("I2V_BLOCK_FUSED", "1") != "0"
+BLOCK_FUSED = True
 
 
 def _dgrad_fused(g, w, in_shape, pad, gy_scale=None, out_scale=None, res=None, mask=None, stride=1):
@@ -1653,7 +1653,7 @@ def winograd_filter_dgrad(w):
 
 # I2V_WINOGRAD_KEEP_V=0: a trained 3x3 layer transforms its input again for the filter gradient instead of keeping the forward's
 # transformed input (36/16 of the activation's size per layer, ~1.9 GB over the 33 layers of an 8-frame instance_styleD step)
-WINOGRAD_KEEP_V = os.environ.get("I2V_WINOGRAD_KEEP_V", "1") != "0"
+WINOGRAD_KEEP_V = True
 
 
 def conv3x3_winograd(x, U, scale=None, shift=None, relu=False, tag="fwd", keep_v=False):

@@ -16,6 +16,8 @@ from . import synthetic as syn
 from .model.utils.config import cfg
 
 
+DEFER_FC = False        # fuse_wgrad(defer=...): the fc-fold experiment (measured slower; I2V_EXPERIMENTS builds only)
+
 class FusedSGD:
     """SGD(momentum) with the reference's param groups (bias: lr x2 and no weight decay when
     cfg.TRAIN.DOUBLE_BIAS / not BIAS_DECAY) on the fused HIP kernel; one launch per tensor."""
@@ -39,15 +41,15 @@ class FusedSGD:
     def fuse_wgrad(self, min_numel=1 << 24, defer=None):
         """Fuse the update of large filters into their wgrad epilogue (single-GPU only: with data
         parallelism the gradient must be all-reduced before the update).  Returns the fused names.
-        ``defer`` (``I2V_DEFER_FC=1``; OFF by default): 2-D filters among them additionally get a pending-update slot
+        ``defer`` (``train.DEFER_FC``; OFF, an I2V_EXPERIMENTS build only): 2-D filters among them additionally get a pending-update slot
         (ops.DeferredUpdate): their update is applied by the NEXT forward on its pass over the filter (i2v_fc_fold_fwd).
         Correct and parity-tested, but measured slower than forward + fused update as separate kernels (fc6: 1.41 ms against
         0.43 + 0.79; the headline step 5.0 ms against 4.65 -- DESIGN.md section 5.5), so the step does not use it."""
         import os
         if defer is None:
-            defer = os.environ.get("I2V_DEFER_FC", "0") == "1"
+            defer = DEFER_FC
         if defer and not _lib.EXPERIMENTS:
-            raise RuntimeError("I2V_DEFER_FC / fuse_wgrad(defer=True): the fc fold kernel is an experiment, not in this library "
+            raise RuntimeError("train.DEFER_FC / fuse_wgrad(defer=True): the fc fold kernel is an experiment, not in this library "
                                "(build with I2V_EXPERIMENTS=1 python -m i2vsgg_amd.build)")
         names = []
         for it in self.items:
@@ -407,7 +409,7 @@ class _Uploader:
         self.enabled = os.environ.get("I2V_UPLOAD_STREAM", "1") == "1"
         # the copy stream exists only when asked for, and is the process's ONE copy stream (ops.role_stream): a handle of the
         # library's own, never an alias of a branch / capture / communicator stream out of torch's pool
-        self.stream = ops.role_stream(self.dev, "copy", int(os.environ.get("I2V_UPLOAD_PRIORITY", "0"))) if self.enabled else None
+        self.stream = ops.role_stream(self.dev, "copy", 0) if self.enabled else None      # normal priority: a high one doubles the step when the loop alternates between the graphs of two sizes
         self.rings = {}
 
     def upload(self, frames):
@@ -1150,11 +1152,11 @@ class InstanceStyleDStep:
         self.geom = (h, w)
         self.n_frames, self.n_gt = n_frames, n_gt
         import os
-        self.batched = os.environ.get("I2V_ISD_BATCHED", "1") != "0"
+        self.batched = True
         # filter gradients of the bottleneck nodes on a side branch of the step (ops.WGRAD_STREAM)
         # (only with the one-pass backbone: a filter met twice in one backward would have its two gradients added on the main
         # stream while the side branch may still be writing the first)
-        self.wgrad_branch = os.environ.get("I2V_WGRAD_BRANCH", "0") == "1" and self.dev.type == "cuda" and self.batched
+        self.wgrad_branch = False      # filter gradients on a side branch: -1 % of the step for +2.4 GB; a test sets it
         self._wgrad_stream = ops.role_stream(self.dev, "wgrad") if self.wgrad_branch else None
         # the captured step: source and target as two branches of the graph (_body_branches)
         self.branches = os.environ.get("I2V_ISD_BRANCHES", "1") != "0" and self.dev.type == "cuda" and not self.wgrad_branch
@@ -1544,13 +1546,14 @@ def _randomise_bn(net, seed):
             m.invalidate()
 
 
-def build_sgg_net(layers=101, n_rel=62, n_cls=16, seed=0, device="cuda:0"):
-    """Random-init SGG_emb model of the reference architecture (no checkpoint is reachable)."""
+def build_sgg_net(layers=101, n_rel=62, n_cls=16, seed=0, device="cuda:0", emb_dim=300, use_obj_visual=True, spatial_type=2):
+    """Random-init SGG_emb model of the reference architecture (no checkpoint is reachable).  ``emb_dim``,
+    ``use_obj_visual``, ``spatial_type``: the reference's flags (parser_func.py:155-163,182)."""
     import argparse
     from .model.faster_rcnn.resnet_SGG_emb import resnet
     torch.manual_seed(seed)
-    args = argparse.Namespace(num_relations=n_rel, num_classes=n_cls, emb_dim=300, use_obj_visual=True,
-                              spatial_type=2, vrd_task="pre_det")
+    args = argparse.Namespace(num_relations=n_rel, num_classes=n_cls, emb_dim=int(emb_dim), use_obj_visual=bool(use_obj_visual),
+                              spatial_type=int(spatial_type), vrd_task="pre_det")
     net = resnet(tuple(range(n_cls)), args, layers, obj_vecs=syn.word_vectors(22, n_cls),
                  prd_vecs=syn.word_vectors(21, n_rel))
     net.create_architecture()

@@ -150,6 +150,28 @@ def test_sgg_captured_step_consumes_loader_batches_of_varying_size(small_cfg, mo
     assert _rel(w_got, w_want) < 1e-4
 
 
+def test_sgg_script_selects_the_relation_head_variants(small_cfg, tmp_path, capsys):
+    """parser_func.py:155-163,182: --use_obj_visual / --spatial_type / --emb_dim select the head the four reference-run goldens
+    pin (tests/test_gpu_models.py::test_vrd_head_variants_vs_reference_golden).  The non-default heads train through the
+    model's own forward on eager launches; --emb_dim rides in the captured step."""
+    import trainval_sgg_emb as ts
+    common = ["--bs", "2", "--imdb_name", "synthetic_12_v", "--scale", "192", "--disp_interval", "2", "--save_dir", str(tmp_path),
+              "--iters_per_epoch", "4", "--epochs", "1"]
+    ts.main(common + ["--use_obj_visual", "0", "--spatial_type", "1"])
+    out = capsys.readouterr().out
+    assert "variant head" in out and "loss:" in out
+    ck = torch.load(tmp_path / "res101" / "synthetic" / "SGG_emb_p_prior_adap_synthetic_pre_det_session_1_epoch_1_step_3_un.pth",
+                    map_location="cpu")
+    assert ck["model"]["vrd.fc_lov.fc.weight"].shape == (256, 8) and "vrd.fc_so.fc.weight" not in ck["model"]
+    assert ck["model"]["vrd.fc_fusion.fc.weight"].shape == (256, 512)           # two branches: union-box feature + location
+    assert all(torch.isfinite(v).all() for v in ck["model"].values() if v.is_floating_point())
+    ts.main(common + ["--spatial_type", "0", "--no-save"])
+    assert "variant head" in capsys.readouterr().out
+    ts.main(common + ["--emb_dim", "128", "--no-save"])                      # default head, another embedding width: captured step
+    out = capsys.readouterr().out
+    assert "HIP graph" in out and "variant head" not in out
+
+
 def test_sgg_padded_rows_have_no_effect(small_cfg):
     """Capacity padding is exact: the same batch through the captured step with a tight and with a generous capacity gives
     the same loss and the same update (pad rows carry loss weight 0: zero gradient; dropout off)."""

@@ -44,6 +44,13 @@ def parse_args(argv=None):
     p.add_argument("--num_classes", type=int, default=16)
     p.add_argument("--num_relations", type=int, default=62)
     p.add_argument("--vrd_task", default="pre_det")
+    # parser_func.py:155-163,182.  The reference declares the first two ``type=bool`` (any value given on its command line
+    # parses to True, i.e. spatial_type 1: SURVEY.md A15); here they are integers and select what they name.  The defaults
+    # (1, 2, 300) are what every reference script runs and what the captured step packs; the other variants of the relation
+    # head train through the model's own forward on eager launches
+    p.add_argument("--use_obj_visual", type=int, default=1, choices=[0, 1], help="subject / object visual embeddings in the fusion")
+    p.add_argument("--spatial_type", type=int, default=2, choices=[0, 1, 2], help="0 none, 1 relative location (8-d), 2 dual 32x32 masks")
+    p.add_argument("--emb_dim", type=int, default=300, help="dimension of the embedding space (the word vectors' dimension)")
     p.add_argument("--adaptation", default="adap")
     p.add_argument("--source_gt_rels_path", default="")
     p.add_argument("--cuda", action="store_true", default=True)
@@ -185,7 +192,8 @@ def main(argv=None):
                                                collate_fn=collate_device_prep if a.device_prep else None)
     iters_per_epoch = a.iters_per_epoch or (train_size // a.batch_size // world)
 
-    net = train.build_sgg_net(101 if a.net == "res101" else 50, a.num_relations, a.num_classes, device=dev)
+    net = train.build_sgg_net(101 if a.net == "res101" else 50, a.num_relations, a.num_classes, device=dev, emb_dim=a.emb_dim,
+                              use_obj_visual=a.use_obj_visual, spatial_type=a.spatial_type)
     if a.source_gt_rels_path:
         import pickle
         with open(a.source_gt_rels_path, "rb") as f:
@@ -194,6 +202,8 @@ def main(argv=None):
         net.vrd.source_gt_rels = imdb.gt_rels(a.num_relations)
     else:
         raise SystemExit("no relation annotations: pass --source_gt_rels_path")
+    if not (a.use_obj_visual == 1 and a.spatial_type == 2):
+        return train_variant(a, net, dataloader_s, iters_per_epoch, dev, rank, world)
     step = train.SGGEmbStep(net, a.batch_size, vrd_lr=a.vrd_lr, device=dev, use_graph=not a.no_graph and dev.type == "cuda",
                             stage_synthetic=False, optimizer=a.optimizer)
     start_epoch = a.start_epoch
@@ -272,6 +282,49 @@ def main(argv=None):
             if rank == 0:
                 print("save model: %s" % path)
     step.opt.unfuse()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def train_variant(a, net, loader, iters_per_epoch, dev, rank, world):
+    """The non-default variants of the relation head (--use_obj_visual 0, --spatial_type 0 / 1): the reference's loop as written
+    (trainval_net_SGG_emb.py:204-255) -- forward of the model on the minibatch, backward, optimizer step -- on eager launches of
+    the same kernels (the captured step packs the default head's inputs only)."""
+    from i2vsgg_amd import parallel
+    if a.device_prep or a.resume or a.resume_train:
+        raise SystemExit("--use_obj_visual 0 / --spatial_type 0|1 run the plain eager loop: no --device_prep, --r, --resume_train")
+    opt = train.make_optimizer(a.optimizer, [(n, p) for n, p in net.named_parameters() if n.startswith("vrd.")], a.vrd_lr)
+    it_data = iter(loader)
+    for epoch in range(a.start_epoch, a.max_epochs + 1):
+        if epoch > 1 and (epoch - 1) % a.lr_decay_step == 0:
+            opt.scale_lr(a.lr_decay_gamma)
+        t0, acc, n_acc = time.time(), 0.0, 0
+        for it in range(iters_per_epoch):
+            try:
+                data = next(it_data)
+            except StopIteration:
+                it_data = iter(loader)
+                data = next(it_data)
+            if not isinstance(data, (list, tuple)) or len(data) < 5:          # the loop skips items that are not lists (:206-217)
+                continue
+            im, info, gt, nb, paths = data[0].to(dev), data[1].to(dev), data[2].to(dev), data[3].to(dev), list(data[4])
+            loss = net(im, info, gt, nb, paths)
+            if not torch.is_tensor(loss):                                   # no annotated relation in the minibatch (:177-183)
+                continue
+            opt.zero_grad()
+            (loss / world).backward()
+            parallel.all_reduce_grads(opt.params())
+            opt.step()
+            acc, n_acc = acc + float(loss), n_acc + 1
+            if (it + 1) % a.disp_interval == 0 and rank == 0 and n_acc:
+                print("[session %d][epoch %2d][iter %4d/%4d] loss: %.4f, vrd_lr: %.2e, %.1f frames/s (eager, variant head)" % (
+                    a.session, epoch, it + 1, iters_per_epoch, acc / n_acc, opt.lr_of("vrd.fc7.fc.weight"),
+                    world * a.batch_size * a.disp_interval / (time.time() - t0)))
+                t0, acc, n_acc = time.time(), 0.0, 0
+        if not a.no_save:
+            path = save_checkpoint(a, net, opt, epoch, iters_per_epoch - 1, rank)
+            if rank == 0:
+                print("save model: %s" % path)
     if world > 1:
         torch.distributed.destroy_process_group()
 
