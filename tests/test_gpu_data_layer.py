@@ -153,7 +153,7 @@ def test_sgg_captured_step_consumes_loader_batches_of_varying_size(small_cfg, mo
 def test_sgg_script_selects_the_relation_head_variants(small_cfg, tmp_path, capsys):
     """parser_func.py:155-163,182: --use_obj_visual / --spatial_type / --emb_dim select the head the four reference-run goldens
     pin (tests/test_gpu_models.py::test_vrd_head_variants_vs_reference_golden).  The non-default heads train through the
-    model's own forward on eager launches; --emb_dim rides in the captured step."""
+    model's own forward on eager launches; --emb_dim composes only without the visual embeddings, as in the reference."""
     import trainval_sgg_emb as ts
     common = ["--bs", "2", "--imdb_name", "synthetic_12_v", "--scale", "192", "--disp_interval", "2", "--save_dir", str(tmp_path),
               "--iters_per_epoch", "4", "--epochs", "1"]
@@ -167,9 +167,10 @@ def test_sgg_script_selects_the_relation_head_variants(small_cfg, tmp_path, caps
     assert all(torch.isfinite(v).all() for v in ck["model"].values() if v.is_floating_point())
     ts.main(common + ["--spatial_type", "0", "--no-save"])
     assert "variant head" in capsys.readouterr().out
-    ts.main(common + ["--emb_dim", "128", "--no-save"])                      # default head, another embedding width: captured step
-    out = capsys.readouterr().out
-    assert "HIP graph" in out and "variant head" not in out
+    ts.main(common + ["--emb_dim", "128", "--use_obj_visual", "0", "--no-save"])
+    assert "variant head" in capsys.readouterr().out
+    with pytest.raises(SystemExit):                      # fc_so is FC(300*2, 256) in the reference: no other width composes with it
+        ts.main(common + ["--emb_dim", "128", "--no-save"])
 
 
 def test_sgg_padded_rows_have_no_effect(small_cfg):

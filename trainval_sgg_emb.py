@@ -202,6 +202,10 @@ def main(argv=None):
         net.vrd.source_gt_rels = imdb.gt_rels(a.num_relations)
     else:
         raise SystemExit("no relation annotations: pass --source_gt_rels_path")
+    if a.emb_dim != 300 and a.use_obj_visual:
+        # resnet_SGG_emb.py:86,97: so_vis_embeddings is FC(4096, emb_dim) but fc_so is FC(300*2, 256) -- the reference's own
+        # head only composes at emb_dim 300 while the visual embeddings are on (kept: checkpoints carry that shape)
+        raise SystemExit("--emb_dim %d needs --use_obj_visual 0: fc_so is FC(300*2, 256) in the reference (resnet_SGG_emb.py:97)" % a.emb_dim)
     if not (a.use_obj_visual == 1 and a.spatial_type == 2):
         return train_variant(a, net, dataloader_s, iters_per_epoch, dev, rank, world)
     step = train.SGGEmbStep(net, a.batch_size, vrd_lr=a.vrd_lr, device=dev, use_graph=not a.no_graph and dev.type == "cuda",
@@ -290,7 +294,7 @@ def train_variant(a, net, loader, iters_per_epoch, dev, rank, world):
     """The non-default variants of the relation head (--use_obj_visual 0, --spatial_type 0 / 1): the reference's loop as written
     (trainval_net_SGG_emb.py:204-255) -- forward of the model on the minibatch, backward, optimizer step -- on eager launches of
     the same kernels (the captured step packs the default head's inputs only)."""
-    from i2vsgg_amd import parallel
+    from i2vsgg_amd import parallel, train
     if a.device_prep or a.resume or a.resume_train:
         raise SystemExit("--use_obj_visual 0 / --spatial_type 0|1 run the plain eager loop: no --device_prep, --r, --resume_train")
     opt = train.make_optimizer(a.optimizer, [(n, p) for n, p in net.named_parameters() if n.startswith("vrd.")], a.vrd_lr)
@@ -307,7 +311,9 @@ def train_variant(a, net, loader, iters_per_epoch, dev, rank, world):
                 data = next(it_data)
             if not isinstance(data, (list, tuple)) or len(data) < 5:          # the loop skips items that are not lists (:206-217)
                 continue
-            im, info, gt, nb, paths = data[0].to(dev), data[1].to(dev), data[2].to(dev), data[3].to(dev), list(data[4])
+            # annotations are looked up by the last path component (trainval_net_SGG_emb.py:217)
+            im, info, gt, nb = data[0].to(dev), data[1].to(dev), data[2].to(dev), data[3].to(dev)
+            paths = [str(q).split("/")[-1] for q in data[4]]
             loss = net(im, info, gt, nb, paths)
             if not torch.is_tensor(loss):                                   # no annotated relation in the minibatch (:177-183)
                 continue
