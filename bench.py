@@ -317,7 +317,7 @@ def profile_eager(body, n_prof, dev):
     return [dict(t=e0.elapsed_time(e1) * 1e-3, flops=fl, tag=tag, desc=d, bytes=by) for e0, e1, fl, tag, d, by in rec]
 
 
-def pmc_traffic(kernel_key, names=("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json")):
+def pmc_traffic(kernel_key, names=("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json")):
     """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ for this round
     (rocprofv3 cannot run inside the timed process); None when there is no summary."""
     for name in names:
