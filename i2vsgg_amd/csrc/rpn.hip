@@ -153,37 +153,101 @@ __global__ void gather_dets(const unsigned long long* __restrict__ keys, int P, 
 
 // ------------------------------------------------------------------ NMS
 // (1) mask kernel: 64x64 tiles of the upper triangle; one wave per tile, lane = row.
-//     nms_cpu.py:13,20-29: areas with +1, IoU = inter / (area_i + area_j - inter).
-__global__ void __launch_bounds__(64)
+//     nms_cpu.py:13,20-29: areas with +1, IoU = inter / (area_i + area_j - inter); a column suppresses when !(IoU <= thresh).
+//
+// The kernel is VALU-bound (72 M pairs at N = 12000: the loop was 40 instructions per pair, 11 of them the IEEE division, 4
+// canonicalising moves in front of fmaxf / fminf, 6 for a variable 64-bit shift).  Round 5: the 64 columns are a compile-time
+// loop (bit positions are constants), max / min are the hardware instructions, and the division is replaced by an EXACT test
+// that needs it only inside a band of 2^-21 around the threshold:
+//     ovr_f = fl(inter / d), d = fl(fl(area_i + area_j) - inter) > 0; rounding is monotone, so inter/d <= thresh implies
+//     ovr_f <= thresh, and inter/d >= thresh (1 + 2^-22) implies ovr_f > thresh.  With thi = fl(thresh (1 + 2^-21)),
+//     tlo = fl(thresh (1 - 2^-21)) (the 2^-21 absorbs the two roundings of each product):
+//     inter < fl(tlo d)  =>  inter < thresh d  =>  not suppressed;
+//     inter > fl(thi d)  =>  inter > thresh d (1 + 2^-22)  =>  suppressed;
+//     otherwise (or a box with a non-positive side, or a NaN): the division, as before, after the loop.
+//     The keep lists stay bit-exact against nms_cpu (golden vectors: 36 cases, uniform and clustered).
+__device__ inline float hw_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ inline float hw_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+constexpr int NMS_MASK_WAVES = 1;        // row blocks (waves) per workgroup sharing one column block's boxes: measured 1 / 2 / 4 waves 47.2 / 47.6 / 52.5 us at N = 12000 (18.0 / 19.4 / 18.4 at 6000)
+
+__global__ void __launch_bounds__(64 * NMS_MASK_WAVES)
 nms_mask_kernel(const float* __restrict__ dets, int n, int nblk, float thresh,
                 unsigned long long* __restrict__ mask) {
-    const int cb = blockIdx.x, rb = blockIdx.y, img = blockIdx.z;
-    if (cb < rb) return;
-    __shared__ float sb[64 * 5];
+    const int cb = blockIdx.x, img = blockIdx.z;
+    const int lane = threadIdx.x & 63, rb = blockIdx.y * NMS_MASK_WAVES + (threadIdx.x >> 6);
+    if (cb < (int)blockIdx.y * NMS_MASK_WAVES) return;            // the whole group lies below the diagonal (uniform)
+    __shared__ __attribute__((aligned(16))) float sc[5][64];      // column boxes, one field per row: x1, y1, x2, y2, area
     const float* D = dets + (long long)img * n * 5;
     const int ccount = min(64, n - cb * 64);
-    if ((int)threadIdx.x < ccount) {
-        const float* p = D + ((long long)cb * 64 + threadIdx.x) * 5;
-        sb[threadIdx.x * 5 + 0] = p[0]; sb[threadIdx.x * 5 + 1] = p[1];
-        sb[threadIdx.x * 5 + 2] = p[2]; sb[threadIdx.x * 5 + 3] = p[3];
-        sb[threadIdx.x * 5 + 4] = (p[2] - p[0] + 1.0f) * (p[3] - p[1] + 1.0f);
+    __shared__ unsigned long long s_cbad;                         // columns whose box has a non-positive side (or a NaN): decided by the division
+    if (threadIdx.x < 64) {
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+        if (lane < ccount) {
+            const float* p = D + ((long long)cb * 64 + lane) * 5;
+            c0 = p[0]; c1 = p[1]; c2 = p[2]; c3 = p[3];
+        }
+        const float cw = c2 - c0 + 1.0f, ch = c3 - c1 + 1.0f;
+        sc[0][lane] = c0; sc[1][lane] = c1; sc[2][lane] = c2; sc[3][lane] = c3;
+        sc[4][lane] = cw * ch;
+        const unsigned long long bad = __ballot(!(cw > 0.f && ch > 0.f));
+        if (lane == 0) s_cbad = bad;
     }
     __syncthreads();
-    const int row = rb * 64 + threadIdx.x;
-    if (row >= n) return;
+    const int row = rb * 64 + lane;
+    if (cb < rb || rb >= nblk || row >= n) return;
     const float* p = D + (long long)row * 5;
     const float x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3];
-    const float area = (x2 - x1 + 1.0f) * (y2 - y1 + 1.0f);
-    unsigned long long bits = 0;
-    const int jstart = (cb == rb) ? threadIdx.x + 1 : 0;
-    for (int j = jstart; j < ccount; ++j) {
-        float xx1 = fmaxf(x1, sb[j * 5]), yy1 = fmaxf(y1, sb[j * 5 + 1]);
-        float xx2 = fminf(x2, sb[j * 5 + 2]), yy2 = fminf(y2, sb[j * 5 + 3]);
-        float w = fmaxf(0.0f, xx2 - xx1 + 1.0f), h = fmaxf(0.0f, yy2 - yy1 + 1.0f);
-        float inter = w * h;
-        float ovr = inter / (area + sb[j * 5 + 4] - inter);
-        if (!(ovr <= thresh)) bits |= 1ull << j;       // nms_cpu.py:31 keeps ovr <= thresh
+    const float rw = x2 - x1 + 1.0f, rh = y2 - y1 + 1.0f;
+    const float area = rw * rh;
+    // For boxes with positive sides d = fl(fl(area_i + area_j) - inter) > 0 always (inter <= min of the two areas: the clipped
+    // extents are not larger than either box's, and rounding is monotone), so the loop need not test it; a row or a column
+    // with a non-positive side or a NaN goes to the division as a whole.
+    const float thi = thresh * 1.000000476837158203125f, tlo = thresh * 0.999999523162841796875f;     // thresh (1 +- 2^-21)
+    unsigned w[2] = {0u, 0u}, unc[2] = {0u, 0u};          // suppression bits; pairs the band test could not decide
+#pragma unroll
+    for (int j4 = 0; j4 < 64; j4 += 4) {
+        const float4 X1 = *(const float4*)&sc[0][j4], Y1 = *(const float4*)&sc[1][j4], X2 = *(const float4*)&sc[2][j4],
+                     Y2 = *(const float4*)&sc[3][j4], AR = *(const float4*)&sc[4][j4];
+        const float cx1[4] = {X1.x, X1.y, X1.z, X1.w}, cy1[4] = {Y1.x, Y1.y, Y1.z, Y1.w}, cx2[4] = {X2.x, X2.y, X2.z, X2.w},
+                    cy2[4] = {Y2.x, Y2.y, Y2.z, Y2.w}, car[4] = {AR.x, AR.y, AR.z, AR.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j4 + u;
+            const unsigned bit = 1u << (j & 31);
+            const float xx1 = hw_max(x1, cx1[u]), yy1 = hw_max(y1, cy1[u]);
+            const float xx2 = hw_min(x2, cx2[u]), yy2 = hw_min(y2, cy2[u]);
+            const float ww = hw_max(0.0f, xx2 - xx1 + 1.0f), hh = hw_max(0.0f, yy2 - yy1 + 1.0f);
+            const float inter = ww * hh;
+            const float d = area + car[u] - inter;
+            // two compares, two selects; nothing in this loop branches
+            const int over = inter > thi * d, under = inter < tlo * d;
+            w[j >> 5] |= over ? bit : 0u;
+            unc[j >> 5] |= (over | under) ? 0u : bit;
+        }
     }
+    {
+        const unsigned long long bad = !(rw > 0.f && rh > 0.f) ? ~0ull : s_cbad;
+        unc[0] |= (unsigned)bad; unc[1] |= (unsigned)(bad >> 32);
+    }
+    // the undecided pairs (inter within 2^-21 of thresh * d, or d <= 0 / NaN): the reference's own expression
+    for (int h = 0; h < 2; ++h) {
+        unsigned m = unc[h];
+        while (m) {
+            const int jj = __builtin_ctz(m), j = 32 * h + jj;
+            m &= m - 1;
+            const float xx1 = fmaxf(x1, sc[0][j]), yy1 = fmaxf(y1, sc[1][j]);
+            const float xx2 = fminf(x2, sc[2][j]), yy2 = fminf(y2, sc[3][j]);
+            const float ww = fmaxf(0.0f, xx2 - xx1 + 1.0f), hh = fmaxf(0.0f, yy2 - yy1 + 1.0f);
+            const float inter = ww * hh;
+            const float ovr = inter / (area + sc[4][j] - inter);
+            if (!(ovr <= thresh)) w[h] |= 1u << jj;         // nms_cpu.py:31 keeps ovr <= thresh
+            else w[h] &= ~(1u << jj);
+        }
+    }
+    unsigned long long bits = ((unsigned long long)w[1] << 32) | w[0];
+    if (cb == rb) bits &= lane == 63 ? 0ull : (~0ull << (lane + 1));      // the diagonal tile: columns after the row
+    if (ccount < 64) bits &= (1ull << ccount) - 1ull;                                     // columns past the end
     mask[((long long)img * n + row) * nblk + cb] = bits;
 }
 
@@ -246,6 +310,11 @@ nms_scan_kernel(const unsigned long long* __restrict__ mask, int n, int nblk, in
     if (threadIdx.x == 0) num_out[img] = s_count;
 }
 
+// Round 5 built and measured a form with the ROLES SPLIT (wave 0 only resolves and carries the next three verdict words of the
+// rows it keeps in scalar registers; the other 15 waves fetch the KEPT rows' words only and fold them two blocks later; one
+// barrier per block, then none: LDS counters polled both ways): bit-exact on every golden case and SLOWER -- 264 us with one
+// barrier, 370-420 us polling, against 186 us for the form below (N = 12000 clustered; DESIGN.md 5.10 has the stamps).  Neither
+// the barrier count nor a drained prefetch (LDS-only barriers: 185 us) is what a block's ~2k cycles are made of.
 // Pipelined variant for n <= 12288 (every RPN case): the mask rows of block rb+1 are fetched into
 // registers (4 rows per wave x 3 words per lane) while block rb is being resolved and folded in, so
 // global-load latency is off the serial chain; the chain per 64-row block is the 64-step resolve in
@@ -464,7 +533,7 @@ ProposalWs carve(void* ws, int B, long long n_all, int n_top) {
 int launch_nms(const float* dets, int n_img, int n, float thresh, int max_keep, int* keep, int* num,
                unsigned long long* mask, hipStream_t st) {
     const int nblk = (n + 63) / 64;
-    nms_mask_kernel<<<dim3(nblk, nblk, n_img), 64, 0, st>>>(dets, n, nblk, thresh, mask);
+    nms_mask_kernel<<<dim3(nblk, i2v_cdiv(nblk, NMS_MASK_WAVES), n_img), 64 * NMS_MASK_WAVES, 0, st>>>(dets, n, nblk, thresh, mask);
     if (nblk - 1 <= 64 * SCAN_PIPE_WORDS)
         nms_scan_pipelined_kernel<<<n_img, SCAN_THREADS, 0, st>>>(mask, n, nblk, max_keep, keep, num);
     else
