@@ -177,6 +177,14 @@ def cpu_baseline_stages(threads):
     fnp = feat.numpy()
     pooled_np = cops.roi_align_avg_fwd(fnp, rois, 7, 7, 1.0 / 16.0)
     out["roi_align_avg_fwd"] = _median_time(lambda: cops.roi_align_avg_fwd(fnp, rois, 7, 7, 1.0 / 16.0))
+    try:        # the one stage whose REFERENCE code exists as a binary: ROIAlignForwardCpu (roi_align.c:80-136) from oracle/_ref,
+                # where that built artefact travelled, + avg_pool2d as RoIAlignAvg does (kind "reference" for this stage alone)
+        from oracle import build_ref
+        if build_ref.available():
+            out["roi_align_avg_fwd_reference_c"] = _median_time(lambda: torch.nn.functional.avg_pool2d(
+                torch.from_numpy(build_ref.roi_align_fwd(fnp, rois, 8, 8, 1.0 / 16.0)), kernel_size=2, stride=1))
+    except Exception:            # noqa: BLE001 -- an optional extra
+        pass
     g = np.ones_like(pooled_np)
     out["roi_align_avg_bwd"] = _median_time(lambda: cops.roi_align_avg_bwd(g, rois, fnp.shape, 1.0 / 16.0))
     pooled = torch.from_numpy(pooled_np)
