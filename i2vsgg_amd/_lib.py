@@ -135,14 +135,14 @@ lib = _load()
 # The library reads no environment variable; the documented I2V_* tuning switches are forwarded here, once, at import.
 TUNE = {"I2V_CONV_SPEC": 0, "I2V_SPLIT_TARGET": 1, "I2V_SPLIT_TARGET_SKINNY": 2, "I2V_SPLIT_BELOW": 3, "I2V_SPLIT_ATOMICS": 4,
         "I2V_BIG_FC_TILE": 5, "I2V_WGRAD_V2": 6, "I2V_WGRAD_FUSED_TILE": 7, "I2V_WINO_ROWS": 8, "I2V_ROIPOOL_C128": 9, "I2V_CONV_GEMM": 10, "I2V_STAGGER": 11, "I2V_ROIALIGN_COLS": 12, "I2V_WGRAD_PER_CU": 13, "I2V_WGRAD_XCD": 14, "I2V_FC_FOLD": 15, "I2V_GEMM_X3": 16,
-        "I2V_GEMM_PERSIST": 17, "I2V_WGRAD_PRIO": 18, "I2V_STREAM_TILE": 19, "I2V_KGROUPS": 20, "I2V_WGRAD_ORDERED_GFLOP": 21}
+        "I2V_GEMM_PERSIST": 17, "I2V_WGRAD_PRIO": 18, "I2V_STREAM_TILE": 19, "I2V_KGROUPS": 20, "I2V_WGRAD_ORDERED_GFLOP": 21, "I2V_GEMM_DMA": 22}
 EXPERIMENTS = bool(lib.i2v_build_flags() & 1)      # built with -DI2V_EXPERIMENTS (I2V_EXPERIMENTS=1 python -m i2vsgg_amd.build)
 # The knobs the environment may set (README.md has the table): the ones a deployment has a reason to move.  The rest of TUNE --
 # switches of variants that were measured and lost (I2V_ROIALIGN_COLS: the round-1 / round-2 forward kernels; I2V_WGRAD_PRIO,
 # I2V_STAGGER, I2V_CONV_SPEC, I2V_GEMM_PERSIST, I2V_GEMM_X3, I2V_FC_FOLD: experiments) -- is reachable through
 # lib.i2v_set_tuning (tests, tools) and from the environment only in an I2V_EXPERIMENTS build.
 ENV_TUNE = ("I2V_SPLIT_ATOMICS", "I2V_SPLIT_TARGET", "I2V_SPLIT_TARGET_SKINNY", "I2V_SPLIT_BELOW", "I2V_BIG_FC_TILE",
-            "I2V_WGRAD_FUSED_TILE", "I2V_WGRAD_PER_CU", "I2V_KGROUPS", "I2V_WGRAD_ORDERED_GFLOP", "I2V_WINO_ROWS")
+            "I2V_WGRAD_FUSED_TILE", "I2V_WGRAD_PER_CU", "I2V_KGROUPS", "I2V_WGRAD_ORDERED_GFLOP", "I2V_WINO_ROWS", "I2V_GEMM_DMA")
 for _name, _key in TUNE.items():
     if _name not in ENV_TUNE and not EXPERIMENTS:
         continue

@@ -725,7 +725,23 @@ conv_igemm_f32(const ConvP p_in) {
 // its own, the groups' partial tiles meet in LDS (register order, conflict-free 16-byte rows) and group 0 adds them IN GROUP
 // ORDER ((p0 + p1) + p2) + p3 -- deterministic -- and runs the one fused epilogue.  Same waves per SIMD as four co-resident
 // split workgroups, no partial ever leaves the CU, no arrival counter.  K must be a multiple of KG x 32 (the host checks).
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool CLK = false, bool MASK = false, bool X3 = false, int KG = 1>
+// STG (round 6): how a stage reaches LDS.  0: global -> VGPR -> ds_write_b128 (rounds 2-5).  1 / 2: LDS-DMA
+// (buffer_load_dwordx4 ... lds): no staging registers, no ds_write, no LDS store-path cycles; the DMA lands lane-linear
+// (wave-uniform base + lane x 16 bytes), so the image's column swizzle rides on the SOURCE address -- each 128-byte (64-byte)
+// row piece is still one contiguous run of the operand row, its 16-byte columns permuted among the lanes that fetch it.
+// Two buffers, one raw s_barrier per stage: [vmcnt(0): my pieces of stage i have landed | barrier: everyone's have, and everyone
+// is done with the other buffer | request stage i + 1 into it | multiply stage i].  1: 32-k stages in the rounds-2-5 image
+// (128-byte rows, column ^ (row >> 1) & 7).  2: 16-k stages, 64-byte rows, column ^ (-(row >> 2)) & 3 (the four 16-lane groups of
+// a ds_read_b128 still touch 16 distinct 16-byte slots): half the LDS per workgroup, twice the barriers.  Same fragment
+// ownership, same k order per accumulator: bit-equal to STG 0 (tools/micro/gemm_lab.hip measured the forms side by side).
+// The requests are inline asm: hipcc counts a builtin LDS-DMA as a pending LDS write and drains vmcnt(0) in front of every
+// ds_read.  Its own loads (epilogue operands) may sit in the same queue: returns are in order, so an extra load can only make a
+// counted wait wait longer, never shorter.
+__device__ inline void lds_dma16(unsigned dst, unsigned voff, __amdgpu_buffer_rsrc_t r, unsigned soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(voff), "s"(r), "s"(soff) : "memory");
+}
+
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool CLK = false, bool MASK = false, bool X3 = false, int KG = 1, int STG = 0>
 __global__ void __launch_bounds__(THREADS * KG)
 conv_gemm_f32(const ConvP p_in) {
     ConvP p = p_in;
@@ -742,6 +758,8 @@ conv_gemm_f32(const ConvP p_in) {
     constexpr int A_LD = (BM * 8 + THREADS - 1) / THREADS, B_LD = (BN * 8 + THREADS - 1) / THREADS;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     static_assert(KG == 1 || (!CLK && !X3), "the K-group form has no diagnostic / bf16-split instantiation");
+    static_assert(STG == 0 || (KG == 1 && !CLK && !X3), "the LDS-DMA form is the plain 4-wave kernel");
+    constexpr int BKL = STG == 2 ? 16 : BKS;                   // k per LDS stage
     // KG > 1: the four waves of a K group synchronise among THEMSELVES between stages (an arrival counter in LDS: release,
     // add, poll, acquire) -- an s_barrier would march all 16 waves in lock step, every SIMD's four waves staging together and
     // multiplying together; free-running groups drift apart like co-resident workgroups do, one group's staging under another's
@@ -763,12 +781,12 @@ conv_gemm_f32(const ConvP p_in) {
     if constexpr (KG > 1) {
         if (threadIdx.x < KG) kcnt[threadIdx.x] = 0;
     }
-    constexpr int GROUP_FLOATS = 2 * (BM + BN) * BKS;          // one K group's two stage buffers
+    constexpr int GROUP_FLOATS = 2 * (BM + BN) * BKL;          // one K group's two stage buffers
     extern __shared__ __attribute__((aligned(16))) float smem_all[];
     const int gid = KG > 1 ? (int)(threadIdx.x >> 8) : 0;      // K group of this wave (4 waves per group)
     float* smem = smem_all + gid * GROUP_FLOATS;
-    float (*As)[BM * BKS] = reinterpret_cast<float (*)[BM * BKS]>(smem);
-    float (*Bs)[BN * BKS] = reinterpret_cast<float (*)[BN * BKS]>(smem + 2 * BM * BKS);
+    float (*As)[BM * BKL] = reinterpret_cast<float (*)[BM * BKL]>(smem);
+    float (*Bs)[BN * BKL] = reinterpret_cast<float (*)[BN * BKL]>(smem + 2 * BM * BKL);
 
     const int tid = KG > 1 ? (int)(threadIdx.x & (THREADS - 1)) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -840,13 +858,51 @@ conv_gemm_f32(const ConvP p_in) {
             }
         }
     };
+    // ---- LDS-DMA staging (STG > 0).  A stage = NP 1-KB pieces (PR rows of the A tile, then of the B tile); wave w requests
+    // pieces w, w + 4, ...  A lane's logical 16-byte column is the same for all pieces of its wave: the swizzle term of a row
+    // repeats with the piece stride (8 rows x an even piece count for the 128-byte rows; 16 rows for the 64-byte rows).
+    constexpr int PR = 256 / BKL, CPR = BKL / 4;
+    constexpr int NPA = BM / PR, NPB = BN / PR, NP = NPA + NPB, PMAX = (NP + 3) / 4, REM = NP % 4;
+    static_assert(STG == 0 || (BM % PR == 0 && BN % PR == 0 && (BKL == 16 || NPA % 2 == 0)), "whole pieces, one swizzle term per wave");
+    const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lchunk = BKL == 32 ? ((lane & 7) ^ ((wave_s * 4 + (lane >> 4)) & 7)) : ((lane & 3) ^ ((-(lane >> 4)) & 3));
+    unsigned d_vk[STG > 0 ? PMAX : 1];
+    __amdgpu_buffer_rsrc_t d_rs[STG > 0 ? PMAX : 1];
+    if constexpr (STG > 0) {
+#pragma unroll
+        for (int q = 0; q < PMAX; ++q) {
+            const int pc = q * 4 + wave_s;
+            const bool isA = pc < NPA;                                      // wave-uniform
+            const int row = (isA ? pc : pc - NPA) * PR + lane / CPR;
+            const int g = (isA ? m0 : n0) + row;
+            d_vk[q] = (pc < NP && g < (isA ? p.M : p.N)) ? ((unsigned)(g * p.K) + (unsigned)(lchunk * 4)) * 4u : INV;
+            d_rs[q] = isA ? xr : wr;
+        }
+    }
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+    auto dma_issue = [&](int k0, int S) {
+        const unsigned so = (unsigned)k0 * 4u;
+        const unsigned kinv = ~(unsigned)((k0 + lchunk * 4 - kend) >> 31) & INV;      // a partial last stage: lanes beyond kend read zeros
+        const unsigned a_dst = lds_base + (unsigned)(S * BM * BKL * 4), b_dst = lds_base + (unsigned)((2 * BM + S * BN) * BKL * 4);
+#pragma unroll
+        for (int q = 0; q < PMAX; ++q) {
+            const int pc = q * 4 + wave_s;
+            if (REM == 0 || q < PMAX - 1 || wave_s < REM)
+                lds_dma16(pc < NPA ? a_dst + (unsigned)(pc * 1024) : b_dst + (unsigned)((pc - NPA) * 1024), d_vk[q] | kinv, d_rs[q], so);
+        }
+    };
+    auto dma_wait_barrier = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my pieces of the stage have landed ...
+        __builtin_amdgcn_s_barrier();                          // ... everyone's have; and everyone is done with the other buffer
+    };
 #ifdef I2V_EXPERIMENTS
     if (p.knob > 0) {                     // experiment (I2V_TUNE_STAGGER): co-resident workgroups start ~knob kcycles apart
         const int r = (blockIdx.x >> 8) & 3;
         for (int i = 0; i < r * p.knob; ++i) __builtin_amdgcn_s_sleep(16);
     }
 #endif
-    gload(kbeg);                          // first: everything below hides behind this round trip
+    if constexpr (STG > 0) dma_issue(kbeg, 0);
+    else gload(kbeg);                     // first: everything below hides behind this round trip
 
     // Operands of the epilogue.  A lane owns channels n .. n+3 of pixel m for every fragment (i, j):
     //   m = m0 + (wm*TM + i)*16 + (lane & 15),   n = n0 + (wn*TN + j)*16 + 4*(lane >> 4)
@@ -921,18 +977,19 @@ conv_gemm_f32(const ConvP p_in) {
                 }
             return;
         }
+        auto swzl = [](int row) { return BKL == 32 ? ((row >> 1) & 7) : ((-(row >> 2)) & 3); };
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < BKL / 16; ++h) {
             float4 av[TM], bv[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int row = (wm * TM + i) * 16 + fr;
-                av[i] = *(const float4*)&As[buf][row * BKS + (((h * 4 + fg) ^ ((row >> 1) & 7)) << 2)];
+                av[i] = *(const float4*)&As[buf][row * BKL + (((h * 4 + fg) ^ swzl(row)) << 2)];
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int row = (wn * TN + j) * 16 + fr;
-                bv[j] = *(const float4*)&Bs[buf][row * BKS + (((h * 4 + fg) ^ ((row >> 1) & 7)) << 2)];
+                bv[j] = *(const float4*)&Bs[buf][row * BKL + (((h * 4 + fg) ^ swzl(row)) << 2)];
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -947,11 +1004,30 @@ conv_gemm_f32(const ConvP p_in) {
                     }
         }
     };
+    int buf = 0, k0 = kbeg;
+    if constexpr (STG > 0) {
+        for (; k0 + 2 * BKL < kend; k0 += BKL) {      // every stage but the last two
+            dma_wait_barrier();
+            dma_issue(k0 + BKL, buf ^ 1);
+            compute(buf);
+            buf ^= 1;
+        }
+        if (k0 + BKL < kend) {                        // two stages left: the last one's operands, then the residual tile
+            dma_wait_barrier();
+            dma_issue(k0 + BKL, buf ^ 1);
+            issue_res();
+            compute(buf);
+            buf ^= 1;
+        } else {
+            issue_res();
+        }
+        dma_wait_barrier();
+        compute(buf);
+    } else {
     if constexpr (KG > 1) __syncthreads();           // the arrival counters are zero (the first stage's loads are in flight)
     sstore(0);
     stage_barrier();
     if constexpr (CLK) c_t1 = __builtin_amdgcn_s_memtime();
-    int buf = 0, k0 = kbeg;
     for (; k0 + 2 * BKS < kend; k0 += BKS) {          // every stage but the last two
         gload(k0 + BKS);
         // the next stage's loads are REQUESTED here: left alone the scheduler sinks them below 35 of the stage's 40 MFMAs (shorter
@@ -976,6 +1052,7 @@ conv_gemm_f32(const ConvP p_in) {
         issue_res();
     }
     compute(buf);                                     // last stage (no barrier: nothing is staged after it)
+    }
     if constexpr (CLK) c_t2 = __builtin_amdgcn_s_memtime();
     if constexpr (KG > 1) {
         // the K groups' partial tiles meet in LDS: every group but the first leaves its accumulators in its own (now idle)
@@ -1482,6 +1559,8 @@ void launch_tile(const ConvP& p, bool spec, hipStream_t st) {
             set_max_lds(conv_gemm_f32<WAVES_M, WAVES_N, TM, TN>);
             set_max_lds(conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, true>);
             set_max_lds(conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true>);
+            set_max_lds(conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, false, false, 1, 1>);
+            set_max_lds(conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true, false, 1, 1>);
             return true;
         }();
         (void)once_g;
@@ -1506,6 +1585,19 @@ void launch_tile(const ConvP& p, bool spec, hipStream_t st) {
             return;
         }
 #endif
+        // round 6: LDS-DMA staging (I2V_TUNE_GEMM_DMA: 1 = 32-k stages, 2 = 16-k stages / half the LDS; 0 = through registers)
+        const int dma = g_i2v_tuning[I2V_TUNE_GEMM_DMA];
+        if (dma > 0 && !p.clk && !g_i2v_tuning[I2V_TUNE_GEMM_X3]) {
+            const bool mask = (p.flags & I2V_EPI_MASK) != 0;
+            if (dma == 2) {
+                if (mask) conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true, false, 1, 2><<<grid, THREADS, lds_g / 2, st>>>(p);
+                else conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, false, false, 1, 2><<<grid, THREADS, lds_g / 2, st>>>(p);
+            } else {
+                if (mask) conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true, false, 1, 1><<<grid, THREADS, lds_g, st>>>(p);
+                else conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, false, false, 1, 1><<<grid, THREADS, lds_g, st>>>(p);
+            }
+            return;
+        }
         if (p.flags & I2V_EPI_MASK) conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true><<<grid, THREADS, lds_g, st>>>(p);
         else if (p.clk) conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, true><<<grid, THREADS, lds_g, st>>>(p);
 #ifdef I2V_EXPERIMENTS

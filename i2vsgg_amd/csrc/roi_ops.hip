@@ -388,7 +388,8 @@ roi_align_bwd_row_kernel(const float* __restrict__ gout, const float* __restrict
     float* stage = rowbuf + (size_t)(W + 2) * 128;                          // [RAB_BATCH][RAB_MAXA][128]
     unsigned short* list = (unsigned short*)(stage + RAB_BATCH * RAB_MAXA * 128);   // [4][256]: wave w's hits among ITS 256 candidates,
                                                                             // (index in the segment) * 2 + (hs + 1 == h); the list = the four in wave order
-    __shared__ int s_cnt[4];
+    __shared__ int s_cnt[2][4];          // by segment parity: a segment without a hit has ONE barrier, so a fast wave may write the
+                                         // next segment's count while a slow one still reads this segment's (round-5 advice)
     __shared__ TapRec s_rec[RAB_BATCH][RAB_MAXA];
     const int PH = P7 ? 7 : PH_, PW = P7 ? 7 : PW_;
     const int AH = PH + AVG, AW = PW + AVG;
@@ -406,6 +407,7 @@ roi_align_bwd_row_kernel(const float* __restrict__ gout, const float* __restrict
     RAB_T(c_begin);
     for (int i = threadIdx.x; i < (W + 2) * 32; i += 256) ((float4*)rowbuf)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int base = 0; base < n_pairs; base += RAB_SEG) {
+        const int sp = (base / RAB_SEG) & 1;
         RAB_T(c_l0);
         // ---- the list of this segment.  Wave w looks at candidates [256 w, 256 w + 256) in four rounds and appends its hits to
         // its own quarter of the list (a ballot and a running count: no barrier); a pair of another frame is dismissed on its
@@ -433,10 +435,10 @@ roi_align_bwd_row_kernel(const float* __restrict__ gout, const float* __restrict
                 if (hit) list[256 * wave + cnt + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(2 * il + dy);
                 cnt += __popcll(m);
             }
-            if (lane == 0) s_cnt[wave] = cnt;
+            if (lane == 0) s_cnt[sp][wave] = cnt;
         }
         __syncthreads();
-        const int p1 = s_cnt[0], p2 = p1 + s_cnt[1], p3 = p2 + s_cnt[2], n = p3 + s_cnt[3];
+        const int p1 = s_cnt[sp][0], p2 = p1 + s_cnt[sp][1], p3 = p2 + s_cnt[sp][2], n = p3 + s_cnt[sp][3];
         auto entry = [&](int e) {           // the e-th listed pair: global pair index * 2 + dy
             const int w = (e >= p1) + (e >= p2) + (e >= p3);
             const int off = w == 0 ? 0 : (w == 1 ? p1 : (w == 2 ? p2 : p3));

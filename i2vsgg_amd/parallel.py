@@ -31,6 +31,15 @@ def rank():
     return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
+def any_rank(flag, device="cpu"):
+    """True on every rank when ``flag`` is true on at least one (a collective: every rank must call it).  Single process: ``flag``."""
+    if world_size() <= 1:
+        return bool(flag)
+    t = torch.tensor([1.0 if flag else 0.0], device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return bool(t.item() > 0)
+
+
 def capture_kwargs():
     """Extra arguments for ``torch.cuda.graph`` while a process group exists.  ProcessGroupNCCL's watchdog thread polls the
     events of collectives still on its list (those of the eager warm-up steps) with hipEventQuery; under the default GLOBAL

@@ -273,7 +273,8 @@ size_t  i2v_conv_split_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t 
 #define I2V_TUNE_STREAM_TILE         19   /* 1 (default): pointwise layers of at most four K stages over >= 16384 rows (HBM-bound) take the 80x64 tile whatever the cost model says; 0: cost model */
 #define I2V_TUNE_KGROUPS             20   /* 2 (round 5): the same with TWO wave groups (8 waves, two 39 KB stage regions: the workgroup shares its CU); 1 / 4: a pointwise GEMM the plan would split over K runs as one 16-wave workgroup per tile whose four wave groups split K and meet in LDS (no partial tile through memory) when one round of such tiles covers >= 70 % of the CUs: 4-10 % faster than the split across workgroups as a kernel on its own, 9 % SLOWER inside the overlapped step (a workgroup that owns a CU's LDS and registers shuts the other branches' workgroups out: profiles/r04_kgroups.txt); 0 (default): split-K across workgroups, partials through the caller's workspace */
 #define I2V_TUNE_WGRAD_ORDERED_GFLOP 21   /* a filter gradient (or a linear layer's data gradient run on that kernel) whose reduction is split takes the ORDERED finish -- partials through the caller's split workspace, summed in split order, at most 16 splits -- when the problem is below this many GFLOP (default 8: the relation head's layers; 0: never; the instance_styleD backbone's larger ones keep fp32 atomics) */
-#define I2V_TUNE_COUNT               22
+#define I2V_TUNE_GEMM_DMA            22   /* how the pointwise / plain-GEMM kernel stages its operand tiles (round 6).  0: global -> registers -> ds_write_b128 (rounds 2-5).  1: LDS-DMA (buffer_load ... lds, the column swizzle on the source address), 32-k stages, same LDS image.  2: LDS-DMA with 16-k stages (64-byte LDS rows): half the LDS per workgroup, twice the barriers.  Bit-equal results in all three */
+#define I2V_TUNE_COUNT               23
 /* Keys CONV_SPEC (> 0), STAGGER, FC_FOLD, GEMM_X3, GEMM_PERSIST, WGRAD_PRIO are experiments: I2V_ERR_UNSUPPORTED for any value
  * but "off" unless the library was built with -DI2V_EXPERIMENTS (i2v_build_flags). */
 int32_t i2v_set_tuning(int32_t key, int32_t value);

@@ -882,13 +882,37 @@ def test_pointwise_gemm_kernel_equals_generic_kernel(ops, M, K, N, res):
     x4, w4 = x.view(M, K, 1, 1), w.view(N, K, 1, 1)
     r4 = r.view(M, N, 1, 1) if res else None
     out = {}
+    from i2vsgg_amd._lib import TUNE
+    dma0, atomics0 = lib.i2v_get_tuning(TUNE["I2V_GEMM_DMA"]), lib.i2v_get_tuning(TUNE["I2V_SPLIT_ATOMICS"])
     try:
         assert lib.i2v_get_tuning(20) == 0       # I2V_KGROUPS off (the default): the split across workgroups shares the generic kernel's K cuts
         for mode in (1, 0):
             assert lib.i2v_set_tuning(10, mode) == 0
             out[mode] = ops.conv2d(x4, w4, sc, sh, r4, 1, 0, relu=True).view(M, N).clone()
+        # round 6: the three staging forms of conv_gemm_f32 (through registers / LDS-DMA with 32-k / 16-k stages) for the
+        # cost model's tile and for every forced tile: the same bits
+        assert lib.i2v_set_tuning(10, 1) == 0
+        for stg in (0, 1, 2):
+            assert lib.i2v_set_tuning(TUNE["I2V_GEMM_DMA"], stg) == 0
+            assert torch.equal(ops.conv2d(x4, w4, sc, sh, r4, 1, 0, relu=True).view(M, N), out[0]), ("staging form", stg)
+        # a forced tile has its own split-K plan (other K cuts, possibly more than four parts: ordered finish, not atomics):
+        # the forms are compared tile by tile
+        assert lib.i2v_set_tuning(TUNE["I2V_SPLIT_ATOMICS"], 0) == 0
+        for tile in range(6):
+            assert lib.i2v_conv_set_tile(tile) == 0
+            for stg in (0, 1, 2):
+                assert lib.i2v_set_tuning(TUNE["I2V_GEMM_DMA"], stg) == 0
+                got = ops.conv2d(x4, w4, sc, sh, r4, 1, 0, relu=True).view(M, N)
+                if stg == 0:
+                    first = got.clone()
+                    np.testing.assert_allclose(first.cpu().numpy(), out[0].cpu().numpy(), rtol=2e-5, atol=2e-5)
+                else:
+                    assert torch.equal(got, first), ("staging form", stg, "tile", tile)
     finally:
         lib.i2v_set_tuning(10, 1)
+        lib.i2v_set_tuning(TUNE["I2V_GEMM_DMA"], dma0)
+        lib.i2v_set_tuning(TUNE["I2V_SPLIT_ATOMICS"], atomics0)
+        lib.i2v_conv_set_tile(-1)
     assert torch.equal(out[1], out[0])
     ref = x.double() @ w.double().t() * sc.double() + sh.double()
     if res:

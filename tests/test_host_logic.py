@@ -245,6 +245,19 @@ for a, b in zip(lin.parameters(), ref.parameters()):
     assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-7), (a.grad - b.grad).abs().max()
 m = parallel.max_over_ranks(float(rk + 1), dev)
 assert m == 2.0
+# a step in which only rank 0 has a loss (trainval_sgg_emb.train_variant: the reference's `continue` is single-process):
+# every rank learns it from one all-reduced count, rank 1 takes part in the exchange with zero gradients
+for q in list(lin.parameters()) + list(ref.parameters()):
+    q.grad = None
+have = rk == 0
+assert parallel.any_rank(have) is True
+if have:
+    (torch.nn.functional.mse_loss(lin(x[lo:hi]), y[lo:hi]) / world).backward()
+parallel.all_reduce_grads(list(lin.parameters()))
+(torch.nn.functional.mse_loss(ref(x[0:4]), y[0:4]) / world).backward()
+for a, b in zip(lin.parameters(), ref.parameters()):
+    assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-7), (a.grad - b.grad).abs().max()
+assert parallel.any_rank(False) is False
 parallel.barrier()
 dist.destroy_process_group()
 print("rank", rk, "ok")

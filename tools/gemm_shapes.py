@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""The product's pointwise GEMM (i2v_conv_fwd, 1x1) on the shapes the round-6 review names, alone and as three co-running
+chains (three streams: what a step's three graph branches look like to a CU), for the cost model's tile and for every forced
+tile.  One HIP-event pair around `reps` back-to-back launches behind a blocker GEMM (alone); for the co-run the three streams
+start behind one event and the slowest stream's end is the time."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+import torch  # noqa: E402
+
+from i2vsgg_amd import ops  # noqa: E402
+from i2vsgg_amd._lib import lib  # noqa: E402
+
+DEV = "cuda:0"
+TILES = ["128x128", "128x64", "96x64", "80x64", "64x64", "32x64"]
+blocker = torch.randn(8192, 8192, device=DEV)
+
+
+def alone(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    best = 1e30
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.mm(blocker, blocker)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
+    return best
+
+
+def corun(fns, reps):
+    streams = [torch.cuda.Stream() for _ in fns]
+    best = 1e30
+    for _ in range(4):
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True)
+        ends = [torch.cuda.Event(enable_timing=True) for _ in fns]
+        torch.mm(blocker, blocker)
+        e0.record()
+        for s in streams:
+            s.wait_event(e0)
+        for _ in range(reps):
+            for s, fn in zip(streams, fns):
+                with torch.cuda.stream(s):
+                    fn()
+        for s, e in zip(streams, ends):
+            e.record(s)
+        torch.cuda.synchronize()
+        best = min(best, max(e0.elapsed_time(e) for e in ends) * 1e3 / (reps * len(fns)))
+    return best
+
+
+cases = [("4096^3", 4096, 4096, 4096, False, 10), ("layer3 conv1, 4 frames", 9576, 1024, 256, False, 30),
+         ("layer3 conv3, 2 frames (+res)", 4788, 256, 1024, True, 30), ("layer3 conv1, 2 frames", 4788, 1024, 256, False, 30),
+         ("layer3 conv3, 1 frame (+res)", 2394, 256, 1024, True, 30), ("layer3 conv1, 1 frame", 2394, 1024, 256, False, 30),
+         ("layer2 conv3, 1 frame (+res)", 9375, 128, 512, True, 30), ("layer2 conv1, 1 frame", 9375, 512, 128, False, 30)]
+only = sys.argv[1:]
+for name, M, K, N, res, reps in cases:
+    if only and not any(o in name for o in only):
+        continue
+    fl = 2.0 * M * N * K
+    ops_ = []
+    for c in range(3):
+        x = torch.randn(M, K, 1, 1, device=DEV)
+        w = torch.randn(N, K, 1, 1, device=DEV) / K ** 0.5
+        sc, sh = torch.rand(N, device=DEV) + 0.5, torch.rand(N, device=DEV)
+        r = torch.randn(M, N, 1, 1, device=DEV) if res else None
+        ctx = ops.LaunchContext(DEV)
+        ops_.append((x, w, sc, sh, r, ctx))
+
+    def make(c):
+        x, w, sc, sh, r, ctx = ops_[c]
+
+        def fn():
+            with ctx, torch.no_grad():
+                ops.conv2d(x, w, sc, sh, r, 1, 0, relu=True)
+        return fn
+    fns = [make(c) for c in range(3)]
+    print("== %s  M %d K %d N %d (%.2f GFLOP)" % (name, M, K, N, fl * 1e-9), flush=True)
+    for t in [-1] + list(range(len(TILES))):
+        lib.i2v_conv_set_tile(t if t >= 0 else -1)
+        a = alone(fns[0], reps)
+        c3 = corun(fns, reps)
+        print("   tile %-8s alone %8.2f us %6.1f TF | 3 chains %8.2f us/launch %6.1f TF" % (
+            TILES[t] if t >= 0 else "model", a, fl / a / 1e6, c3, fl / c3 / 1e6), flush=True)
+    lib.i2v_conv_set_tile(-1)

@@ -309,18 +309,26 @@ def train_variant(a, net, loader, iters_per_epoch, dev, rank, world):
             except StopIteration:
                 it_data = iter(loader)
                 data = next(it_data)
-            if not isinstance(data, (list, tuple)) or len(data) < 5:          # the loop skips items that are not lists (:206-217)
-                continue
-            # annotations are looked up by the last path component (trainval_net_SGG_emb.py:217)
-            im, info, gt, nb = data[0].to(dev), data[1].to(dev), data[2].to(dev), data[3].to(dev)
-            paths = [str(q).split("/")[-1] for q in data[4]]
-            loss = net(im, info, gt, nb, paths)
-            if not torch.is_tensor(loss):                                   # no annotated relation in the minibatch (:177-183)
+            loss = None
+            if isinstance(data, (list, tuple)) and len(data) >= 5:          # the loop skips items that are not lists (:206-217)
+                # annotations are looked up by the last path component (trainval_net_SGG_emb.py:217)
+                im, info, gt, nb = data[0].to(dev), data[1].to(dev), data[2].to(dev), data[3].to(dev)
+                paths = [str(q).split("/")[-1] for q in data[4]]
+                loss = net(im, info, gt, nb, paths)
+                if not torch.is_tensor(loss):                               # no annotated relation in the minibatch (:177-183)
+                    loss = None
+            # The reference's `continue` is a single-process one.  With several ranks the exchange is a collective: a rank
+            # without a loss still brings (zero) gradients, and the step is skipped only when NO rank has one -- every rank
+            # learns that from the same all-reduced count, so all of them take the same branch (round-5 advice)
+            if not parallel.any_rank(loss is not None, dev):
                 continue
             opt.zero_grad()
-            (loss / world).backward()
+            if loss is not None:
+                (loss / world).backward()
             parallel.all_reduce_grads(opt.params())
             opt.step()
+            if loss is None:
+                continue
             acc, n_acc = acc + float(loss), n_acc + 1
             if (it + 1) % a.disp_interval == 0 and rank == 0 and n_acc:
                 print("[session %d][epoch %2d][iter %4d/%4d] loss: %.4f, vrd_lr: %.2e, %.1f frames/s (eager, variant head)" % (
