@@ -325,15 +325,32 @@ def profile_eager(body, n_prof, dev):
     return [dict(t=e0.elapsed_time(e1) * 1e-3, flops=fl, tag=tag, desc=d, bytes=by) for e0, e1, fl, tag, d, by in rec]
 
 
-def pmc_traffic(kernel_key, names=("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json")):
-    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ for this round
-    (rocprofv3 cannot run inside the timed process); None when there is no summary."""
+def record_is_current(rec):
+    """A committed rocprofv3 summary names the kernel sources it measured (``source_digests``, rounds 6+): it is quoted only
+    while those files are the ones this library was built from.  Older records carry no digests and are quoted as they are
+    (their file name says which round's kernels they saw)."""
+    want = rec.get("source_digests")
+    if not want:
+        return True
+    from i2vsgg_amd import build as _b
+    try:
+        return _b.source_digests(sorted(want)) == want
+    except OSError:
+        return False
+
+
+def pmc_traffic(kernel_key, names=("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json")):
+    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
+    the timed process): the newest record whose kernel sources are the loaded library's; None when there is none."""
     for name in names:
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             try:
                 with open(path) as f:
-                    return json.load(f)[kernel_key]["hbm_bytes_per_launch_corrected"], "profiles/" + name
+                    rec = json.load(f)
+                if not record_is_current(rec):
+                    continue
+                return rec[kernel_key]["hbm_bytes_per_launch_corrected"], "profiles/" + name
             except Exception:
                 continue
     return None, None
@@ -351,7 +368,7 @@ def by_kind(rec, n_prof):
 # ----------------------------------------------------------------------------- the metric's second half: ROI ops / NMS
 ROI_NMS_CASES = ("roi_align_avg_fwd_1x32", "roi_align_avg_bwd_1x32", "roi_align_avg_fwd_4x32", "roi_align_avg_bwd_4x32",
                  "roi_pool_geom_fwd_2x64", "nms_12000_to_2000", "nms_6000_to_300")
-ROI_NMS_PMC = "r05_roi_nms_pmc.json"
+ROI_NMS_PMC = ("r06_roi_nms_pmc.json", "r05_roi_nms_pmc.json")
 COLD_BYTES = 512 << 20          # a rotation's working set: twice the 256 MiB Infinity Cache
 
 
@@ -451,19 +468,25 @@ def time_roi_nms_case(dev, case, blocker, reps=20):
 
 def run_roi_nms(dev, reps=20, only=None):
     """``also.roi_nms`` and the top-level ``roofline_hbm``: every case of ROI_NMS_CASES in both cache states.  Per state:
-    ``events_us`` (live, this run), and from the committed rocprofv3 passes of the SAME launches (profiles/r05_roi_nms_pmc.json,
+    ``events_us`` (live, this run), and from the committed rocprofv3 passes of the SAME launches (profiles/r06_roi_nms_pmc.json,
     tools/roi_nms_pmc.sh: >= 100 launches per pass, the first 5 dropped) ``rocprof_us``, ``traffic`` (HBM bytes per op from the
     FETCH_SIZE / WRITE_SIZE passes, corrected as the guide prescribes) and ``frac`` = algorithmic bytes / rocprof_us / 8 TB/s
     (``frac_events`` beside it; where no rocprof record exists ``frac`` falls back to the event time and ``source`` says so)."""
     import torch
-    pmc = {}
-    path = os.path.join(ROOT, "profiles", ROI_NMS_PMC)
-    if os.path.exists(path):
-        try:
-            with open(path) as f:
-                pmc = json.load(f).get("cases", {})
-        except Exception:
-            pmc = {}
+    pmc, pmc_name = {}, None
+    for cand in ROI_NMS_PMC:
+        path = os.path.join(ROOT, "profiles", cand)
+        if os.path.exists(path):
+            try:
+                with open(path) as f:
+                    rec = json.load(f)
+                # a record of OTHER kernels (roi_ops.hip / rpn.hip edited since) is not quoted: the next older record, or -- when
+                # none is current -- frac falls back to this run's events
+                if record_is_current(rec):
+                    pmc, pmc_name = rec.get("cases", {}), cand
+                    break
+            except Exception:
+                continue
     out = {}
     blocker = torch.randn(8192, 8192, device=dev)
     for name in ROI_NMS_CASES:
@@ -479,7 +502,7 @@ def run_roi_nms(dev, reps=20, only=None):
             if p:
                 st.update(rocprof_us=p["avg_us"], achieved=nbytes / p["avg_us"] / 1e3, frac=nbytes / p["avg_us"] / 1e3 / 8000.0,
                           traffic=p["hbm_bytes_corrected"], traffic_over_algorithmic=p["traffic_over_algorithmic"],
-                          source="profiles/" + ROI_NMS_PMC)
+                          source="profiles/" + pmc_name)
             else:
                 st.update(rocprof_us=None, achieved=nbytes / us / 1e3, frac=st["frac_events"], traffic=None,
                           source="HIP events of this run (no rocprofv3 record for this case)")
@@ -774,7 +797,7 @@ def run_instance_styled(a, rank, world, dev, steps, warmup, frames_per_rank=4):
     achieved = f_wg_exec / max(t_wg, 1e-12) / 1e12
     # the PMC passes of THIS configuration (tools/profile_bench.sh isd), not the headline's (whose conv_wgrad2_f32 launches
     # are the relation head's skinny GEMMs)
-    traffic, traffic_src = pmc_traffic("conv_wgrad2_f32", ("r04_instance_styled_pmc_summary.json", "r03_instance_styled_pmc_summary.json", "r02_instance_styled_pmc_summary.json"))
+    traffic, traffic_src = pmc_traffic("conv_wgrad2_f32", ("r06_instance_styled_pmc_summary.json", "r05_instance_styled_pmc_summary.json", "r04_instance_styled_pmc_summary.json", "r03_instance_styled_pmc_summary.json", "r02_instance_styled_pmc_summary.json"))
     line = {
         "metric": "frames/sec (600x1000, 32 ROI/frame)", "value": world * 2 * frames_per_rank * steps / elapsed,
         "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
@@ -1013,12 +1036,14 @@ def main():
         # the GPU box grants a CPU share (16 cores per GPU), not the whole host: never oversubscribe
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         threads = min(16, cores)
-        sec = cpu_baseline([threads])
+        second = 8 if threads > 8 else max(1, threads // 2)       # a second run at half the threads
+        sec = cpu_baseline([threads, second] if second != threads else [threads])
         try:
             stages = cpu_baseline_stages(threads)
         except Exception as e:              # noqa: BLE001 -- the end-to-end figure above stands on its own
             stages = {"error": repr(e)[:400]}
-        line["cpu_baseline"] = {"value": 1.0 / sec[threads], "unit": "frames/s", "cores": threads, "kind": "port",
+        line["cpu_baseline"] = {"value": 1.0 / sec[threads], "unit": "frames/s", "cores": threads, "threads": threads, "kind": "port",
+                                "by_threads": {str(t): {"frames_per_s": 1.0 / v, "s_per_frame": v} for t, v in sec.items()},
                                 "sample": "1 frame 600x1000: ResNet-101 C4 fwd + vrd head fwd/bwd/SGD for 32 boxes + 32 pairs; 2 "
                                           "warm-up + 5 timed, median %.2f s" % sec[threads],
                                 "stages": stages,

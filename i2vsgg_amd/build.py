@@ -43,6 +43,17 @@ def _digest():
     return h.hexdigest()
 
 
+def source_digests(files):
+    """{file: sha256[:16]} of kernel sources under csrc/: what a committed rocprofv3 summary records about the library it
+    measured, and what bench.py compares before it quotes the summary (a record of other kernels is not quoted)."""
+    import hashlib
+    out = {}
+    for f in files:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            out[f] = hashlib.sha256(fh.read()).hexdigest()[:16]
+    return out
+
+
 def _stale(digest):
     if not os.path.exists(OUT) or not os.path.exists(STAMP):
         return True

@@ -15,7 +15,10 @@ pytestmark = pytest.mark.gpu
 
 from i2vsgg_amd import synthetic as syn  # noqa: E402
 
+from conftest import record_margin  # noqa: E402
+
 DEV = "cuda:0"
+TARGET_SET_OVERLAP = 0.9     # share of the oracle's 32 target proposals the HIP model must reproduce (as a row set)
 SET = ["ANCHOR_SCALES", "[8, 16, 32]", "ANCHOR_RATIOS", "[0.5,1,2]", "MAX_NUM_GT_BOXES", "30"]
 
 
@@ -188,7 +191,8 @@ def test_instance_styled_target_half_full_size_vs_oracle(fresh_cfg):
     rois_o, _ = rpn.proposal_layer(prob[:, 9:].numpy(), box.numpy(), info, 12000, 32, 0.7)
     a = {tuple(np.round(x, 1)) for x in rois[0] if x[1:].any()}
     o = {tuple(np.round(x, 1)) for x in rois_o[0] if x[1:].any()}
-    assert len(a & o) >= 0.9 * len(o), (len(a & o), len(o))
+    record_margin("target_half_full_size_vs_oracle", "proposal set overlap (of %d)" % len(o), len(a & o) / len(o), TARGET_SET_OVERLAP)
+    assert len(a & o) >= TARGET_SET_OVERLAP * len(o), (len(a & o), len(o))
     pooled = torch.from_numpy(cops.roi_align_avg_fwd(feat.numpy(), rois.reshape(-1, 5), 7, 7, 1.0 / 16.0))      # the HIP path's own rois
     with torch.no_grad():
         d_inst_o = nets.netd_pixel(pooled, po, 0.1)

@@ -13,6 +13,9 @@ from i2vsgg_amd import synthetic as syn  # noqa: E402
 
 DEV = "cuda:0"
 REL = 1e-3
+SET_OVERLAP = 0.95      # share of the reference's proposals the HIP model must reproduce (as row sets)
+AS_SHIPPED = 1e-2       # the four sampling-dependent losses of the model as shipped (its own proposals in front of the sampler)
+from conftest import record_margin  # noqa: E402
 
 
 def test_instance_styled_source_and_target_losses_vs_oracle():
@@ -71,7 +74,8 @@ def test_instance_styled_source_and_target_losses_vs_oracle():
         for b in range(B):
             a = {tuple(np.round(x, 1)) for x in src_rois[b] if x[1:].any()}
             o = {tuple(np.round(x, 1)) for x in rois_o[b] if x[1:].any()}
-            assert len(a & o) >= 0.95 * len(o), (len(a & o), len(o))
+            record_margin("source_and_target_losses_vs_oracle", "proposal set overlap, frame %d (of %d)" % (b, len(o)), len(a & o) / len(o), SET_OVERLAP)
+            assert len(a & o) >= SET_OVERLAP * len(o), (len(a & o), len(o))
         rs = np.random.RandomState(3)
         L, T, IW, OW = rpn.anchor_target_layer(fh, fw, gt, info, rs)
         pair = cls.view(B, 2, 9 * fh, fw).permute(0, 2, 3, 1).reshape(-1, 2)
@@ -182,9 +186,11 @@ def test_instance_styled_step_vs_reference_run_golden(gold, tag, B, H, W):
             for got, ref in ((seen[0][b], g[tag + "_rpn_rois_src"][b]), (seen[1][b], g[tag + "_rpn_rois_tgt"][b])):
                 a = {tuple(np.round(x, 1)) for x in got if x[1:].any()}
                 o = {tuple(np.round(x, 1)) for x in ref if x[1:].any()}
-                assert len(a & o) >= 0.95 * len(o), (len(a & o), len(o))
-        for i in range(8):                                  # the four that depend on which rows were sampled: 1e-2 as shipped
-            tol = REL if i in (0, 1, 5, 7) else 1e-2
+                record_margin("reference_run_golden[%s]" % tag, "proposal set overlap, frame %d (of %d)" % (b, len(o)), len(a & o) / len(o), SET_OVERLAP)
+                assert len(a & o) >= SET_OVERLAP * len(o), (len(a & o), len(o))
+        for i in range(8):                                  # the four that depend on which rows were sampled: AS_SHIPPED
+            tol = REL if i in (0, 1, 5, 7) else AS_SHIPPED
+            record_margin("reference_run_golden[%s]" % tag, "as shipped: " + names[i], abs(losses[i] - want[i]) / abs(want[i]), tol)
             assert abs(losses[i] - want[i]) <= tol * abs(want[i]), (names[i], losses[i], want[i])
         as_shipped = losses
 

@@ -81,6 +81,9 @@ summary = {
     "mfma_utilisation_from_counters": {k: mfma_block(k) for k in ("conv_gemm_f32", "conv_igemm_f32", "conv_wgrad2_f32")},
     "per_kernel": per,
 }
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from i2vsgg_amd import build as _build  # noqa: E402
+summary["source_digests"] = _build.source_digests(["conv.hip", "winograd.hip"])     # bench.py quotes this record only for these kernels
 json.dump(summary, open(prefix + "_pmc_summary.json", "w"), indent=1)
 print(json.dumps({k: summary[k] for k in ("conv_gemm_f32", "conv_igemm_f32")}))
 

@@ -70,6 +70,9 @@ for log in sorted(glob.glob("%s/*.trace.log" % out)):
         "ops": N, "dropped": drop, "sets": meta["sets"], "avg_us": tot_us, "algorithmic_gbs": alg / tot_us / 1e3,
         "algorithmic_frac_of_8TBs": alg / tot_us / 1e3 / HBM_PEAK, "hbm_bytes_corrected": tot_hbm, "hbm_gbs": tot_hbm / tot_us / 1e3,
         "traffic_over_algorithmic": tot_hbm / alg, "kernels": kernels}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from i2vsgg_amd import build as _build  # noqa: E402
+res["source_digests"] = _build.source_digests(["roi_ops.hip", "rpn.hip"])      # bench.py quotes this record only for these kernels
 json.dump(res, open(dest, "w"), indent=1)
 for case, states in res["cases"].items():
     for state in ("warm", "cold"):
