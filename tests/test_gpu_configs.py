@@ -18,7 +18,7 @@ from i2vsgg_amd import synthetic as syn  # noqa: E402
 from conftest import record_margin  # noqa: E402
 
 DEV = "cuda:0"
-TARGET_SET_OVERLAP = 0.9     # share of the oracle's 32 target proposals the HIP model must reproduce (as a row set)
+TARGET_SET_OVERLAP = 30 / 32     # of the oracle's 32 target proposals at most two may differ (observed 31 / 32: profiles/r06_parity_margins.txt; rounds 1-5: 0.9)
 SET = ["ANCHOR_SCALES", "[8, 16, 32]", "ANCHOR_RATIOS", "[0.5,1,2]", "MAX_NUM_GT_BOXES", "30"]
 
 

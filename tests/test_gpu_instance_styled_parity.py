@@ -13,8 +13,20 @@ from i2vsgg_amd import synthetic as syn  # noqa: E402
 
 DEV = "cuda:0"
 REL = 1e-3
-SET_OVERLAP = 0.95      # share of the reference's proposals the HIP model must reproduce (as row sets)
-AS_SHIPPED = 1e-2       # the four sampling-dependent losses of the model as shipped (its own proposals in front of the sampler)
+# Bounds of the loose comparisons, set from what one run records (profiles/r06_parity_margins.txt; the tests append what they see
+# to gpurun_out/parity_margins.txt on every run): proposal sets of 1000-2000 rows overlap 0.9883-0.9967 -> 0.98 (a margin of
+# 0.008: ~16 swapped near-ties of 2000); the 32-row target sets 31/32-32/32 -> at most TWO rows may differ; the four
+# sampling-dependent losses of the model as shipped deviate <= 4.1e-6 (the sampled rows coincide) -> north_star's 1e-3, like
+# the other four (rounds 1-5 allowed 1e-2 and 0.95 / 0.90 without knowing the actual values).
+SET_OVERLAP = 0.98
+AS_SHIPPED = 1e-3
+
+
+def min_overlap(n):
+    """Rows of an n-row reference proposal set the HIP model must reproduce."""
+    return SET_OVERLAP * n if n >= 500 else n - 2
+
+
 from conftest import record_margin  # noqa: E402
 
 
@@ -74,8 +86,8 @@ def test_instance_styled_source_and_target_losses_vs_oracle():
         for b in range(B):
             a = {tuple(np.round(x, 1)) for x in src_rois[b] if x[1:].any()}
             o = {tuple(np.round(x, 1)) for x in rois_o[b] if x[1:].any()}
-            record_margin("source_and_target_losses_vs_oracle", "proposal set overlap, frame %d (of %d)" % (b, len(o)), len(a & o) / len(o), SET_OVERLAP)
-            assert len(a & o) >= SET_OVERLAP * len(o), (len(a & o), len(o))
+            record_margin("source_and_target_losses_vs_oracle", "proposal set overlap, frame %d (of %d)" % (b, len(o)), len(a & o) / len(o), min_overlap(len(o)) / len(o))
+            assert len(a & o) >= min_overlap(len(o)), (len(a & o), len(o))
         rs = np.random.RandomState(3)
         L, T, IW, OW = rpn.anchor_target_layer(fh, fw, gt, info, rs)
         pair = cls.view(B, 2, 9 * fh, fw).permute(0, 2, 3, 1).reshape(-1, 2)
@@ -186,9 +198,9 @@ def test_instance_styled_step_vs_reference_run_golden(gold, tag, B, H, W):
             for got, ref in ((seen[0][b], g[tag + "_rpn_rois_src"][b]), (seen[1][b], g[tag + "_rpn_rois_tgt"][b])):
                 a = {tuple(np.round(x, 1)) for x in got if x[1:].any()}
                 o = {tuple(np.round(x, 1)) for x in ref if x[1:].any()}
-                record_margin("reference_run_golden[%s]" % tag, "proposal set overlap, frame %d (of %d)" % (b, len(o)), len(a & o) / len(o), SET_OVERLAP)
-                assert len(a & o) >= SET_OVERLAP * len(o), (len(a & o), len(o))
-        for i in range(8):                                  # the four that depend on which rows were sampled: AS_SHIPPED
+                record_margin("reference_run_golden[%s]" % tag, "proposal set overlap, frame %d (of %d)" % (b, len(o)), len(a & o) / len(o), min_overlap(len(o)) / len(o))
+                assert len(a & o) >= min_overlap(len(o)), (len(a & o), len(o))
+        for i in range(8):                                  # the four that depend on which rows were sampled: AS_SHIPPED (1e-3 too)
             tol = REL if i in (0, 1, 5, 7) else AS_SHIPPED
             record_margin("reference_run_golden[%s]" % tag, "as shipped: " + names[i], abs(losses[i] - want[i]) / abs(want[i]), tol)
             assert abs(losses[i] - want[i]) <= tol * abs(want[i]), (names[i], losses[i], want[i])

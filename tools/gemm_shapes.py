@@ -68,8 +68,10 @@ for name, M, K, N, res, reps in cases:
     fl = 2.0 * M * N * K
     ops_ = []
     for c in range(3):
-        x = torch.randn(M, K, 1, 1, device=DEV)
-        w = torch.randn(N, K, 1, 1, device=DEV) / K ** 0.5
+        # uniform [-1, 1) operands, the convention of /opt/skills/guides (what the lab uses too): the clock the chip holds
+        # depends on the data, so rates measured on other distributions do not compare
+        x = torch.rand(M, K, 1, 1, device=DEV) * 2 - 1
+        w = torch.rand(N, K, 1, 1, device=DEV) * 2 - 1
         sc, sh = torch.rand(N, device=DEV) + 0.5, torch.rand(N, device=DEV)
         r = torch.randn(M, N, 1, 1, device=DEV) if res else None
         ctx = ops.LaunchContext(DEV)

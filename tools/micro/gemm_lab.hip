@@ -29,6 +29,7 @@ struct GP {
     const float* a; const float* w; float* y;
     int M, N, K, k_per_split;
     unsigned a_bytes, w_bytes;
+    unsigned long long* clk;        // non-null: per workgroup {prologue, K loop, epilogue} shader cycles + {start, end} in 100 MHz ticks
 };
 
 template <int N> __device__ inline void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -37,6 +38,19 @@ template <int N> __device__ inline void wait_vm() { asm volatile("s_waitcnt vmcn
 __device__ inline void dma16(unsigned dst, unsigned voff, __amdgpu_buffer_rsrc_t r, unsigned soff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
+
+struct Stamp {
+    unsigned long long t0, t1, t2, r0;
+    __device__ inline void begin(const GP& p) { if (p.clk) { r0 = __builtin_amdgcn_s_memrealtime(); t0 = __builtin_amdgcn_s_memtime(); } }
+    __device__ inline void loop(const GP& p) { if (p.clk) t1 = __builtin_amdgcn_s_memtime(); }
+    __device__ inline void done(const GP& p) { if (p.clk) t2 = __builtin_amdgcn_s_memtime(); }
+    __device__ inline void end(const GP& p) {
+        if (p.clk && threadIdx.x == 0) {
+            unsigned long long* o = p.clk + 8 * ((size_t)blockIdx.y * gridDim.x + blockIdx.x);
+            o[0] = t1 - t0; o[1] = t2 - t1; o[2] = __builtin_amdgcn_s_memtime() - t2; o[3] = r0; o[4] = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+};
 
 __device__ inline int xcd_tile() {
     const int nt = gridDim.x, q = nt >> 3, r = nt & 7, x = blockIdx.x & 7, i = blockIdx.x >> 3;
@@ -60,6 +74,8 @@ template <int WM, int WN, int TM, int TN>
 __global__ void __launch_bounds__(THREADS) gemm_r(const GP p) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     constexpr int A_LD = (BM * 8 + THREADS - 1) / THREADS, B_LD = (BN * 8 + THREADS - 1) / THREADS;
+    Stamp st;
+    st.begin(p);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float (*As)[BM * BKS] = reinterpret_cast<float (*)[BM * BKS]>(smem);
     float (*Bs)[BN * BKS] = reinterpret_cast<float (*)[BN * BKS]>(smem + 2 * BM * BKS);
@@ -137,6 +153,7 @@ __global__ void __launch_bounds__(THREADS) gemm_r(const GP p) {
     gload(kbeg);
     sstore(0);
     __syncthreads();
+    st.loop(p);
     int buf = 0, k0 = kbeg;
     for (; k0 + BKS < kend; k0 += BKS) {
         gload(k0 + BKS);
@@ -147,7 +164,9 @@ __global__ void __launch_bounds__(THREADS) gemm_r(const GP p) {
         buf ^= 1;
     }
     compute(buf);
+    st.done(p);
     store_tile<WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, fr, fg);
+    st.end(p);
 }
 
 // ------------------------------------------------------------------ D: LDS-DMA ring
@@ -168,6 +187,8 @@ __device__ __forceinline__ void gemm_d_body(const GP& p) {
     constexpr int H = BK / 16;                                     // 16-k halves per stage
     static_assert(BM % PR == 0 && BN % PR == 0, "whole pieces");
     static_assert(NBUF >= 2 && (FP != 2 || NBUF >= 3), "the early-publish form needs three buffers");
+    Stamp st;
+    st.begin(p);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -245,6 +266,8 @@ __device__ __forceinline__ void gemm_d_body(const GP& p) {
     };
 #pragma unroll
     for (int s = 0; s < D; ++s) issue(s);
+    wait_keep(std::integral_constant<int, D - 1>{});      // (the loop's first wait, taken here so that the K-loop stamp starts with stage 0 in LDS)
+    st.loop(p);
     float4 a0[TM], b0[TN], a1[TM], b1[TN];
     if constexpr (FP < 2) {
         for (int i = 0; i < nst; ++i) {
@@ -303,8 +326,10 @@ __device__ __forceinline__ void gemm_d_body(const GP& p) {
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    st.done(p);
     wait_vm<0>();            // the out-of-range requests of the tail have landed before the LDS goes back
     store_tile<WM, WN, TM, TN>(p, acc, m0, n0, wm, wn, fr, fg);
+    st.end(p);
 }
 
 template <int WM, int WN, int TM, int TN, int NBUF, int FP, int BK>
@@ -413,6 +438,7 @@ int main(int argc, char** argv) {
             const int ksteps = sh.K / BKS;
             p.k_per_split = ((ksteps + sh.splitk - 1) / sh.splitk) * BKS;
             p.a_bytes = (unsigned)(an * 4); p.w_bytes = (unsigned)(wn * 4);
+            p.clk = nullptr;
             return p;
         };
         auto grid = [&](const Variant& v) { return dim3(((sh.M + v.bm - 1) / v.bm) * ((sh.N + v.bn - 1) / v.bn), sh.splitk, 1); };
@@ -479,6 +505,50 @@ int main(int argc, char** argv) {
                 }
                 if (r > 0) us3[vi].push_back(worst * 1000.f / (3 * reps));
             }
+        // stamped passes (their own launches, never timed): one launch alone; one launch of chain 0 while chains 1 and 2 run the
+        // same kernel beside it.  Per workgroup: prologue / K loop / epilogue shader cycles; medians over the workgroups
+        std::vector<std::string> stamp_txt(vs.size());
+        {
+            unsigned long long* dclk;
+            const size_t maxwg = 1 << 16;
+            CK(hipMalloc(&dclk, maxwg * 8 * sizeof(unsigned long long)));
+            std::vector<unsigned long long> hc(maxwg * 8);
+            for (size_t vi = 0; vi < vs.size(); ++vi) {
+                const auto& v = vs[vi];
+                const dim3 g = grid(v);
+                const size_t nwg = (size_t)g.x * g.y;
+                if (nwg > maxwg) continue;
+                char buf[512]; std::string txt;
+                for (int mode = 0; mode < 2; ++mode) {
+                    CK(hipDeviceSynchronize());
+                    CK(hipMemset(dclk, 0, nwg * 8 * sizeof(unsigned long long)));
+                    if (mode == 1)
+                        for (int i = 0; i < 6; ++i)
+                            for (int c = 1; c < 3; ++c) { GP q = params(v, c); hipLaunchKernelGGL(v.fn, g, dim3(THREADS), v.lds, st[c], q); }
+                    GP p = params(v, 0);
+                    if (mode == 1) for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(v.fn, g, dim3(THREADS), v.lds, st[0], p);
+                    p.clk = dclk;
+                    hipLaunchKernelGGL(v.fn, g, dim3(THREADS), v.lds, st[0], p);
+                    CK(hipDeviceSynchronize());
+                    CK(hipMemcpy(hc.data(), dclk, nwg * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                    std::vector<double> pro, loop, epi;
+                    unsigned long long r0 = ~0ull, r1 = 0;
+                    for (size_t w = 0; w < nwg; ++w) {
+                        pro.push_back((double)hc[8 * w]); loop.push_back((double)hc[8 * w + 1]); epi.push_back((double)hc[8 * w + 2]);
+                        r0 = std::min(r0, hc[8 * w + 3]); r1 = std::max(r1, hc[8 * w + 4]);
+                    }
+                    auto med = [](std::vector<double>& x) { std::sort(x.begin(), x.end()); return x[x.size() / 2]; };
+                    const int ksteps = sh.K / BKS;
+                    const int stages32 = (ksteps + sh.splitk - 1) / sh.splitk;       // 32-k stages per workgroup
+                    const double lp = med(loop);
+                    snprintf(buf, sizeof buf, " | %s: prologue %5.0f loop %6.0f (%5.0f per 32 k) epilogue %5.0f cyc, span %5.1f us",
+                             mode ? "beside 2 chains" : "alone", med(pro), lp, lp / stages32, med(epi), (double)(r1 - r0) / 100.0);
+                    txt += buf;
+                }
+                stamp_txt[vi] = txt;
+            }
+            CK(hipFree(dclk));
+        }
         for (size_t vi = 0; vi < vs.size(); ++vi) {
             auto& u = us[vi];
             std::sort(u.begin(), u.end());
@@ -487,6 +557,7 @@ int main(int argc, char** argv) {
             const float med = u[u.size() / 2], mn = u[0], c3 = u3[0];
             printf("   %-16s med %8.2f us  min %8.2f us  %6.1f TF | 3 chains: %8.2f us/launch %6.1f TF | %s\n", vs[vi].name.c_str(), med, mn,
                    flop / med * 1e-6, c3, flop / c3 * 1e-6, equal[vi] ? "bit-equal" : "MISMATCH");
+            if (!stamp_txt[vi].empty()) printf("   %-16s stamps%s\n", "", stamp_txt[vi].c_str());
         }
         for (int c = 0; c < 3; ++c) { CK(hipFree(da[c])); CK(hipFree(dw[c])); CK(hipFree(dy[c])); }
         CK(hipFree(dref));
