@@ -53,12 +53,14 @@ def capture_kwargs():
 
 
 def wait_for_collectives(device):
-    """Before a capture: every collective launched so far has finished AND has left the watchdog's work list (it drops a
-    finished work on its next pass, every ~100 ms)."""
+    """Before a capture: every collective launched so far has finished (a device synchronisation).  Round 5 also slept 0.3 s
+    here so that the watchdog had dropped the finished works from its list -- a guess about its polling period.  It is not
+    needed: what made the watchdog's ``hipEventQuery`` an error was the GLOBAL capture mode, and every capture made while a
+    process group exists runs THREAD_LOCAL (``capture_kwargs``), under which a query from the watchdog's thread is legal
+    whenever it comes; the works it may still hold after the synchronisation are complete, so the query has nothing to wait
+    for either."""
     if dist.is_available() and dist.is_initialized() and device.type == "cuda":
-        import time
         torch.cuda.synchronize(device)
-        time.sleep(0.3)
 
 
 def init_from_env(backend=None):
@@ -134,6 +136,82 @@ def all_reduce_grads_finish(token):
 def all_reduce_grads(params, group=None):
     """Sum-all-reduce ``p.grad`` of every parameter (loss was pre-scaled by 1/world)."""
     all_reduce_grads_finish(all_reduce_grads_start(params, group))
+
+
+# ---- the detector step's exchange in buckets, each issued as soon as its gradients exist (round 6) ---------------------------
+# nn.DataParallel reduces inside backward() (trainval_net_instance_styleD_bilinear.py:200-201, :324-333); rounds 1-5 issued ONE
+# all-reduce of the 202 MB after the whole backward and the join of the step's two branches -- all of it exposed.  The
+# parameters are cut into a few buckets in BACKWARD order (heads + layer4 + RPN first, layer3 in slices, the early layers
+# last); a bucket's sum over the step's branches and its all-reduce are queued on an exchange stream behind the points at
+# which each branch has produced the bucket's last gradient, so the exchange of bucket k runs beside the backward of the
+# layers below it.  Every rank issues the same collectives in the same order (the bucket list is a function of the parameter
+# names only; a parameter without a gradient contributes zeros).
+
+class BucketMarks:
+    """Where, on a branch's stream, each bucket's gradients are complete: a parameter's hook calls ``hit(bucket)``, which
+    records an event on the current stream (the last record of a bucket stands).  On the CPU (gloo rehearsal) there is no
+    stream to mark: the bucket is only noted."""
+
+    def __init__(self, cuda):
+        self.cuda, self.events, self.order = bool(cuda), {}, []
+
+    def hit(self, bucket):
+        if bucket not in self.events:
+            self.order.append(bucket)
+        ev = None
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+        self.events[bucket] = ev
+
+
+def exchange_in_buckets(params, buckets, grad_sets, marks=(), stream=None, group=None):
+    """``buckets``: lists of indices into ``params`` in backward order.  ``grad_sets``: one gradient tuple per branch (``None``
+    where a branch has no gradient for a parameter).  Per bucket, in order: wait (on ``stream``, if given: the current stream is
+    expected to BE it) for every branch's mark of the bucket, add the branches' gradients into ``p.grad``, start the all-reduce.
+    The caller finishes with ``all_reduce_grads_finish`` on every returned token (``finish_buckets``)."""
+    tokens = []
+    for k, idx in enumerate(buckets):
+        if stream is not None:
+            for m in marks:
+                ev = m.events.get(k)
+                if ev is not None:
+                    stream.wait_event(ev)
+        first, rest_a, rest_b = [], [], []
+        for i in idx:
+            gs = [g[i] for g in grad_sets if g[i] is not None]
+            params[i].grad = gs[0] if gs else None
+            for extra in gs[1:]:
+                rest_a.append(gs[0]); rest_b.append(extra)
+        if rest_a:
+            torch._foreach_add_(rest_a, rest_b)
+        tokens.append(all_reduce_grads_start([params[i] for i in idx], group))
+    return tokens
+
+
+def finish_buckets(tokens):
+    for t in tokens:
+        all_reduce_grads_finish(t)
+
+
+def detector_buckets(names, slices=3):
+    """Bucket id per parameter name of the instance_styleD detector, in backward order: 0 = everything above layer3 (the
+    layer4 head, classifier, box regressor, netD_pixel, the RPN), 1 .. ``slices`` = layer3 (``RCNN_base.6.<block>``) from its
+    last block down, ``slices`` + 1 = the rest (layer2, layer1, netD_style, context heads).  -> (ids, number of buckets)."""
+    import re
+    blocks = sorted({int(m.group(1)) for n in names for m in [re.match(r"RCNN_base\.6\.(\d+)\.", n)] if m})
+    nb = len(blocks)
+    ids = []
+    for n in names:
+        m = re.match(r"RCNN_base\.6\.(\d+)\.", n)
+        if m and nb:
+            pos = nb - 1 - blocks.index(int(m.group(1)))            # 0 = the last block (first in the backward)
+            ids.append(1 + min(slices - 1, pos * slices // nb))
+        elif n.startswith(("RCNN_top.", "RCNN_cls_score.", "RCNN_bbox_pred.", "netD_pixel.", "RCNN_rpn.")):
+            ids.append(0)
+        else:
+            ids.append(slices + 1)
+    return ids, slices + 2
 
 
 # ---- tensor parallelism for the one layer where data parallelism is the wrong cut --------------------------------

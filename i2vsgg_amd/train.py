@@ -1175,6 +1175,15 @@ class InstanceStyleDStep:
         if stage_synthetic:           # a loop fed by data loaders stages its own first minibatch (``stage_batch``)
             self.reseed(seed)
         self.opt = make_optimizer(optimizer, list(net.named_parameters()), lr)
+        # the gradient exchange in buckets (parallel.exchange_in_buckets; only when an exchange exists): bucket of every
+        # parameter, and a hook per parameter that marks, on the stream its gradient was produced on, where its bucket stands
+        ids, _ = parallel.detector_buckets([it["name"] for it in self.opt.items])
+        used = sorted(set(ids))
+        self._buckets = [[i for i, b in enumerate(ids) if b == k] for k in used]
+        self._marks = None            # the parallel.BucketMarks of the branch whose backward is being queued
+        for i, p in enumerate(self.opt.params()):
+            p.register_hook(lambda g, k=used.index(ids[i]): self._bucket_hit(k))
+        self._exchange_stream = ops.role_stream(self.dev, "exchange") if self.dev.type == "cuda" else None
         # total, det = the four detection losses summed, the four discriminator terms (trainval_net_instance...:276-296), then the
         # four detection losses one by one (rpn_loss_cls, rpn_loss_box, RCNN_loss_cls, RCNN_loss_bbox: :276-279)
         self.names = ["total", "det", "dloss_s", "dloss_t", "dloss_s_style", "dloss_t_style"] + \
@@ -1361,22 +1370,45 @@ class InstanceStyleDStep:
             v["_tgt"] = part
             return {k: t.detach() for k, t in v.items()}, g
 
-        with ops.branch(s_src, main), self.ctx_src:
-            v, grads["s"] = source()
-            vals.update(v)
-        with ops.branch(s_tgt, main), self.ctx_tgt:
-            v, grads["t"] = target()
-            vals.update(v)
-        ops.join(main, s_src, s_tgt)
-        both = [(a, b) for a, b in zip(grads["s"], grads["t"]) if a is not None and b is not None]
-        if both:
-            torch._foreach_add_([a for a, _ in both], [b for _, b in both])
-        for p, a, b in zip(params, grads["s"], grads["t"]):
-            p.grad = a if a is not None else b
+        exchange = parallel.exchange_enabled()
+        marks = {}
+        try:
+            with ops.branch(s_src, main), self.ctx_src:
+                self._marks = marks["s"] = parallel.BucketMarks(True) if exchange else None
+                v, grads["s"] = source()
+                vals.update(v)
+            with ops.branch(s_tgt, main), self.ctx_tgt:
+                self._marks = marks["t"] = parallel.BucketMarks(True) if exchange else None
+                v, grads["t"] = target()
+                vals.update(v)
+        finally:
+            self._marks = None
+        if exchange:
+            # Round 6: the exchange is a THIRD branch of the step graph.  Bucket k (backward order: heads + layer4 + RPN, layer3
+            # in three slices, the early layers) is summed over the two domains and all-reduced as soon as BOTH branches have
+            # queued its last gradient -- an event edge from each -- so the 80 MB of bucket 0 cross xGMI beside the backward of
+            # layer3, each layer3 slice beside the next, and only the last bucket (layer2 / layer1 / netD_style, ~10 MB) is
+            # exposed.  Rounds 1-5: one all-reduce of all 202 MB after the join.
+            s_x = self._exchange_stream
+            with ops.branch(s_x, main):
+                tokens = parallel.exchange_in_buckets(params, self._buckets, [grads["s"], grads["t"]], (marks["s"], marks["t"]), s_x)
+                parallel.finish_buckets(tokens)
+            ops.join(main, s_src, s_tgt, s_x)
+        else:
+            ops.join(main, s_src, s_tgt)
+            both = [(a, b) for a, b in zip(grads["s"], grads["t"]) if a is not None and b is not None]
+            if both:
+                torch._foreach_add_([a for a, _ in both], [b for _, b in both])
+            for p, a, b in zip(params, grads["s"], grads["t"]):
+                p.grad = a if a is not None else b
         vals["total"] = vals.pop("_src") + vals.pop("_tgt")
-        parallel.all_reduce_grads(params)
         self.opt.step()
         self._loss_buf.copy_(torch.stack([vals[k].detach().reshape(()) for k in self.names]))
+
+    def _bucket_hit(self, k):
+        m = self._marks
+        if m is not None:
+            m.hit(k)
 
     def _device_sampling(self, on):
         atl = self.net.RCNN_rpn.RPN_anchor_target
