@@ -1183,7 +1183,6 @@ class InstanceStyleDStep:
         self._marks = None            # the parallel.BucketMarks of the branch whose backward is being queued
         for i, p in enumerate(self.opt.params()):
             p.register_hook(lambda g, k=used.index(ids[i]): self._bucket_hit(k))
-        self._exchange_stream = ops.role_stream(self.dev, "exchange") if self.dev.type == "cuda" else None
         # total, det = the four detection losses summed, the four discriminator terms (trainval_net_instance...:276-296), then the
         # four detection losses one by one (rpn_loss_cls, rpn_loss_box, RCNN_loss_cls, RCNN_loss_bbox: :276-279)
         self.names = ["total", "det", "dloss_s", "dloss_t", "dloss_s_style", "dloss_t_style"] + \
@@ -1384,16 +1383,17 @@ class InstanceStyleDStep:
         finally:
             self._marks = None
         if exchange:
-            # Round 6: the exchange is a THIRD branch of the step graph.  Bucket k (backward order: heads + layer4 + RPN, layer3
-            # in three slices, the early layers) is summed over the two domains and all-reduced as soon as BOTH branches have
-            # queued its last gradient -- an event edge from each -- so the 80 MB of bucket 0 cross xGMI beside the backward of
-            # layer3, each layer3 slice beside the next, and only the last bucket (layer2 / layer1 / netD_style, ~10 MB) is
-            # exposed.  Rounds 1-5: one all-reduce of all 202 MB after the join.
-            s_x = self._exchange_stream
-            with ops.branch(s_x, main):
-                tokens = parallel.exchange_in_buckets(params, self._buckets, [grads["s"], grads["t"]], (marks["s"], marks["t"]), s_x)
-                parallel.finish_buckets(tokens)
-            ops.join(main, s_src, s_tgt, s_x)
+            # Round 6: the exchange runs on the CAPTURING stream, which has nothing else to do between the fork of the two domain
+            # branches and their join.  Bucket k (backward order: heads + layer4 + RPN, layer3 in three slices, the early layers)
+            # is summed over the two domains and all-reduced as soon as BOTH branches have queued its last gradient -- an event
+            # edge from each -- so the 80 MB of bucket 0 cross xGMI beside the backward of layer3, each layer3 slice beside the
+            # next, and only the last bucket (layer2 / layer1 / netD_style, ~10 MB) is exposed.  Rounds 1-5: one all-reduce of
+            # all 202 MB after the join.  (Not a third forked branch: RCCL runs a collective on a stream of its own forked from
+            # the issuing one, and a fork inside a forked branch ends hipStreamEndCapture in a host segfault -- DESIGN.md 5.1;
+            # the first form of this schedule died exactly so.)
+            tokens = parallel.exchange_in_buckets(params, self._buckets, [grads["s"], grads["t"]], (marks["s"], marks["t"]), main)
+            parallel.finish_buckets(tokens)
+            ops.join(main, s_src, s_tgt)
         else:
             ops.join(main, s_src, s_tgt)
             both = [(a, b) for a, b in zip(grads["s"], grads["t"]) if a is not None and b is not None]
