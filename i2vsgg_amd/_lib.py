@@ -63,7 +63,8 @@ SIGNATURES = {
     "i2v_conv_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "i2v_conv_wgrad": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _z, _p]),
     "i2v_conv_dgrad_fused": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p, _z, _p, _z, _p]),
-    "i2v_conv_wgrad_scaled": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "i2v_conv_wgrad_scaled": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p, _z, _p]),
+    "i2v_ordered_fallbacks": (_i, [_i]),
     "i2v_conv3x3_winograd4_dgrad": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p, _z, _p]),
     "i2v_conv3x3_winograd4_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "i2v_conv3x3_winograd4_wgrad": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _z, _p]),

@@ -1483,6 +1483,7 @@ unsigned long long* g_clk = nullptr;   // i2v_conv_debug_clock()
 // partial tiles].  The counters must be zero before the first launch that uses the workspace; every launch leaves them
 // zero again (the last workgroup to arrive at a tile resets its counter).  Launches that share a workspace must be
 // ordered on the device (same stream, or graph edges): two concurrently running launches need two workspaces.
+static int g_ordered_fallbacks = 0;      // i2v_ordered_fallbacks(): reductions asked to be ordered that ran on fp32 atomics
 constexpr int kSplitCounters = 1024;
 constexpr size_t kSplitCounterBytes = sizeof(int) * kSplitCounters;
 
@@ -1735,6 +1736,7 @@ int run_conv(ConvP p, hipStream_t st, void* split_ws = nullptr, size_t split_ws_
     const bool in_kernel = wants_ws && split_ws && kSplitCounterBytes + ws_need <= split_ws_bytes;
     // dry == 1: 0 = y needs no clear (no split, or the split is finished in-kernel), else the split factor
     if (p.dry) return (p.splitk > 1 && !in_kernel) ? p.splitk : 0;
+    if (p.splitk > 1 && !in_kernel && g_split_atomics == 0) ++g_ordered_fallbacks;      // order was asked for; the workspace (or a size cap) refused
     if (in_kernel) {
         p.cnt = reinterpret_cast<int*>(split_ws);
         p.ws = reinterpret_cast<float*>(static_cast<char*>(split_ws) + kSplitCounterBytes);
@@ -1840,6 +1842,12 @@ struct WgP {
     // order by the last workgroup to arrive at the tile's counter (the protocol of conv_igemm_f32's split-K finish): the sum
     // does not depend on arrival order, no clear of gw in front.  ord_ws == NULL: fp32 atomics into a cleared gw.
     float* ord_ws; int* ord_cnt; int ord_splits, ord_tiles, ord_acc;      // ord_acc: gw += sum (beta = 1) instead of gw = sum
+    // two-pass ordered finish (round 6): a split of MORE parts than one finisher should read (or of the first-generation kernel,
+    // which has no in-kernel finish): every split stores its partial filter in gw's own layout at part_ws[(split * planes + plane)
+    // * N * K ...] with plain stores, and a reduce pass (wgrad_reduce_kernel, or the Winograd filter gradient's final transform)
+    // sums the parts in split order.  No counter, no clear of gw, all of the chip reads the parts.
+    float* part_ws;
+    int part_cap;                          // a caller-owned part_ws (launch_wgrad's ext_part): the parts it has room for
 };
 
 template <int BM, int BN>   // BM over n (Cout), BN over k; 4 waves as 2x2, 64x64 tiles: BM=BN=64 -> wave 32x32
@@ -1947,6 +1955,8 @@ conv_wgrad_f32(const WgP p) {
                         p.gw[o] = pv - p.lr * mv;
                     } else if (p.direct) {
                         p.gw[o] = acc[i][j][r];
+                    } else if (p.part_ws) {
+                        p.part_ws[(long long)blockIdx.y * p.N * p.K + o] = acc[i][j][r];
                     } else {
                         atomicAdd(p.gw + o, acc[i][j][r]);
                     }
@@ -2319,6 +2329,15 @@ conv_wgrad2_f32(const WgP p_in) {
                 *(float4*)(p.gw + o) = g;
             }
         }
+    } else if (p.part_ws) {
+        // ---- two-pass ordered finish: my partial tile in gw's layout, slot (split, plane); the reduce pass sums the slots in order
+        float* dst = p.part_ws + ((long long)by * (p.nbatch > 1 ? p.nbatch : 1) + bz) * ((long long)p.N * p.K);
+        for (int e = tid; e < BMW * (BNW / 4); e += THREADS) {
+            const int row = e / (BNW / 4), col = (e % (BNW / 4)) * 4;
+            const int n = n0 + row, k = k0 + col;
+            if (n >= p.N || k >= p.K) continue;                     // K % 4 == 0
+            *(float4*)(dst + (long long)n * p.K + k) = *(const float4*)&smem[row * CROW + col];
+        }
     } else if (p.ord_ws) {
         // ---- ordered finish: my partial tile to the workspace (sc1: coherent across the XCDs without fences), arrival count,
         // the last workgroup of the tile sums the partials in split order -- four in flight per round -- and writes gw
@@ -2353,14 +2372,14 @@ conv_wgrad2_f32(const WgP p_in) {
                 const float4 mine4 = *(const float4*)&smem[row * CROW + col];
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (p.ord_acc) v = *(const float4*)(p.gw + o);
-                for (int s0 = 0; s0 < nsplit; s0 += 4) {
-                    float4 u[4];
+                for (int s0 = 0; s0 < nsplit; s0 += 8) {               // eight parts in flight (round 5: four -- twice the round trips)
+                    float4 u[8];
 #pragma unroll
-                    for (int sp = 0; sp < 4; ++sp)
+                    for (int sp = 0; sp < 8; ++sp)
                         u[sp] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
                             wsr, (s0 + sp < nsplit && s0 + sp != my) ? off + (unsigned)((s0 + sp) * split_stride * sizeof(float)) : 0xFFFFFFF0u, 0, SC01));
 #pragma unroll
-                    for (int sp = 0; sp < 4; ++sp) {                    // slots >= nsplit were read out of range: zeros
+                    for (int sp = 0; sp < 8; ++sp) {                    // slots >= nsplit were read out of range: zeros
                         const float4 t = s0 + sp == my ? mine4 : u[sp];
                         if (s0 == 0 && sp == 0 && !p.ord_acc) v = t;
                         else { v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
@@ -2511,6 +2530,13 @@ __global__ void __launch_bounds__(256) adam_multi_kernel(const AdamMulti t) {
 // counts its arrival, and the LAST one adds the gridDim.x partials of every column in block order -- eight in flight per round --
 // onto gbias: bit-reproducible where fp32 atomics (the workspace-free form) add in arrival order.  Every thread of the
 // workgroup must call it (barriers inside); ``live`` = the thread owns four columns.
+// Round 6: TWO LEVELS when there are more than kColsumGroup row blocks (netD_style's 37500-row projections keep their hundreds
+// of row blocks -- they must stream at full rate -- and were left on atomics): the blocks of a group of kColsumGroup meet first,
+// the group's last arriver adds the group's partials in block order and stores the group sum; the last GROUP to finish adds
+// the group sums in group order.  Nobody reads more than kColsumGroup + #groups rows, the order of every addition is fixed by
+// the block indices.  Counters: cnt[blockIdx.y * (1 + groups)] for the groups' meeting, + 1 + g for group g; rows of partials:
+// part[block] then part2 = part + gridDim.x rows: [group].
+constexpr int kColsumGroup = 32;
 __device__ inline void colsum_finish4(float4 s, int n, int N, bool live, float* __restrict__ gbias, float* part, int* cnt) {
     if (!part) {
         if (live) {
@@ -2522,33 +2548,69 @@ __device__ inline void colsum_finish4(float4 s, int n, int N, bool live, float* 
     constexpr int SC01 = 16;
     const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void*)part, 0, 0x7FFFFFF0, 0x00020000);
     const unsigned rowb = (unsigned)N * 4u, off = (unsigned)n * 4u;
-    if (live) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s), pr, blockIdx.x * rowb + off, 0, SC01);
+    const int nb = gridDim.x, my = blockIdx.x;
+    const int ngroups = (nb + kColsumGroup - 1) / kColsumGroup, grp = my / kColsumGroup;
+    const int g0 = grp * kColsumGroup, gn = min(kColsumGroup, nb - g0);          // my group: blocks g0 .. g0 + gn - 1
+    int* cbase = cnt + blockIdx.y * (1 + ngroups);
+    if (live) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, s), pr, (unsigned)my * rowb + off, 0, SC01);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     __shared__ int cs_last;
     if (threadIdx.x == 0) {
-        const int arrived = __hip_atomic_fetch_add(cnt + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = arrived == (int)gridDim.x - 1;
-        if (last) __hip_atomic_store(cnt + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int* c = ngroups > 1 ? cbase + 1 + grp : cbase;
+        const int arrived = __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = arrived == gn - 1;
+        if (last) __hip_atomic_store(c, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        cs_last = last;
+    }
+    __syncthreads();
+    if (!cs_last) return;
+    // the group's partials in block order (mine from its register); one level: onto gbias directly, as in round 5
+    float4 t = ngroups > 1 ? make_float4(0.f, 0.f, 0.f, 0.f) : (live ? *(const float4*)(gbias + n) : make_float4(0.f, 0.f, 0.f, 0.f));
+    if (live) {
+        for (int b0 = 0; b0 < gn; b0 += 8) {
+            float4 u[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                u[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                    pr, (b0 + k < gn && g0 + b0 + k != my) ? (unsigned)(g0 + b0 + k) * rowb + off : 0xFFFFFFF0u, 0, SC01));
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float4 v = g0 + b0 + k == my ? s : u[k];       // slots beyond the group were read out of range: zeros
+                t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            }
+        }
+    }
+    if (ngroups == 1) {
+        if (live) *(float4*)(gbias + n) = t;
+        return;
+    }
+    // second level: my group's sum to row (nb + grp); the last group to arrive adds the group sums in group order onto gbias
+    if (live) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t), pr, (unsigned)(nb + grp) * rowb + off, 0, SC01);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int arrived = __hip_atomic_fetch_add(cbase, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = arrived == ngroups - 1;
+        if (last) __hip_atomic_store(cbase, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         cs_last = last;
     }
     __syncthreads();
     if (!cs_last || !live) return;
-    float4 t = *(const float4*)(gbias + n);
-    const int nb = gridDim.x, my = blockIdx.x;
-    for (int b0 = 0; b0 < nb; b0 += 8) {
+    float4 r = *(const float4*)(gbias + n);
+    for (int b0 = 0; b0 < ngroups; b0 += 8) {
         float4 u[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k)
             u[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-                pr, (b0 + k < nb && b0 + k != my) ? (unsigned)(b0 + k) * rowb + off : 0xFFFFFFF0u, 0, SC01));
+                pr, (b0 + k < ngroups && b0 + k != grp) ? (unsigned)(nb + b0 + k) * rowb + off : 0xFFFFFFF0u, 0, SC01));
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const float4 v = b0 + k == my ? s : u[k];
-            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            const float4 v = b0 + k == grp ? t : u[k];
+            r.x += v.x; r.y += v.y; r.z += v.z; r.w += v.w;
         }
     }
-    *(float4*)(gbias + n) = t;
+    *(float4*)(gbias + n) = r;
 }
 
 // g_pre = gy * (y > 0); g = g_pre * scale[n]; gbias[n] += sum_m g_pre.  One streaming pass: thread = 4 columns
@@ -2631,7 +2693,7 @@ epilogue_bwd_narrow_kernel(const float* __restrict__ gy, const float* __restrict
 __global__ void __launch_bounds__(256)
 epilogue_bwd_scalar_kernel(const float* __restrict__ gy, const float* __restrict__ y, const float* __restrict__ scale,
                            float* __restrict__ g, float* __restrict__ gpre, float* __restrict__ gbias, long long M,
-                           int N, int relu, int rows_per_blk, float* __restrict__ g_t) {
+                           int N, int relu, int rows_per_blk, float* __restrict__ g_t, float* __restrict__ part) {
     const int n = blockIdx.y * 256 + threadIdx.x;
     if (n >= N) return;
     const long long r0 = (long long)blockIdx.x * rows_per_blk;
@@ -2646,14 +2708,79 @@ epilogue_bwd_scalar_kernel(const float* __restrict__ gy, const float* __restrict
         if (g) g[r * N + n] = v * sc;
         if (g_t) g_t[(long long)n * M + r] = v * sc;
     }
-    if (gbias) atomicAdd(gbias + n, s);
+    if (gbias && part) part[(long long)blockIdx.x * N + n] = s;       // ordered: the row blocks' sums side by side, added in block order by a reduce pass
+    else if (gbias) atomicAdd(gbias + n, s);
 }
 
 }  // namespace
 
 
+// Reductions that were asked to be ordered (I2V_TUNE_SPLIT_ATOMICS == 0) and fell back to fp32 atomics because the caller's
+// workspace was absent or too small (round-5 advice: the fallback was silent).  i2v_ordered_fallbacks() reads / resets it.
+extern "C" int32_t i2v_ordered_fallbacks(int32_t reset) {
+    const int n = g_ordered_fallbacks;
+    if (reset) g_ordered_fallbacks = 0;
+    return n;
+}
+
+namespace {
+// second pass of the two-pass ordered filter gradient: gw[plane][i] = (acc ? gw : 0) + part[0][plane][i] + part[1][plane][i] + ...
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ gw, int splits, int planes, long long nk4, long long bsw, int acc) {
+    const long long total = (long long)planes * nk4;
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += 256ll * gridDim.x) {
+        const long long plane = e / nk4, i = e - plane * nk4;
+        float4* o = (float4*)(gw + plane * bsw) + i;
+        float4 v = acc ? *o : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4* src = (const float4*)part + plane * nk4 + i;
+        for (int s0 = 0; s0 < splits; s0 += 8) {
+            float4 u[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) u[k] = s0 + k < splits ? src[(long long)(s0 + k) * planes * nk4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (s0 + k < splits) { v.x += u[k].x; v.y += u[k].y; v.z += u[k].z; v.w += u[k].w; }
+        }
+        *o = v;
+    }
+}
+__global__ void __launch_bounds__(256)
+wgrad_reduce_scalar_kernel(const float* __restrict__ part, float* __restrict__ gw, int splits, long long nk, int acc) {
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < nk; e += 256ll * gridDim.x) {
+        float v = acc ? gw[e] : 0.f;
+        for (int s0 = 0; s0 < splits; s0 += 16) {           // sixteen loads in flight, added in split order
+            float u[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) u[k] = s0 + k < splits ? part[(long long)(s0 + k) * nk + e] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (s0 + k < splits) v += u[k];
+        }
+        gw[e] = v;
+    }
+}
+}  // namespace
+
 // picks the kernel + pixel split for one wgrad problem; returns false when v2 cannot be used
 constexpr int kWgradOrderedMax = 16;     // most splits the ordered finish of a filter gradient sums (one workgroup reads them all)
+
+// the pixel split launch_wgrad gives an unfused problem of `planes` x (N x K) filters over M reduction rows
+static int wgrad_split_count(long long M, int N, int K, int planes, int tm, int tk, int rs) {
+    const long long tiles = (long long)i2v_cdiv(N, tm) * i2v_cdiv(K, tk), all_tiles = tiles * planes;
+    const int msteps = i2v_cdiv(M, rs), per_cu = g_i2v_tuning[I2V_TUNE_WGRAD_PER_CU];
+    int splits = (int)((long long)per_cu * NUM_CU / all_tiles);
+    if (splits < 2) splits = (int)(((long long)per_cu * NUM_CU + all_tiles - 1) / all_tiles);
+    if (splits > msteps / 4) splits = msteps / 4;
+    if (splits < 1) splits = 1;
+    return splits;
+}
+
+// (csrc/winograd.hip) the parts a 36-plane Winograd filter gradient is split into when its sum is ordered: what its workspace holds
+int i2v_internal_wgrad_plane_splits(long long T, int Cout, int Cin) {
+    const int s = wgrad_split_count(T, Cout, Cin, 36, 64, 64, BKS);
+    const int mps = i2v_cdiv(i2v_cdiv(T, BKS), s) * BKS;
+    return i2v_cdiv(T, mps);
+}
 
 static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st, void* split_ws = nullptr, size_t split_ws_bytes = 0) {
     const long long xb = (long long)p.B * p.H * p.W * p.Cin * 4, gb = (long long)p.M * p.N * 4;
@@ -2673,44 +2800,47 @@ static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st, void* s
     const int rs = v2 ? BKS : 16;
     int splits = 1;
     const int msteps = i2v_cdiv(p.M, rs);
-    if (!fused) {
-        // one round of workgroups: floor, not ceil (144 tiles x 8 splits = 1152 workgroups on 1024 slots ran 1.5 rounds)
-        const int per_cu = g_i2v_tuning[I2V_TUNE_WGRAD_PER_CU];
-        const long long all_tiles = tiles * (p.nbatch > 1 ? p.nbatch : 1);
-        splits = (int)((long long)per_cu * NUM_CU / all_tiles);
-        if (splits < 2) splits = (int)(((long long)per_cu * NUM_CU + all_tiles - 1) / all_tiles);   // more than half a round of tiles: as before
-        if (splits > msteps / 4) splits = msteps / 4;
-        if (splits < 1) splits = 1;
-    }
+    // one round of workgroups: floor, not ceil (144 tiles x 8 splits = 1152 workgroups on 1024 slots ran 1.5 rounds)
+    if (!fused) splits = wgrad_split_count(p.M, p.N, p.K, p.nbatch > 1 ? p.nbatch : 1, tm, tk, rs);
     // Ordered finish (round 5; a caller that passes its split workspace): the split of a SMALL problem (under I2V_TUNE_WGRAD_ORDERED_GFLOP = 8 GFLOP: the
     // relation head's conv_lo filters, its linear layers' data gradients), capped at kWgradOrderedMax parts, is summed in split
     // order by the tile's last workgroup instead of with atomics -- bit-reproducible, and no clear of gw.  A large one (the
     // instance_styleD backbone: up to 254 splits to fill the chip) keeps the atomics.
     const int planes = p.nbatch > 1 ? p.nbatch : 1;
-    bool ordered = false;
-    // (measured: with the backbone's 8-16-way splits ordered too, configs[2] went 46.1 -> 48.4 ms -- the finisher's serial reads
-    // are a tail on every one of ~200 launches -- so only small problems take the ordered finish)
+    // Round 6: every split a caller wants ordered IS ordered, whatever its size.  Up to kWgradOrderedMax parts of the
+    // second-generation kernel meet in the workspace as tiles and the tile's last workgroup sums them (round 5); more parts --
+    // the instance_styleD backbone splits up to 254 ways to fill the chip -- and the first-generation kernel (Cout % 4 != 0)
+    // store their partial FILTERS side by side and a reduce pass adds them in split order (part_ws; round 5 left these on
+    // atomics, and ran the first-generation kernel UNSPLIT when order was asked for: the RPN's 18-row cls_score gradient over
+    // 9576 pixels on eight workgroups, 300 us instead of 9 -- that alone was the "+4 %" ordered sums cost configs[2]).
+    const bool ext_part = p.part_ws != nullptr;       // the caller reduces (the Winograd filter gradient's final transform): its own slab
     const double ord_flops = 1e9 * g_i2v_tuning[I2V_TUNE_WGRAD_ORDERED_GFLOP], flops = 2.0 * p.M * p.N * p.K * planes;
-    if (v2 && !fused && split_ws && splits > 1 && g_i2v_tuning[I2V_TUNE_SPLIT_ATOMICS] == 0 && flops < ord_flops) {
-        // a split beyond kWgradOrderedMax parts is capped only where that costs nothing (under 1 GFLOP: conv_lo.0's 128-way
-        // split of a 0.3 GFLOP problem); a larger problem that wants more parts to fill the chip keeps them and the atomics
-        if (splits > kWgradOrderedMax && flops < 1e9) splits = kWgradOrderedMax;
-        const size_t need = kSplitCounterBytes + (size_t)splits * tiles * planes * (size_t)(tm * tk) * sizeof(float);
-        ordered = splits <= kWgradOrderedMax && tiles * planes <= kSplitCounters && need <= split_ws_bytes && need < (1ull << 31);
-    }
-    // the first-generation kernel (Cout % 4 != 0: a 62-row linear layer's data gradient run on this kernel with the roles
-    // swapped) has no ordered finish: a small problem whose caller asks for reproducible sums is not split at all
-    if (!v2 && !fused && split_ws && splits > 1 && g_i2v_tuning[I2V_TUNE_SPLIT_ATOMICS] == 0 && flops < ord_flops)
-        splits = 1;
+    const bool want_ord = !fused && !ext_part && splits > 1 && g_i2v_tuning[I2V_TUNE_SPLIT_ATOMICS] == 0 && flops < ord_flops;
+    // a split beyond kWgradOrderedMax parts is capped where that costs nothing (under 1 GFLOP: conv_lo.0's 128-way split of a
+    // 0.3 GFLOP problem): the in-kernel finish needs no second launch
+    if (want_ord && split_ws && v2 && splits > kWgradOrderedMax && flops < 1e9) splits = kWgradOrderedMax;
+    if (ext_part && splits > p.part_cap) splits = p.part_cap > 0 ? p.part_cap : 1;
     p.m_per_split = i2v_cdiv(msteps, splits) * rs;
     splits = i2v_cdiv(p.M, p.m_per_split);
     p.direct = (splits == 1 && beta == 0.f) || fused;
-    if (ordered && splits > 1) {
-        p.ord_cnt = reinterpret_cast<int*>(split_ws);
-        p.ord_ws = reinterpret_cast<float*>(static_cast<char*>(split_ws) + kSplitCounterBytes);
-        p.ord_splits = splits; p.ord_tiles = (int)tiles; p.ord_acc = beta != 0.f;
+    bool two_pass = false;
+    if (ext_part) {
+        if (splits == 1) p.part_ws = nullptr;         // one part: written straight to gw (the caller passed its slot 0 as gw)
+    } else if (want_ord && splits > 1) {
+        const size_t need_ord = kSplitCounterBytes + (size_t)splits * tiles * planes * (size_t)(tm * tk) * sizeof(float);
+        const size_t need_part = kSplitCounterBytes + (size_t)splits * planes * (size_t)p.N * p.K * sizeof(float);
+        if (split_ws && v2 && splits <= kWgradOrderedMax && tiles * planes <= kSplitCounters && need_ord <= split_ws_bytes && need_ord < (1ull << 31)) {
+            p.ord_cnt = reinterpret_cast<int*>(split_ws);
+            p.ord_ws = reinterpret_cast<float*>(static_cast<char*>(split_ws) + kSplitCounterBytes);
+            p.ord_splits = splits; p.ord_tiles = (int)tiles; p.ord_acc = beta != 0.f;
+        } else if (split_ws && need_part <= split_ws_bytes) {
+            p.part_ws = reinterpret_cast<float*>(static_cast<char*>(split_ws) + kSplitCounterBytes);      // the counters in front stay zero
+            two_pass = true;
+        } else {
+            ++g_ordered_fallbacks;                    // no workspace, or too small: fp32 atomics (i2v_ordered_fallbacks() tells)
+        }
     }
-    if (beta == 0.f && !p.direct && !p.ord_ws)
+    if (beta == 0.f && !p.direct && !p.ord_ws && !p.part_ws)
         hipMemsetAsync(p.gw, 0, (p.nbatch > 1 ? (size_t)(p.nbatch - 1) * p.bsw : 0) * sizeof(float) + (size_t)p.N * p.K * sizeof(float), st);
     p.x_bytes = (unsigned)xb;
     p.gy_bytes = (unsigned)gb;
@@ -2730,6 +2860,17 @@ static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st, void* s
     else if (fused) conv_wgrad2_f32<2, 2, true><<<grid, THREADS, 0, st>>>(p);
     else if (g_clk) { p.clk = g_clk; p.abl = g_ablate; conv_wgrad2_f32<2, 2, false, true><<<grid, THREADS, 0, st>>>(p); }
     else conv_wgrad2_f32<2, 2><<<grid, THREADS, 0, st>>>(p);
+    if (ext_part) p.ord_splits = splits;              // what the caller's reduce pass must sum
+    if (two_pass) {
+        const long long nk = (long long)p.N * p.K;
+        if ((nk & 3) == 0) {
+            const long long total = (long long)planes * (nk / 4);
+            wgrad_reduce_kernel<<<(unsigned)std::min<long long>(i2v_cdiv(total, 256), 2048), 256, 0, st>>>(
+                p.part_ws, p.gw, splits, planes, nk / 4, planes > 1 ? p.bsw : nk, beta != 0.f);
+        } else {
+            wgrad_reduce_scalar_kernel<<<(unsigned)std::min<long long>(i2v_cdiv(nk, 256), 2048), 256, 0, st>>>(p.part_ws, p.gw, splits, nk, beta != 0.f);
+        }
+    }
     return true;
 }
 
@@ -2984,7 +3125,8 @@ static int conv_wgrad_impl(const float* x, const float* gy, float* gw, const flo
 // beta is an explicit argument of the shared implementation (round-3 advice: the accumulating entry point used to pass it
 // through a thread_local global, where an early return could have left it at 1).
 static int32_t gemm_tn_batched_impl(const float* x, const float* gy, float* gw, int32_t M, int32_t N, int32_t K, int32_t nbatch,
-                                    long long stride_x, long long stride_gy, long long stride_gw, float beta, void* stream) {
+                                    long long stride_x, long long stride_gy, long long stride_gw, float beta, void* stream,
+                                    int part_cap = 0, int* part_splits = nullptr) {
     I2V_CHECK_ARG(x && gy && gw && M > 0 && N > 0 && K > 0 && nbatch > 0, "gemm_tn_batched: bad argument");
     I2V_CHECK_ARG(N % 4 == 0 && K % 4 == 0, "gemm_tn_batched: N and K must be multiples of 4");
     I2V_CHECK_ARG(nbatch == 1 || stride_gw == (long long)N * K, "gemm_tn_batched: gw batches must be contiguous");
@@ -2999,9 +3141,29 @@ static int32_t gemm_tn_batched_impl(const float* x, const float* gy, float* gw, 
         i2v_set_error("gemm_tn_batched: operand larger than 2 GiB per batch");
         return I2V_ERR_UNSUPPORTED;
     }
+    if (part_splits) {          // i2v_internal_gemm_tn_batched_parts: gw = a slab of part_cap slots of nbatch x (N x K); slot s = split s
+        p.part_ws = gw; p.part_cap = part_cap;
+    }
     launch_wgrad(p, beta, false, (hipStream_t)stream);
+    if (part_splits) *part_splits = p.part_ws ? p.ord_splits : 1;
     I2V_CHECK_LAUNCH("gemm_tn_batched");
     return I2V_OK;
+}
+
+// (csrc/winograd.hip) parts[0] = parts[0] + parts[1] + ... in part order, all planes in parallel (in place: an element is read and
+// written by one thread)
+int32_t i2v_internal_reduce_parts(float* parts, int nparts, int planes, long long nk, void* stream) {
+    const long long total = (long long)planes * (nk / 4);
+    wgrad_reduce_kernel<<<(unsigned)std::min<long long>(i2v_cdiv(total, 256), 4096), 256, 0, (hipStream_t)stream>>>(
+        parts, parts, nparts, planes, nk / 4, nk, 0);
+    return I2V_OK;
+}
+
+// (csrc/winograd.hip) the same GEMMs with the split parts left SIDE BY SIDE in ``parts`` ([split][plane][N x K], room for
+// ``cap`` splits) for the caller's own ordered sum; *splits = how many were written (1: the result itself)
+int32_t i2v_internal_gemm_tn_batched_parts(const float* x, const float* gy, float* parts, int32_t M, int32_t N, int32_t K,
+                                           int32_t nbatch, long long stride_x, long long stride_gy, int cap, int* splits, void* stream) {
+    return gemm_tn_batched_impl(x, gy, parts, M, N, K, nbatch, stride_x, stride_gy, (long long)N * K, 0.f, stream, cap, splits);
 }
 
 extern "C" int32_t i2v_gemm_tn_batched(const float* x, const float* gy, float* gw, int32_t M, int32_t N, int32_t K,
@@ -3026,8 +3188,9 @@ extern "C" int32_t i2v_conv_wgrad(const float* x, const float* gy, float* gw, in
 
 extern "C" int32_t i2v_conv_wgrad_scaled(const float* x, const float* gy, const float* row_scale, float* gw, int32_t B,
                                          int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW,
-                                         int32_t stride, int32_t pad, float beta, void* stream) {
-    return conv_wgrad_impl(x, gy, gw, row_scale, B, H, W, Cin, Cout, KH, KW, stride, pad, beta, stream);
+                                         int32_t stride, int32_t pad, float beta, void* ws, size_t ws_bytes, void* stream) {
+    // ws: as i2v_conv_wgrad's (round 6: the trained bottlenecks' 1x1 filter gradients are ordered through it too)
+    return conv_wgrad_impl(x, gy, gw, row_scale, B, H, W, Cin, Cout, KH, KW, stride, pad, beta, stream, ws, ws_bytes);
 }
 
 // wgrad with the SGD(momentum) update of that filter fused into the accumulator epilogue: the gradient
@@ -3069,11 +3232,19 @@ extern "C" int32_t i2v_epilogue_bwd(const float* gy, const float* y, const float
     // ... and small tensors only (at most 2^21 elements: the relation head's layers): a large one (netD_style's 37500 x 2560
     // projections) needs its hundreds of row blocks to stream at full rate (measured: configs[2] 46.3 -> 48.1 ms with every
     // tensor held to <= 32 row blocks), so it keeps the atomics
-    const bool want_ord = gbias && vec && split_ws && g_i2v_tuning[I2V_TUNE_SPLIT_ATOMICS] == 0 && M * (long long)N <= (1ll << 21);
+    // round 6: large tensors too -- they keep their row blocks (full streaming rate) and the sums meet in two levels
+    // (colsum_finish4); `small` = the tensors round 5 ordered by cutting them into few row blocks
+    const bool want_ord = gbias && vec && g_i2v_tuning[I2V_TUNE_SPLIT_ATOMICS] == 0;
+    const bool small = M * (long long)N <= (1ll << 21);
     auto ordered = [&](long long nblk, int ncolblk, float*& part, int*& cnt) {
         part = nullptr; cnt = nullptr;
-        const size_t need = kSplitCounterBytes + (size_t)nblk * N * sizeof(float);
-        if (!want_ord || nblk < 2 || ncolblk > kSplitCounters || need > split_ws_bytes || need >= (1ull << 31)) return;
+        if (!want_ord || nblk < 2) return;
+        const long long groups = (nblk + kColsumGroup - 1) / kColsumGroup;
+        const size_t need = kSplitCounterBytes + (size_t)(nblk + groups) * N * sizeof(float);
+        if (!split_ws || (long long)ncolblk * (1 + groups) > kSplitCounters || need > split_ws_bytes || need >= (1ull << 31)) {
+            ++g_ordered_fallbacks;
+            return;
+        }
         cnt = reinterpret_cast<int*>(split_ws);
         part = reinterpret_cast<float*>(static_cast<char*>(split_ws) + kSplitCounterBytes);
     };
@@ -3087,18 +3258,29 @@ extern "C" int32_t i2v_epilogue_bwd(const float* gy, const float* y, const float
         // few workgroups: same-address atomics retire one per ~150 ns, so 256 contenders cost more than the rows
         int rpb = lanes * 64;
         while (rpb > lanes && i2v_cdiv(M, rpb) < 48) rpb >>= 1;
-        if (want_ord) while (i2v_cdiv(M, rpb) > 64) rpb <<= 1;           // the finisher sums at most 64 partials per column
+        if (want_ord && small) while (i2v_cdiv(M, rpb) > 64) rpb <<= 1;  // small tensors: at most 64 partials per column (two groups)
         ordered(i2v_cdiv(M, rpb), 1, part, cnt);
         epilogue_bwd_narrow_kernel<<<(unsigned)i2v_cdiv(M, rpb), 256, 0, (hipStream_t)stream>>>(gy, y, scale, g, gpre,
                                                                                               gbias, M, N, relu, rpb, part, cnt);
         I2V_CHECK_LAUNCH("epilogue_bwd");
         return I2V_OK;
     }
-    if (want_ord && vec) while (i2v_cdiv(M, rows) > 32 && rows < 1024) rows <<= 1;   // at most 32 row blocks to sum
+    if (want_ord && vec && small) while (i2v_cdiv(M, rows) > 32 && rows < 1024) rows <<= 1;   // small tensors: at most 32 row blocks (one level)
     dim3 grid(i2v_cdiv(M, rows), i2v_cdiv(N, cols));
     ordered(grid.x, (int)grid.y, part, cnt);
-    if (vec) epilogue_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(gy, y, scale, g, gpre, gbias, M, N, relu, rows, g_t, part, cnt);
-    else epilogue_bwd_scalar_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(gy, y, scale, g, gpre, gbias, M, N, relu, rows, g_t);
+    if (vec) {
+        epilogue_bwd_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(gy, y, scale, g, gpre, gbias, M, N, relu, rows, g_t, part, cnt);
+    } else {
+        // N % 4 != 0 (the RPN's 18-channel cls_score): ordered = partial rows + the reduce pass of the filter gradients
+        float* sp = nullptr;
+        if (gbias && grid.x > 1 && g_i2v_tuning[I2V_TUNE_SPLIT_ATOMICS] == 0) {
+            if (split_ws && kSplitCounterBytes + (size_t)grid.x * N * sizeof(float) <= split_ws_bytes)
+                sp = reinterpret_cast<float*>(static_cast<char*>(split_ws) + kSplitCounterBytes);
+            else ++g_ordered_fallbacks;
+        }
+        epilogue_bwd_scalar_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(gy, y, scale, g, gpre, gbias, M, N, relu, rows, g_t, sp);
+        if (sp) wgrad_reduce_scalar_kernel<<<(unsigned)i2v_cdiv(N, 256), 256, 0, (hipStream_t)stream>>>(sp, gbias, (int)grid.x, N, 1);
+    }
     I2V_CHECK_LAUNCH("epilogue_bwd");
     return I2V_OK;
 }

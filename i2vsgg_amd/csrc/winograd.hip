@@ -11,6 +11,7 @@
 // xi = 4*row + col of the 4x4 transform domain.  Only the GEMM uses the matrix cores; the two transforms are
 // streaming kernels that overlap with MFMA work of the other stream.
 #include "common.h"
+#include <algorithm>
 
 extern "C" int32_t i2v_gemm_tn_batched(const float* x, const float* gy, float* gw, int32_t M, int32_t N, int32_t K,
                                        int32_t nbatch, long long stride_x, long long stride_gy, long long stride_gw,
@@ -490,8 +491,10 @@ wino4_gy_kernel(const float* __restrict__ gy, float* __restrict__ Y, int B, int 
 }
 
 // gw[n][ky][kx][c] = beta * gw + row_scale[n] * (G^T X G)[ky][kx],  X[6r+q][n][c]
+// nparts > 1 (round 6, ordered sums): X holds the pixel split's parts side by side ([part][36][Cout x Cin]); they are added
+// here in part order -- the plane GEMMs' second pass costs no launch of its own
 __global__ void wino4_wgrad_final_kernel(const float* __restrict__ X, float* __restrict__ gw, const float* __restrict__ row_scale,
-                                         int Cout, int Cin, float beta) {
+                                         int Cout, int Cin, float beta, int nparts) {
     const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (idx >= (long long)Cout * Cin) return;
     const int c = (int)(idx % Cin), n = (int)(idx / Cin);
@@ -501,7 +504,11 @@ __global__ void wino4_wgrad_final_kernel(const float* __restrict__ X, float* __r
     for (int q = 0; q < 6; ++q) {
         float x[6], o[3];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) x[r] = X[(long long)(6 * r + q) * plane + idx];
+        for (int r = 0; r < 6; ++r) {
+            float v = X[(long long)(6 * r + q) * plane + idx];
+            for (int s = 1; s < nparts; ++s) v += X[((long long)s * 36 + (6 * r + q)) * plane + idx];
+            x[r] = v;
+        }
         gt6(x, o);
 #pragma unroll
         for (int k = 0; k < 3; ++k) t[k][q] = o[k];
@@ -646,8 +653,11 @@ extern "C" int32_t i2v_conv3x3_winograd4_dgrad(const float* gy, const float* U, 
 extern "C" size_t i2v_conv3x3_winograd4_wgrad_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 256;
     const size_t T = (size_t)B * ((H + 3) / 4) * ((W + 3) / 4);
+    // the last region holds the 36 plane gradients -- once per part of the pixel split, so that an ordered sum
+    // (I2V_TUNE_SPLIT_ATOMICS == 0) can leave the parts side by side for the final transform to add in order
+    const size_t parts = (size_t)i2v_internal_wgrad_plane_splits((long long)T, Cout, Cin);
     return i2v_align(36 * T * Cin * sizeof(float)) + i2v_align(36 * T * Cout * sizeof(float)) +
-           i2v_align(36 * (size_t)Cout * Cin * sizeof(float));
+           i2v_align(36 * (size_t)Cout * Cin * sizeof(float) * (parts > 1 ? parts : 1));
 }
 
 // Filter gradient of a stride-1 / pad-1 3x3 layer in the F(4x4,3x3) domain: gw (Cout,3,3,Cin) = beta * gw +
@@ -676,10 +686,30 @@ static int winograd4_wgrad_impl(const float* x, const float* v_in, const float* 
     if (v_in) V = const_cast<float*>(v_in);         // the forward's transformed input (i2v_conv3x3_winograd4_fwd_keep)
     else if (rows & 1) wino4_input_rows_kernel<<<dim3((unsigned)i2v_cdiv(T * Cin, 256), 6), 256, 0, st>>>(x, V, B, H, W, Cin, th, tw);
     else wino4_input_kernel<<<(unsigned)i2v_cdiv(T * Cin, 256), 256, 0, st>>>(x, V, B, H, W, Cin, th, tw);
+    if (g_i2v_tuning[I2V_TUNE_SPLIT_ATOMICS] == 0) {
+        // ordered: the parts of the pixel split side by side in X (the workspace has room for the planned count; fewer is legal),
+        // no clear of X, summed in part order by the final transform
+        const size_t room = ws_bytes - (size_t)((char*)X - (char*)ws);
+        const int cap = (int)std::min<size_t>(room / (36 * (size_t)Cout * Cin * sizeof(float)), 1 << 20);
+        int nparts = 1;
+        wino4_gy_kernel<<<(unsigned)i2v_cdiv(T * Cout, 256), 256, 0, st>>>(gy, Y, B, H, W, Cout, th, tw, nullptr, 0);
+        int rc = i2v_internal_gemm_tn_batched_parts(V, Y, X, (int32_t)T, Cout, Cin, 36, T * Cin, T * Cout, cap, &nparts, stream);
+        if (rc) return rc;
+        // two parts (layer3 / layer4) are added by the final transform itself; more (layer1: 28, layer2: 7 at eight frames) first
+        // meet in slot 0 through the parallel reduce pass -- the final transform has one thread per filter element and would read
+        // 36 x parts values each in a dependent chain (measured: 42 us per call instead of 9)
+        if (nparts > 2) {
+            i2v_internal_reduce_parts(X, nparts, 36, (long long)Cout * Cin, stream);
+            nparts = 1;
+        }
+        wino4_wgrad_final_kernel<<<(unsigned)i2v_cdiv((long long)Cout * Cin, 256), 256, 0, st>>>(X, gw, row_scale, Cout, Cin, beta, nparts);
+        I2V_CHECK_LAUNCH("conv3x3_winograd4_wgrad");
+        return I2V_OK;
+    }
     wino4_gy_kernel<<<(unsigned)i2v_cdiv(T * Cout, 256), 256, 0, st>>>(gy, Y, B, H, W, Cout, th, tw, X, 9ll * Cout * Cin);
     int rc = i2v_gemm_tn_batched_acc(V, Y, X, (int32_t)T, Cout, Cin, 36, T * Cin, T * Cout, (long long)Cout * Cin, stream);
     if (rc) return rc;
-    wino4_wgrad_final_kernel<<<(unsigned)i2v_cdiv((long long)Cout * Cin, 256), 256, 0, st>>>(X, gw, row_scale, Cout, Cin, beta);
+    wino4_wgrad_final_kernel<<<(unsigned)i2v_cdiv((long long)Cout * Cin, 256), 256, 0, st>>>(X, gw, row_scale, Cout, Cin, beta, 1);
     I2V_CHECK_LAUNCH("conv3x3_winograd4_wgrad");
     return I2V_OK;
 }

@@ -580,6 +580,18 @@ def _split_ws(device):
     return ws.buf
 
 
+_side_ws = {}
+
+
+def _side_split_ws(device):
+    """The split workspace of the filter-gradient side branch (one per device: the branch is one ordered stream)."""
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    ws = _side_ws.get(key)
+    if ws is None:
+        ws = _side_ws[key] = SplitWorkspace(device)
+    return ws.buf
+
+
 def _conv_fwd_raw(x, w, scale, shift, res, stride, pad, flags, out=None):
     B, Cin, H, W = x.shape
     Cout, _, KH, KW = w.shape
@@ -698,18 +710,18 @@ def _conv_wgrad_raw(x, g, w_shape, stride, pad, tag="wgrad", row_scale=None, win
     with _Timed(2.0 * B * g.shape[2] * g.shape[3] * Cout * KH * KW * Cin, tag,
                 "N%d K%d M%d" % (Cout, KH * KW * Cin, B * g.shape[2] * g.shape[3]) + (" (wgrad form)" if tag != "wgrad" else ""),
                 4 * (x.numel() + g.numel() + gw.numel())):
+        # ordered sum of a split reduction (bit-reproducible; no atomics, no clear) through the split workspace in force.  A call
+        # on the filter-gradient side branch (InstanceStyleDStep.wgrad_branch) runs beside the main chain's GEMMs that own that
+        # workspace -- launches sharing one must be ordered on the device -- so the side branch has a workspace of its own
+        # (round 6; round 5 left its sums on atomics)
+        side = WGRAD_STREAM is not None and torch.cuda.current_stream().cuda_stream == WGRAD_STREAM.cuda_stream
+        sws = _side_split_ws(x.device) if side else _split_ws(x.device)
         if row_scale is not None:
             check(lib.i2v_conv_wgrad_scaled(ptr(x), ptr(g), ptr(row_scale), ptr(gw), B, H, W, Cin, Cout, KH, KW, stride, pad,
-                                            beta, stream()), "conv_wgrad_scaled")
+                                            beta, ptr(sws), sws.numel(), stream()), "conv_wgrad_scaled")
         else:
-            # ordered sum of a split reduction (bit-reproducible; no atomics, no clear) through the split workspace in force --
-            # unless this call runs on the filter-gradient side branch (I2V_WGRAD_BRANCH), beside the main chain's GEMMs that
-            # own that workspace: launches sharing one must be ordered on the device, so there the sum stays atomic
-            side = WGRAD_STREAM is not None and torch.cuda.current_stream().cuda_stream == WGRAD_STREAM.cuda_stream
-            sws = None if side else _split_ws(x.device)
             check(lib.i2v_conv_wgrad(ptr(x), ptr(g), ptr(gw), B, H, W, Cin, Cout, KH, KW, stride, pad, beta,
-                                     ptr(sws) if sws is not None else None, sws.numel() if sws is not None else 0, stream()),
-                  "conv_wgrad")
+                                     ptr(sws), sws.numel(), stream()), "conv_wgrad")
     return gw
 
 

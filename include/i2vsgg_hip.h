@@ -255,7 +255,7 @@ size_t  i2v_conv_split_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t 
 #define I2V_TUNE_SPLIT_TARGET         1   /* workgroups per CU a split-K launch aims for (default 2) */
 #define I2V_TUNE_SPLIT_TARGET_SKINNY  2   /* the same for GEMMs of <= 256 rows (-1: as SPLIT_TARGET) */
 #define I2V_TUNE_SPLIT_BELOW          3   /* split K only when the unsplit grid has fewer tiles than this (default 256) */
-#define I2V_TUNE_SPLIT_ATOMICS        4   /* how reductions that are split across workgroups are finished.  2 (process default, round 4's rule): split-K GEMMs of up to four parts and outputs of >= 2^18 elements through the caller's workspace, summed in split order by the last workgroup to arrive; everything else (more parts, small outputs, split filter gradients, bias column sums) with fp32 atomics.  0: EVERY such reduction ordered -- any number of split-K parts, filter gradients (up to 16 parts, I2V_TUNE_WGRAD_ORDERED_GFLOP), bias column sums of tensors up to 2^21 elements: bit-reproducible; what the relation step selects for its head (measured: free there, +4 % on the instance_styleD step, whose launches are larger).  1: always atomics */
+#define I2V_TUNE_SPLIT_ATOMICS        4   /* how reductions that are split across workgroups are finished.  2 (process default, round 4's rule): split-K GEMMs of up to four parts and outputs of >= 2^18 elements through the caller's workspace, summed in split order by the last workgroup to arrive; everything else (more parts, small outputs, split filter gradients, bias column sums) with fp32 atomics.  0: EVERY such reduction ordered (what both step objects select for their launch contexts: bit-reproducible results) -- any number of split-K parts; filter gradients of up to 16 parts in the kernel, of more parts and of filters with Cout % 4 != 0 through side-by-side partial filters and a reduce pass (round 6); the 36-plane filter gradient of the Winograd domain (its final transform adds the parts); bias column sums of any size in two levels of 32 row blocks (round 6).  A reduction whose workspace is missing or too small falls back to atomics and is counted (i2v_ordered_fallbacks).  1: always atomics */
 #define I2V_TUNE_BIG_FC_TILE          5   /* tile index for the long skinny GEMMs (rows <= 256, K >= 16384); -1: cost model */
 #define I2V_TUNE_WGRAD_V2             6   /* 0: first-generation wgrad kernel, 1: default, 2/3: larger tiles */
 #define I2V_TUNE_WGRAD_FUSED_TILE     7   /* 128 (default) or 64: filters per workgroup of the fused wgrad+SGD kernel */
@@ -272,7 +272,7 @@ size_t  i2v_conv_split_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t 
 #define I2V_TUNE_WGRAD_PRIO          18   /* experiment: n > 0 = the filter-gradient kernel lowers a wave's issue priority as it advances (3 - ((stage >> (n-1)) & 3)); 0 = off */
 #define I2V_TUNE_STREAM_TILE         19   /* 1 (default): pointwise layers of at most four K stages over >= 16384 rows (HBM-bound) take the 80x64 tile whatever the cost model says; 0: cost model */
 #define I2V_TUNE_KGROUPS             20   /* 2 (round 5): the same with TWO wave groups (8 waves, two 39 KB stage regions: the workgroup shares its CU); 1 / 4: a pointwise GEMM the plan would split over K runs as one 16-wave workgroup per tile whose four wave groups split K and meet in LDS (no partial tile through memory) when one round of such tiles covers >= 70 % of the CUs: 4-10 % faster than the split across workgroups as a kernel on its own, 9 % SLOWER inside the overlapped step (a workgroup that owns a CU's LDS and registers shuts the other branches' workgroups out: profiles/r04_kgroups.txt); 0 (default): split-K across workgroups, partials through the caller's workspace */
-#define I2V_TUNE_WGRAD_ORDERED_GFLOP 21   /* a filter gradient (or a linear layer's data gradient run on that kernel) whose reduction is split takes the ORDERED finish -- partials through the caller's split workspace, summed in split order, at most 16 splits -- when the problem is below this many GFLOP (default 8: the relation head's layers; 0: never; the instance_styleD backbone's larger ones keep fp32 atomics) */
+#define I2V_TUNE_WGRAD_ORDERED_GFLOP 21   /* a split filter gradient takes an ordered finish (I2V_TUNE_SPLIT_ATOMICS == 0) only when the problem is below this many GFLOP (default 1000000: always; round 5's default was 8 -- its only ordered form, one finisher reading every part, was a tail on the large launches; 0: never) */
 #define I2V_TUNE_GEMM_DMA            22   /* how the pointwise / plain-GEMM kernel stages its operand tiles (round 6).  0: global -> registers -> ds_write_b128 (rounds 2-5).  1: LDS-DMA (buffer_load ... lds, the column swizzle on the source address), 32-k stages, same LDS image.  2: LDS-DMA with 16-k stages (64-byte LDS rows): half the LDS per workgroup, twice the barriers.  Bit-equal results in all three */
 #define I2V_TUNE_COUNT               23
 /* Keys CONV_SPEC (> 0), STAGGER, FC_FOLD, GEMM_X3, GEMM_PERSIST, WGRAD_PRIO are experiments: I2V_ERR_UNSUPPORTED for any value
@@ -307,7 +307,12 @@ int32_t i2v_conv_dgrad_fused(const float* gy, const float* w, const float* gy_sc
                              void* stream);
 int32_t i2v_conv_wgrad_scaled(const float* x, const float* gy, const float* row_scale, float* gw, int32_t B,
                               int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH, int32_t KW,
-                              int32_t stride, int32_t pad, float beta, void* stream);
+                              int32_t stride, int32_t pad, float beta, void* split_workspace, size_t split_workspace_bytes,
+                              void* stream);      /* split_workspace: as i2v_conv_wgrad's (round 6); NULL: fp32 atomics */
+/* Reductions that were asked to be ordered (I2V_TUNE_SPLIT_ATOMICS == 0) but ran on fp32 atomics because the caller's split
+ * workspace was absent or too small (or a size cap was exceeded), since the last reset: a step that promises bit-reproducible
+ * results asserts 0 after its warm-up.  reset != 0: zero the count after reading it. */
+int32_t i2v_ordered_fallbacks(int32_t reset);
 int32_t i2v_conv3x3_winograd4_dgrad(const float* gy, const float* U, const float* out_scale, const float* mask,
                                     float* gx, int32_t B, int32_t H, int32_t W, int32_t Cout, int32_t Cin,
                                     void* workspace, size_t workspace_bytes, void* stream);
