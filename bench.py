@@ -979,24 +979,6 @@ def main():
                 s1.opt.unfuse()
                 return pick(ld)
 
-            def gemm_x3():
-                # what bounds the step, NOT the metric: the same step with the K loops of the pointwise / plain GEMMs
-                # on the bf16 matrix pipe as a three-term split (I2V_TUNE_GEMM_X3: 16-bit-mantissa products, fp32 everything else)
-                from i2vsgg_amd._lib import lib as _l
-                _l.i2v_set_tuning(16, 1)
-                try:
-                    nx = train_mod().build_sgg_net(a.layers, device=dev)
-                    sx = train_mod().SGGEmbStep(nx, 2, seed=1 + rank, device=dev, use_graph=not a.no_graph)
-                    sx.capture(warmup=2)
-                    el = timed_steps(sx, a.warmup, a.steps, dev)
-                    out = {"value": world * 2 * a.steps / el, "unit": "frames/s", "ms_per_step": 1e3 * el / a.steps, "steps": a.steps,
-                           "dtype": "f32 in / out / accumulate; products of the pointwise and plain GEMMs as hi*hi + hi*lo + lo*hi on bf16 "
-                                    "MFMA (16 mantissa bits): REDUCED precision, an experiment, not the metric",
-                           "loss": float(sx.loss), "loss_fp32": line["config"]["loss"]}
-                    sx.opt.unfuse()
-                    return out
-                finally:
-                    _l.i2v_set_tuning(16, 0)
 
             def isd():
                 # configs[2]: fewer steps (a step is ~10x longer), its own roofline block
@@ -1014,9 +996,6 @@ def main():
             torch.cuda.empty_cache()
             also("sgg_loader", lambda: loader(False))
             also("sgg_loader_u8", lambda: loader(True))
-            from i2vsgg_amd import _lib as _l2
-            if _l2.EXPERIMENTS:          # an I2V_EXPERIMENTS build only: the default library has no bf16-split kernel
-                also("sgg_gemm_x3", gemm_x3)
             also("roi_nms", lambda: run_roi_nms(dev))
             if "error" not in line["also"]["roi_nms"]:
                 line["roofline_hbm"] = roofline_hbm(line["also"]["roi_nms"])

@@ -74,8 +74,6 @@ SIGNATURES = {
     "i2v_conv3x3_winograd4_fwd_keep": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p, _z, _p]),
     "i2v_conv3x3_winograd4_wgrad_v": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p, _z, _p]),
     "i2v_conv_wgrad_sgd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _p]),
-    "i2v_fc_fold_supported": (_i, [_i, _i, _i, _i]),
-    "i2v_fc_fold_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _f, _p]),
     "i2v_epilogue_bwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _i, _p, _p, _z, _p]),
     "i2v_maxpool3x3s2_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "i2v_sgd_momentum": (_i, [_p, _p, _p, _l, _f, _f, _f, _p]),
@@ -137,19 +135,28 @@ lib = _load()
 TUNE = {"I2V_CONV_SPEC": 0, "I2V_SPLIT_TARGET": 1, "I2V_SPLIT_TARGET_SKINNY": 2, "I2V_SPLIT_BELOW": 3, "I2V_SPLIT_ATOMICS": 4,
         "I2V_BIG_FC_TILE": 5, "I2V_WGRAD_V2": 6, "I2V_WGRAD_FUSED_TILE": 7, "I2V_WINO_ROWS": 8, "I2V_ROIPOOL_C128": 9, "I2V_CONV_GEMM": 10, "I2V_STAGGER": 11, "I2V_ROIALIGN_COLS": 12, "I2V_WGRAD_PER_CU": 13, "I2V_WGRAD_XCD": 14, "I2V_FC_FOLD": 15, "I2V_GEMM_X3": 16,
         "I2V_GEMM_PERSIST": 17, "I2V_WGRAD_PRIO": 18, "I2V_STREAM_TILE": 19, "I2V_KGROUPS": 20, "I2V_WGRAD_ORDERED_GFLOP": 21, "I2V_GEMM_DMA": 22}
-EXPERIMENTS = bool(lib.i2v_build_flags() & 1)      # built with -DI2V_EXPERIMENTS (I2V_EXPERIMENTS=1 python -m i2vsgg_amd.build)
-# The knobs the environment may set (README.md has the table): the ones a deployment has a reason to move.  The rest of TUNE --
-# switches of variants that were measured and lost (I2V_ROIALIGN_COLS: the round-1 / round-2 forward kernels; I2V_WGRAD_PRIO,
-# I2V_STAGGER, I2V_CONV_SPEC, I2V_GEMM_PERSIST, I2V_GEMM_X3, I2V_FC_FOLD: experiments) -- is reachable through
-# lib.i2v_set_tuning (tests, tools) and from the environment only in an I2V_EXPERIMENTS build.
+# The knobs the environment may set (README.md has the table): the ones a deployment has a reason to move.  The rest of TUNE is
+# reachable through lib.i2v_set_tuning (tests, tools): I2V_ROIALIGN_COLS, I2V_WGRAD_V2, I2V_CONV_GEMM, ... select older forms of
+# kernels; I2V_CONV_SPEC, I2V_STAGGER, I2V_FC_FOLD, I2V_GEMM_X3, I2V_GEMM_PERSIST, I2V_WGRAD_PRIO are the reserved indices of
+# experiment kernels that left the library in round 6 (the library refuses any value but "off").
 ENV_TUNE = ("I2V_SPLIT_ATOMICS", "I2V_SPLIT_TARGET", "I2V_SPLIT_TARGET_SKINNY", "I2V_SPLIT_BELOW", "I2V_BIG_FC_TILE",
             "I2V_WGRAD_FUSED_TILE", "I2V_WGRAD_PER_CU", "I2V_KGROUPS", "I2V_WGRAD_ORDERED_GFLOP", "I2V_WINO_ROWS", "I2V_GEMM_DMA")
+# Settled A/B switches of rounds 1-5 that no longer read the environment (their comments in ops.py / train.py name the module
+# attribute that replaced them).  A run that still sets one would measure the default without knowing (round-5 advice): say so.
+RETIRED_ENV = ("I2V_WINOGRAD_TRAIN", "I2V_BLOCK_FUSED", "I2V_WINOGRAD_WGRAD", "I2V_KEEP_V", "I2V_WGRAD_BRANCH", "I2V_ISD_BATCHED",
+               "I2V_DEFER_FC", "I2V_EXPERIMENTS")
 for _name, _key in TUNE.items():
-    if _name not in ENV_TUNE and not EXPERIMENTS:
+    if os.environ.get(_name) in (None, ""):
         continue
+    if _name not in ENV_TUNE:
+        raise ImportError("i2vsgg_amd: %s is set but is not an environment knob (README.md lists them); it would be ignored. "
+                          "Use i2vsgg_amd._lib.lib.i2v_set_tuning(TUNE[%r], value) from a tool or test" % (_name, _name))
+    if lib.i2v_set_tuning(_key, int(os.environ[_name])) != 0:
+        raise ImportError("i2vsgg_amd: %s=%s refused: %s" % (_name, os.environ[_name], lib.i2v_last_error().decode()))
+for _name in RETIRED_ENV:
     if os.environ.get(_name) not in (None, ""):
-        if lib.i2v_set_tuning(_key, int(os.environ[_name])) != 0:
-            raise ImportError("i2vsgg_amd: %s=%s refused: %s" % (_name, os.environ[_name], lib.i2v_last_error().decode()))
+        import warnings
+        warnings.warn("i2vsgg_amd: %s is set but no longer read (a settled switch of rounds 1-5): the default runs" % _name)
 
 
 def check(rc, what):

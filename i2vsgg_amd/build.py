@@ -6,22 +6,15 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libi2vsgg_hip.so")
-# I2V_EXPERIMENTS=1 in the environment of the build: -DI2V_EXPERIMENTS and csrc/fcfold.hip -- the kernel variants that were
-# built, measured and lost in rounds 1-3 (profiles/r03_persistent_gemm.txt) plus the diagnostic
-# instantiations behind tools/conv_ablate.py.  The default library (what __graft_entry__.build() makes, what the tests, the
-# bench and the training scripts load) carries none of them.
-EXPERIMENTS = os.environ.get("I2V_EXPERIMENTS", "0") == "1"
-SOURCES = ["api.cpp", "roi_ops.hip", "rpn.hip", "conv.hip", "heads.hip", "image.hip", "winograd.hip", "dstyle.hip"] + \
-    (["fcfold.hip"] if EXPERIMENTS else [])
+SOURCES = ["api.cpp", "roi_ops.hip", "rpn.hip", "conv.hip", "heads.hip", "image.hip", "winograd.hip", "dstyle.hip"]
 # -ffp-contract=off: box / IoU / ROIAlign arithmetic must round once per operation like the
 # reference's CPU path (no FMA contraction), or NMS threshold decisions can flip.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
-         "-Wno-unused-value", "-Wno-unused-result"] + (["-DI2V_EXPERIMENTS"] if EXPERIMENTS else [])
+         "-Wno-unused-value", "-Wno-unused-result"]
 # MFMA accumulators in VGPRs, not AGPRs: measured on MI355X (tools/micro/mfma_rate.hip, tools/conv_ablate.py) a
 # back-to-back v_mfma_f32_16x16x4_f32 stream issues every 32 cycles with VGPR accumulators but only every ~45
 # cycles in the AGPR form hipcc picks by default for these kernels.
-EXTRA = {"conv.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "dstyle.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],
-         "fcfold.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+EXTRA = {"conv.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"], "dstyle.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 STAMP = os.path.join(HERE, "build", "stamp.json")

@@ -27,11 +27,7 @@ int g_i2v_tuning[I2V_TUNE_COUNT] = {
 };
 
 extern "C" int32_t i2v_build_flags(void) {
-#ifdef I2V_EXPERIMENTS
-    return I2V_BUILD_EXPERIMENTS;
-#else
     return 0;
-#endif
 }
 
 extern "C" int32_t i2v_set_tuning(int32_t key, int32_t value) {
@@ -39,33 +35,19 @@ extern "C" int32_t i2v_set_tuning(int32_t key, int32_t value) {
         i2v_set_error("set_tuning: unknown key %d", key);
         return I2V_ERR_ARG;
     }
-#ifndef I2V_EXPERIMENTS
-    // The losing experiments of rounds 1-3 (measurements under profiles/) are compiled only with -DI2V_EXPERIMENTS
-    // (I2V_EXPERIMENTS=1 python -m i2vsgg_amd.build): the default library does not carry their kernels, so their knobs
-    // accept nothing but "off".
-    const bool experiment = key == I2V_TUNE_CONV_SPEC ? value > 0
-                          : (key == I2V_TUNE_FC_FOLD || key == I2V_TUNE_GEMM_X3 || key == I2V_TUNE_GEMM_PERSIST ||
-                             key == I2V_TUNE_WGRAD_PRIO || key == I2V_TUNE_STAGGER) ? value != 0 : false;
-    if (experiment) {
-        i2v_set_error("set_tuning: key %d is an experiment; this library was built without -DI2V_EXPERIMENTS", key);
+    // Keys of kernel variants that were built, measured and lost in rounds 1-5 and left the library in round 6 (their record:
+    // DESIGN_HISTORY.md, profiles/): the indices stay reserved, the only value they take is "off".
+    const bool retired = key == I2V_TUNE_CONV_SPEC ? value > 0
+                       : (key == I2V_TUNE_FC_FOLD || key == I2V_TUNE_GEMM_X3 || key == I2V_TUNE_GEMM_PERSIST ||
+                          key == I2V_TUNE_WGRAD_PRIO || key == I2V_TUNE_STAGGER) ? value != 0 : false;
+    if (retired) {
+        i2v_set_error("set_tuning: key %d belonged to an experiment kernel that is no longer in the library", key);
         return I2V_ERR_UNSUPPORTED;
     }
-#endif
     g_i2v_tuning[key] = value;
     return I2V_OK;
 }
 
-#ifndef I2V_EXPERIMENTS
-// csrc/fcfold.hip (a linear layer's forward that applies the previous step's pending SGD update on its pass over the filter:
-// built, parity-tested, measured slower than forward + fused update as two kernels -- DESIGN.md 5.6) is not part of the
-// default build; its entry points answer "unsupported" and the host keeps the two-kernel path.
-extern "C" int32_t i2v_fc_fold_supported(int32_t, int32_t, int32_t, int32_t) { return 0; }
-extern "C" int32_t i2v_fc_fold_fwd(const float*, const float*, const float*, const int32_t*, float*, float*, const float*, float*,
-                                   int32_t, int32_t, int32_t, int32_t, float, float, float, void*) {
-    i2v_set_error("fc_fold_fwd: this library was built without -DI2V_EXPERIMENTS");
-    return I2V_ERR_UNSUPPORTED;
-}
-#endif
 
 extern "C" int32_t i2v_get_tuning(int32_t key) {
     return (key < 0 || key >= I2V_TUNE_COUNT) ? I2V_ERR_ARG : g_i2v_tuning[key];

@@ -31,7 +31,6 @@ constexpr int KTAB_MAX = 2560;  // filter-tap table entries (K/4): KH*KW*Cin <= 
 constexpr int BKS = 32;         // k per LDS stage of the forward/dgrad kernel (= floats per LDS row)
 constexpr int LDS_ROW = 20;     // floats per staged row (16 + 4 pad)
 constexpr int THREADS = 256;
-constexpr bool PIPE_FRAGS = false;   // software-pipelined fragment reads in the 4-wave K loop (costs 20 VGPRs)
 constexpr int kSplitInKernelMax = 4;   // most splits the in-kernel split-K finish sums (else: atomics)
 
 struct ConvP {
@@ -53,7 +52,6 @@ struct ConvP {
     unsigned long long* clk;     // diagnostic only (i2v_conv_debug_clock): per-workgroup {shader cycles, 100 MHz ticks}
     float* ws;                   // split-K partial tiles [split][tile][BM*BN] (nullptr: fp32 atomics into y)
     int* cnt;                    // split-K arrival counters, one per tile, zero between launches
-    int knob;                    // experiment knob of conv_gemm_f32 (I2V_TUNE_STAGGER): 0 = off
     int nbatch;                  // > 1: blockIdx.z selects one of nbatch independent GEMMs (Winograd planes)
     long long bsx, bsw, bsy;     // element strides between the batches of x, w and y
 };
@@ -71,14 +69,8 @@ __device__ inline void split_k(const ConvP& p, int k, int& ky, int& kx, int& c) 
 // each 16-deep half, so one ds_read_b128 feeds four MFMAs (A and B use the same permutation).
 // LDS rows are 128 B, unpadded, with the 16-B column XOR-swizzled by (row>>1)&7: the four
 // 16-lane groups of a ds_read_b128 then touch 16 distinct slots of the 256-B bank row.
-//
-// SPEC = true: 8 waves per workgroup, specialised.  Waves 4-7 ("loaders") do all the address math,
-// global loads and LDS stores; waves 0-3 ("MFMA waves") only read fragments and issue MFMAs.  At ~1
-// workgroup per CU (the 4788-row layer3 GEMMs) a single wave per SIMD would otherwise serialise
-// {address math + loads, LDS reads, MFMAs, LDS stores, barrier}; here the loader wave of a SIMD runs
-// beside its MFMA wave (VALU/VMEM and the matrix pipe issue independently).
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool SPEC, int ABL = 0>
-__global__ void __launch_bounds__(SPEC ? 2 * THREADS : THREADS)
+template <int WAVES_M, int WAVES_N, int TM, int TN>
+__global__ void __launch_bounds__(THREADS)
 conv_igemm_f32(const ConvP p_in) {
     ConvP p = p_in;
     if (p.nbatch > 1) {              // batched GEMM: same shapes, different operands (uniform: blockIdx.z)
@@ -87,7 +79,7 @@ conv_igemm_f32(const ConvP p_in) {
         p.y += (long long)blockIdx.z * p.bsy;
     }
     constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
-    constexpr int NT = SPEC ? 2 * THREADS : THREADS;      // threads per workgroup
+    constexpr int NT = THREADS;      // threads per workgroup
     constexpr int A_LD = (BM * 8 + THREADS - 1) / THREADS, B_LD = (BN * 8 + THREADS - 1) / THREADS;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     // one LDS block: [A stage 0 | A stage 1 | B stage 0 | B stage 1 | tap table]; after the K loop the
@@ -105,7 +97,7 @@ conv_igemm_f32(const ConvP p_in) {
     const int gtid = threadIdx.x;                 // 0..NT-1
     unsigned long long t0c = 0, t0r = 0;
     if (p.clk) { t0c = __builtin_amdgcn_s_memtime(); t0r = __builtin_amdgcn_s_memrealtime(); }
-    const int tid = gtid & (THREADS - 1);         // staging role (loader waves when SPEC) / epilogue lane
+    const int tid = gtid & (THREADS - 1);         // staging role / epilogue lane
     const int lane = gtid & 63, wave = (gtid >> 6) & 3;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int tiles_n = (p.N + BN - 1) / BN;
@@ -212,7 +204,6 @@ conv_igemm_f32(const ConvP p_in) {
 #pragma unroll
     for (int q = 0; q < B_LD; ++q) b_vk[q] = b_off4[q] == INV ? INV : b_off4[q] + (unsigned)kg * 4u;
     auto stage_load = [&](float4 (&A)[A_LD], float4 (&Bq)[B_LD], int k0) {
-        if constexpr (!SPEC) {
             if (k0 + BKS <= kend && (is1x1 || tap_uni)) {
                 unsigned so_a = (unsigned)k0 * 4u, kp = 0;
                 if (!is1x1) {
@@ -230,7 +221,7 @@ conv_igemm_f32(const ConvP p_in) {
                     Bq[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, b_vk[q], (unsigned)k0 * 4u, 0));
                 return;
             }
-        }
+        
         const int k = k0 + kg;
         const unsigned kinv = ~(unsigned)((k - kend) >> 31) & INV;      // INV when k >= kend
         const unsigned k4 = (unsigned)k * 4u;
@@ -278,12 +269,6 @@ conv_igemm_f32(const ConvP p_in) {
     const int fr = lane & 15, fg = lane >> 4;
     // fragment reads of one 16-deep half (h = 0/1) of a stage, and the 4*TM*TN MFMAs that consume them
     auto rd = [&](float4 (&av)[TM], float4 (&bv)[TN], int buf, int h) {
-        if constexpr (ABL & 8) {          // diagnostic: no LDS fragment reads (operands are lane constants)
-#pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = make_float4(1.f + lane, 2.f + buf, 3.f, 4.f);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = make_float4(1.f, 2.f + lane, 3.f + buf, 4.f);
-        } else {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int row = (wm * TM + i) * 16 + fr;
@@ -294,7 +279,7 @@ conv_igemm_f32(const ConvP p_in) {
                 const int row = (wn * TN + j) * 16 + fr;
                 bv[j] = *(const float4*)&Bs[buf][row * BKS + (((h * 4 + fg) ^ ((row >> 1) & 7)) << 2)];
             }
-        }
+        
     };
     auto mm = [&](const float4 (&av)[TM], const float4 (&bv)[TN]) {
         // k component outermost: consecutive MFMAs hit DIFFERENT accumulators (the 16x16x4 f32
@@ -310,7 +295,7 @@ conv_igemm_f32(const ConvP p_in) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[i][j], 0, 0, 0);
                 }
     };
-    auto compute = [&](int buf) {         // un-pipelined form (diagnostic variants only)
+    auto compute = [&](int buf) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             float4 av[TM], bv[TN];
@@ -318,12 +303,6 @@ conv_igemm_f32(const ConvP p_in) {
             mm(av, bv);
         }
     };
-    // Software-pipelined stage: two fragment register sets.  The reads of the second half are issued before
-    // the MFMAs of the first, and the first half of the NEXT stage is read right after the barrier that
-    // publishes it, before the MFMAs of this stage's second half -- every ds_read has ~20 MFMAs (640 cycles)
-    // to land.  (Reading and consuming a half back to back left the matrix pipe idle for one LDS round trip
-    // per half: 1580 instead of 1280 cycles per stage with nothing else running.)
-    float4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
     // residual tile: issued before the K loop so that its latency hides behind the MFMAs (small
     // tiles only: C_LD float4 registers per thread)
     constexpr int C_LD = (BM * (BN / 4) + NT - 1) / NT;
@@ -344,145 +323,19 @@ conv_igemm_f32(const ConvP p_in) {
     }
     unsigned long long t1c = 0;
     if (p.clk) t1c = __builtin_amdgcn_s_memtime();
-    if constexpr (SPEC) {
-        if (gtid >= THREADS) {                // ---- loader waves
-            // four register sets: the loads of stages s+2 .. s+5 are in flight while stage s computes.  A CU
-            // ingests only ~12 B/clk with one 18 KB stage in flight (L1 miss capacity x L2 latency; measured with
-            // tools/conv_ablate.py) -- the matrix pipe needs ~14 B/clk at this tile shape -- so the loaders keep
-            // ~70 KB in flight; they hold no accumulators, the extra sets are free here.
-            constexpr int NSET = 4;
-            float4 ra2[NSET][A_LD], rb2[NSET][B_LD];
-            auto gl = [&](auto SET, int k0) {
-                constexpr int S = decltype(SET)::value;
-                stage_load(ra2[S], rb2[S], k0);
-            };
-            auto st = [&](auto SET, auto BUF) {
-                constexpr int S = decltype(SET)::value, Bf = decltype(BUF)::value;
-#pragma unroll
-                for (int q = 0; q < A_LD; ++q) {
-                    const int row = (tid >> 3) + q * (THREADS / 8);
-                    if (row < BM) *(float4*)&As[Bf][row * BKS + ((kc ^ ((row >> 1) & 7)) << 2)] = ra2[S][q];
-                }
-#pragma unroll
-                for (int q = 0; q < B_LD; ++q) {
-                    const int row = (tid >> 3) + q * (THREADS / 8);
-                    if (row < BN) *(float4*)&Bs[Bf][row * BKS + ((kc ^ ((row >> 1) & 7)) << 2)] = rb2[S][q];
-                }
-            };
-            using I0 = std::integral_constant<int, 0>;
-            using I1 = std::integral_constant<int, 1>;
-            using I2 = std::integral_constant<int, 2>;
-            using I3 = std::integral_constant<int, 3>;
-            gl(I0{}, kbeg);
-            st(I0{}, I0{});
-            // loads past kend are issued unconditionally (masked to out-of-range offsets, they move no
-            // data): a load under a condition makes the in-flight count unknowable and the compiler
-            // falls back to s_waitcnt vmcnt(0) before every LDS store
-            gl(I1{}, kbeg + 1 * BKS);
-            gl(I2{}, kbeg + 2 * BKS);
-            gl(I3{}, kbeg + 3 * BKS);
-            gl(I0{}, kbeg + 4 * BKS);
-            __syncthreads();                  // stage 0 visible
-            // stage s computes from LDS buffer s&1; this iteration publishes stage s+1 (register set (s+1)&3)
-            // into buffer (s+1)&1 and refills that set with stage s+5
-            // (no `break` inside the unrolled group: the compiler routes a mid-loop exit through the loop
-            // header, and the wait-count pass then sees this step's own refill as the load it must wait
-            // for -- vmcnt(0), a full drain, once per group)
-#define I2V_LOADER_STEP(SET, BUF)                                   \
-            if (p.clk) c_t0 = __builtin_amdgcn_s_memtime();         \
-            if (k0 + BKS < kend) st(SET{}, BUF{});                  \
-            if (p.clk) { c_t1 = __builtin_amdgcn_s_memtime(); c_st += c_t1 - c_t0; } \
-            gl(SET{}, k0 + 5 * BKS);                                \
-            if (p.clk) { c_t0 = __builtin_amdgcn_s_memtime(); c_gl += c_t0 - c_t1; } \
-            __syncthreads();                                        \
-            if (p.clk) c_bar += __builtin_amdgcn_s_memtime() - c_t0; \
-            k0 += BKS;
-            unsigned long long c_t0 = 0, c_t1 = 0, c_st = 0, c_gl = 0, c_bar = 0;
-            const int nst = (kend - kbeg + BKS - 1) / BKS;
-            int k0 = kbeg, sdone = 0;
-            for (; sdone + 4 <= nst; sdone += 4) {
-                I2V_LOADER_STEP(I1, I1)
-                I2V_LOADER_STEP(I2, I0)
-                I2V_LOADER_STEP(I3, I1)
-                I2V_LOADER_STEP(I0, I0)
-            }
-            const int rem = nst - sdone;
-            if (rem >= 1) {
-                I2V_LOADER_STEP(I1, I1)
-                if (rem >= 2) {
-                    I2V_LOADER_STEP(I2, I0)
-                    if (rem >= 3) { I2V_LOADER_STEP(I3, I1) }
-                }
-            }
-#undef I2V_LOADER_STEP
-            if (p.clk && gtid == THREADS) {
-                unsigned long long* o = p.clk + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
-                o[4] = c_st; o[5] = c_gl; o[6] = c_bar;
-            }
-        } else {                              // ---- MFMA waves
-            __syncthreads();
-            int buf = 0;
-            unsigned long long c_mm = 0;
-            rd(fa0, fb0, 0, 0);
-            for (int k0 = kbeg; k0 < kend; k0 += BKS) {
-                const unsigned long long a0 = p.clk ? __builtin_amdgcn_s_memtime() : 0ull;
-                rd(fa1, fb1, buf, 1);
-                mm(fa0, fb0);
-                const unsigned long long a1 = p.clk ? __builtin_amdgcn_s_memtime() : 0ull;
-                __syncthreads();
-                const unsigned long long a2 = p.clk ? __builtin_amdgcn_s_memtime() : 0ull;
-                if (k0 + BKS < kend) rd(fa0, fb0, buf ^ 1, 0);
-                mm(fa1, fb1);
-                if (p.clk) c_mm += (__builtin_amdgcn_s_memtime() - a2) + (a1 - a0);
-                buf ^= 1;
-            }
-            if (p.clk && gtid == 0) p.clk[8 * (blockIdx.y * gridDim.x + blockIdx.x) + 7] = c_mm;
-        }
-    } else {
-        gload(kbeg);
-        sstore(0);
-        if constexpr (ABL != 0) {
-            __syncthreads();
-            int buf = 0;
-            const bool no_stage = p.ablate & 1, no_mfma = p.ablate & 2;
-            for (int k0 = kbeg; k0 < kend; k0 += BKS) {
-                const bool more = k0 + BKS < kend && !no_stage;
-                if (more) gload(k0 + BKS);
-                if (!no_mfma) compute(buf);
-                if (more) sstore(buf ^ 1);
-                if constexpr (!(ABL & 4)) __syncthreads();
-                buf ^= 1;
-            }
-        } else if constexpr (!PIPE_FRAGS) {
-            // one fragment register set: 118 VGPRs -> four waves per SIMD (the pipelined form below needs 138 -> three)
-            __syncthreads();
-            int buf = 0;
-            for (int k0 = kbeg; k0 < kend; k0 += BKS) {
-                const bool more = k0 + BKS < kend;
-                if (more) gload(k0 + BKS);
-                compute(buf);
-                if (more) sstore(buf ^ 1);
-                __syncthreads();
-                buf ^= 1;
-            }
-        } else {
-            const bool no_stage = p.ablate & 1, no_mfma = p.ablate & 2;
-            if (kbeg + BKS < kend && !no_stage) gload(kbeg + BKS);
-            __syncthreads();
-            rd(fa0, fb0, 0, 0);
-            int buf = 0;
-            for (int k0 = kbeg; k0 < kend; k0 += BKS) {
-                const bool more = k0 + BKS < kend && !no_stage;
-                rd(fa1, fb1, buf, 1);
-                if (more && !(p.ablate & 64)) sstore(buf ^ 1);  // stage s+1: its loads were issued a stage ago
-                if (k0 + 2 * BKS < kend && !no_stage && !(p.ablate & 128)) gload(k0 + 2 * BKS);
-                if (!no_mfma) mm(fa0, fb0);
-                __syncthreads();                              // stage s+1 published, stage s-1's buffer free
-                if (k0 + BKS < kend) rd(fa0, fb0, buf ^ 1, 0);
-                if (!no_mfma) mm(fa1, fb1);
-                buf ^= 1;
-            }
-        }
+    gload(kbeg);
+    sstore(0);
+    // one fragment register set: 118 VGPRs -> four waves per SIMD (a software-pipelined two-set form needed 138 -> three, and
+    // measured no faster with four co-resident waves: DESIGN_HISTORY.md)
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BKS) {
+        const bool more = k0 + BKS < kend;
+        if (more) gload(k0 + BKS);
+        compute(buf);
+        if (more) sstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
     }
 
     if (p.clk && gtid == 0) {     // diagnostic build path: stamps go to their own buffer, never to an output
@@ -497,15 +350,14 @@ conv_igemm_f32(const ConvP p_in) {
     // through LDS so that global stores (and the residual loads) are whole 16-B-per-lane rows
     // instead of 64-B fragments of a line.  (Every wave's last fragment reads completed before the
     // barrier of the last loop iteration, so the stage buffers are free.)
-    if (!SPEC || gtid < THREADS) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    smem[((wm * TM + i) * 16 + 4 * fg + r) * CROW + (wn * TN + j) * 16 + fr] = acc[i][j][r];
-    }
+            for (int r = 0; r < 4; ++r)
+                smem[((wm * TM + i) * 16 + 4 * fg + r) * CROW + (wn * TN + j) * 16 + fr] = acc[i][j][r];
+
     __syncthreads();
     const bool split = p.splitk > 1;
     auto out_index = [&](int m) -> long long {
@@ -547,7 +399,7 @@ conv_igemm_f32(const ConvP p_in) {
         }
         __syncthreads();
         if (!*flag) {
-            if (p.clk && gtid == 0 && !SPEC)
+            if (p.clk && gtid == 0)
                 p.clk[8 * (blockIdx.y * gridDim.x + blockIdx.x) + 4] = __builtin_amdgcn_s_memtime() - t0c;
             return;
         }
@@ -694,7 +546,7 @@ conv_igemm_f32(const ConvP p_in) {
             p.y[o] = v;
         }
     }
-    if (p.clk && gtid == 0 && !SPEC) {
+    if (p.clk && gtid == 0) {
         __builtin_amdgcn_s_waitcnt(0);
         unsigned long long* o = p.clk + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
         o[4] = __builtin_amdgcn_s_memtime() - t0c;           // whole kernel, this workgroup
@@ -712,12 +564,6 @@ conv_igemm_f32(const ConvP p_in) {
 // 16-B store per fragment, no LDS round trip, no barrier.  Staging, swizzled LDS image and the K loop are conv_igemm_f32's.
 // Split-K (<= kSplitInKernelMax): partial tiles go to the caller's workspace in REGISTER order (fragment, wave, lane), the
 // last workgroup to arrive sums them in split order -- same protocol as conv_igemm_f32, whole-wave 1-KB rows.
-// X3 (opt-in, I2V_TUNE_GEMM_X3; the default build of every step is the fp32 MFMA): the products run on the bf16 matrix
-// pipe as a THREE-term split -- each fp32 operand is staged as hi = bf16(x), lo = bf16(x - hi) (16 mantissa bits together)
-// and a * b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi, accumulated in fp32 by v_mfma_f32_16x16x32_bf16: one 16-cycle MFMA covers
-// 32 k where the fp32 form needs eight 32-cycle ones, so the K loop costs 3/16 of its fp32 time; the dropped a_lo b_lo term is
-// 2^-16 of a product.  Inputs, outputs, accumulators and the epilogue stay fp32; the LDS row (32 k) keeps its 128 bytes
-// (16-byte columns 0-3 = hi of k 8c..8c+7, columns 4-7 = lo), the accumulator layout is that of every 16x16 MFMA.
 // KG > 1 (round 4): INTRA-WORKGROUP K split.  A GEMM too short in M x N to fill the chip (layer3 conv1 of a frame pair: 240
 // tiles of 80x64 for 1024 slots, K = 1024) used to run as 3 K-splits of 4 waves whose partial tiles crossed the fabric
 // (sc1 write-through + re-read by the last arriver: 14.7 + 9.8 MB per launch beside the layer's own 25.6 MB).  Here ONE
@@ -741,7 +587,7 @@ __device__ inline void lds_dma16(unsigned dst, unsigned voff, __amdgpu_buffer_rs
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(voff), "s"(r), "s"(soff) : "memory");
 }
 
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool CLK = false, bool MASK = false, bool X3 = false, int KG = 1, int STG = 0>
+template <int WAVES_M, int WAVES_N, int TM, int TN, bool CLK = false, bool MASK = false, int KG = 1, int STG = 0>
 __global__ void __launch_bounds__(THREADS * KG)
 conv_gemm_f32(const ConvP p_in) {
     ConvP p = p_in;
@@ -757,8 +603,8 @@ conv_gemm_f32(const ConvP p_in) {
     constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
     constexpr int A_LD = (BM * 8 + THREADS - 1) / THREADS, B_LD = (BN * 8 + THREADS - 1) / THREADS;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
-    static_assert(KG == 1 || (!CLK && !X3), "the K-group form has no diagnostic / bf16-split instantiation");
-    static_assert(STG == 0 || (KG == 1 && !CLK && !X3), "the LDS-DMA form is the plain 4-wave kernel");
+    static_assert(KG == 1 || !CLK, "the K-group form has no diagnostic instantiation");
+    static_assert(STG == 0 || (KG == 1 && !CLK), "the LDS-DMA form is the plain 4-wave kernel");
     constexpr int BKL = STG == 2 ? 16 : BKS;                   // k per LDS stage
     // KG > 1: the four waves of a K group synchronise among THEMSELVES between stages (an arrival counter in LDS: release,
     // add, poll, acquire) -- an s_barrier would march all 16 waves in lock step, every SIMD's four waves staging together and
@@ -831,31 +677,16 @@ conv_gemm_f32(const ConvP p_in) {
         for (int q = 0; q < B_LD; ++q)
             rb[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, b_vk[q] | kinv, so, 0));
     };
-    // X3: four fp32 (k = 4 kc .. 4 kc + 3) -> four hi bf16 (8 bytes into column kc/2, half kc&1) + four lo bf16 (column 4 + kc/2)
-    auto split_store = [&](float* rowp, int row, float4 v) {
-        const bf16x4 hi = __builtin_convertvector((f32x4){v.x, v.y, v.z, v.w}, bf16x4);
-        const f32x4 hf = __builtin_convertvector(hi, f32x4);
-        const bf16x4 lo = __builtin_convertvector((f32x4){v.x - hf[0], v.y - hf[1], v.z - hf[2], v.w - hf[3]}, bf16x4);
-        const int sw = (row >> 1) & 7;
-        *(bf16x4*)&rowp[((((kc >> 1)) ^ sw) << 2) + ((kc & 1) << 1)] = hi;
-        *(bf16x4*)&rowp[(((4 + (kc >> 1)) ^ sw) << 2) + ((kc & 1) << 1)] = lo;
-    };
     auto sstore = [&](int S) {
 #pragma unroll
         for (int q = 0; q < A_LD; ++q) {
             const int row = (tid >> 3) + q * (THREADS / 8);
-            if (row < BM) {
-                if constexpr (X3) split_store(&As[S][row * BKS], row, ra[q]);
-                else *(float4*)&As[S][row * BKS + ((kc ^ ((row >> 1) & 7)) << 2)] = ra[q];
-            }
+            if (row < BM) *(float4*)&As[S][row * BKS + ((kc ^ ((row >> 1) & 7)) << 2)] = ra[q];
         }
 #pragma unroll
         for (int q = 0; q < B_LD; ++q) {
             const int row = (tid >> 3) + q * (THREADS / 8);
-            if (row < BN) {
-                if constexpr (X3) split_store(&Bs[S][row * BKS], row, rb[q]);
-                else *(float4*)&Bs[S][row * BKS + ((kc ^ ((row >> 1) & 7)) << 2)] = rb[q];
-            }
+            if (row < BN) *(float4*)&Bs[S][row * BKS + ((kc ^ ((row >> 1) & 7)) << 2)] = rb[q];
         }
     };
     // ---- LDS-DMA staging (STG > 0).  A stage = NP 1-KB pieces (PR rows of the A tile, then of the B tile); wave w requests
@@ -895,12 +726,6 @@ conv_gemm_f32(const ConvP p_in) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my pieces of the stage have landed ...
         __builtin_amdgcn_s_barrier();                          // ... everyone's have; and everyone is done with the other buffer
     };
-#ifdef I2V_EXPERIMENTS
-    if (p.knob > 0) {                     // experiment (I2V_TUNE_STAGGER): co-resident workgroups start ~knob kcycles apart
-        const int r = (blockIdx.x >> 8) & 3;
-        for (int i = 0; i < r * p.knob; ++i) __builtin_amdgcn_s_sleep(16);
-    }
-#endif
     if constexpr (STG > 0) dma_issue(kbeg, 0);
     else gload(kbeg);                     // first: everything below hides behind this round trip
 
@@ -952,31 +777,6 @@ conv_gemm_f32(const ConvP p_in) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     auto compute = [&](int buf) {
-        if constexpr (X3) {
-            // lane (fr, fg): 8 bf16 = k 8 fg .. 8 fg + 7 of row fr, hi from column fg, lo from column 4 + fg: one MFMA covers the stage
-            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = (wm * TM + i) * 16 + fr;
-                ah[i] = *(const bf16x8*)&As[buf][row * BKS + ((fg ^ ((row >> 1) & 7)) << 2)];
-                al[i] = *(const bf16x8*)&As[buf][row * BKS + (((4 + fg) ^ ((row >> 1) & 7)) << 2)];
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = (wn * TN + j) * 16 + fr;
-                bh[j] = *(const bf16x8*)&Bs[buf][row * BKS + ((fg ^ ((row >> 1) & 7)) << 2)];
-                bl[j] = *(const bf16x8*)&Bs[buf][row * BKS + (((4 + fg) ^ ((row >> 1) & 7)) << 2)];
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {          // small terms first; weights are the ROW operand as below
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
-                }
-            return;
-        }
         auto swzl = [](int row) { return BKL == 32 ? ((row >> 1) & 7) : ((-(row >> 2)) & 3); };
 #pragma unroll
         for (int h = 0; h < BKL / 16; ++h) {
@@ -1200,218 +1000,6 @@ conv_gemm_f32(const ConvP p_in) {
     stamp();
 }
 
-#ifdef I2V_EXPERIMENTS      // measured slower than one tile per workgroup (profiles/r03_persistent_gemm.txt): not in the default build
-// ---------------------------------------------------------------- persistent form of conv_gemm_f32
-// The same GEMM, staging, LDS image, MFMA order and register epilogue as conv_gemm_f32 (bit-equal results), scheduled as a
-// STREAM OF STAGES: a workgroup owns several tiles (b, b + G, b + 2G, ... of the XCD-aware tile order, G workgroups) and never
-// stops loading -- the operands of the next tile's first stage are requested under the current tile's last stage, and the
-// epilogue's stores drain under the next tile's K loop.  conv_gemm_f32 launches every tile at once: all workgroups of the chip
-// load, then compute, then store IN PHASE; here only the last tile of a workgroup ends in a store burst.
-// A tile queue fed by atomics was tried first and lost by 4x: same-address atomics retire one per ~70 ns at the L2 (8 queues,
-// ~1000 workgroups), and a wave's loads return in order behind its fetch.
-template <int WAVES_M, int WAVES_N, int TM, int TN, bool MASK = false>
-__global__ void __launch_bounds__(THREADS, (TM * TN <= 5 ? 4 : TM * TN <= 6 ? 3 : 2))      // waves per SIMD the register budget is held to
-conv_gemm_pers_f32(const ConvP p) {
-    constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
-    constexpr int A_LD = (BM * 8 + THREADS - 1) / THREADS, B_LD = (BN * 8 + THREADS - 1) / THREADS;
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float (*As)[BM * BKS] = reinterpret_cast<float (*)[BM * BKS]>(smem);
-    float (*Bs)[BN * BKS] = reinterpret_cast<float (*)[BN * BKS]>(smem + 2 * BM * BKS);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int fr = lane & 15, fg = lane >> 4;
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int T = ((p.M + BM - 1) / BM) * tiles_n;
-    const int kc = tid & 7, kg = kc * 4;
-    const int kend = p.K;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
-    constexpr unsigned INV = 0x80000000u;
-
-    // ---- this workgroup's tiles: virtual blocks vb = blockIdx.x + i * gridDim.x (gridDim.x is a multiple of 8, so all of them
-    // sit on this workgroup's XCD) in conv_gemm_f32's XCD-aware order over T virtual blocks
-    auto tile_of = [&](int vb) {
-        const int qq = T >> 3, r = T & 7, x = vb & 7, i = vb >> 3;
-        return (x < r ? x * (qq + 1) : r * (qq + 1) + (x - r) * qq) + i;
-    };
-    unsigned a_vk[A_LD], b_vk[B_LD];
-    auto set_tile = [&](int tile) {               // staging offsets of a tile's rows
-        const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-#pragma unroll
-        for (int qq = 0; qq < A_LD; ++qq) {
-            const int row = (tid >> 3) + qq * (THREADS / 8);
-            const int m = m0 + row;
-            a_vk[qq] = (row < BM && m < p.M) ? ((unsigned)(m * p.K) + (unsigned)kg) * 4u : INV;
-        }
-#pragma unroll
-        for (int qq = 0; qq < B_LD; ++qq) {
-            const int row = (tid >> 3) + qq * (THREADS / 8);
-            const int n = n0 + row;
-            b_vk[qq] = (row < BN && n < p.N) ? ((unsigned)(n * p.K) + (unsigned)kg) * 4u : INV;
-        }
-    };
-    float4 ra[A_LD], rb[B_LD];
-    auto gload = [&](int k0) {
-        const unsigned so = (unsigned)k0 * 4u;
-        const unsigned kinv = ~(unsigned)((k0 + kg - kend) >> 31) & INV;
-#pragma unroll
-        for (int qq = 0; qq < A_LD; ++qq)
-            ra[qq] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xr, a_vk[qq] | kinv, so, 0));
-#pragma unroll
-        for (int qq = 0; qq < B_LD; ++qq)
-            rb[qq] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wr, b_vk[qq] | kinv, so, 0));
-    };
-    auto sstore = [&](int S) {
-#pragma unroll
-        for (int qq = 0; qq < A_LD; ++qq) {
-            const int row = (tid >> 3) + qq * (THREADS / 8);
-            if (row < BM) *(float4*)&As[S][row * BKS + ((kc ^ ((row >> 1) & 7)) << 2)] = ra[qq];
-        }
-#pragma unroll
-        for (int qq = 0; qq < B_LD; ++qq) {
-            const int row = (tid >> 3) + qq * (THREADS / 8);
-            if (row < BN) *(float4*)&Bs[S][row * BKS + ((kc ^ ((row >> 1) & 7)) << 2)] = rb[qq];
-        }
-    };
-
-    // operands of the epilogue: always-issued buffer loads (conv_gemm_f32 has the rationale)
-    constexpr bool PREFETCH_RES = TM * TN <= 8;
-    const unsigned n_bytes = (unsigned)p.N * 4u;
-    const __amdgpu_buffer_rsrc_t scr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.scale ? p.scale : p.shift ? p.shift : (const float*)p.x), 0, n_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t shr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.shift ? p.shift : (const float*)p.x), 0, n_bytes, 0x00020000);
-    const unsigned long long y_bytes = (unsigned long long)p.M * p.N * 4ull;
-    const unsigned y_lim = (unsigned)(y_bytes < 0x7FFFFFF0ull ? y_bytes : 0x7FFFFFF0ull);
-    const __amdgpu_buffer_rsrc_t resr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : (const float*)p.x), 0, y_lim, 0x00020000);
-    const __amdgpu_buffer_rsrc_t mskr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.mask ? p.mask : (const float*)p.x), 0, y_lim, 0x00020000);
-    const unsigned sc_inv = (p.flags & I2V_EPI_SCALE) ? 0u : INV;
-    const unsigned sh_inv = ((p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) && p.shift) ? 0u : INV;
-    const unsigned res_inv = (p.flags & I2V_EPI_RESIDUAL) ? 0u : INV;
-    float4 sc[TN], sh[TN], rres[PREFETCH_RES ? TM : 1][PREFETCH_RES ? TN : 1];
-    auto issue_epi = [&](int m0, int n0) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + (wn * TN + j) * 16 + 4 * fg;
-            const unsigned off = n < p.N ? (unsigned)n * 4u : INV;
-            sc[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(scr, off | sc_inv, 0, 0));
-            sh[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(shr, off | sh_inv, 0, 0));
-        }
-        if constexpr (PREFETCH_RES) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int m = m0 + (wm * TM + i) * 16 + fr, n = n0 + (wn * TN + j) * 16 + 4 * fg;
-                    const unsigned off = (m < p.M && n < p.N) ? (unsigned)(m * p.N + n) * 4u : INV;
-                    rres[i][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(resr, off | res_inv, 0, 2));
-                }
-        }
-    };
-
-    f32x4 acc[TM][TN];
-    auto compute = [&](int buf) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float4 av[TM], bv[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = (wm * TM + i) * 16 + fr;
-                av[i] = *(const float4*)&As[buf][row * BKS + (((h * 4 + fg) ^ ((row >> 1) & 7)) << 2)];
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = (wn * TN + j) * 16 + fr;
-                bv[j] = *(const float4*)&Bs[buf][row * BKS + (((h * 4 + fg) ^ ((row >> 1) & 7)) << 2)];
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        const float a = t == 0 ? av[i].x : t == 1 ? av[i].y : t == 2 ? av[i].z : av[i].w;
-                        const float b = t == 0 ? bv[j].x : t == 1 ? bv[j].y : t == 2 ? bv[j].z : bv[j].w;
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, acc[i][j], 0, 0, 0);
-                    }
-        }
-    };
-    auto finish = [&](int m, int n, int j, f32x4 v, float4 rr, float4 mk) {
-        if (m >= p.M || n >= p.N) return;
-        float4 o = make_float4(v[0], v[1], v[2], v[3]);
-        if (p.flags & I2V_EPI_SCALE) { o.x *= sc[j].x; o.y *= sc[j].y; o.z *= sc[j].z; o.w *= sc[j].w; }
-        if ((p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS)) && p.shift) { o.x += sh[j].x; o.y += sh[j].y; o.z += sh[j].z; o.w += sh[j].w; }
-        if (p.flags & I2V_EPI_RESIDUAL) { o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
-        if (p.flags & I2V_EPI_RELU) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-        if constexpr (MASK) { o.x = mk.x > 0.f ? o.x : 0.f; o.y = mk.y > 0.f ? o.y : 0.f; o.z = mk.z > 0.f ? o.z : 0.f; o.w = mk.w > 0.f ? o.w : 0.f; }
-        *(float4*)(p.y + (long long)m * p.N + n) = o;
-    };
-
-    int vb = blockIdx.x;                       // < T (launch_tile)
-    int cur = tile_of(vb);
-    set_tile(cur);
-    gload(0);
-    int buf = 0;
-    while (cur >= 0) {
-        const int m0 = (cur / tiles_n) * BM, n0 = (cur % tiles_n) * BN;
-        vb += gridDim.x;
-        const int nxt = vb < T ? tile_of(vb) : -1;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        sstore(buf);                                      // stage 0: requested under the previous tile's last stage
-        __syncthreads();
-        int k0 = 0;
-        for (; k0 + 2 * BKS < kend; k0 += BKS) {          // every stage but the last two
-            gload(k0 + BKS);
-            __builtin_amdgcn_sched_barrier(0);            // requested HERE, not where the scheduler would sink them (conv_gemm_f32)
-            compute(buf);
-            sstore(buf ^ 1);
-            __syncthreads();
-            buf ^= 1;
-        }
-        gload(k0 + BKS);                                  // last stage's operands, then the epilogue's (returns are in order)
-        issue_epi(m0, n0);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(buf);
-        sstore(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
-        if (nxt >= 0) { set_tile(nxt); gload(0); }        // the next tile's first stage rides under this tile's last
-        __builtin_amdgcn_sched_barrier(0);
-        compute(buf);
-        buf ^= 1;
-        // epilogue in registers; the stores drain under whatever this workgroup and its neighbours do next
-        float4 mk[TM][TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                mk[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (MASK) {
-                    const int m = m0 + (wm * TM + i) * 16 + fr, n = n0 + (wn * TN + j) * 16 + 4 * fg;
-                    const unsigned off = (m < p.M && n < p.N) ? (unsigned)(m * p.N + n) * 4u : INV;
-                    mk[i][j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(mskr, off, 0, 0));
-                }
-            }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int m = m0 + (wm * TM + i) * 16 + fr, n = n0 + (wn * TN + j) * 16 + 4 * fg;
-                float4 rr;
-                if constexpr (PREFETCH_RES) rr = rres[PREFETCH_RES ? i : 0][PREFETCH_RES ? j : 0];
-                else {
-                    const unsigned off = (m < p.M && n < p.N) ? (unsigned)(m * p.N + n) * 4u : INV;
-                    rr = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(resr, off | res_inv, 0, 2));
-                }
-                finish(m, n, j, acc[i][j], rr, mk[i][j]);
-            }
-        cur = nxt;
-    }
-}
-#endif  // I2V_EXPERIMENTS
 
 // epilogue of the split-K path (partials were accumulated with fp32 atomics)
 __global__ void conv_epilogue_kernel(float* __restrict__ y, const float* __restrict__ scale,
@@ -1462,15 +1050,13 @@ inline int ilog2_exact(int v) {
 }
 
 constexpr int NUM_CU = 256;
-int g_force_tile = -1;           // i2v_conv_set_tile(): tuning hook (low byte: tile, bits 8-9: spec mode + 1)
+int g_force_tile = -1;           // i2v_conv_set_tile(): tuning hook (the tile index)
 int g_ablate = 0;
 unsigned long long* g_clk = nullptr;   // i2v_conv_debug_clock()
 // Tuning knobs live in g_i2v_tuning (i2v_set_tuning; the library itself reads no environment variable).
-// CONV_SPEC: -1 / 0 plain 4-wave kernel, 1 loader/MFMA specialised 8-wave kernel, 2 specialised when <= 3 workgroups per CU.
 // SPLIT_TARGET (workgroups per CU a split-K launch aims for), measured inside the step: 3 for the skinny FC GEMMs makes the
 // step 1 % faster (4.89 vs 4.94 ms) although fc6 forward alone goes from 410 to 556 us and its time becomes unstable; 3
 // for everything the same, 4 slower (5.21).  The default (2) is the setting that is best for the kernels on their own.
-#define g_spec_mode g_i2v_tuning[I2V_TUNE_CONV_SPEC]
 #define g_split_target g_i2v_tuning[I2V_TUNE_SPLIT_TARGET]
 #define g_split_target_skinny g_i2v_tuning[I2V_TUNE_SPLIT_TARGET_SKINNY]
 #define g_split_below g_i2v_tuning[I2V_TUNE_SPLIT_BELOW]
@@ -1505,9 +1091,9 @@ int launch_kgroups(const ConvP& p, hipStream_t st) {
     // exactly what the launch asks for: the kernel also has a few bytes of static LDS, and the attribute call fails (leaving
     // the 64 KB default in force) when dynamic + static would exceed the CU's 160 KB
     static const hipError_t once_k = [] {
-        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, false, false, KG>,
+        hipError_t e = hipFuncSetAttribute((const void*)conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, false, KG>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, need);
-        hipError_t e2 = hipFuncSetAttribute((const void*)conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true, false, KG>,
+        hipError_t e2 = hipFuncSetAttribute((const void*)conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true, KG>,
                                             hipFuncAttributeMaxDynamicSharedMemorySize, need);
         return e != hipSuccess ? e : e2;
     }();
@@ -1518,103 +1104,58 @@ int launch_kgroups(const ConvP& p, hipStream_t st) {
     }
     const int tiles = i2v_cdiv(p.M, BM) * i2v_cdiv(p.N, BN);
     if (p.flags & I2V_EPI_MASK)
-        conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true, false, KG><<<dim3(tiles, 1, 1), THREADS * KG, need, st>>>(p);
+        conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true, KG><<<dim3(tiles, 1, 1), THREADS * KG, need, st>>>(p);
     else
-        conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, false, false, KG><<<dim3(tiles, 1, 1), THREADS * KG, need, st>>>(p);
+        conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, false, KG><<<dim3(tiles, 1, 1), THREADS * KG, need, st>>>(p);
     return I2V_OK;
 }
 
 template <int WAVES_M, int WAVES_N, int TM, int TN>
-void launch_tile(const ConvP& p, bool spec, hipStream_t st) {
+void launch_tile(const ConvP& p, hipStream_t st) {
     constexpr int BM = WAVES_M * TM * 16, BN = WAVES_N * TN * 16;
     const int tiles = i2v_cdiv(p.M, BM) * i2v_cdiv(p.N, BN);
     const size_t stage = (size_t)(2 * (BM + BN) * BKS + p.ktab_entries) * sizeof(float);
     const size_t epi = (size_t)BM * (BN + 4) * sizeof(float);
     const size_t lds = stage > epi ? stage : epi;
     static bool once = [] {
-        set_max_lds(conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false>);
-#ifdef I2V_EXPERIMENTS
-        set_max_lds(conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, true>);
-        if constexpr (WAVES_M == 1) {
-            set_max_lds(conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false, 4>);
-            set_max_lds(conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false, 12>);
-        }
-#endif
+        set_max_lds(conv_igemm_f32<WAVES_M, WAVES_N, TM, TN>);
         return true;
     }();
     (void)once;
-#ifdef I2V_EXPERIMENTS
-    if constexpr (WAVES_M == 1) {      // diagnostic instantiations (tools/conv_ablate.py), 80x64 tile only
-        if ((p.ablate & 12) == 4) { conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false, 4><<<dim3(tiles, p.splitk, p.nbatch > 1 ? p.nbatch : 1), THREADS, lds, st>>>(p); return; }
-        if ((p.ablate & 12) == 12) { conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false, 12><<<dim3(tiles, p.splitk, p.nbatch > 1 ? p.nbatch : 1), THREADS, lds, st>>>(p); return; }
-    }
-#else
-    spec = false;                      // the 8-wave loader / MFMA specialisation is an experiment (I2V_EXPERIMENTS builds only)
-#endif
     const dim3 grid(tiles, p.splitk, p.nbatch > 1 ? p.nbatch : 1);
     // pointwise layers / plain GEMMs whose split-K (if any) is finished in the kernel: the lean specialisation
     const bool pointwise = p.KH == 1 && p.KW == 1 && p.pad == 0 && p.pad_x == 0 && p.stride == 1 && p.ostride == 1 &&
                            p.Ho == p.H && p.Wo == p.W && (p.N & 3) == 0 && (p.K & 3) == 0 && (p.splitk <= 1 || p.ws);
-    if (pointwise && !spec && g_i2v_tuning[I2V_TUNE_CONV_GEMM] && !p.ablate) {
+    if (pointwise && g_i2v_tuning[I2V_TUNE_CONV_GEMM]) {
         static bool once_g = [] {
             set_max_lds(conv_gemm_f32<WAVES_M, WAVES_N, TM, TN>);
             set_max_lds(conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, true>);
             set_max_lds(conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true>);
-            set_max_lds(conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, false, false, 1, 1>);
-            set_max_lds(conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true, false, 1, 1>);
+            set_max_lds(conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, false, 1, 1>);
+            set_max_lds(conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true, 1, 1>);
             return true;
         }();
         (void)once_g;
         const size_t lds_g = (size_t)(2 * (BM + BN) * BKS) * sizeof(float);
-#ifdef I2V_EXPERIMENTS
-        // persistent form (stream of stages): unsplit, unbatched, at least two K stages, at least two tiles per workgroup
-        const int per = g_i2v_tuning[I2V_TUNE_GEMM_PERSIST];
-        if (per > 0 && p.splitk <= 1 && p.nbatch <= 1 && p.K > BKS && !p.clk && !g_i2v_tuning[I2V_TUNE_GEMM_X3] && tiles >= 2 * NUM_CU) {
-            static const int slots = [&] {
-                set_max_lds(conv_gemm_pers_f32<WAVES_M, WAVES_N, TM, TN>);
-                set_max_lds(conv_gemm_pers_f32<WAVES_M, WAVES_N, TM, TN, true>);
-                int n = 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_gemm_pers_f32<WAVES_M, WAVES_N, TM, TN>, THREADS, lds_g) != hipSuccess || n < 1) n = 1;
-                return n * NUM_CU;
-            }();
-            // per tiles per workgroup at least (2 by default), as many workgroups as fit at once at most, a multiple of 8
-            int g = (i2v_cdiv(tiles, per < 2 ? 2 : per) + 7) & ~7;
-            if (g > slots) g = slots;
-            if (g > tiles) g = tiles & ~7;
-            if (p.flags & I2V_EPI_MASK) conv_gemm_pers_f32<WAVES_M, WAVES_N, TM, TN, true><<<g, THREADS, lds_g, st>>>(p);
-            else conv_gemm_pers_f32<WAVES_M, WAVES_N, TM, TN><<<g, THREADS, lds_g, st>>>(p);
-            return;
-        }
-#endif
         // round 6: LDS-DMA staging (I2V_TUNE_GEMM_DMA: 1 = 32-k stages, 2 = 16-k stages / half the LDS; 0 = through registers)
         const int dma = g_i2v_tuning[I2V_TUNE_GEMM_DMA];
-        if (dma > 0 && !p.clk && !g_i2v_tuning[I2V_TUNE_GEMM_X3]) {
+        if (dma > 0 && !p.clk) {
             const bool mask = (p.flags & I2V_EPI_MASK) != 0;
             if (dma == 2) {
-                if (mask) conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true, false, 1, 2><<<grid, THREADS, lds_g / 2, st>>>(p);
-                else conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, false, false, 1, 2><<<grid, THREADS, lds_g / 2, st>>>(p);
+                if (mask) conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true, 1, 2><<<grid, THREADS, lds_g / 2, st>>>(p);
+                else conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, false, 1, 2><<<grid, THREADS, lds_g / 2, st>>>(p);
             } else {
-                if (mask) conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true, false, 1, 1><<<grid, THREADS, lds_g, st>>>(p);
-                else conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, false, false, 1, 1><<<grid, THREADS, lds_g, st>>>(p);
+                if (mask) conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true, 1, 1><<<grid, THREADS, lds_g, st>>>(p);
+                else conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, false, 1, 1><<<grid, THREADS, lds_g, st>>>(p);
             }
             return;
         }
         if (p.flags & I2V_EPI_MASK) conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, true><<<grid, THREADS, lds_g, st>>>(p);
         else if (p.clk) conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, true><<<grid, THREADS, lds_g, st>>>(p);
-#ifdef I2V_EXPERIMENTS
-        else if (g_i2v_tuning[I2V_TUNE_GEMM_X3]) {      // opt-in: 3-term bf16 split on the bf16 matrix pipe
-            static bool once_x = [] { set_max_lds(conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, false, true>); return true; }();
-            (void)once_x;
-            conv_gemm_f32<WAVES_M, WAVES_N, TM, TN, false, false, true><<<grid, THREADS, lds_g, st>>>(p);
-        }
-#endif
         else conv_gemm_f32<WAVES_M, WAVES_N, TM, TN><<<grid, THREADS, lds_g, st>>>(p);
         return;
     }
-#ifdef I2V_EXPERIMENTS
-    if (spec) { conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, true><<<grid, 2 * THREADS, lds, st>>>(p); return; }
-#endif
-    conv_igemm_f32<WAVES_M, WAVES_N, TM, TN, false><<<grid, THREADS, lds, st>>>(p);
+    conv_igemm_f32<WAVES_M, WAVES_N, TM, TN><<<grid, THREADS, lds, st>>>(p);
 }
 
 struct TileCfg { int bm, bn; float eff; };
@@ -1645,7 +1186,6 @@ int run_conv(ConvP p, hipStream_t st, void* split_ws = nullptr, size_t split_ws_
     p.w_bytes = (unsigned)wb;
     p.clk = g_clk;
     p.ablate = g_ablate;
-    p.knob = g_i2v_tuning[I2V_TUNE_STAGGER];
     const int force = p.force_tile;
     const int ksteps = i2v_cdiv(p.K, BKS);
     // tile + split-K choice: minimise (rounds over the 256 CUs) x (MACs per workgroup) / efficiency.
@@ -1702,10 +1242,10 @@ int run_conv(ConvP p, hipStream_t st, void* split_ws = nullptr, size_t split_ws_
     int kg_tile = -1;
     {
         const bool pw = p.KH == 1 && p.KW == 1 && p.pad == 0 && p.pad_x == 0 && p.stride == 1 && p.ostride == 1 && p.Ho == p.H &&
-                        p.Wo == p.W && (p.N & 3) == 0 && (p.K & 3) == 0 && g_i2v_tuning[I2V_TUNE_CONV_GEMM] && !p.ablate;
+                        p.Wo == p.W && (p.N & 3) == 0 && (p.K & 3) == 0 && g_i2v_tuning[I2V_TUNE_CONV_GEMM];
         const int kgn = g_i2v_tuning[I2V_TUNE_KGROUPS] == 2 ? 2 : kKGroups;       // wave groups: 2 (round 5), or 4 (1 / 4)
-        if (g_i2v_tuning[I2V_TUNE_KGROUPS] && pw && g_spec_mode <= 0 && !p.clk && p.nbatch <= 1 && p.splitk >= 2 && force < 0 &&
-            p.K % (kgn * BKS) == 0 && p.K / kgn >= 2 * BKS && !g_i2v_tuning[I2V_TUNE_GEMM_X3] &&
+        if (g_i2v_tuning[I2V_TUNE_KGROUPS] && pw && !p.clk && p.nbatch <= 1 && p.splitk >= 2 && force < 0 &&
+            p.K % (kgn * BKS) == 0 && p.K / kgn >= 2 * BKS &&
             (long long)p.M * p.N >= (1 << 18)) {
             static const int kg_bm[4] = {80, 64, 48, 32};
             const int nt = i2v_cdiv(p.N, 64);
@@ -1743,10 +1283,6 @@ int run_conv(ConvP p, hipStream_t st, void* split_ws = nullptr, size_t split_ws_
     }
     const long long ytotal = (long long)p.M * p.N;
     if (p.splitk > 1 && !p.ws && !(p.flags & I2V_EPI_ZEROED)) hipMemsetAsync(p.y, 0, (size_t)ytotal * sizeof(float), st);
-    // wave specialisation pays where few workgroups share a CU (nothing else hides the staging)
-    const long long nblocks = (long long)i2v_cdiv(p.M, kTiles[cfg].bm) * i2v_cdiv(p.N, kTiles[cfg].bn) * p.splitk;
-    // measured neutral on the backbone shapes (l2 c2 +6 %, l3 ds -12 %): off unless forced
-    const bool spec = g_spec_mode < 0 ? false : (g_spec_mode == 2 ? nblocks <= 3 * NUM_CU : g_spec_mode != 0);
     if (kg_tile >= 0 && g_i2v_tuning[I2V_TUNE_KGROUPS] == 2) {
         switch (kg_tile) {
             case 0: return launch_kgroups<1, 4, 5, 1, 2>(p, st);
@@ -1764,12 +1300,12 @@ int run_conv(ConvP p, hipStream_t st, void* split_ws = nullptr, size_t split_ws_
         }
     }
     switch (cfg) {
-        case 0: launch_tile<2, 2, 4, 4>(p, spec, st); break;
-        case 1: launch_tile<2, 2, 4, 2>(p, spec, st); break;
-        case 2: launch_tile<2, 2, 3, 2>(p, spec, st); break;
-        case 3: launch_tile<1, 4, 5, 1>(p, spec, st); break;
-        case 4: launch_tile<2, 2, 2, 2>(p, spec, st); break;
-        default: launch_tile<2, 2, 1, 2>(p, spec, st); break;
+        case 0: launch_tile<2, 2, 4, 4>(p, st); break;
+        case 1: launch_tile<2, 2, 4, 2>(p, st); break;
+        case 2: launch_tile<2, 2, 3, 2>(p, st); break;
+        case 3: launch_tile<1, 4, 5, 1>(p, st); break;
+        case 4: launch_tile<2, 2, 2, 2>(p, st); break;
+        default: launch_tile<2, 2, 1, 2>(p, st); break;
     }
     if (p.splitk > 1 && !p.ws && (p.flags & (I2V_EPI_SCALE | I2V_EPI_BIAS | I2V_EPI_RESIDUAL | I2V_EPI_RELU | I2V_EPI_MASK))) {
         if (p.N % 4 == 0)
@@ -1836,7 +1372,6 @@ struct WgP {
     unsigned x_bytes, gy_bytes;            // buffer descriptor sizes (v2 kernel)
     int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo, M, N, K, m_per_split, lgCin;
     unsigned long long* clk;               // diagnostic (i2v_conv_debug_clock): per-workgroup stamps, CLK instantiation only
-    int prio;                              // I2V_TUNE_WGRAD_PRIO: 0 off, n: wave priority 3 - ((stage >> (n-1)) & 3)
     int abl;                               // diagnostic instantiation only: ablation bits (i2v_conv_set_tile bits 10-12)
     // ordered finish of a split over pixels (round 5): partial tiles through the caller's split workspace, summed in split
     // order by the last workgroup to arrive at the tile's counter (the protocol of conv_igemm_f32's split-K finish): the sum
@@ -2253,19 +1788,6 @@ conv_wgrad2_f32(const WgP p_in) {
     int buf = 0;
     for (int ms = mbeg; ms < mend; ms += BKS) {
         const bool more = ms + BKS < mend;
-#ifdef I2V_EXPERIMENTS
-        if (p.prio) {
-            // experiment (I2V_TUNE_WGRAD_PRIO): issue priority falls with progress, so the co-resident workgroups of a CU stay
-            // together instead of retiring one by one (the arbiter favours the oldest wave: ends spread 84 .. 108 us around a
-            // 93 us median on the layer3 shapes, the last workgroup alone cannot keep the matrix pipe busy)
-            switch (3 - ((((ms - mbeg) / BKS) >> (p.prio - 1)) & 3)) {
-                case 0: __builtin_amdgcn_s_setprio(0); break;
-                case 1: __builtin_amdgcn_s_setprio(1); break;
-                case 2: __builtin_amdgcn_s_setprio(2); break;
-                default: __builtin_amdgcn_s_setprio(3); break;
-            }
-        }
-#endif
         if constexpr (CLK) {        // diagnostic instantiation only (tools/wgrad_phase.py ABL=..): 1 = no staging after the first stage, 2 = no MFMAs
             if (more && !(p.abl & 1)) gload(ms + BKS);
             if (!(p.abl & 2)) compute(buf);
@@ -2852,7 +2374,6 @@ static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st, void* s
         p.r_tiles = (int)tiles; p.r_splits = splits; p.r_total = (int)total;
         grid = dim3((unsigned)((total + 7) / 8 * 8), 1, 1);
     }
-    p.prio = g_i2v_tuning[I2V_TUNE_WGRAD_PRIO];
     if (!v2) conv_wgrad_f32<64, 64><<<grid, THREADS, 0, st>>>(p);
     else if (fused && tm == 128 && tk == 64) conv_wgrad2_f32<4, 2, true><<<grid, THREADS, 0, st>>>(p);
     else if (tm == 128 && tk == 128) conv_wgrad2_f32<4, 4><<<grid, THREADS, 0, st>>>(p);
@@ -2903,16 +2424,12 @@ extern "C" int32_t i2v_debug_clock_stamp(void* out2, void* stream) {
 }
 
 extern "C" int32_t i2v_conv_set_tile(int32_t cfg) {
-    if (cfg < 0) { g_force_tile = -1; g_spec_mode = -1; g_ablate = 0; return I2V_OK; }
-#ifndef I2V_EXPERIMENTS
-    if (((cfg >> 8) & 3) == 2 || ((cfg >> 10) & 255)) {
-        i2v_set_error("conv_set_tile: the 8-wave specialisation and the ablation bits need a -DI2V_EXPERIMENTS build");
+    if (cfg < 0) { g_force_tile = -1; g_ablate = 0; return I2V_OK; }
+    if (cfg >> 8) {         // rounds 1-5: bits 8-9 selected the 8-wave loader / MFMA specialisation, bits 10+ ablation instantiations
+        i2v_set_error("conv_set_tile: bits above the tile index selected experiment kernels that left the library in round 6");
         return I2V_ERR_UNSUPPORTED;
     }
-#endif
     g_force_tile = (cfg & 0xFF) == 0xFF ? -1 : (cfg & 0xFF);
-    g_spec_mode = ((cfg >> 8) & 3) - 1;
-    g_ablate = (cfg >> 10) & 255;
     return I2V_OK;
 }
 

@@ -739,108 +739,6 @@ class FusedEntry(tuple):
         return self
 
 
-class DeferredUpdate:
-    """Pending SGD update of ONE large linear layer (vrd.fc6 / fc7): the backward of step i leaves (x_i, g_i) here instead of
-    running the filter-gradient kernel; the forward of step i+1 applies the update tile by tile while it streams the filter
-    (``i2v_fc_fold_fwd``: one pass over the 822 MB of fc6 per step instead of two).  Nothing reads the filter between a
-    step's backward and the next step's forward, so the trajectory is the undeferred one; whoever does read it outside the
-    loop (checkpoints, evaluation, a learning-rate change) calls ``flush()`` first -- FusedSGD does.
-    ``valid`` is the device-side flag the kernel reads (a captured forward must not depend on host state); ``armed`` and
-    ``rows`` are its host twins."""
-    ROWS = 128
-
-    def __init__(self, w, owner=None):
-        N, K = w.shape[0], w[0].numel()
-        self.w, self.owner = w, owner
-        self.pend_x = torch.zeros((self.ROWS, K), device=w.device)
-        self.pend_g = torch.zeros((self.ROWS, N), device=w.device)
-        self.valid = torch.zeros((1,), dtype=torch.int32, device=w.device)
-        self.rows, self.armed = 0, False
-
-    def tensors(self):
-        return [self.pend_x, self.pend_g, self.valid]
-
-    def flush(self):
-        """Apply the pending update now (the fused filter-gradient + SGD kernel) and disarm."""
-        if not self.armed:
-            return
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("DeferredUpdate.flush() inside a graph capture")
-        cfg = FUSED_SGD.get(self.w.data_ptr())
-        if cfg is not None:
-            M, N, K = self.rows, self.pend_g.shape[1], self.pend_x.shape[1]
-            x4, g4, w4 = self.pend_x[:M].view(M, K, 1, 1), self.pend_g[:M].view(M, N, 1, 1), self.w.detach().view(N, K, 1, 1)
-            if _conv_wgrad_sgd_raw(x4, g4, w4, cfg, 1, 0) != 0:       # a shape the fused kernel does not take: two kernels
-                gw = _conv_wgrad_raw(x4, g4, (N, K, 1, 1), 1, 0)
-                sgd_momentum_(w4, gw.contiguous(), cfg[0], cfg[1], cfg[2], cfg[3])
-        self.valid.zero_()
-        self.armed = False
-
-
-# parameter storage pointer -> DeferredUpdate (train.FusedSGD.fuse_wgrad registers the big linear layers here as well as in
-# FUSED_SGD, which keeps holding their (momentum, lr, momentum factor, weight decay))
-DEFERRED_SGD = {}
-
-
-def flush_deferred():
-    for st in DEFERRED_SGD.values():
-        st.flush()
-
-
-class _LinearDeferredFn(torch.autograd.Function):
-    """y = relu?(x w^T + b) of a layer registered in DEFERRED_SGD: the forward applies the pending update of the previous
-    step on its way through the filter, the backward leaves this step's (x, g) pending and returns no filter gradient."""
-
-    @staticmethod
-    def forward(ctx, x, w, b, relu):
-        st = DEFERRED_SGD[w.data_ptr()]
-        m, lr, mom, wd = FUSED_SGD[w.data_ptr()]
-        x = x.contiguous()
-        M, K = x.shape
-        N = w.shape[0]
-        y = ARENA.take_flat(M * N) if ARENA is not None else None
-        y = y.view(M, N) if y is not None else torch.zeros((M, N), device=x.device, dtype=torch.float32)
-        with _Timed(2.0 * M * N * K + (2.0 * st.rows * N * K if st.armed else 0.0), "fwd",
-                    "M%d N%d K%d fold (+ pending wgrad M%d, SGD)" % (M, N, K, st.rows if st.armed else 0),
-                    4 * (x.numel() + (st.rows * (K + N) if st.armed else 0) + (4 if st.armed else 1) * w.numel() + y.numel())):
-            check(lib.i2v_fc_fold_fwd(ptr(x), ptr(st.pend_x), ptr(st.pend_g), ptr(st.valid), ptr(w), ptr(m), ptr(b), ptr(y), M,
-                                      st.rows, N, K, float(lr), float(mom), float(wd), stream()), "fc_fold_fwd")
-        if relu:
-            y = torch.relu(y)       # out of place: y is a view of the arena, whose version counter every in-place aten op bumps
-        ctx.relu = bool(relu)
-        ctx.save_for_backward(x, w, y if relu else None)
-        return y
-
-    @staticmethod
-    def backward(ctx, gy):
-        x, w, y = ctx.saved_tensors
-        st = DEFERRED_SGD[w.data_ptr()]
-        M, K = x.shape
-        N = w.shape[0]
-        gy = gy.contiguous()
-        gbias = None
-        if ctx.needs_input_grad[2]:
-            gbias = ARENA.take_flat(N) if ARENA is not None else None
-            if gbias is None:
-                gbias = torch.zeros((N,), device=gy.device, dtype=torch.float32)
-        g = st.pend_g[:M]
-        need_gx = ctx.needs_input_grad[0]
-        as_wgrad = need_gx and _linear_dgrad_as_wgrad((M, K, 1, 1), (N, K, 1, 1), 1, 0)
-        g_t = torch.empty((N, M, 1, 1), device=gy.device, dtype=torch.float32) if as_wgrad else None
-        # one pass over gy: g = gy * (y > 0) straight into the pending buffer, the bias column sums, g^T for the data gradient
-        check(lib.i2v_epilogue_bwd(ptr(gy), ptr(y) if ctx.relu else None, None, ptr(g), None, ptr(gbias), M, N, int(ctx.relu),
-                                   ptr(g_t), *_sws_args(), stream()), "epilogue_bwd")
-        gx = None
-        if need_gx:      # with THIS step's filter: the pending update is only applied by the next forward
-            w4 = w.view(N, K, 1, 1)
-            gx = (_conv_wgrad_raw(w4, g_t, (M, K, 1, 1), 1, 0, tag="dgrad") if as_wgrad
-                  else _conv_dgrad_raw(g.view(M, N, 1, 1), w4, (M, K, 1, 1), 1, 0)).view(M, K)
-        st.pend_x[:M].copy_(x)
-        st.valid.fill_(1)
-        st.rows, st.armed = M, True
-        return gx, None, gbias, None
-
-
 def _conv_wgrad_sgd_raw(x, g, w, cfg, stride, pad):
     m, lr, mom, wd = cfg
     B, Cin, H, W = x.shape
@@ -1138,12 +1036,6 @@ def conv2d(x, w, scale=None, shift=None, res=None, stride=1, pad=0, relu=False, 
 def linear(x, w, b=None, relu=False):
     """nn.Linear (+ReLU) as a 1x1 conv over (M,1,1,K): x (M,K), w (N,K) -> (M,N)."""
     M, K = x.shape
-    st = DEFERRED_SGD.get(w.data_ptr()) if DEFERRED_SGD else None
-    if st is not None:
-        if torch.is_grad_enabled() and w.requires_grad and x.is_cuda and M <= st.ROWS and w.data_ptr() in FUSED_SGD and \
-                lib.i2v_fc_fold_supported(M, st.rows, w.shape[0], K):
-            return _LinearDeferredFn.apply(x, w, b, bool(relu))
-        st.flush()              # any other reader of the filter (evaluation, an unsupported shape) sees it updated
     y = conv2d(x.contiguous().view(M, K, 1, 1), w.view(w.shape[0], K, 1, 1), None, b, None, 1, 0, relu)
     return y.view(M, w.shape[0])
 

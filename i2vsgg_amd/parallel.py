@@ -52,15 +52,27 @@ def capture_kwargs():
     return {}
 
 
+WATCHDOG_PERIOD_S = 0.1       # ProcessGroupNCCL::kWatchdogThreadSleepMillis (torch/csrc/distributed/c10d/ProcessGroupNCCL.hpp): one pass per 100 ms
+
+
 def wait_for_collectives(device):
-    """Before a capture: every collective launched so far has finished (a device synchronisation).  Round 5 also slept 0.3 s
-    here so that the watchdog had dropped the finished works from its list -- a guess about its polling period.  It is not
-    needed: what made the watchdog's ``hipEventQuery`` an error was the GLOBAL capture mode, and every capture made while a
-    process group exists runs THREAD_LOCAL (``capture_kwargs``), under which a query from the watchdog's thread is legal
-    whenever it comes; the works it may still hold after the synchronisation are complete, so the query has nothing to wait
-    for either."""
+    """Before a capture: every collective launched so far has finished AND has left the watchdog's work list.
+
+    The watchdog thread polls the end events of the works on its list (``hipEventQuery``) and drops a finished work on its
+    next pass.  While a capture runs that query can abort the process -- the watchdog throws, nothing catches it: under the
+    GLOBAL capture mode always (round 5), and under THREAD_LOCAL (``capture_kwargs``) still sometimes: the works of the warm-up
+    steps were recorded on RCCL's own stream, which the captured collectives pull INTO the capture.  Round 6 tried the
+    synchronisation alone -- THREAD_LOCAL should make the query legal -- and the full GPU suite aborted in the instance_styleD
+    rehearsal after three clean runs (profiles/r06_watchdog_abort.txt).  So the list must be EMPTY when the capture starts.
+    torch offers no call for that (no ``_wait_for_pending_works`` on this build; ``Work.wait()`` is a stream wait, and
+    ``Work.is_completed()`` is true long before the watchdog's copy is gone), which leaves the watchdog's own clock: after a
+    device synchronisation every work is complete, and one full pass later -- two periods, to be safe against a pass that
+    was under way -- the list is empty.  Works issued DURING a capture are never put on the list (ProcessGroupNCCL skips
+    ``workEnqueue`` while capturing)."""
     if dist.is_available() and dist.is_initialized() and device.type == "cuda":
+        import time
         torch.cuda.synchronize(device)
+        time.sleep(3 * WATCHDOG_PERIOD_S)
 
 
 def init_from_env(backend=None):

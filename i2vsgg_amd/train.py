@@ -16,7 +16,6 @@ from . import synthetic as syn
 from .model.utils.config import cfg
 
 
-DEFER_FC = False        # fuse_wgrad(defer=...): the fc-fold experiment (measured slower; I2V_EXPERIMENTS builds only)
 
 class FusedSGD:
     """SGD(momentum) with the reference's param groups (bias: lr x2 and no weight decay when
@@ -38,19 +37,11 @@ class FusedSGD:
                 lr=lr * ((T.DOUBLE_BIAS + 1) if is_bias else 1),
                 wd=(wd if T.BIAS_DECAY else 0.0) if is_bias else wd))
 
-    def fuse_wgrad(self, min_numel=1 << 24, defer=None):
+    def fuse_wgrad(self, min_numel=1 << 24):
         """Fuse the update of large filters into their wgrad epilogue (single-GPU only: with data
         parallelism the gradient must be all-reduced before the update).  Returns the fused names.
-        ``defer`` (``train.DEFER_FC``; OFF, an I2V_EXPERIMENTS build only): 2-D filters among them additionally get a pending-update slot
-        (ops.DeferredUpdate): their update is applied by the NEXT forward on its pass over the filter (i2v_fc_fold_fwd).
-        Correct and parity-tested, but measured slower than forward + fused update as separate kernels (fc6: 1.41 ms against
-        0.43 + 0.79; the headline step 5.0 ms against 4.65 -- DESIGN.md section 5.5), so the step does not use it."""
-        import os
-        if defer is None:
-            defer = DEFER_FC
-        if defer and not _lib.EXPERIMENTS:
-            raise RuntimeError("train.DEFER_FC / fuse_wgrad(defer=True): the fc fold kernel is an experiment, not in this library "
-                               "(build with I2V_EXPERIMENTS=1 python -m i2vsgg_amd.build)")
+        (Rounds 3-5 carried a second form, ``defer``: the update applied by the NEXT forward on its pass over the filter --
+        parity-tested, 1.41 ms against 0.43 + 0.79 as two kernels, never used; it left the tree in round 6, DESIGN_HISTORY.md 5.6.)"""
         names = []
         for it in self.items:
             p = it["p"]
@@ -63,8 +54,6 @@ class FusedSGD:
                 ops.FUSED_SGD[p.data_ptr()] = ops.FusedEntry(it["m"], it["lr"], self.momentum, it["wd"], self)
                 self._fused_keys.append(p.data_ptr())
                 names.append(it["name"])
-                if defer and p.dim() == 2 and p.is_cuda and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0:
-                    ops.DEFERRED_SGD[p.data_ptr()] = ops.DeferredUpdate(p, self)
         return names
 
     def _mine(self, table, k):
@@ -72,29 +61,19 @@ class FusedSGD:
         return ent if ent is not None and getattr(ent, "owner", None) is self else None
 
     def flush_pending(self):
-        """Apply the updates the deferred layers still hold (before anything outside the training step reads their filters:
-        checkpoints, evaluation, a learning-rate change)."""
-        for k in self._fused_keys:
-            st = self._mine(ops.DEFERRED_SGD, k)
-            if st is not None:
-                st.flush()
+        """Nothing is pending: every update is applied inside the step (rounds 3-5 had a deferred form for fc6 / fc7; callers that
+        read filters outside the step keep calling this)."""
 
     def pending_state(self):
-        """Tensors + host state of the pending updates (for a snapshot of the training state)."""
-        sts = [ops.DEFERRED_SGD[k] for k in self._fused_keys if self._mine(ops.DEFERRED_SGD, k) is not None]
-        return [t for st in sts for t in st.tensors()], [(st.rows, st.armed) for st in sts]
+        return [], []
 
     def restore_pending(self, host):
-        sts = [ops.DEFERRED_SGD[k] for k in self._fused_keys if self._mine(ops.DEFERRED_SGD, k) is not None]
-        for st, (rows, armed) in zip(sts, host):
-            st.rows, st.armed = rows, armed
+        pass
 
     def unfuse(self):
-        self.flush_pending()
         for k in self._fused_keys:
-            for table in (ops.FUSED_SGD, ops.DEFERRED_SGD):
-                if self._mine(table, k) is not None:          # not an entry a newer optimizer made at a reused address
-                    del table[k]
+            if self._mine(ops.FUSED_SGD, k) is not None:      # not an entry a newer optimizer made at a reused address
+                del ops.FUSED_SGD[k]
         self._fused_keys = []
 
     def __del__(self):

@@ -47,11 +47,7 @@ extern "C" {
 
 int32_t     i2v_version(void);
 const char* i2v_last_error(void);
-/* bit set: I2V_BUILD_EXPERIMENTS = compiled with -DI2V_EXPERIMENTS (the measured-and-lost kernel variants of rounds 1-3 and the
- * diagnostic instantiations: persistent GEMM, bf16 three-term split, 8-wave loader/MFMA specialisation, fc fold, stagger /
- * priority knobs).  The default build carries none of them; their tuning keys then accept only "off" and their entry
- * points return I2V_ERR_UNSUPPORTED. */
-#define I2V_BUILD_EXPERIMENTS 1
+/* 0 (rounds 3-5: bit 0 = a build with the experiment kernels, which left the tree in round 6; kept so that old callers link) */
 int32_t     i2v_build_flags(void);
 
 /* ---- streams of the host's own ---------------------------------------------------
@@ -251,7 +247,7 @@ int32_t i2v_conv_fwd_splits(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_
 size_t  i2v_conv_split_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t KH,
                                        int32_t KW, int32_t stride, int32_t pad);
 /* Tuning knobs (process-wide, host side only; the library reads no environment variable).  key = I2V_TUNE_*. */
-#define I2V_TUNE_CONV_SPEC            0   /* -1/0 plain 4-wave conv kernel, 1 loader+MFMA specialised, 2 specialised at <= 3 workgroups/CU */
+#define I2V_TUNE_CONV_SPEC            0   /* retired (rounds 1-5: the 8-wave loader / MFMA specialisation of conv_igemm_f32): only <= 0 is accepted */
 #define I2V_TUNE_SPLIT_TARGET         1   /* workgroups per CU a split-K launch aims for (default 2) */
 #define I2V_TUNE_SPLIT_TARGET_SKINNY  2   /* the same for GEMMs of <= 256 rows (-1: as SPLIT_TARGET) */
 #define I2V_TUNE_SPLIT_BELOW          3   /* split K only when the unsplit grid has fewer tiles than this (default 256) */
@@ -262,29 +258,28 @@ size_t  i2v_conv_split_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t 
 #define I2V_TUNE_WINO_ROWS            8   /* bit 0 / 1: row-split Winograd input / output transform; -1: by size (small launches split); default 0: never -- the split wins for a layer3 launch alone (34 against 37 us) and loses inside the step graphs, whose branches already fill the chip (4.59 against 4.61 ms) */
 #define I2V_TUNE_ROIPOOL_C128         9   /* 1 (default): 128-channel ROIPool forward kernel for NHWC maps */
 #define I2V_TUNE_CONV_GEMM           10   /* 1 (default): pointwise layers / plain GEMMs on the lean conv_gemm_f32 kernel */
-#define I2V_TUNE_STAGGER             11   /* experiment: co-resident conv_gemm_f32 workgroups start this many kcycles apart (0 = off) */
+#define I2V_TUNE_STAGGER             11   /* retired (start-time stagger of co-resident workgroups): only 0 is accepted */
 #define I2V_TUNE_ROIALIGN_COLS       12   /* ROIAlign forward, NHWC: 2 (default) = one ROI x 128 channels per workgroup, sample values meet in LDS, each tap through the L2 once (NHWC output, <= 64 sample points; else as 1); 1 = column-pair workgroups (round 2); 0 = one output row per workgroup (round 1) */
 #define I2V_TUNE_WGRAD_PER_CU        13   /* workgroups per CU a split-over-pixels wgrad launch aims for (default 4) */
 #define I2V_TUNE_WGRAD_XCD           14   /* 1 (default): a filter-gradient split's tiles share an XCD when the split count is a multiple of 8 */
-#define I2V_TUNE_FC_FOLD             15   /* diagnostic ablation bits of i2v_fc_fold_fwd (0 = the kernel as shipped): 1 no gradient MFMAs, 2 no forward MFMAs, 4 no x loads, 8 no filter / momentum stores, 16 no xp staging */
-#define I2V_TUNE_GEMM_X3             16   /* opt-in (default 0 = fp32 MFMA everywhere): 1 = the pointwise / plain-GEMM kernel multiplies on the bf16 matrix pipe as a three-term split (hi*hi + hi*lo + lo*hi of two 8-bit-mantissa halves; fp32 in, fp32 accumulate, fp32 out) */
-#define I2V_TUNE_GEMM_PERSIST        17   /* n >= 1: unsplit pointwise / plain GEMMs run on the persistent form of the kernel (a workgroup streams through >= max(n, 2) tiles, the next tile's operands requested under the current tile's last stage); bit-equal, measured slower; 0 (default) = one tile per workgroup */
-#define I2V_TUNE_WGRAD_PRIO          18   /* experiment: n > 0 = the filter-gradient kernel lowers a wave's issue priority as it advances (3 - ((stage >> (n-1)) & 3)); 0 = off */
+#define I2V_TUNE_FC_FOLD             15   /* retired (ablation bits of the fc-fold kernel, DESIGN_HISTORY.md 5.6): only 0 is accepted */
+#define I2V_TUNE_GEMM_X3             16   /* retired (three-term bf16 split of the pointwise GEMM, DESIGN_HISTORY.md 5.7): only 0 is accepted */
+#define I2V_TUNE_GEMM_PERSIST        17   /* retired (persistent form of the pointwise GEMM, profiles/r03_persistent_gemm.txt): only 0 is accepted */
+#define I2V_TUNE_WGRAD_PRIO          18   /* retired (falling wave priority in the filter-gradient kernel): only 0 is accepted */
 #define I2V_TUNE_STREAM_TILE         19   /* 1 (default): pointwise layers of at most four K stages over >= 16384 rows (HBM-bound) take the 80x64 tile whatever the cost model says; 0: cost model */
 #define I2V_TUNE_KGROUPS             20   /* 2 (round 5): the same with TWO wave groups (8 waves, two 39 KB stage regions: the workgroup shares its CU); 1 / 4: a pointwise GEMM the plan would split over K runs as one 16-wave workgroup per tile whose four wave groups split K and meet in LDS (no partial tile through memory) when one round of such tiles covers >= 70 % of the CUs: 4-10 % faster than the split across workgroups as a kernel on its own, 9 % SLOWER inside the overlapped step (a workgroup that owns a CU's LDS and registers shuts the other branches' workgroups out: profiles/r04_kgroups.txt); 0 (default): split-K across workgroups, partials through the caller's workspace */
 #define I2V_TUNE_WGRAD_ORDERED_GFLOP 21   /* a split filter gradient takes an ordered finish (I2V_TUNE_SPLIT_ATOMICS == 0) only when the problem is below this many GFLOP (default 1000000: always; round 5's default was 8 -- its only ordered form, one finisher reading every part, was a tail on the large launches; 0: never) */
 #define I2V_TUNE_GEMM_DMA            22   /* how the pointwise / plain-GEMM kernel stages its operand tiles (round 6).  0: global -> registers -> ds_write_b128 (rounds 2-5).  1: LDS-DMA (buffer_load ... lds, the column swizzle on the source address), 32-k stages, same LDS image.  2: LDS-DMA with 16-k stages (64-byte LDS rows): half the LDS per workgroup, twice the barriers.  Bit-equal results in all three */
 #define I2V_TUNE_COUNT               23
-/* Keys CONV_SPEC (> 0), STAGGER, FC_FOLD, GEMM_X3, GEMM_PERSIST, WGRAD_PRIO are experiments: I2V_ERR_UNSUPPORTED for any value
- * but "off" unless the library was built with -DI2V_EXPERIMENTS (i2v_build_flags). */
+/* Keys CONV_SPEC (> 0), STAGGER, FC_FOLD, GEMM_X3, GEMM_PERSIST, WGRAD_PRIO belonged to kernel variants that were measured and lost
+ * (DESIGN_HISTORY.md) and left the library in round 6: I2V_ERR_UNSUPPORTED for any value but "off"; the indices stay reserved. */
 int32_t i2v_set_tuning(int32_t key, int32_t value);
 int32_t i2v_get_tuning(int32_t key);
-/* tuning hook: cfg < 0 = cost model; else low byte = tile shape 0..5 (0xFF = cost model),
- * bits 8-9 = 0 auto / 1 plain 4-wave kernel / 2 loader+MFMA specialised 8-wave kernel */
+/* tuning hook: cfg < 0 = cost model; else cfg = tile shape 0..5 (0xFF = cost model).  Bits above the low byte selected
+ * experiment kernels in rounds 1-5: I2V_ERR_UNSUPPORTED now */
 int32_t i2v_conv_set_tile(int32_t cfg);
 /* diagnostic: when buf != NULL every conv workgroup writes 8 u64 to buf[8*wg ..]: {K-loop shader cycles, 100 MHz
- * ticks since kernel start, setup cycles, total cycles, then (specialised kernel only) loader LDS-store / load-issue /
- * barrier cycles and MFMA-wave compute cycles}; the in-kernel clock is total cycles / ticks * 100 MHz */
+ * ticks since kernel start, setup cycles, total cycles, ...}; the in-kernel clock is total cycles / ticks * 100 MHz */
 int32_t i2v_conv_debug_clock(void* buf);
 /* diagnostic: one-lane kernel writing {shader-clock counter, 100 MHz counter} to out2[0..1] on `stream`; two stamps around
  * a stretch of work give the shader clock the chip held over it (tools/step_clock.py) */
@@ -388,17 +383,6 @@ int32_t i2v_conv3x3_winograd4_fwd(const float* x, const float* U, const float* s
 int32_t i2v_conv_wgrad_sgd(const float* x, const float* gy, float* w, float* m, int32_t B, int32_t H, int32_t W,
                            int32_t Cin, int32_t Cout, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                            float lr, float momentum, float weight_decay, void* stream);
-
-/* A large linear layer with ONE pass over its filter per training step (vrd.fc6, resnet_SGG_emb.py:83,:146-151, under the
- * optimizer step of trainval_net_SGG_emb.py:253-255): the SGD(momentum) update left pending by the previous step's backward --
- * gw = g_pending^T x_pending, g' = gw + wd*w, m = mom*m + g', w -= lr*m -- is applied tile by tile while this step's forward
- * y[r][n] += sum_k x[r][k] w[n][k] (+ bias[n]) streams the filter, on the fresh tile.  x (M,K), x_pending (M_pending,K),
- * g_pending (M_pending,N) row-major; w, m (N,K) updated in place; y (M,N) must arrive zeroed (accumulated with fp32 atomics).
- * *pending_valid (device int32) == 0: no update, plain forward.  i2v_fc_fold_supported: rows <= 128, N % 64 == 0, K % 64 == 0. */
-int32_t i2v_fc_fold_supported(int32_t M, int32_t M_pending, int32_t N, int32_t K);
-int32_t i2v_fc_fold_fwd(const float* x, const float* x_pending, const float* g_pending, const int32_t* pending_valid,
-                        float* w, float* m, const float* bias, float* y, int32_t M, int32_t M_pending, int32_t N, int32_t K,
-                        float lr, float momentum, float weight_decay, void* stream);
 
 /* epilogue backward, one streaming pass: g_pre = gy * (y>0) [relu]; g = g_pre * scale[n] (scale may be NULL);
  * gbias[n] += column sums of g_pre.  g, gpre and gbias may each be NULL; in-place (g == gy or gpre == gy) allowed.

@@ -544,29 +544,18 @@ def test_dstyle_pool(ops):
     np.testing.assert_allclose(d2.grad.cpu().numpy(), x2.grad.numpy(), rtol=1e-6, atol=1e-6)
 
 
-def _experiments():
-    from i2vsgg_amd import _lib
-    return _lib.EXPERIMENTS
-
-
-needs_experiments = pytest.mark.skipif("not __import__('i2vsgg_amd._lib', fromlist=['EXPERIMENTS']).EXPERIMENTS",
-                                       reason="the default library carries no experiment kernels (I2V_EXPERIMENTS=1 python -m "
-                                              "i2vsgg_amd.build builds them)")
-
-
 def test_cpu_tensor_is_rejected_loudly(ops):
     with pytest.raises(Exception):
         ops.roi_align(torch.zeros(1, 4, 8, 8), torch.zeros(1, 5), 7, 7, 1 / 16.0)
 
 
-@pytest.mark.parametrize("spec", [1, 2])
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
-def test_conv_every_tile_shape(ops, tile, spec):
-    """Each (BM x BN) instantiation of conv_igemm_f32 -- plain 4-wave (spec=1) and, in I2V_EXPERIMENTS builds, loader/MFMA
-    specialised 8-wave (spec=2) -- forced through the tuning hook, incl. ragged M/N/K edges, residual and split-K."""
+def test_conv_every_tile_shape(ops, tile):
+    """Each (BM x BN) instantiation of conv_igemm_f32 forced through the tuning hook, incl. ragged M/N/K edges, residual and
+    split-K.  (Rounds 1-5 had a second, 8-wave loader / MFMA form per tile behind an experiments build: gone in round 6 -- the
+    hook refuses its bits.)"""
     from i2vsgg_amd import _lib
-    if spec == 2 and not _lib.EXPERIMENTS:
-        pytest.skip("the 8-wave specialisation is an experiment: not in the default library")
+    assert _lib.lib.i2v_conv_set_tile(tile | (2 << 8)) != 0 and b"experiment" in _lib.lib.i2v_last_error()
     rng = np.random.default_rng(tile)
     x = rng.standard_normal((2, 72, 13, 17), dtype=np.float32)          # M = 442 (ragged), K = 648 (not /32)
     w = (rng.standard_normal((100, 72, 3, 3), dtype=np.float32) / 25).astype(np.float32)
@@ -575,7 +564,7 @@ def test_conv_every_tile_shape(ops, tile, spec):
     x8 = rng.standard_normal((1, 512, 5, 6), dtype=np.float32)                       # M = 30, deep K -> split-K
     w8 = (rng.standard_normal((64, 512, 3, 3), dtype=np.float32) / 60).astype(np.float32)
     ref8 = F.conv2d(torch.from_numpy(x8), torch.from_numpy(w8), padding=1)
-    _lib.lib.i2v_conv_set_tile(tile | (spec << 8))
+    assert _lib.lib.i2v_conv_set_tile(tile) == 0
     try:
         y = ops.conv2d(torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV), pad=1)
         y2 = ops.conv2d(torch.from_numpy(x).to(DEV), torch.from_numpy(w).to(DEV), None, None, res.to(DEV), 1, 1, relu=True)
@@ -984,35 +973,6 @@ def test_intra_workgroup_k_split_equals_memory_split(ops, M, K, N, res, mask):
             lib.i2v_set_tuning(TUNE["I2V_KGROUPS"], 0)
 
 
-@pytest.mark.parametrize("M,K,N,res,tile", [(75000, 64, 256, True, 3), (18750, 128, 512, True, 2), (9000, 256, 1024, True, 5),
-                                              (37500, 256, 64, False, 4), (20000, 96, 200, False, 3)])
-@needs_experiments
-def test_persistent_gemm_equals_one_tile_per_workgroup(ops, M, K, N, res, tile):
-    """conv_gemm_pers_f32 (I2V_GEMM_PERSIST: a workgroup streams through several tiles, the next tile's operands requested under
-    the current tile's last stage) is the same arithmetic as conv_gemm_f32: bit-equal outputs, ragged M / N / K included."""
-    from i2vsgg_amd._lib import TUNE, lib
-    rng = np.random.default_rng(M + K + N)
-    x = torch.from_numpy(rng.standard_normal((M, K), dtype=np.float32)).to(DEV)
-    w = torch.from_numpy((rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)).to(DEV)
-    sc = torch.from_numpy(rng.uniform(0.5, 1.5, N).astype(np.float32)).to(DEV)
-    sh = torch.from_numpy(rng.uniform(-0.5, 0.5, N).astype(np.float32)).to(DEV)
-    r4 = torch.from_numpy(rng.standard_normal((M, N), dtype=np.float32)).to(DEV).view(M, N, 1, 1) if res else None
-    out = {}
-    try:
-        lib.i2v_conv_set_tile(tile)
-        for mode in (0, 2, 3):
-            assert lib.i2v_set_tuning(TUNE["I2V_GEMM_PERSIST"], mode) == 0
-            out[mode] = ops.conv2d(x.view(M, K, 1, 1), w.view(N, K, 1, 1), sc, sh, r4, 1, 0, relu=True).view(M, N).clone()
-    finally:
-        lib.i2v_set_tuning(TUNE["I2V_GEMM_PERSIST"], 0)
-        lib.i2v_conv_set_tile(-1)
-    assert torch.equal(out[2], out[0]) and torch.equal(out[3], out[0])
-    ref = x.double() @ w.double().t() * sc.double() + sh.double()
-    if res:
-        ref = ref + r4.view(M, N).double()
-    np.testing.assert_allclose(out[2].cpu().numpy(), torch.relu(ref).float().cpu().numpy(), rtol=2e-5, atol=2e-5)
-
-
 def test_pointwise_gemm_kernel_batched_planes(ops):
     """The 36 element-wise planes of a Winograd F(4x4,3x3) layer3 convolution as one batched launch on conv_gemm_f32."""
     from i2vsgg_amd._lib import lib, ptr, stream
@@ -1218,64 +1178,6 @@ def test_filter_gradient_split_groups_on_one_xcd(B, C, N, H, W, k):
     assert float((on - off).abs().max()) <= 2e-5 * scale          # atomics: summation order differs
 
 
-@needs_experiments
-def test_deferred_fc_update_equals_the_fused_update():
-    """i2v_fc_fold_fwd (vrd.fc6 / fc7 in the relation step): the SGD(momentum) update left pending by step i's backward and
-    applied inside step i+1's forward GEMM gives the outputs, filters and momenta of the undeferred schedule (forward, then
-    the fused filter-gradient + SGD kernel) -- rows < 128, pending and current minibatches of different sizes, a K that does
-    not fill every K range, data gradients on and off, flush() of the last update."""
-    from i2vsgg_amd import ops
-    rng = np.random.default_rng(23)
-    for (N, K, rows, need_gx) in ((192, 1600, (64, 37, 128, 100), False), (256, 4096, (128, 128, 128), True)):
-        w0 = (rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
-        b0 = rng.standard_normal((N,), dtype=np.float32) * 0.1
-        xs = [rng.standard_normal((m, K), dtype=np.float32) for m in rows]
-        gys = [rng.standard_normal((m, N), dtype=np.float32) for m in rows]
-        res = []
-        for deferred in (False, True):
-            w = torch.from_numpy(w0.copy()).to(DEV).requires_grad_()
-            b = torch.from_numpy(b0.copy()).to(DEV).requires_grad_()
-            m = torch.full((N, K), 0.01, device=DEV)
-            ops.FUSED_SGD[w.data_ptr()] = (m, 1e-2, 0.9, 5e-4)
-            if deferred:
-                ops.DEFERRED_SGD[w.data_ptr()] = ops.DeferredUpdate(w)
-            ys, gxs, gbs = [], [], []
-            try:
-                for x_np, gy_np in zip(xs, gys):
-                    x = torch.from_numpy(x_np).to(DEV).requires_grad_(need_gx)
-                    y = ops.linear(x, w, b, relu=True)
-                    y.backward(torch.from_numpy(gy_np).to(DEV))
-                    ys.append(y.detach().cpu().numpy().copy())
-                    gxs.append(x.grad.cpu().numpy().copy() if need_gx else None)
-                    gbs.append(b.grad.cpu().numpy().copy())
-                    b.grad = None
-                    if w.grad is not None:           # a shape the fused filter-gradient + SGD kernel does not take: separate update
-                        assert not deferred
-                        ops.sgd_momentum_(w.data, w.grad, m, 1e-2, 0.9, 5e-4)
-                        w.grad = None
-                if deferred:
-                    st = ops.DEFERRED_SGD[w.data_ptr()]
-                    assert st.armed and st.rows == rows[-1]
-                    with torch.no_grad():
-                        y_eval = ops.linear(torch.from_numpy(xs[0]).to(DEV), w, b, relu=True)     # a reader outside the loop: flushes first
-                    assert not st.armed and int(st.valid) == 0
-                else:
-                    with torch.no_grad():
-                        y_eval = ops.linear(torch.from_numpy(xs[0]).to(DEV), w, b, relu=True)
-            finally:
-                ops.FUSED_SGD.clear()
-                ops.DEFERRED_SGD.clear()
-            res.append((ys, gxs, gbs, w.detach().cpu().numpy().copy(), m.cpu().numpy().copy(), y_eval.cpu().numpy().copy()))
-        (y0, gx0, gb0, wa, ma, e0), (y1, gx1, gb1, wb, mb, e1) = res
-        assert not np.array_equal(wa, w0)
-        for i in range(len(rows)):
-            assert _rel_err(y1[i], y0[i]) < 1e-5, (N, K, i)
-            assert _rel_err(gb1[i], gb0[i]) < 1e-5
-            if need_gx:
-                assert _rel_err(gx1[i], gx0[i]) < 1e-5
-        assert _rel_err(wb, wa) < 1e-6 and _rel_err(mb, ma) < 1e-5 and _rel_err(e1, e0) < 1e-5
-
-
 def test_pair_gather_and_single_workgroup_bce_match_torch():
     """ops.pair_gather ([obj[ixs] | obj[ixo]] per relation pair, resnet_SGG_emb.py:170-176) forward and backward against
     index_select / cat under autograd (repeated and unused rows, a pad index pair (0, 0)); ops.bce_rows against
@@ -1308,50 +1210,6 @@ def test_pair_gather_and_single_workgroup_bce_match_torch():
     assert abs(float(a) - float(b)) < 1e-6 * abs(float(b))
     torch.testing.assert_close(ga, z.grad, rtol=1e-5, atol=1e-9)
     assert all(float(ops.bce_rows(z.detach(), t, w)) == float(a) for _ in range(5))
-
-
-@needs_experiments
-def test_gemm_three_term_bf16_split_is_opt_in_and_16_bit_accurate():
-    """I2V_TUNE_GEMM_X3 (off by default): the pointwise / plain-GEMM kernel with its products on the bf16 matrix pipe as
-    hi*hi + hi*lo + lo*hi.  (1) operands that are exact in bf16 (small integers) give the fp32 kernel's bits -- the layout of
-    the split LDS image and of the 16x16x32 fragments is right for every tile shape, K tails, split-K, the fused epilogue;
-    (2) random fp32 operands agree with the fp32 kernel to ~2^-16 of the output scale; (3) the switch is off unless set."""
-    from i2vsgg_amd import ops
-    from i2vsgg_amd._lib import lib
-    X3 = 16
-    assert lib.i2v_get_tuning(X3) == 0
-    rng = np.random.default_rng(31)
-    shapes = [(4788, 256, 1024), (2394, 1024, 256), (600, 64, 256), (9375, 128, 512), (128, 4096, 4096), (333, 100, 36)]
-    try:
-        for (M, K, N) in shapes:
-            for integers in (True, False):
-                if integers:
-                    x = rng.integers(-8, 9, (M, K)).astype(np.float32)
-                    w = rng.integers(-4, 5, (N, K)).astype(np.float32)
-                else:
-                    x = rng.standard_normal((M, K), dtype=np.float32)
-                    w = (rng.standard_normal((N, K), dtype=np.float32) / np.sqrt(K)).astype(np.float32)
-                xd = torch.from_numpy(x).to(DEV).view(M, K, 1, 1).contiguous(memory_format=torch.channels_last)
-                wd = torch.from_numpy(w).to(DEV).view(N, K, 1, 1).contiguous(memory_format=torch.channels_last)
-                sc = torch.from_numpy(rng.uniform(0.5, 1.5, N).astype(np.float32)).to(DEV) if not integers else None
-                sh = torch.from_numpy(rng.uniform(-1, 1, N).astype(np.float32)).to(DEV) if not integers else None
-                res = torch.from_numpy(rng.standard_normal((M, N), dtype=np.float32)).to(DEV).view(M, N, 1, 1) if not integers else None
-                out = []
-                for mode in (0, 1):
-                    lib.i2v_set_tuning(X3, mode)
-                    with torch.no_grad():
-                        out.append(ops.conv2d(xd, wd, sc, sh, res, 1, 0, relu=not integers).view(M, N).cpu().numpy())
-                if integers:
-                    assert np.array_equal(out[0], out[1]), (M, K, N)
-                else:
-                    ref = np.maximum((x.astype(np.float64) @ w.astype(np.float64).T) * sc.cpu().numpy() + sh.cpu().numpy()
-                                     + res.view(M, N).cpu().numpy(), 0)
-                    scale = np.abs(ref).max()
-                    e32, e3 = np.abs(out[0] - ref).max() / scale, np.abs(out[1] - ref).max() / scale
-                    assert e32 < 3e-6 and e3 < 4e-5, (M, K, N, e32, e3)
-                    assert not np.array_equal(out[0], out[1])
-    finally:
-        lib.i2v_set_tuning(X3, 0)
 
 
 def test_fused_loss_and_target_arithmetic_matches_the_torch_expressions():
@@ -1427,12 +1285,13 @@ def test_fused_loss_and_target_arithmetic_matches_the_torch_expressions():
     assert float(ga[~live].abs().max()) == 0.0               # aten gives NaN there (inf * 0 through sqrt'); the kernel gives 0
 
 
-EXPERIMENT_KNOBS = {"I2V_CONV_SPEC", "I2V_STAGGER", "I2V_GEMM_PERSIST", "I2V_WGRAD_PRIO", "I2V_GEMM_X3", "I2V_FC_FOLD"}
+RETIRED_KNOBS = {"I2V_CONV_SPEC", "I2V_STAGGER", "I2V_GEMM_PERSIST", "I2V_WGRAD_PRIO", "I2V_GEMM_X3", "I2V_FC_FOLD"}
 KNOBS = [("I2V_CONV_SPEC", 1), ("I2V_CONV_SPEC", 2), ("I2V_SPLIT_TARGET", 3), ("I2V_SPLIT_TARGET_SKINNY", 3), ("I2V_SPLIT_BELOW", 0),
          ("I2V_SPLIT_BELOW", 2048), ("I2V_SPLIT_ATOMICS", 1), ("I2V_BIG_FC_TILE", -1), ("I2V_WGRAD_V2", 0), ("I2V_WGRAD_V2", 2),
          ("I2V_WGRAD_V2", 3), ("I2V_WINO_ROWS", -1), ("I2V_WINO_ROWS", 3), ("I2V_ROIPOOL_C128", 0), ("I2V_CONV_GEMM", 0),
          ("I2V_STAGGER", 4), ("I2V_ROIALIGN_COLS", 0), ("I2V_ROIALIGN_COLS", 1), ("I2V_WGRAD_PER_CU", 2), ("I2V_WGRAD_XCD", 0), ("I2V_GEMM_PERSIST", 2),
-         ("I2V_WGRAD_PRIO", 2), ("I2V_STREAM_TILE", 0), ("I2V_GEMM_X3", 1), ("I2V_KGROUPS", 1)]
+         ("I2V_WGRAD_PRIO", 2), ("I2V_STREAM_TILE", 0), ("I2V_GEMM_X3", 1), ("I2V_KGROUPS", 1), ("I2V_KGROUPS", 2), ("I2V_GEMM_DMA", 0),
+         ("I2V_GEMM_DMA", 2), ("I2V_SPLIT_ATOMICS", 0), ("I2V_WGRAD_ORDERED_GFLOP", 0)]
 
 
 def test_every_tuning_knob_keeps_the_results(ops):
@@ -1440,7 +1299,7 @@ def test_every_tuning_knob_keeps_the_results(ops):
     a non-default value (i2v_set_tuning, the call the environment variables are forwarded to): pointwise / strided / 3x3
     (Winograd) / 5x5 forward, data and filter gradients, the skinny split-K GEMM of the relation head, ROIPool and RoIAlignAvg give
     what the defaults give -- bit for bit where the knob only moves work around, within fp32 summation-order noise where it changes
-    a split or a tile, within 2^-16 products for the bf16 three-term split."""
+    a split or a tile."""
     from i2vsgg_amd._lib import TUNE, lib
     rng = np.random.default_rng(5)
     t = lambda *sh: torch.from_numpy(rng.standard_normal(sh, dtype=np.float32)).to(DEV)
@@ -1470,15 +1329,14 @@ def test_every_tuning_knob_keeps_the_results(ops):
         out["roi_align"] = ops.roi_align(xc, rois, 7, 7, 1.0 / 16)
         return {k: v.clone() for k, v in out.items()}
 
-    from i2vsgg_amd._lib import EXPERIMENTS
     base = run()
     assert all(torch.isfinite(v).all() for v in base.values())
     for name, value in KNOBS:
         key = TUNE[name]
         old = lib.i2v_get_tuning(key)
-        if name in EXPERIMENT_KNOBS and not EXPERIMENTS:
-            # the default library carries no experiment kernels: their knobs accept nothing but "off", loudly
-            assert lib.i2v_set_tuning(key, value) == -4 and b"I2V_EXPERIMENTS" in lib.i2v_last_error()
+        if name in RETIRED_KNOBS:
+            # the experiment kernels left the library (round 6): their reserved keys accept nothing but "off", loudly
+            assert lib.i2v_set_tuning(key, value) == -4 and b"experiment" in lib.i2v_last_error()
             assert lib.i2v_get_tuning(key) == old
             continue
         try:

@@ -91,7 +91,7 @@ def save_checkpoint(a, net, opt, epoch, last_step, rank):
     """The reference's per-epoch dict (:310-317; net_utils.py:119-120): ``epoch`` holds the NEXT epoch, the model sits
     under the reference's state_dict keys.  A column-parallel fc6 is reassembled first (every rank takes part in the
     gather, rank 0 writes), so the file loads on any number of GPUs and under the reference's layer shapes."""
-    opt.flush_pending()               # fc6 / fc7 hold their last update until the next forward (ops.DeferredUpdate)
+    opt.flush_pending()               # (a no-op since round 6: no update is deferred any more)
     w6, b6 = net.vrd.gather_fc6()
     if rank != 0:
         return None
