@@ -1199,6 +1199,13 @@ int run_conv(ConvP p, hipStream_t st, void* split_ws = nullptr, size_t split_ws_
             splitk = (int)((target * NUM_CU + t - 1) / t);
             splitk = splitk > ksteps / 4 ? ksteps / 4 : splitk;
             if (splitk < 1) splitk = 1;
+            // Under round 4's rule (SPLIT_ATOMICS == 2) a large output split more than kSplitInKernelMax ways leaves the in-kernel
+            // finish: fp32 atomics, a clear in front, a separate epilogue pass and the generic kernel -- none of which the 1.05
+            // below prices.  Found on 600x801 frames (round 6, tools/size_probe.py): layer3 conv1 of ONE frame (M = 1900) took
+            // 128x128 tiles x 8 splits = 240 workgroups, "one round", and ran at 42 TF on conv_igemm_f32 where the 64x64 x 4 plan
+            // runs at 80 on conv_gemm_f32 -- the loader-fed step was 7 % slower on the SMALLER frames.  Such outputs split at most
+            // kSplitInKernelMax ways.
+            if (g_split_atomics == 2 && splitk > kSplitInKernelMax && (long long)p.M * p.N >= (1 << 18)) splitk = kSplitInKernelMax;
         }
         const long long blocks = t * splitk;
         const long long rounds = (blocks + NUM_CU - 1) / NUM_CU;
