@@ -60,7 +60,9 @@ def corun(fns, reps):
 cases = [("4096^3", 4096, 4096, 4096, False, 10), ("layer3 conv1, 4 frames", 9576, 1024, 256, False, 30),
          ("layer3 conv3, 2 frames (+res)", 4788, 256, 1024, True, 30), ("layer3 conv1, 2 frames", 4788, 1024, 256, False, 30),
          ("layer3 conv3, 1 frame (+res)", 2394, 256, 1024, True, 30), ("layer3 conv1, 1 frame", 2394, 1024, 256, False, 30),
-         ("layer2 conv3, 1 frame (+res)", 9375, 128, 512, True, 30), ("layer2 conv1, 1 frame", 9375, 512, 128, False, 30)]
+         ("layer2 conv3, 1 frame (+res)", 9375, 128, 512, True, 30), ("layer2 conv1, 1 frame", 9375, 512, 128, False, 30),
+         # the relation head's fc6 forward: 128 rows against the 822 MB filter (streams from HBM), in an ordered context as in the step
+         ("fc6 forward (ordered ctx)", 128, 50176, 4096, False, 10)]
 only = sys.argv[1:]
 for name, M, K, N, res, reps in cases:
     if only and not any(o in name for o in only):
@@ -74,7 +76,7 @@ for name, M, K, N, res, reps in cases:
         w = torch.rand(N, K, 1, 1, device=DEV) * 2 - 1
         sc, sh = torch.rand(N, device=DEV) + 0.5, torch.rand(N, device=DEV)
         r = torch.randn(M, N, 1, 1, device=DEV) if res else None
-        ctx = ops.LaunchContext(DEV)
+        ctx = ops.LaunchContext(DEV, ordered="ordered" in name)
         ops_.append((x, w, sc, sh, r, ctx))
 
     def make(c):

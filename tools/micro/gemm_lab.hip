@@ -390,6 +390,12 @@ int main(int argc, char** argv) {
     vs.push_back(vd<2, 2, 4, 2, 2, 0, 16>("D2 128x64 k16"));
     vs.push_back(vd<2, 2, 4, 2, 3, 0, 16>("D3 128x64 k16"));
     vs.push_back(vd<2, 2, 4, 2, 3, 2, 16>("D3 128x64 k16 fp2"));
+    vs.push_back(vd<2, 2, 4, 2, 3, 0>("D3 128x64 fp0"));
+    vs.push_back(vd<2, 2, 4, 2, 3, 1>("D3 128x64 fp1"));
+    vs.push_back(vd<2, 2, 4, 2, 4, 0>("D4 128x64 fp0"));
+    vs.push_back(vd<2, 2, 4, 2, 4, 2>("D4 128x64 fp2"));
+    vs.push_back(vd<2, 2, 4, 2, 4, 0, 16>("D4 128x64 k16"));
+    vs.push_back(vd<2, 2, 4, 2, 6, 0, 16>("D6 128x64 k16"));
     vs.push_back(vr<2, 2, 4, 4>("R  128x128"));
     vs.push_back(vd<2, 2, 4, 4, 2, 0>("D2 128x128 fp0"));
     vs.push_back(vd<2, 2, 4, 4, 2, 0, 16>("D2 128x128 k16"));
@@ -402,7 +408,10 @@ int main(int argc, char** argv) {
         {"l3c3x2 (4788x1024x256)", 4788, 1024, 256, 1},
         {"l3c1x2 split3 (4788x256x1024)", 4788, 256, 1024, 3},
         {"l3c3x1 (2394x1024x256)", 2394, 1024, 256, 1},
+        {"fc6 forward (128x4096x50176, 8 splits; the 822 MB filter streams from HBM)", 128, 4096, 50176, 8},
+        {"fc6 forward, 4 splits", 128, 4096, 50176, 4},
     };
+    const char* only = argc > 2 ? argv[2] : nullptr;
     for (const auto& v : vs) {
         int nb = 0;
         CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, v.fn, THREADS, v.lds));
@@ -416,6 +425,7 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (auto& e : ec) CK(hipEventCreate(&e));
     for (const auto& sh : shapes) {
+        if (only && !strstr(sh.name, only)) continue;
         const size_t an = (size_t)sh.M * sh.K, wn = (size_t)sh.N * sh.K, yn = (size_t)sh.M * sh.N * sh.splitk;
         std::vector<float> ha(an), hw(wn);
         unsigned s = 12345u;
