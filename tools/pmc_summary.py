@@ -6,7 +6,7 @@
 <out_dir>/fetch, <out_dir>/write: `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes (csv); <out_dir>/trace: the
 `--kernel-trace --stats` pass.  FETCH_SIZE / WRITE_SIZE are KB; on gfx950 FETCH_SIZE reports half of the bytes of
 wide coalesced streaming reads (MI355X_MICROARCH.md, HBM section) and is doubled here."""
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, json, os, re, sys
 
 out, steps, prefix = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 

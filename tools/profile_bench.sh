@@ -2,7 +2,7 @@
 # The rocprofv3 evidence behind bench.py's roofline block; run on the GPU box from the repo root.
 #   tools/profile_bench.sh [steps] [warmup]   -> gpurun_out/prof_bench/{trace,fetch,write} + gpurun_out/${TAG}_* (copy to profiles/)
 set -e
-steps=${1:-6}; warm=${2:-2}; TAG=${3:-r05}
+steps=${1:-6}; warm=${2:-2}; TAG=${3:-r06}
 export TMPDIR=/tmp
 out=gpurun_out/prof_bench
 rm -rf $out; mkdir -p $out

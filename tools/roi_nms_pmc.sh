@@ -3,10 +3,10 @@
 # packed maps, NMS), warm and cold: kernel trace + FETCH_SIZE + WRITE_SIZE as three separate passes per case and state (the
 # counters do not fit one pass; never combined with a trace domain).  One process per case, state and pass, so that a kernel's
 # rows belong to exactly one case.
-#   tools/roi_nms_pmc.sh [out_dir] [dest.json] [cases...] -> <out_dir>/<case>.<state>/{trace,fetch,write} and profiles/r05_roi_nms_pmc.json
+#   tools/roi_nms_pmc.sh [out_dir] [dest.json] [cases...] -> <out_dir>/<case>.<state>/{trace,fetch,write} and profiles/r06_roi_nms_pmc.json
 set -e
 out=${1:-gpurun_out/roi_pmc}
-dest=${2:-profiles/r05_roi_nms_pmc.json}
+dest=${2:-profiles/r06_roi_nms_pmc.json}
 shift 2 2>/dev/null || true
 export TMPDIR=/tmp
 rm -rf $out; mkdir -p $out
