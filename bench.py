@@ -602,9 +602,13 @@ def run_sgg(a, rank, world, dev, frames_per_rank=2):
                    "parallelism": ("dp%d (frames sharded) + vrd.fc6 cut by output columns across the ranks: RCCL all-reduce of the "
                                    "other 84 MB of gradients, 30 MB of activation gathers for fc6" % world) if tp
                    else "dp%d (frames sharded, RCCL all-reduce of vrd grads)" % world,
-                   "schedule": ("one graph per step: [head fwd+bwd (+ gradient exchange) + SGD of batch k] beside the backbone fwd "
-                                "of batch k+1 (one graph branch per frame); every step = 1 backbone pass + 1 head pass + 1 update, all "
-                                "inside the timed region") if step.overlap
+                   "schedule": (("one graph per step: [head fwd+bwd (+ gradient exchange) + SGD of batch k] beside [stem..layer3[:%d] "
+                                 "of batch k+2, both frames per launch] beside [layer3[%d:] of batch k+1]; every step = 1 backbone pass "
+                                 "(its two halves on consecutive minibatches) + 1 head pass + 1 update, all inside the timed region"
+                                 % (step.cut, step.cut)) if step.stage_split else
+                                ("one graph per step: [head fwd+bwd (+ gradient exchange) + SGD of batch k] beside the backbone fwd "
+                                 "of batch k+1 (one graph branch per frame); every step = 1 backbone pass + 1 head pass + 1 update, all "
+                                 "inside the timed region")) if step.overlap
                    else "one graph per step: backbone fwd, head fwd+bwd, fused wgrad+SGD" if graphed else "eager launches",
                    "loss": loss},
         "roofline": {"bound": "mfma", "kernel": "conv_gemm_f32 (pointwise bottleneck layers and the other plain GEMMs it serves; one "
@@ -690,9 +694,11 @@ def run_sgg_loader(a, rank, world, dev, frames_per_rank=2, n_batches=8, u8=False
         pos[0] += 1
         stage(batches[pos[0] % len(batches)])
         step()
-    for _ in range(len(batches) + 1):     # every frame size met once: its graph is captured outside the timed region
-        fn()
+    for _ in range(len(batches) + 3):     # every frame size (backbone cut by stage: every pair of consecutive sizes) met once: its
+        fn()                              # graph is captured outside the timed region
+    bubbles = step.n_bubbles
     elapsed = timed_steps(fn, a.warmup, a.steps, dev)
+    assert step.n_bubbles == bubbles, "a timed call ran no head"
     sizes = sorted({hw(d) for d in batches})
     # The same graphs with their minibatch RESIDENT (staged once, replayed): what the loader-fed step would take if staging cost
     # nothing -- the loader's frames are not 600x1000 (five resolutions, 460-640 kpixel), so the headline's resident step is not
@@ -702,7 +708,8 @@ def run_sgg_loader(a, rank, world, dev, frames_per_rank=2, n_batches=8, u8=False
         if hw(d) in res_ms:
             continue
         stage(d)
-        step()
+        for _ in range(1 + step.lag):     # the pipeline holds only this minibatch from here on
+            step()
         res_ms[hw(d)] = 1e3 * timed_steps(step, 2, max(a.steps // 2, 5), dev) / max(a.steps // 2, 5)
     resident_same = sum(res_ms[hw(d)] for d in batches) / len(batches)
     rels = net.vrd.source_gt_rels

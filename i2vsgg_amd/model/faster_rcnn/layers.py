@@ -214,6 +214,22 @@ class C4Base(nn.Sequential):
             feat = blocks[-1](feat, out=out)
         return (feat, feat1) if tap else feat
 
+    # The same pass in two halves (train.SGGEmbStep's stage-split schedule, round 6): stem .. layer3[:cut] -> ``out`` (any
+    # channels_last tensor of that block's output shape), and layer3[cut:] from there -> the C4 map.  0 < cut < len(layer3).
+    def forward_front(self, im, cut, out=None):
+        x = self[5](self[4](self.stem(im)))
+        blocks = list(self[6])[:cut]
+        for blk in blocks[:-1]:
+            x = blk(x)
+        return blocks[-1](x, out=out) if out is not None else blocks[-1](x)
+
+    def forward_back(self, mid, cut, out=None, end=None):
+        blocks = list(self[6])[cut:end]
+        x = mid
+        for blk in blocks[:-1]:
+            x = blk(x)
+        return blocks[-1](x, out=out) if out is not None else blocks[-1](x)
+
 
 def load_reference_state(module, state_dict, strict=False):
     """load_state_dict that tolerates NCHW-contiguous checkpoint tensors (copy_ keeps OUR layout)."""

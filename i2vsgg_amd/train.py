@@ -454,6 +454,13 @@ class _FrameSet:
         self.graph = None             # None: not captured yet; False: capture failed (eager launches for this size)
         self.fitted = False
         self.tick = 0
+        # stage-split schedule (round 6): this size as the FRONT half's (stem .. layer3[:cut]) and as the BACK half's
+        # (layer3[cut:]) input; a graph is captured per (front size, back size) pair -- the back half of a call works on the
+        # previous minibatch, whose size may differ
+        self.ctx_front = ops.LaunchContext(device, arena=arena)
+        self.ctx_back = ops.LaunchContext(device, arena=arena)
+        self.fitted_front = self.fitted_back = False
+        self.graphs = {}              # back size key -> graph (or False)
 
 
 class SGGEmbStep:
@@ -468,6 +475,11 @@ class SGGEmbStep:
     frame].  The branches own disjoint device state (``ops.LaunchContext``: zero arena, split-K workspace, scratch) and
     meet only at graph edges: the feature-map hand-off (one copy before the fork) and the join.  There is one graph launch
     per step on the caller's stream, no side stream, no event and no priority for a caller to get wrong.
+
+    Round 6 (``bb_split="stage"``, the default): the backbone half is cut by STAGE, not by frame -- [head of batch k-2] beside
+    [stem .. layer3[:cut] of batch k, all frames] beside [layer3[cut:] of batch k-1, all frames]; a minibatch reaches the head two
+    calls after its ``stage()`` (``lag`` 2, three slots in -> mid -> cur; ``bubble`` / ``run_staged`` for loops).  The paragraphs
+    below describe the one-call pipeline of ``bb_split="frame"`` / ``"none"``; the stage form differs only in the extra slot.
 
     Minibatches move through a two-slot pipeline so that ``stage()`` may be called at any time between steps:
     ``stage(b)`` writes the frames of b (read by the NEXT call's backbone branches) and its head inputs into the ``in``
@@ -490,7 +502,7 @@ class SGGEmbStep:
 
     def __init__(self, net, n_frames, vrd_lr=1e-4, seed=1, device="cuda:0", h=600, w=1000, n_boxes=32, n_pairs=32,
                  use_graph=True, fuse_sgd=True, zero_arena=True, overlap=None, max_graphs=16, trace_rows=0, stage_synthetic=True,
-                 optimizer="sgd"):
+                 optimizer="sgd", bb_split=None):
         import os
         self.net, self.dev, self.n_frames = net, torch.device(device), n_frames
         if not (net.vrd.use_obj_visual and net.vrd.spatial_type == 2):
@@ -517,8 +529,31 @@ class SGGEmbStep:
         self._pipelined = False                          # (until then a call is the sequential eager step)
         self._graphs_on = False
         self.zero_arena = zero_arena
-        self.bb_split = os.environ.get("I2V_BB_SPLIT", "1") == "1" and use_graph and n_frames > 1
-        self._frame_streams = [ops.role_stream(self.dev, ("frame", f)) for f in range(n_frames)] if self.bb_split else []
+        # How the backbone half is cut into graph branches beside the head (I2V_BB_SPLIT / ``bb_split``):
+        #   "stage" (default, round 6): by STAGE -- [stem .. layer3[:cut] of batch k+2] and [layer3[cut:] of batch k+1], every
+        #           kernel over ALL frames of its minibatch; a batch reaches the head two calls after it was staged (``lag`` 2);
+        #   "frame" (rounds 2-5): one branch per frame of batch k+1 (``lag`` 1);
+        #   "none": one branch for the whole backbone of batch k+1.
+        mode = bb_split if bb_split is not None else os.environ.get("I2V_BB_SPLIT", "stage")
+        mode = {"1": "frame", "0": "none", "2": "stage"}.get(str(mode), str(mode))
+        if mode not in ("stage", "frame", "none"):
+            raise ValueError("SGGEmbStep: bb_split must be 'stage', 'frame' or 'none', got %r" % (mode,))
+        self.stage_split = mode == "stage" and use_graph
+        self.bb_split = mode == "frame" and use_graph and n_frames > 1
+        # blocks of layer3 in the front half: 6-7 of ResNet-101's 23 balance the chains (tools/stage_split_probe.py); never more
+        # than a third of the stage (ResNet-50 has 6)
+        n3 = len(net.RCNN_base[6])
+        self.cut = max(1, min(int(os.environ.get("I2V_STAGE_CUT", "6")), max(n3 // 3, 1), n3 - 1))
+        self._frame_streams = [ops.role_stream(self.dev, ("frame", f)) for f in range(max(n_frames, 2))] \
+            if (self.bb_split or self.stage_split) else []
+        # host-side twins of the three head-input slots (which minibatch each holds) and of what the head has trained: with
+        # the backbone cut by stage a batch reaches the head two calls after its stage(); in a loop that stages a new batch
+        # before every call the second call would find the FIRST batch in ``cur`` again -- that call runs no head (``bubble``)
+        self._id_inp = self._id_mid = self._id_cur = 0
+        self._last_trained, self.n_bubbles = -1, 0
+        self._mid_key = None          # key of the frame set whose front-half output ``mid_next`` holds
+        self.mid_next_flat = self.mid_cur_flat = None
+        self.mid_slot = None
         self._side = None
         self.ctx_head = ops.LaunchContext(self.dev, arena=zero_arena, ordered=True)      # head branch: bit-reproducible sums
         self.ctx_bb = ops.LaunchContext(self.dev, arena=zero_arena)        # eager backbone passes (any size)
@@ -538,8 +573,19 @@ class SGGEmbStep:
 
     @property
     def lag(self):
-        """1 when a call trains the batch staged BEFORE the one staged last (the overlapped schedule in force), else 0."""
-        return 1 if self._pipelined else 0
+        """How many calls after its ``stage()`` a minibatch reaches the head: 0 sequential, 1 overlapped with the backbone cut by
+        frame (or not at all), 2 with the backbone cut by stage.  After ``capture()`` the first ``lag - 1`` calls run no head
+        (``bubble``: the pipeline fills); a loop ends with ``lag`` calls without a new ``stage()`` (``flush``)."""
+        return (2 if self.stage_split else 1) if self._pipelined else 0
+
+    @property
+    def bubble(self):
+        """True when the NEXT call will run no head (backbone cut by stage): the head's slot holds a minibatch it has already
+        trained while a newer one waits behind it in the pipeline -- the call advances the backbone halves only and its return
+        value is stale (``n_bubbles`` counts them).  In a loop that stages before every call that is the second call; a resident
+        minibatch (nothing newer staged) is trained by every call."""
+        return bool(self._pipelined and self.stage_split and self._id_cur <= self._last_trained
+                    and max(self._id_mid, self._id_inp) > self._id_cur)
 
     # ------------------------------------------------------------------ compatibility views
     @property
@@ -646,6 +692,7 @@ class SGGEmbStep:
             lay = self._layout(nb, npair)
             if self.inp is None or not self.inp.same_layout(lay):
                 self.cur = _Slot(lay, self.dev)
+                self.mid_slot = _Slot(lay, self.dev)
                 self.inp = _Slot(lay, self.dev, host=True)
                 self._bind(nb, npair)
             if self.tp:
@@ -656,17 +703,22 @@ class SGGEmbStep:
             lay = self._layout(self.cap_boxes, self.cap_pairs)
             if self.inp is None or not self.inp.same_layout(lay):
                 old, old_caps = (self.cur if self.inp is not None else None), getattr(self, "_caps", None)
+                old_mid = self.mid_slot if self.inp is not None else None
                 self.cur = _Slot(lay, self.dev)
+                self.mid_slot = _Slot(lay, self.dev)             # stage-split schedule: the batch between ``in`` and ``cur``
                 self.inp = _Slot(lay, self.dev, host=True)
                 self._bind(self.cap_boxes, self.cap_pairs)
-                if old is not None and self._pipelined:          # the batch in flight moves to the larger slot
+                if old is not None and self._pipelined:          # the batches in flight move to the larger slots
                     ob, op = old_caps
-                    o, n = old.views, self.cur.views
-                    n["rois"][:ob].copy_(o["rois"][:ob]); n["rois"][self.cap_boxes:self.cap_boxes + op].copy_(o["rois"][ob:])
-                    n["ix12"][:op].copy_(o["ix12"][:op]); n["ix12"][self.cap_pairs:self.cap_pairs + op].copy_(o["ix12"][op:])
-                    for name in ("labels", "masks", "wrow"):
-                        n[name][:op].copy_(o[name])
-                    n["extent"].copy_(o["extent"])
+                    for src, dst in ((old, self.cur), (old_mid, self.mid_slot)):
+                        if src is None:
+                            continue
+                        o, n = src.views, dst.views
+                        n["rois"][:ob].copy_(o["rois"][:ob]); n["rois"][self.cap_boxes:self.cap_boxes + op].copy_(o["rois"][ob:])
+                        n["ix12"][:op].copy_(o["ix12"][:op]); n["ix12"][self.cap_pairs:self.cap_pairs + op].copy_(o["ix12"][op:])
+                        for name in ("labels", "masks", "wrow"):
+                            n[name][:op].copy_(o[name])
+                        n["extent"].copy_(o["extent"])
         cb, cp = (nb, npair) if not self.use_graph else (self.cap_boxes, self.cap_pairs)
         rois = np.zeros((cb + cp, 5), np.float32)
         rois[:nb], rois[cb:cb + npair] = fields["boxes"], fields["relb"]
@@ -677,6 +729,7 @@ class SGGEmbStep:
         if fs.fh is not None:
             host["extent"][:] = (fs.fh, fs.fw)
         self.inp.write_host(host)
+        self._id_inp += 1
         self._staged = key
         first = not self.primed and self.cur is not None and not self._pipelined
         if first and not getattr(self, "_filled", False):
@@ -743,6 +796,12 @@ class SGGEmbStep:
         if self.fmap_flat is not None:
             new[:self.fmap_flat.numel()].copy_(self.fmap_flat)
             new_h[:self.fmap_head_flat.numel()].copy_(self.fmap_head_flat)
+        if self.stage_split:          # the front half's output (layer3[cut - 1]: the C4 map's shape) of this call and of the last
+            m_next, m_cur = torch.zeros(n, device=self.dev), torch.zeros(n, device=self.dev)
+            if self.mid_next_flat is not None:
+                m_next[:self.mid_next_flat.numel()].copy_(self.mid_next_flat)
+                m_cur[:self.mid_cur_flat.numel()].copy_(self.mid_cur_flat)
+            self.mid_next_flat, self.mid_cur_flat = m_next, m_cur
         self.fmap_flat, self.fmap_head_flat, self.cap_cells = new, new_h, cells
         self.invalidate_graphs()                                 # they hold the old buffers' addresses
 
@@ -782,8 +841,27 @@ class SGGEmbStep:
         """Overlapped schedule: the head of call k reads ``cur`` = batch k-1 while the backbone branches work on the frames of
         batch k; once the head is done, batch k's head inputs (still in ``inp``: the next stage() is ordered behind this call)
         move to ``cur`` for call k+1.  ONE small copy per step."""
-        if self._pipelined:
+        if self._pipelined and self.stage_split:     # three slots: in (batch k) -> mid (k-1) -> cur (k-2, the head's)
+            self.cur.buf.copy_(self.mid_slot.buf)
+            self.mid_slot.buf.copy_(self.inp.buf)
+        elif self._pipelined:
             self.cur.buf.copy_(self.inp.buf)
+
+    def _mid_view(self, flat, fs):
+        n, c = fs.key[0], self._channels
+        return flat[:n * fs.fh * fs.fw * c].view(n, fs.fh, fs.fw, c).permute(0, 3, 1, 2)
+
+    def _front(self, fs, ctx):
+        """stem .. layer3[:cut] of the frames staged last, all frames in one pass -> ``mid_next``."""
+        with ctx:
+            with torch.no_grad():
+                self.net.RCNN_base.forward_front(fs.im, self.cut, out=self._mid_view(self.mid_next_flat, fs))
+
+    def _back(self, fs, ctx):
+        """layer3[cut:] of the previous call's front output (``mid_cur``, a minibatch of size ``fs``) -> the packed feature maps."""
+        with ctx:
+            with torch.no_grad():
+                self.net.RCNN_base.forward_back(self._mid_view(self.mid_cur_flat, fs), self.cut, out=self._fmap_dst(fs))
 
     def _backbone(self, fs):
         with self.ctx_bb:
@@ -857,6 +935,22 @@ class SGGEmbStep:
         main = torch.cuda.current_stream(self.dev)
         self._rotate()
         self.fmap_head_flat.copy_(self.fmap_flat)   # hand-off: features of the batch now in ``cur`` (computed by the previous call)
+        if self.stage_split:
+            # Round 6.  [head of batch k-2] | [front half of batch k: stem .. layer3[:cut]] | [back half of batch k-1].  Three
+            # chains as with one branch per frame, but every backbone kernel runs over BOTH frames: fuller launches, half as
+            # many of them, the Winograd-domain filters read once per pair of frames.  The step is bound by the sum of its
+            # kernels' alone-times with all chains ending together, and 2-frame kernels have less of it:
+            # 4.40 -> 4.08-4.12 ms per step (tools/stage_split_probe.py).  The price is one more call of latency (``lag`` 2).
+            fb = self.shapes[self._mid_key]         # the minibatch whose front half ran in the previous call
+            self.mid_cur_flat.copy_(self.mid_next_flat)
+            sa, sb = self._frame_streams[0], self._frame_streams[1]
+            with ops.branch(sa, main):
+                self._front(fs, fs.ctx_front)
+            with ops.branch(sb, main):
+                self._back(fb, fb.ctx_back)
+            self._head()
+            ops.join(main, sa, sb)
+            return
         if self.bb_split:                   # one branch per frame, forked from the capturing stream itself (a fork inside a
             self._backbone_per_frame(fs, join=False)      # forked branch crashes hipStreamEndCapture on ROCm 7.2)
             self._head()
@@ -873,9 +967,32 @@ class SGGEmbStep:
         if self.overlap and not self.primed:
             fs = self.shapes[self._staged]
             self._measure(fs)
-            self.cur.buf.copy_(self.inp.buf)
-            self._backbone(fs)
+            if self.stage_split:
+                # the batch staged first fills EVERY stage of the pipeline: both backbone halves run here, all three slots hold
+                # it.  A resident minibatch is then trained by every call from the first; a staging loop trains it in its first
+                # call, runs no head in the second (``bubble``: the slot still holds the first batch) and is in step from the third
+                self.cur.buf.copy_(self.inp.buf)
+                self.mid_slot.buf.copy_(self.inp.buf)
+                self._front(fs, self.ctx_bb)
+                self.mid_cur_flat.copy_(self.mid_next_flat)
+                self._back(fs, self.ctx_bb)
+                self._mid_key = self._fmap_key = fs.key
+                self._id_mid = self._id_cur = self._id_inp
+                self._last_trained = -1
+            else:
+                self.cur.buf.copy_(self.inp.buf)
+                self._backbone(fs)
         self.primed = True
+
+    def _fill_call(self, fs):
+        """A call while the stage pipeline fills: the graph's two backbone chains on eager launches, the slots advance, no head."""
+        fb = self.shapes[self._mid_key]
+        self.mid_cur_flat.copy_(self.mid_next_flat)
+        self._back(fb, self.ctx_bb)
+        self._front(fs, self.ctx_bb)
+        self.cur.buf.copy_(self.mid_slot.buf)
+        self.mid_slot.buf.copy_(self.inp.buf)
+        self._fmap_key, self._mid_key = fb.key, fs.key
 
     # ------------------------------------------------------------------ capture
     def invalidate_graphs(self):
@@ -886,6 +1003,7 @@ class SGGEmbStep:
             torch.cuda.synchronize(self.dev)      # a replay may still be running: its executable graph goes only after it
         for fs in self.shapes.values():
             fs.graph = None
+            fs.graphs.clear()
         if dropped:
             import gc
             gc.collect()
@@ -960,6 +1078,8 @@ class SGGEmbStep:
         per-frame arenas are sized by eager backbone passes into scratch outputs (the backbone is frozen), the head half is
         recorded, not run."""
         self._measure(fs)
+        staged = self._pipelined and self.stage_split
+        fb = self.shapes[self._mid_key] if staged else None       # the minibatch the back half of this graph works on
         if self._pipelined and self.bb_split and not fs.fitted:
             for _rep in range(2):
                 for f, ctx in enumerate(fs.ctx):
@@ -968,11 +1088,36 @@ class SGGEmbStep:
                             self.net.RCNN_base(fs.im[f:f + 1])
                     ctx.fit()
             torch.cuda.synchronize(self.dev)
-        fs.fitted = True
-        live = [f for f in self.shapes.values() if f.graph]
-        if len(live) >= self.max_graphs:                          # least recently used goes (after whatever is still running)
+        if staged and not (fs.fitted_front and fb.fitted_back):
+            # arenas of the two half contexts, sized by eager passes into SCRATCH outputs (mid_next / the feature maps hold live
+            # pipeline state: the fitting passes must not write them; what they read may be stale)
+            for _rep in range(2):
+                if not fs.fitted_front:
+                    with fs.ctx_front:
+                        with torch.no_grad():
+                            self.net.RCNN_base.forward_front(fs.im, self.cut)
+                    fs.ctx_front.fit()
+                if not fb.fitted_back:
+                    with fb.ctx_back:
+                        with torch.no_grad():
+                            self.net.RCNN_base.forward_back(self._mid_view(self.mid_cur_flat, fb), self.cut)
+                    fb.ctx_back.fit()
+            fs.fitted_front = fb.fitted_back = True
             torch.cuda.synchronize(self.dev)
-            min(live, key=lambda f: f.tick).graph = None
+        fs.fitted = True
+        if staged:
+            live = [(f, k) for f in self.shapes.values() for k, g in f.graphs.items() if g]
+            if len(live) >= self.max_graphs:                      # least recently used pair goes
+                torch.cuda.synchronize(self.dev)
+                f, k = min(live, key=lambda fk: fk[0].tick)
+                f.graphs[k] = None
+                if f.graph is not None and not any(f.graphs.values()):
+                    f.graph = None
+        else:
+            live = [f for f in self.shapes.values() if f.graph]
+            if len(live) >= self.max_graphs:                          # least recently used goes (after whatever is still running)
+                torch.cuda.synchronize(self.dev)
+                min(live, key=lambda f: f.tick).graph = None
         fmap_key = self._fmap_key
         try:
             g = torch.cuda.CUDAGraph()
@@ -991,9 +1136,13 @@ class SGGEmbStep:
                     self._backbone(fs)
                     self._head()
             fs.graph = g
+            if staged:
+                fs.graphs[fb.key] = g
             return True
         except Exception as e:      # report, fall back to eager launches for this size
             fs.graph = False
+            if staged:
+                fs.graphs[fb.key] = False
             self.graph_error = repr(e)
             ops.reset_branches()
             torch.cuda.synchronize(self.dev)
@@ -1007,7 +1156,27 @@ class SGGEmbStep:
         Before a successful ``capture()`` a call is the sequential eager step."""
         fs = self.shapes[self._staged]
         try:
-            if self._graphs_on:
+            if self._graphs_on and self._pipelined and self.stage_split:
+                self._measure(fs)
+                if self.bubble:
+                    self._fill_call(fs)              # the pipeline fills: both backbone halves, no head
+                    self.n_bubbles += 1
+                else:
+                    self._last_trained = self._id_cur
+                    fb_key = self._mid_key
+                    if fs.graphs.get(fb_key) is None:
+                        self._capture_frames(fs)     # first sight of this (front size, back size) pair
+                    g = fs.graphs.get(fb_key)
+                    self._tick += 1
+                    fs.tick = self._tick
+                    fs.graph = g if g else fs.graph
+                    if g:
+                        replay_graph(g, self.dev)
+                    else:
+                        self._body_overlapped(fs)    # this pair could not be captured: the same schedule on eager launches
+                    self._fmap_key, self._mid_key = fb_key, fs.key
+                self._id_cur, self._id_mid = self._id_mid, self._id_inp      # the slots moved (inside the graph / the fill call)
+            elif self._graphs_on:
                 if fs.graph is None:
                     self._capture_frames(fs)         # first sight of this frame size (or the graphs were invalidated)
                 self._tick += 1
@@ -1030,8 +1199,27 @@ class SGGEmbStep:
         return self.loss
 
     def flush(self):
-        """Overlapped schedule: run the head of the batch staged last (its backbone pass ran in the previous call)."""
+        """Overlapped schedule: one more call without a new ``stage()`` -- the batches already in the pipeline advance one stage
+        (``lag`` such calls end a loop: the last one runs the head of the batch staged last)."""
         return self()
+
+
+def run_staged(step, stagers, keep):
+    """Drive ``step`` (any schedule) over ``1 + len(stagers)`` minibatches: the first one is staged (and the step captured)
+    already, ``stagers[k]()`` stages the next.  One minibatch is staged before every call while there are any; calls go on until
+    the head has trained every minibatch; ``keep[j]`` (a device vector) receives the loss of minibatch j right behind its call
+    (no host synchronisation).  Calls that run no head (``SGGEmbStep.bubble``) are not counted."""
+    trained, nxt, total = 0, 0, len(stagers) + 1
+    while trained < total:
+        if nxt < len(stagers):
+            stagers[nxt]()
+            nxt += 1
+        bubble = getattr(step, "bubble", False)
+        loss = step()
+        if not bubble:
+            keep[trained].copy_(loss)
+            trained += 1
+    return keep
 
 
 _REPLAY_STREAMS = {}

@@ -463,14 +463,15 @@ def test_sgg_step_schedules_match_single_graph(cfg):
     the fused wgrad+SGD update and with the separate update kernels."""
     from i2vsgg_amd import train
     res = {}
-    for key in (("eager", True), ("seq", True), ("overlap", True), ("seq", False), ("overlap", False)):
+    for key in (("eager", True), ("seq", True), ("stage", True), ("frame", True), ("none", True), ("seq", False), ("stage", False)):
         mode, fuse = key
         net = train.build_sgg_net(layers=50, seed=5, device=DEV)
         net.vrd.dropout = False
+        overlapped = mode in ("stage", "frame", "none")      # how the backbone beside the head is cut into graph branches
         step = train.SGGEmbStep(net, 2, seed=3, device=DEV, h=200, w=320, n_boxes=6, n_pairs=5, fuse_sgd=fuse,
-                                use_graph=mode != "eager", overlap=mode == "overlap")
+                                use_graph=mode != "eager", overlap=overlapped, bb_split=mode if overlapped else None)
         assert step.capture(warmup=1) == (mode != "eager"), step.graph_error
-        assert step.overlap == (mode == "overlap")
+        assert step.overlap == overlapped and step.lag == {"stage": 2, "frame": 1, "none": 1}.get(mode, 0)
         losses = [float(step().item()) for _ in range(4)]
         step.opt.flush_pending()            # fc6 / fc7 hold their last update until the next forward (fused update only)
         torch.cuda.synchronize()
@@ -630,7 +631,8 @@ def test_sgg_step_staged_batches_meet_their_features(cfg):
     """A NEW minibatch staged between replays of the captured, overlapped step (what a training loop does; round-1
     advice: reseed() used to race the backbone pass already queued on the side stream): the loss sequence equals the
     eager sequential loop over the same batches -- batch k's boxes / labels always meet batch k's feature map -- with the
-    one-call lag of the pipeline (a batch staged before call k is the head's batch in call k+1)."""
+    lag of the pipeline (a batch staged before call k is the head's batch in call k+1 with the backbone cut by frame or not at
+    all, in call k+2 with the backbone cut by stage: ``train.run_staged`` is the loop for any of them)."""
     from i2vsgg_amd import train
     seeds = [3, 11, 12, 13, 14]
 
@@ -649,28 +651,35 @@ def test_sgg_step_staged_batches_meet_their_features(cfg):
         return losses, w
 
     # the graph run reads each loss right after its call (the device scalar is overwritten by the next replay)
-    def run_graph():
+    def run_graph(split):
         net = train.build_sgg_net(layers=50, seed=5, device=DEV)
         net.vrd.dropout = False
-        step = train.SGGEmbStep(net, 2, seed=seeds[0], device=DEV, h=200, w=320, n_boxes=6, n_pairs=5)
+        step = train.SGGEmbStep(net, 2, seed=seeds[0], device=DEV, h=200, w=320, n_boxes=6, n_pairs=5, bb_split=split)
         assert step.capture(warmup=1) and step.overlap, step.graph_error
+        assert step.lag == (2 if split == "stage" else 1) and not step.bubble
         keep = torch.zeros(len(seeds), device=DEV)
-        for k, sd in enumerate(seeds[1:]):
-            step.reseed(sd)
-            keep[k].copy_(step())
-        keep[len(seeds) - 1].copy_(step.flush())
+        train.run_staged(step, [lambda sd=sd: step.reseed(sd) for sd in seeds[1:]], keep)
+        # cut by stage: the second call of the run finds the first minibatch in the head's slot again and runs no head
+        assert step.n_bubbles == (1 if split == "stage" else 0)
         torch.cuda.synchronize()
         w = net.vrd.fc7.fc.weight.detach().cpu().numpy().copy()
+        # a resident minibatch behind the run: every call trains it, none is a bubble
+        before = float(step.loss)
+        for _ in range(3):
+            assert not step.bubble
+            step()
+        assert step.n_bubbles == (1 if split == "stage" else 0) and float(step.loss) != before
         step.opt.unfuse()
         return keep.tolist(), w
 
     l0, w0 = run_eager()
-    l1, w1 = run_graph()
     assert len(set(round(x, 5) for x in l0)) == len(l0)                     # the batches differ
-    for a, b in zip(l0, l1):
-        assert abs(a - b) <= 1e-5 * abs(a), (l0, l1)          # a mismatched batch / feature pairing is off by 1e-1
-    # eager: one backbone pass over both frames; graph: one branch per frame -- other split-K factors, other fp32 rounding
-    _weights_close(w1, w0, "staged batches, fc7, captured vs eager")
+    for split in ("stage", "frame", "none"):
+        l1, w1 = run_graph(split)
+        for a, b in zip(l0, l1):
+            assert abs(a - b) <= 1e-5 * abs(a), (split, l0, l1)   # a mismatched batch / feature pairing is off by 1e-1
+        # eager: one backbone pass over both frames; graph: other launch shapes -- other split-K factors, other fp32 rounding
+        _weights_close(w1, w0, "staged batches, fc7, captured (%s) vs eager" % split)
 
 
 def test_captured_step_is_idempotent_after_one_warmup(cfg):

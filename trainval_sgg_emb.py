@@ -254,7 +254,7 @@ def main(argv=None):
     if rank == 0:
         print("step: %s" % ("HIP graph, overlapped" if graphed and step.overlap else "HIP graph" if graphed
                             else "eager (%s)" % (step.graph_error or "--no-graph")))
-    pos = 0
+    pos, staged = 0, 1                  # minibatches trained / handed to the step so far (the first one before the capture)
     for epoch in range(start_epoch, a.max_epochs + 1):
         if epoch > 1 and (epoch - 1) % a.lr_decay_step == 0:
             step.opt.scale_lr(a.lr_decay_gamma)              # adjust_learning_rate (net_utils.py:113-116), :196-199
@@ -263,14 +263,20 @@ def main(argv=None):
                 graphed = step.capture(warmup=0)             # rates live in the captured kernel arguments
                 if not graphed and rank == 0:
                     print("re-capture failed, eager launches from here: %s" % step.graph_error)
-        lag = 1 if step.lag else 0          # overlapped: call k trains batch k while the backbone runs batch k+1
+        lag = step.lag                      # overlapped: call k trains batch k while the backbone runs batch k + lag (1 or 2)
         t0, acc = time.time(), torch.zeros((), device=dev)
         for it in range(iters_per_epoch):
-            # overlapped: the batch staged now is the backbone's in this call and the head's in the next one (none is staged
-            # for the very last call: its backbone branch has nothing new to do).  Sequential: the batch of this call
-            if (lag and pos + 1 < total) or (not lag and pos > 0):
-                stage_next()                                 # queued behind the running step, no host synchronisation
-            acc += step()                                    # loss of batch ``pos``
+            # overlapped: the batch staged now is the backbone's in this call and the head's ``lag`` calls later (none is staged
+            # for the last ``lag`` calls: their backbone branches have nothing new to do).  Sequential: the batch of this call
+            while True:
+                if staged < min(total, pos + lag + 1):
+                    stage_next()                             # queued behind the running step, no host synchronisation
+                    staged += 1
+                bubble = step.bubble                         # backbone cut by stage: the second call of a run fills the pipeline
+                loss_k = step()                              # (both backbone halves, no head: its return value is stale)
+                if not bubble:
+                    break
+            acc += loss_k                                    # loss of batch ``pos``
             pos += 1
             if (it + 1) % a.disp_interval == 0:
                 loss = float(acc) / a.disp_interval          # the only host synchronisation of the loop
