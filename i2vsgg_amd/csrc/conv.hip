@@ -1524,7 +1524,13 @@ constexpr bool WGRAD_ROWMAJOR = false;     // LDS image of the filter-gradient k
                                            // arrive (true: no register transposes, conflict-free 16-byte stores, one-float fragment reads merged into
                                            // ds_read2st64_b32 -- bit-equal, measured 3 % slower on the layer3 shapes: 113.8 vs 110.3 us)
 
-template <int TM, int TN, bool FUSED_SGD = false, bool CLK = false>       // tile = (2*TM*16) filters x (2*TN*16) taps, 4 waves as 2x2
+// DMA (round 6, I2V_TUNE_WGRAD_DMA; pointwise / linear problems only: pixel index in == pixel index out): the stage tiles go
+// from global memory to LDS without passing through registers (lds_dma16), as in conv_gemm_f32.  The DMA lands lane-linear, so the
+// LDS image is the [pixel][column] one (WGRAD_ROWMAJOR's) with its 16-column-group swizzle applied to the SOURCE column: a 1-KB
+// piece is 4 (2) consecutive pixel rows of a 64- (128-) column tile.  No staging registers (64 of the 128 VGPRs of the 64x64
+// form), no register transposes, no ds_write; the stage offset rides in the scalar offset of the request, the per-lane offsets
+// are loop constants.  Same MFMA order per accumulator: bit-equal to the register-staged forms.
+template <int TM, int TN, bool FUSED_SGD = false, bool CLK = false, bool DMA = false>       // tile = (2*TM*16) filters x (2*TN*16) taps, 4 waves as 2x2
 __global__ void __launch_bounds__(THREADS)
 conv_wgrad2_f32(const WgP p_in) {
     WgP p = p_in;
@@ -1555,9 +1561,10 @@ conv_wgrad2_f32(const WgP p_in) {
         p.gw += (long long)bz * p.bsw;
     }
     constexpr int BMW = 2 * TM * 16, BNW = 2 * TN * 16;
-    constexpr bool ROWMAJOR = WGRAD_ROWMAJOR;
+    constexpr bool ROWMAJOR = WGRAD_ROWMAJOR || DMA;
+    static_assert(!DMA || (!FUSED_SGD && !CLK), "the LDS-DMA form is the plain gradient kernel");
     constexpr int A_BLK = BMW * 2, B_BLK = BNW * 2;             // (cols/4) * 8 row-groups
-    constexpr int NBLK = (A_BLK + B_BLK + THREADS - 1) / THREADS;
+    constexpr int NBLK = DMA ? 1 : (A_BLK + B_BLK + THREADS - 1) / THREADS;     // (DMA: the register-staging roles below are dead code)
     constexpr int STAGE_FLOATS = 2 * (BMW + BNW) * BKS;
     constexpr int CROW = BNW + 4;
     constexpr int SMEM_FLOATS = STAGE_FLOATS > BMW * CROW ? STAGE_FLOATS : BMW * CROW;
@@ -1788,11 +1795,53 @@ conv_wgrad2_f32(const WgP p_in) {
         }
     }
 
+    int buf = 0;
+    if constexpr (DMA) {
+        // A stage = NPA + NPB pieces of 1 KB (RP pixel rows of the gy tile, then of the x tile); wave w requests pieces w, w + 4, ...
+        constexpr int NPA = BMW / 8, NPB = BNW / 8, NP = NPA + NPB, PMAX = NP / 4;
+        static_assert(NP % 4 == 0, "whole rounds of four pieces");
+        constexpr unsigned INV = 0x80000000u;
+        const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+        unsigned d_vk[PMAX];
+        int d_row[PMAX];
+#pragma unroll
+        for (int q = 0; q < PMAX; ++q) {
+            const int pc = q * 4 + wave_s;
+            const bool isA = pc < NPA;                                   // wave-uniform
+            const int cols = isA ? BMW : BNW, cp = cols / 4, rp = 256 / cols;
+            const int mi = (isA ? pc : pc - NPA) * rp + lane / cp, ch = lane % cp;
+            const int col = ((((ch >> 2) ^ ((mi >> 2) & 3)) << 4) | ((ch & 3) << 2));
+            const int g = (isA ? n0 : k0) + col;
+            d_row[q] = mi;
+            d_vk[q] = g < (isA ? p.N : p.K) ? (unsigned)(mi * (isA ? p.N : p.Cin) + g) * 4u : INV;
+        }
+        const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+        auto dma_issue = [&](int ms, int S) {
+            const unsigned so_a = (unsigned)ms * (unsigned)p.N * 4u, so_b = (unsigned)ms * (unsigned)p.Cin * 4u;
+            const unsigned a_dst = lds_base + (unsigned)(S * BMW * BKS * 4), b_dst = lds_base + (unsigned)((2 * BMW + S * BNW) * BKS * 4);
+            const bool tail = ms + BKS > mend;                           // uniform: only a split's last stage can be partial
+#pragma unroll
+            for (int q = 0; q < PMAX; ++q) {
+                const int pc = q * 4 + wave_s;
+                const bool isA = pc < NPA;
+                const unsigned v = tail ? (d_vk[q] | (ms + d_row[q] < mend ? 0u : INV)) : d_vk[q];
+                lds_dma16(isA ? a_dst + (unsigned)(pc * 1024) : b_dst + (unsigned)((pc - NPA) * 1024), v, isA ? gr : xr, isA ? so_a : so_b);
+            }
+        };
+        dma_issue(mbeg, 0);
+        for (int ms = mbeg; ms < mend; ms += BKS) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my pieces of this stage have landed ...
+            __builtin_amdgcn_s_barrier();                          // ... everyone's have; and everyone is done with the other buffer
+            if (ms + BKS < mend) dma_issue(ms + BKS, buf ^ 1);
+            compute(buf);
+            buf ^= 1;
+        }
+        __syncthreads();                                           // the epilogue reuses the stage buffers
+    } else {
     gload(mbeg);
     sstore(0);
     __syncthreads();
     if constexpr (CLK) c_t1 = __builtin_amdgcn_s_memtime();
-    int buf = 0;
     for (int ms = mbeg; ms < mend; ms += BKS) {
         const bool more = ms + BKS < mend;
         if constexpr (CLK) {        // diagnostic instantiation only (tools/wgrad_phase.py ABL=..): 1 = no staging after the first stage, 2 = no MFMAs
@@ -1808,6 +1857,7 @@ conv_wgrad2_f32(const WgP p_in) {
         if (more) sstore(buf ^ 1);
         __syncthreads();
         buf ^= 1;
+    }
     }
     if constexpr (CLK) c_t2 = __builtin_amdgcn_s_memtime();
 
@@ -2381,7 +2431,14 @@ static bool launch_wgrad(WgP& p, float beta, bool fused, hipStream_t st, void* s
         p.r_tiles = (int)tiles; p.r_splits = splits; p.r_total = (int)total;
         grid = dim3((unsigned)((total + 7) / 8 * 8), 1, 1);
     }
+    // round 6: LDS-DMA staging for the pointwise / linear problems (most of a backbone's filter-gradient time: the 1x1 layers and
+    // the Winograd-domain plane GEMMs)
+    const bool lin = p.KH == 1 && p.KW == 1 && p.pad == 0 && p.stride == 1;
+    const bool dma = v2 && !fused && !g_clk && lin && (p.K % 4 == 0) && g_i2v_tuning[I2V_TUNE_WGRAD_DMA];
     if (!v2) conv_wgrad_f32<64, 64><<<grid, THREADS, 0, st>>>(p);
+    else if (dma && tm == 128 && tk == 128) conv_wgrad2_f32<4, 4, false, false, true><<<grid, THREADS, 0, st>>>(p);
+    else if (dma && tm == 128) conv_wgrad2_f32<4, 2, false, false, true><<<grid, THREADS, 0, st>>>(p);
+    else if (dma) conv_wgrad2_f32<2, 2, false, false, true><<<grid, THREADS, 0, st>>>(p);
     else if (fused && tm == 128 && tk == 64) conv_wgrad2_f32<4, 2, true><<<grid, THREADS, 0, st>>>(p);
     else if (tm == 128 && tk == 128) conv_wgrad2_f32<4, 4><<<grid, THREADS, 0, st>>>(p);
     else if (tm == 128) conv_wgrad2_f32<4, 2><<<grid, THREADS, 0, st>>>(p);

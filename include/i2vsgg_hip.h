@@ -270,7 +270,8 @@ size_t  i2v_conv_split_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t 
 #define I2V_TUNE_KGROUPS             20   /* 2 (round 5): the same with TWO wave groups (8 waves, two 39 KB stage regions: the workgroup shares its CU); 1 / 4: a pointwise GEMM the plan would split over K runs as one 16-wave workgroup per tile whose four wave groups split K and meet in LDS (no partial tile through memory) when one round of such tiles covers >= 70 % of the CUs: 4-10 % faster than the split across workgroups as a kernel on its own, 9 % SLOWER inside the overlapped step (a workgroup that owns a CU's LDS and registers shuts the other branches' workgroups out: profiles/r04_kgroups.txt); 0 (default): split-K across workgroups, partials through the caller's workspace */
 #define I2V_TUNE_WGRAD_ORDERED_GFLOP 21   /* a split filter gradient takes an ordered finish (I2V_TUNE_SPLIT_ATOMICS == 0) only when the problem is below this many GFLOP (default 1000000: always; round 5's default was 8 -- its only ordered form, one finisher reading every part, was a tail on the large launches; 0: never) */
 #define I2V_TUNE_GEMM_DMA            22   /* how the pointwise / plain-GEMM kernel stages its operand tiles (round 6).  0: global -> registers -> ds_write_b128 (rounds 2-5).  1: LDS-DMA (buffer_load ... lds, the column swizzle on the source address), 32-k stages, same LDS image.  2: LDS-DMA with 16-k stages (64-byte LDS rows): half the LDS per workgroup, twice the barriers.  Bit-equal results in all three */
-#define I2V_TUNE_COUNT               23
+#define I2V_TUNE_WGRAD_DMA           23   /* staging of the second-generation filter-gradient kernel on pointwise / linear problems (round 6).  0: global -> registers -> transposing ds_write_b128.  1: LDS-DMA into the [pixel][column] image, the group swizzle on the source column.  Bit-equal */
+#define I2V_TUNE_COUNT               24
 /* Keys CONV_SPEC (> 0), STAGGER, FC_FOLD, GEMM_X3, GEMM_PERSIST, WGRAD_PRIO belonged to kernel variants that were measured and lost
  * (DESIGN_HISTORY.md) and left the library in round 6: I2V_ERR_UNSUPPORTED for any value but "off"; the indices stay reserved. */
 int32_t i2v_set_tuning(int32_t key, int32_t value);

@@ -1178,6 +1178,42 @@ def test_filter_gradient_split_groups_on_one_xcd(B, C, N, H, W, k):
     assert float((on - off).abs().max()) <= 2e-5 * scale          # atomics: summation order differs
 
 
+@pytest.mark.parametrize("B,C,N,H,W", [(2, 256, 128, 38, 63), (1, 72, 196, 19, 23), (3, 64, 64, 7, 7), (1, 1024, 256, 5, 3)])
+def test_filter_gradient_lds_dma_staging_is_bit_equal(B, C, N, H, W):
+    """Round 6: the pointwise filter gradient stages its tiles by LDS-DMA (I2V_TUNE_WGRAD_DMA, conv_wgrad2_f32<.., DMA>): a
+    [pixel][column] LDS image, the group swizzle on the source column, the stage offset in the request's scalar offset.  Same MFMA
+    order per accumulator as the register-staged kernel: the SAME BITS with ordered sums, for every tile shape, on channel counts
+    that leave partial tiles (72, 196), pixel counts that leave a partial last stage, and the 36-plane batched form the Winograd
+    filter gradient uses; both within 1e-5 of float64 torch."""
+    from i2vsgg_amd import ops
+    from i2vsgg_amd._lib import TUNE, lib
+    torch.manual_seed(11)
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    x, g = cl(torch.randn(B, C, H, W, device=DEV)), cl(torch.randn(B, N, H, W, device=DEV))
+    want = torch.nn.grad.conv2d_weight(x.double(), (N, C, 1, 1), g.double(), 1, 0)
+    scale = float(want.abs().max())
+    ctx = ops.LaunchContext(DEV, ordered=True)
+    keys = [TUNE["I2V_WGRAD_DMA"], TUNE["I2V_WGRAD_V2"]]
+    old = [lib.i2v_get_tuning(k) for k in keys]
+    assert old[0] == 1                                      # the default
+    try:
+        for tiles in (1, 2, 3):                             # 64x64, 128x128, 128x64
+            got = {}
+            for dma in (0, 1):
+                assert lib.i2v_set_tuning(keys[0], dma) == 0 and lib.i2v_set_tuning(keys[1], tiles) == 0
+                with ctx, torch.no_grad():
+                    got[dma] = (ops._conv_wgrad_raw(x, g, (N, C, 1, 1), 1, 0).clone(),
+                                ops._conv_wgrad_raw(x, g, (N, C, 3, 3), 1, 1, winograd=True).clone()
+                                if ops._winograd_wgrad_ok(x, (N, C, 3, 3), 1, 1) else None)
+            assert torch.equal(got[0][0], got[1][0]), (tiles, float((got[0][0] - got[1][0]).abs().max()))
+            assert float((got[1][0].double() - want).abs().max()) <= 1e-5 * scale
+            if got[0][1] is not None:
+                assert torch.equal(got[0][1], got[1][1]), tiles
+    finally:
+        for k, v in zip(keys, old):
+            lib.i2v_set_tuning(k, v)
+
+
 def test_pair_gather_and_single_workgroup_bce_match_torch():
     """ops.pair_gather ([obj[ixs] | obj[ixo]] per relation pair, resnet_SGG_emb.py:170-176) forward and backward against
     index_select / cat under autograd (repeated and unused rows, a pad index pair (0, 0)); ops.bce_rows against
@@ -1291,7 +1327,7 @@ KNOBS = [("I2V_CONV_SPEC", 1), ("I2V_CONV_SPEC", 2), ("I2V_SPLIT_TARGET", 3), ("
          ("I2V_WGRAD_V2", 3), ("I2V_WINO_ROWS", -1), ("I2V_WINO_ROWS", 3), ("I2V_ROIPOOL_C128", 0), ("I2V_CONV_GEMM", 0),
          ("I2V_STAGGER", 4), ("I2V_ROIALIGN_COLS", 0), ("I2V_ROIALIGN_COLS", 1), ("I2V_WGRAD_PER_CU", 2), ("I2V_WGRAD_XCD", 0), ("I2V_GEMM_PERSIST", 2),
          ("I2V_WGRAD_PRIO", 2), ("I2V_STREAM_TILE", 0), ("I2V_GEMM_X3", 1), ("I2V_KGROUPS", 1), ("I2V_KGROUPS", 2), ("I2V_GEMM_DMA", 0),
-         ("I2V_GEMM_DMA", 2), ("I2V_SPLIT_ATOMICS", 0), ("I2V_WGRAD_ORDERED_GFLOP", 0)]
+         ("I2V_GEMM_DMA", 2), ("I2V_SPLIT_ATOMICS", 0), ("I2V_WGRAD_ORDERED_GFLOP", 0), ("I2V_WGRAD_DMA", 0)]
 
 
 def test_every_tuning_knob_keeps_the_results(ops):
