@@ -577,6 +577,231 @@ roi_align_bwd_row_kernel(const float* __restrict__ gout, const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------- backward as a gather, round 6: waves that never meet
+// Same ownership (a workgroup = one frame, one map row, 128 channels; every gradient element written once, no atomics) and the
+// same list phase as roi_align_bwd_row_kernel.  What changed is the add.  Round 5 gave a lane ONE channel and one cell parity:
+// 32 LDS instructions per (pair, wave) for 16 taps x 32 channels, four-byte accesses, the staged gradients and tap records
+// passed between waves through LDS with two barriers per batch of four pairs -- the LDS pipe's instruction rate was the bound
+// (~1000 cycles per pair).  Here a wave owns 32 channels of the row buffer for the whole launch and a lane is
+// (sample column, 4 channels): the sample gradients go from grad_out to registers (four 16-byte loads with the 2x2 mean, four
+// pairs in flight per wave), a pair's two taps per column are two 16-byte read-add-writes -- 1 + 4 LDS instructions per
+// (pair, wave) -- and nothing is handed between waves but the tap records, made once per chunk of 32 listed pairs (one record per
+// thread, one barrier).  Sample columns of a narrow box may share a cell: a record carries the ROUND its column is added in
+// (columns of one round have distinct cells; one round unless a bin is narrower than a cell), so the sums keep a fixed order:
+// pair, round, left tap before right tap.
+constexpr int RB2_CHUNK = 32;           // listed pairs whose tap records are made together (8 threads per pair)
+struct TapRec2 { unsigned off; float wl, wr; int meta; };   // row-buffer byte offsets of the two taps' cells (left | right << 16, wave 0's, 4-channel group 0's),
+                                                             // their weights (the 2x2 mean's 1/4 folded in), round | rounds of the pair << 8
+
+template <int AVG, int P7>
+__global__ void __launch_bounds__(256, 3)
+roi_align_bwd_row2_kernel(const float* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gfeat, int R, int PH_,
+                          int PW_, float scale, int B, int C, int H, int W) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* rowbuf = lds;                                                    // [W + 2][128]: cell x, wave w's 32 channels at x * 128 + ((w ^ (x & 3)) << 5)
+                                                                            // (neighbouring cells of one access fall into different bank quarters);
+                                                                            // rows W, W + 1: a bin for taps outside the map
+    unsigned short* list = (unsigned short*)(rowbuf + (size_t)(W + 2) * 128);       // [4][256], as in roi_align_bwd_row_kernel
+    __shared__ int s_cnt[2][4];
+    __shared__ __attribute__((aligned(16))) TapRec2 s_rec[RB2_CHUNK][8];
+    const int PH = P7 ? 7 : PH_, PW = P7 ? 7 : PW_;
+    const int AH = PH + AVG, AW = PW + AVG;
+    const int n_pairs = R * AH;
+    const int nchunk = C >> 7;
+    const int chunk = blockIdx.x % nchunk, b = (blockIdx.x / nchunk) % B, hk = blockIdx.x / (nchunk * B);
+    const int h = (hk & 1) ? H / 2 - 1 - (hk >> 1) : H / 2 + (hk >> 1);    // rows from the middle of the map outwards (longest lists first)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sxl = lane >> 3, c4g = lane & 7;                             // my sample column; my 4 of the wave's 32 channels
+    constexpr int NQ = AVG ? 4 : 1;
+    const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gout), 0, 0x7FFFFFFCu, 0x00020000);
+    const unsigned cbase = (unsigned)((chunk << 7) + (wave << 5) + (c4g << 2));
+    // Everything a pair needs per lane is a loop constant: the byte offset of my channels in the pooled columns my sample column
+    // reads (pw = sx - 1 and sx with the 2x2 mean; the out-of-range bit where the column does not exist) and the XOR that turns a
+    // record's cell offset into MY slot of the cell.  The pair itself (roi, sample row) is wave-uniform: its part of the address
+    // is scalar arithmetic and rides in the scalar offset of the loads -- the vector pipe was the bound of the first form of this
+    // kernel (~120 vector instructions per pair and wave, three waves per SIMD: 1570 cycles per pair).
+    const unsigned lcol0 = (sxl < AW && sxl - AVG >= 0 && sxl - AVG < PW) ? ((unsigned)((sxl - AVG) * C) + cbase) * 4u : 0x80000000u;
+    const unsigned lcol1 = (sxl < AW && sxl < PW) ? ((unsigned)(sxl * C) + cbase) * 4u : 0x80000000u;
+    const unsigned lxor = (unsigned)((wave << 7) | (c4g << 4));
+    const unsigned lds_row = (unsigned)(size_t)(__attribute__((address_space(3))) float*)rowbuf;
+    (void)lds_row;
+#ifdef RAB_CLOCKS
+    unsigned long long c_list = 0, c_rec = 0, c_add = 0, c_n = 0;
+#endif
+    RAB_T(c_begin);
+    for (int i = threadIdx.x; i < (W + 2) * 32; i += 256) ((float4*)rowbuf)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = 0; base < n_pairs; base += RAB_SEG) {
+        const int sp = (base / RAB_SEG) & 1;
+        RAB_T(c_l0);
+        {       // ---- the list of this segment (roi_align_bwd_row_kernel's: per-wave sublists, a ballot and a running count, ONE barrier)
+            int cnt = 0;
+            float f0[4], y1[4], y2[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = min(base + 256 * wave + 64 * k + lane, n_pairs - 1);
+                const float* roi = rois + 5 * (long long)(i / AH);
+                f0[k] = roi[0]; y1[k] = roi[2]; y2[k] = roi[4];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int il = 256 * wave + 64 * k + lane, i = base + il;
+                int hit = 0, dy = 0;
+                if (i < n_pairs && (int)f0[k] == b) {
+                    const AxisGeom q = ra_axis(y1[k], y2[k], scale, H, AH, i % AH);
+                    dy = q.s + 1 == h;
+                    hit = q.ok && (q.s == h || dy);
+                }
+                const unsigned long long m = __ballot(hit);
+                if (hit) list[256 * wave + cnt + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(2 * il + dy);
+                cnt += __popcll(m);
+            }
+            if (lane == 0) s_cnt[sp][wave] = cnt;
+        }
+        __syncthreads();
+        const int p1 = s_cnt[sp][0], p2 = p1 + s_cnt[sp][1], p3 = p2 + s_cnt[sp][2], n = p3 + s_cnt[sp][3];
+        RAB_T(c_l1);
+        RAB_ADD(c_list, c_l0, c_l1);
+#ifdef RAB_CLOCKS
+        c_n += n;
+#endif
+        auto entry = [&](int e) {           // the e-th listed pair: global pair index * 2 + dy
+            const int w = (e >= p1) + (e >= p2) + (e >= p3);
+            const int off = w == 0 ? 0 : (w == 1 ? p1 : (w == 2 ? p2 : p3));
+            return 2 * base + (int)list[256 * w + e - off];
+        };
+        // the sample gradients of listed pair e for my column and channels: always issued (a pair past the end, a column or a
+        // window cell that does not exist gets the out-of-range bit: zeros, no traffic), so the loads in flight are countable
+        auto issue = [&](float4 (&q)[NQ], int e, int code) {       // code = entry(min(e, n - 1)), read a step ahead
+            const int pair = __builtin_amdgcn_readfirstlane(code) >> 1;                      // scalar from here on
+            const int r = pair / AH, ah = pair - r * AH;
+            const bool live = e < n;
+            if (AVG) {                  // the (<= 4) pooled cells whose 2x2 window holds the sample, raster order
+                const bool d0 = !(live && ah >= 1), d1 = !(live && ah < PH);
+                // (a dead row's scalar offset must not be negative: the range check subtracts it from the buffer size, and the
+                // out-of-range bit of the vector offset would land in range again)
+                const unsigned b0 = d0 ? 0u : (unsigned)(((r * PH + ah - 1) * PW) * C) * 4u, b1 = d1 ? 0u : (unsigned)(((r * PH + ah) * PW) * C) * 4u;
+                q[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(gr, d0 ? 0x80000000u : lcol0, b0, 0));
+                q[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(gr, d0 ? 0x80000000u : lcol1, b0, 0));
+                q[2] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(gr, d1 ? 0x80000000u : lcol0, b1, 0));
+                q[3] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(gr, d1 ? 0x80000000u : lcol1, b1, 0));
+            } else {
+                q[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(gr, live ? lcol1 : 0x80000000u, (unsigned)(((r * PH + ah) * PW) * C) * 4u, 0));
+            }
+        };
+        auto process = [&](const float4 (&q)[NQ], const TapRec2 rec) {     // a listed pair: my column's two taps
+            float4 v = q[0];
+            if (AVG) {                  // avg_pool2d backward: the windows summed in raster order; grad / 4 (exact) is in the weights
+#pragma unroll
+                for (int d = 1; d < 4; ++d) { v.x += q[d].x; v.y += q[d].y; v.z += q[d].z; v.w += q[d].w; }
+            }
+            const int meta = __builtin_amdgcn_readfirstlane(rec.meta), nr = (meta >> 8) & 255, round = rec.meta & 255;
+            float4* pl = (float4*)((char*)rowbuf + ((rec.off & 0xFFFFu) ^ lxor));
+            float4* pr = (float4*)((char*)rowbuf + ((rec.off >> 16) ^ lxor));
+            const float4 tl = make_float4(v.x * rec.wl, v.y * rec.wl, v.z * rec.wl, v.w * rec.wl);
+            const float4 tr = make_float4(v.x * rec.wr, v.y * rec.wr, v.z * rec.wr, v.w * rec.wr);
+            if (meta >> 16) {           // no column's right cell is another column's left cell (and one round): both cells read at once
+                float4 a = *pl, c = *pr;
+                a.x += tl.x; a.y += tl.y; a.z += tl.z; a.w += tl.w;
+                c.x += tr.x; c.y += tr.y; c.z += tr.z; c.w += tr.w;
+                *pl = a;
+                *pr = c;
+                return;
+            }
+            for (int s = 0; s < nr; ++s) {
+                if (round == s) {
+                    float4 a = *pl;
+                    a.x += tl.x; a.y += tl.y; a.z += tl.z; a.w += tl.w;
+                    *pl = a;
+                    float4 c = *pr;         // (a neighbour's left cell may be my right cell: after the left stores, in order)
+                    c.x += tr.x; c.y += tr.y; c.z += tr.z; c.w += tr.w;
+                    *pr = c;
+                }
+            }
+        };
+        float4 q0[NQ], q1[NQ], q2[NQ], q3[NQ];
+        if (n > 0) { issue(q0, 0, entry(0)); issue(q1, 1, entry(min(1, n - 1))); issue(q2, 2, entry(min(2, n - 1))); issue(q3, 3, entry(min(3, n - 1))); }
+        for (int e0 = 0; e0 < n; e0 += RB2_CHUNK) {
+            RAB_T(c_r0);
+            {       // ---- the chunk's tap records: thread = (pair of the chunk, sample column)
+                const int u = threadIdx.x >> 3, sx = threadIdx.x & 7, e = e0 + u;
+                int cell = W;           // (the bin rows W, W + 1)
+                float wl = 0.f, wr = 0.f;
+                if (e < n && sx < AW) {
+                    const int code = entry(e), pair = code >> 1;
+                    const int r = pair / AH, ah = pair - r * AH;
+                    const float* roi = rois + 5 * (long long)r;
+                    const AxisGeom qr = ra_axis(roi[2], roi[4], scale, H, AH, ah);
+                    const AxisGeom qc = ra_axis(roi[1], roi[3], scale, W, AW, sx);
+                    if (qc.ok) {
+                        const float fh = (code & 1) ? qr.r : (1 - qr.r);
+                        cell = qc.s; wl = fh * (1 - qc.r); wr = fh * qc.r;               // taps on cells ws, ws + 1
+                    }
+                }
+                int round = 0;          // columns before mine that share my cell (cells do not decrease along a pair)
+#pragma unroll
+                for (int k = 1; k < 8; ++k) {
+                    const int c = __shfl_up(cell, k, 8);
+                    if (sx >= k && c == cell && cell < W) ++round;
+                }
+                // does my right cell belong to the next column as its left cell?  (then the pair's taps are added left, then right)
+                const int nxt = __shfl_down(cell, 1, 8);
+                int chained = sx < 7 && cell < W && nxt == cell + 1;
+                int nr = round + 1;                              // over the pair's 8 threads: the most rounds, any chained
+#pragma unroll
+                for (int m = 1; m < 8; m <<= 1) {
+                    nr = max(nr, __shfl_xor(nr, m, 8));
+                    chained |= __shfl_xor(chained, m, 8);
+                }
+                const int indep = nr == 1 && !chained;           // one round, nothing chained
+                TapRec2 rec;
+                rec.off = (unsigned)(cell * 512 + ((cell & 3) << 7)) | ((unsigned)((cell + 1) * 512 + (((cell + 1) & 3) << 7)) << 16);
+                rec.wl = AVG ? wl * 0.25f : wl; rec.wr = AVG ? wr * 0.25f : wr;
+                rec.meta = round | (nr << 8) | (indep << 16);
+                s_rec[u][sx] = rec;
+            }
+            __syncthreads();
+            RAB_T(c_r1);
+            const int ne = min(RB2_CHUNK, n - e0);
+            // four pairs in flight per wave; no wave waits for another.  A step's LDS reads that do not depend on it -- the NEXT
+            // pair's record, the list entry of the pair requested next -- are issued in front of the step's read-add-write, so
+            // they share its round trip (the LDS returns in order) instead of heading chains of their own
+            TapRec2 rec = s_rec[0][sxl];
+            int code = entry(min(e0 + 4, n - 1));
+            auto step = [&](float4 (&q)[NQ], int u) {
+                const TapRec2 recn = s_rec[min(u + 1, RB2_CHUNK - 1)][sxl];
+                const int coden = entry(min(e0 + u + 5, n - 1));
+                if (u < ne) process(q, rec);
+                issue(q, e0 + u + 4, code);
+                rec = recn;
+                code = coden;
+            };
+            for (int u = 0; u < ne; u += 4) {
+                step(q0, u);
+                step(q1, u + 1);
+                step(q2, u + 2);
+                step(q3, u + 3);
+            }
+            __syncthreads();            // the records (and, at the end of a segment, the list) are rewritten next
+            RAB_T(c_r2);
+            RAB_ADD(c_rec, c_r0, c_r1); RAB_ADD(c_add, c_r1, c_r2);
+        }
+    }
+    __syncthreads();
+    RAB_T(c_st0);
+    float* o = gfeat + (((long long)b * H + h) * W) * C + (chunk << 7);
+    for (int i = threadIdx.x; i < W * 32; i += 256) {
+        const int x = i >> 5, c4 = i & 31;
+        *(float4*)(o + (long long)x * C + 4 * c4) = ((const float4*)rowbuf)[x * 32 + ((((c4 >> 3) ^ (x & 3)) << 3) | (c4 & 7))];
+    }
+#ifdef RAB_CLOCKS
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        unsigned long long* o6 = g_rab_clk[blockIdx.x];
+        const unsigned long long c_end = __builtin_amdgcn_s_memtime();
+        o6[0] = c_end - c_begin; o6[1] = c_list; o6[2] = c_rec; o6[3] = c_end - c_st0; o6[4] = c_add; o6[5] = c_n;
+    }
+#endif
+}
+
 // ---------------------------------------------------------------- ROIPool
 // roi_pooling_kernel.cu:24-93.  One workgroup per (roi, 64-channel chunk); lane = channel, the four
 // waves split the pooled rows (ph % 4).  The PHxPW results of the chunk are staged in LDS so that an
@@ -933,7 +1158,8 @@ extern "C" int32_t i2v_roi_align_bwd_gather(const float* gout, const float* rois
     I2V_CHECK_ARG(C % 128 == 0, "roi_align_bwd_gather: C must be a multiple of 128 (NHWC in and out)");
     const size_t AH = PH + avg, AW = PW + avg;
     I2V_CHECK_ARG(AW <= RAB_MAXA, "roi_align_bwd_gather: at most 8 sample columns (pooled_w + avg <= 8)");
-    const size_t lds = (size_t)(W + 2) * 128 * sizeof(float) + (size_t)RAB_BATCH * RAB_MAXA * 128 * sizeof(float) + RAB_SEG * sizeof(unsigned short);
+    const bool form2 = g_i2v_tuning[I2V_TUNE_ROIALIGN_BWD] != 0;        // round 6: waves that never meet (0: round 5's staged batches)
+    const size_t lds = (size_t)(W + 2) * 128 * sizeof(float) + (form2 ? 0 : (size_t)RAB_BATCH * RAB_MAXA * 128 * sizeof(float)) + RAB_SEG * sizeof(unsigned short);
     I2V_CHECK_ARG(lds <= 60 * 1024 && (long long)R * AH < (1ll << 29), "roi_align_bwd_gather: map too wide for the LDS row buffer");
     I2V_CHECK_ARG((long long)B * H * (C / 128) < (1ll << 31), "roi_align_bwd_gather: grid too large");
     I2V_CHECK_ARG((long long)R * PH * PW * C * 4 < (1ll << 31), "roi_align_bwd_gather: grad_out beyond the 2 GiB a 32-bit buffer offset reaches");
@@ -942,11 +1168,17 @@ extern "C" int32_t i2v_roi_align_bwd_gather(const float* gout, const float* rois
         (void)hipFuncSetAttribute((const void*)roi_align_bwd_row_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
         (void)hipFuncSetAttribute((const void*)roi_align_bwd_row_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
         (void)hipFuncSetAttribute((const void*)roi_align_bwd_row_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
+        (void)hipFuncSetAttribute((const void*)roi_align_bwd_row2_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
+        (void)hipFuncSetAttribute((const void*)roi_align_bwd_row2_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
+        (void)hipFuncSetAttribute((const void*)roi_align_bwd_row2_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
         return true;
     }();
     (void)once;
     const dim3 grid(B * H * (C / 128));
-    if (avg && PH == 7 && PW == 7) roi_align_bwd_row_kernel<1, 1><<<grid, 256, lds, st>>>(gout, rois, gfeat, R, PH, PW, scale, B, C, H, W);
+    if (form2 && avg && PH == 7 && PW == 7) roi_align_bwd_row2_kernel<1, 1><<<grid, 256, lds, st>>>(gout, rois, gfeat, R, PH, PW, scale, B, C, H, W);
+    else if (form2 && avg) roi_align_bwd_row2_kernel<1, 0><<<grid, 256, lds, st>>>(gout, rois, gfeat, R, PH, PW, scale, B, C, H, W);
+    else if (form2) roi_align_bwd_row2_kernel<0, 0><<<grid, 256, lds, st>>>(gout, rois, gfeat, R, PH, PW, scale, B, C, H, W);
+    else if (avg && PH == 7 && PW == 7) roi_align_bwd_row_kernel<1, 1><<<grid, 256, lds, st>>>(gout, rois, gfeat, R, PH, PW, scale, B, C, H, W);
     else if (avg) roi_align_bwd_row_kernel<1, 0><<<grid, 256, lds, st>>>(gout, rois, gfeat, R, PH, PW, scale, B, C, H, W);
     else roi_align_bwd_row_kernel<0, 0><<<grid, 256, lds, st>>>(gout, rois, gfeat, R, PH, PW, scale, B, C, H, W);
     I2V_CHECK_LAUNCH("roi_align_bwd_gather");

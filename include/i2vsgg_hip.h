@@ -271,7 +271,8 @@ size_t  i2v_conv_split_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t 
 #define I2V_TUNE_WGRAD_ORDERED_GFLOP 21   /* a split filter gradient takes an ordered finish (I2V_TUNE_SPLIT_ATOMICS == 0) only when the problem is below this many GFLOP (default 1000000: always; round 5's default was 8 -- its only ordered form, one finisher reading every part, was a tail on the large launches; 0: never) */
 #define I2V_TUNE_GEMM_DMA            22   /* how the pointwise / plain-GEMM kernel stages its operand tiles (round 6).  0: global -> registers -> ds_write_b128 (rounds 2-5).  1: LDS-DMA (buffer_load ... lds, the column swizzle on the source address), 32-k stages, same LDS image.  2: LDS-DMA with 16-k stages (64-byte LDS rows): half the LDS per workgroup, twice the barriers.  Bit-equal results in all three */
 #define I2V_TUNE_WGRAD_DMA           23   /* staging of the second-generation filter-gradient kernel on pointwise / linear problems (round 6).  0: global -> registers -> transposing ds_write_b128.  1: LDS-DMA into the [pixel][column] image, the group swizzle on the source column.  Bit-equal */
-#define I2V_TUNE_COUNT               24
+#define I2V_TUNE_ROIALIGN_BWD        24   /* the gather form of the RoIAlign backward (round 6).  1: a wave owns 32 channels of the row buffer, a lane = (sample column, 4 channels), gradients from grad_out to registers, 16-byte read-add-writes.  0: round 5's form (lane = channel x cell parity, gradients and tap records staged in LDS per batch of four pairs) */
+#define I2V_TUNE_COUNT               25
 /* Keys CONV_SPEC (> 0), STAGGER, FC_FOLD, GEMM_X3, GEMM_PERSIST, WGRAD_PRIO belonged to kernel variants that were measured and lost
  * (DESIGN_HISTORY.md) and left the library in round 6: I2V_ERR_UNSUPPORTED for any value but "off"; the indices stay reserved. */
 int32_t i2v_set_tuning(int32_t key, int32_t value);

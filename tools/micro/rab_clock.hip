@@ -1,6 +1,7 @@
-// Where a workgroup of roi_align_bwd_row_kernel spends its time: the kernel of csrc/roi_ops.hip compiled with phase stamps
+// Where a workgroup of the RoIAlign backward spends its time: the kernels of csrc/roi_ops.hip compiled with phase stamps
 // (RAB_CLOCKS), 4 frames x 32 ROIs x 1024 channels on a 38 x 63 map (configs[2]).
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/micro/rab_clock.hip -o tools/micro/rab_clock && tools/micro/rab_clock
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/micro/rab_clock.hip -o tools/micro/rab_clock
+//   tools/micro/rab_clock [frames] [form: 1 = round 6 (waves that never meet), 0 = round 5]
 #define RAB_CLOCKS 1
 #include <cstdarg>
 #include <cstdio>
@@ -14,6 +15,8 @@ int g_i2v_tuning[64];
 
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 4, R = 32 * B, C = 1024, H = 38, W = 63, PH = 7, PW = 7;
+    const int form = argc > 2 ? atoi(argv[2]) : 1;
+    g_i2v_tuning[I2V_TUNE_ROIALIGN_BWD] = form;
     std::vector<float> rois(5 * R), g((size_t)R * PH * PW * C);
     unsigned s = 12345;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) * (1.0f / 16777216.0f); };
@@ -42,7 +45,8 @@ int main(int argc, char** argv) {
     for (int i = 0; i < std::min(nwg, 8192); ++i) { for (int k = 0; k < 6; ++k) sum[k] += clk[(size_t)i * 6 + k]; tot.push_back(clk[(size_t)i * 6]); }
     std::sort(tot.begin(), tot.end());
     printf("%d frames: %.2f us per launch (with stamps), %d workgroups\n", B, 1e3 * ms / N, nwg);
-    printf("per workgroup (s_memtime ticks, 100 MHz => x21 for 2.1 GHz cycles): total %.0f (median %llu, max %llu)  list %.0f  stage+barrier %.0f  request %.0f  add %.0f  pairs %.1f\n",
-           sum[0] / nwg, tot[tot.size() / 2], tot.back(), sum[1] / nwg, sum[2] / nwg, sum[3] / nwg, sum[4] / nwg, sum[5] / nwg);
+    printf("form %d, per workgroup (s_memtime ticks, 100 MHz => x21 for 2.1 GHz cycles): total %.0f (median %llu, max %llu)  list %.0f  %s %.0f  %s %.0f  add %.0f  pairs %.1f\n",
+           form, sum[0] / nwg, tot[tot.size() / 2], tot.back(), sum[1] / nwg, form ? "records+barrier" : "stage+barrier", sum[2] / nwg,
+           form ? "store" : "request", sum[3] / nwg, sum[4] / nwg, sum[5] / nwg);
     return 0;
 }
