@@ -581,27 +581,48 @@ roi_align_bwd_row_kernel(const float* __restrict__ gout, const float* __restrict
 // Same ownership (a workgroup = one frame, one map row, 128 channels; every gradient element written once, no atomics) and the
 // same list phase as roi_align_bwd_row_kernel.  What changed is the add.  Round 5 gave a lane ONE channel and one cell parity:
 // 32 LDS instructions per (pair, wave) for 16 taps x 32 channels, four-byte accesses, the staged gradients and tap records
-// passed between waves through LDS with two barriers per batch of four pairs -- the LDS pipe's instruction rate was the bound
-// (~1000 cycles per pair).  Here a wave owns 32 channels of the row buffer for the whole launch and a lane is
-// (sample column, 4 channels): the sample gradients go from grad_out to registers (four 16-byte loads with the 2x2 mean, four
-// pairs in flight per wave), a pair's two taps per column are two 16-byte read-add-writes -- 1 + 4 LDS instructions per
-// (pair, wave) -- and nothing is handed between waves but the tap records, made once per chunk of 32 listed pairs (one record per
-// thread, one barrier).  Sample columns of a narrow box may share a cell: a record carries the ROUND its column is added in
-// (columns of one round have distinct cells; one round unless a bin is narrower than a cell), so the sums keep a fixed order:
-// pair, round, left tap before right tap.
+// passed between waves through LDS with two barriers per batch of four pairs (~1000 cycles per pair).  Here
+//   * a wave owns 32 channels of the row buffer for the whole launch and a lane is (sample column, 4 channels): a pair's two
+//     taps per column are two 16-byte read-add-writes, 1 + 4 LDS instructions per (pair, wave); nothing is handed between waves
+//     but the tap records, made once per chunk of 32 listed pairs (one record per thread, one barrier);
+//   * the sample gradients go from grad_out to registers, eight pairs in flight per wave.  With the 2x2 mean a sample is the
+//     sum of a 2x2 window of pooled cells, and the windows of neighbouring sample columns share a pooled column: a lane loads
+//     ITS pooled column only (two 16-byte loads: the window's rows) and takes the left column's row sum from the lane two to
+//     its left (DPP row_shr:2 -- the 16 lanes of a DPP row hold all eight columns of two channel groups).  Loading all four
+//     window cells per lane asked the CU's vector L1 for 4 KB per (pair, wave), 1 MB per CU and launch: 64 B per clock made
+//     that ~70 % of the add phase (tools/micro/rab_clock.hip);
+//   * everything of a pair that is wave-uniform (roi, sample row, the byte offsets of its pooled rows) is scalar arithmetic on a
+//     list entry read one step ahead and rides in the scalar offset of the loads; the per-lane part is a loop constant;
+//   * sample columns of a narrow box may share a cell: a record carries the ROUND its column is added in (columns of one round
+//     have distinct cells; one round unless a bin is narrower than a cell).  In a one-round pair a right tap that lands on the
+//     next column's left cell is handed to that column's lane (DPP) and added with its left tap: every cell has one lane, the
+//     pair is one LDS round trip.  The sums keep a fixed order: pair, round, left tap before right tap.
+// A sample gradient is now (g(ah-1, aw-1) + g(ah, aw-1)) + (g(ah-1, aw) + g(ah, aw)) with the mean's 1/4 (exact) folded into
+// the tap weights -- columns first, where the scatter and round 5's gather add in raster order: <= 1 ulp of the sample.
 constexpr int RB2_CHUNK = 32;           // listed pairs whose tap records are made together (8 threads per pair)
-struct TapRec2 { unsigned off; float wl, wr; int meta; };   // row-buffer byte offsets of the two taps' cells (left | right << 16, wave 0's, 4-channel group 0's),
-                                                             // their weights (the 2x2 mean's 1/4 folded in), round | rounds of the pair << 8
+constexpr int RB2_DEPTH = 4;            // pairs in flight per wave
+struct TapRec2 { unsigned off; float wl, wr; int meta; };   // row-buffer byte offsets of the two taps' cells (left | right << 16; slot 0's),
+                                                             // their weights, round | rounds of the pair << 8 | takes the previous column's right tap << 24
+                                                             // | gives its right tap to the next column << 25
+
+__device__ inline float4 rab_row_shr2(float4 v) {           // lane i <- lane i - 2 of its 16-lane DPP row (zeros shifted in)
+    float4 o;
+    o.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.x), 0x112, 0xF, 0xF, true));
+    o.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.y), 0x112, 0xF, 0xF, true));
+    o.z = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.z), 0x112, 0xF, 0xF, true));
+    o.w = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.w), 0x112, 0xF, 0xF, true));
+    return o;
+}
 
 template <int AVG, int P7>
-__global__ void __launch_bounds__(256, 3)
+__global__ void __launch_bounds__(256, 4)
 roi_align_bwd_row2_kernel(const float* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gfeat, int R, int PH_,
                           int PW_, float scale, int B, int C, int H, int W) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* rowbuf = lds;                                                    // [W + 2][128]: cell x, wave w's 32 channels at x * 128 + ((w ^ (x & 3)) << 5)
-                                                                            // (neighbouring cells of one access fall into different bank quarters);
-                                                                            // rows W, W + 1: a bin for taps outside the map
-    unsigned short* list = (unsigned short*)(rowbuf + (size_t)(W + 2) * 128);       // [4][256], as in roi_align_bwd_row_kernel
+    float* rowbuf = lds;                                                    // [W + 2][32 slots of 4 channels]: cell x, 4-channel group j (wave j >> 3) in
+                                                                            // slot j ^ ((x & 7) << 1): the eight cells x two groups of a 16-lane access
+                                                                            // cover the 64 banks; rows W, W + 1: a bin for taps outside the map
+    unsigned short* list = (unsigned short*)(rowbuf + (size_t)(W + 2) * 128);       // [4][256] per-wave sublists, then compacted to [n]
     __shared__ int s_cnt[2][4];
     __shared__ __attribute__((aligned(16))) TapRec2 s_rec[RB2_CHUNK][8];
     const int PH = P7 ? 7 : PH_, PW = P7 ? 7 : PW_;
@@ -611,30 +632,22 @@ roi_align_bwd_row2_kernel(const float* __restrict__ gout, const float* __restric
     const int chunk = blockIdx.x % nchunk, b = (blockIdx.x / nchunk) % B, hk = blockIdx.x / (nchunk * B);
     const int h = (hk & 1) ? H / 2 - 1 - (hk >> 1) : H / 2 + (hk >> 1);    // rows from the middle of the map outwards (longest lists first)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int sxl = lane >> 3, c4g = lane & 7;                             // my sample column; my 4 of the wave's 32 channels
-    constexpr int NQ = AVG ? 4 : 1;
+    const int sxl = (lane >> 1) & 7, c4g = ((lane >> 4) << 1) | (lane & 1);        // my sample column; my 4 of the wave's 32 channels
+    constexpr int NQ = AVG ? 2 : 1;
     const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gout), 0, 0x7FFFFFFCu, 0x00020000);
-    const unsigned cbase = (unsigned)((chunk << 7) + (wave << 5) + (c4g << 2));
-    // Everything a pair needs per lane is a loop constant: the byte offset of my channels in the pooled columns my sample column
-    // reads (pw = sx - 1 and sx with the 2x2 mean; the out-of-range bit where the column does not exist) and the XOR that turns a
-    // record's cell offset into MY slot of the cell.  The pair itself (roi, sample row) is wave-uniform: its part of the address
-    // is scalar arithmetic and rides in the scalar offset of the loads -- the vector pipe was the bound of the first form of this
-    // kernel (~120 vector instructions per pair and wave, three waves per SIMD: 1570 cycles per pair).
-    const unsigned lcol0 = (sxl < AW && sxl - AVG >= 0 && sxl - AVG < PW) ? ((unsigned)((sxl - AVG) * C) + cbase) * 4u : 0x80000000u;
-    const unsigned lcol1 = (sxl < AW && sxl < PW) ? ((unsigned)(sxl * C) + cbase) * 4u : 0x80000000u;
-    const unsigned lxor = (unsigned)((wave << 7) | (c4g << 4));
-    const unsigned lds_row = (unsigned)(size_t)(__attribute__((address_space(3))) float*)rowbuf;
-    (void)lds_row;
+    // loop constants of a lane: the byte offset of my channels in my pooled column (the out-of-range bit where it does not exist),
+    // the XOR that turns a record's cell offset into my slot of the cell
+    const unsigned lcol = (sxl < AW && sxl < PW) ? ((unsigned)(sxl * C) + (unsigned)((chunk << 7) + (wave << 5) + (c4g << 2))) * 4u : 0x80000000u;
+    const unsigned lxor = (unsigned)(((wave << 3) | c4g) << 4);
 #ifdef RAB_CLOCKS
     unsigned long long c_list = 0, c_rec = 0, c_add = 0, c_n = 0;
 #endif
     RAB_T(c_begin);
-    for (int i = threadIdx.x; i < (W + 2) * 32; i += 256) ((float4*)rowbuf)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int base = 0; base < n_pairs; base += RAB_SEG) {
         const int sp = (base / RAB_SEG) & 1;
         RAB_T(c_l0);
+        int cnt = 0;
         {       // ---- the list of this segment (roi_align_bwd_row_kernel's: per-wave sublists, a ballot and a running count, ONE barrier)
-            int cnt = 0;
             float f0[4], y1[4], y2[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -659,52 +672,77 @@ roi_align_bwd_row2_kernel(const float* __restrict__ gout, const float* __restric
         }
         __syncthreads();
         const int p1 = s_cnt[sp][0], p2 = p1 + s_cnt[sp][1], p3 = p2 + s_cnt[sp][2], n = p3 + s_cnt[sp][3];
+        if (n > 0) {
+            // the four sublists close up into ONE list (a wave's entries move down, never up: read, barrier, write): an entry is then
+            // one LDS read away for everyone, instead of a search through the four counts per use
+            const int mine = wave == 0 ? 0 : (wave == 1 ? p1 : (wave == 2 ? p2 : p3));
+            unsigned short keep[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) keep[k] = list[256 * wave + min(64 * k + lane, 255)];
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (64 * k + lane < cnt) list[mine + 64 * k + lane] = keep[k];
+            __syncthreads();
+        }
         RAB_T(c_l1);
         RAB_ADD(c_list, c_l0, c_l1);
 #ifdef RAB_CLOCKS
         c_n += n;
 #endif
-        auto entry = [&](int e) {           // the e-th listed pair: global pair index * 2 + dy
-            const int w = (e >= p1) + (e >= p2) + (e >= p3);
-            const int off = w == 0 ? 0 : (w == 1 ? p1 : (w == 2 ? p2 : p3));
-            return 2 * base + (int)list[256 * w + e - off];
-        };
-        // the sample gradients of listed pair e for my column and channels: always issued (a pair past the end, a column or a
-        // window cell that does not exist gets the out-of-range bit: zeros, no traffic), so the loads in flight are countable
-        auto issue = [&](float4 (&q)[NQ], int e, int code) {       // code = entry(min(e, n - 1)), read a step ahead
-            const int pair = __builtin_amdgcn_readfirstlane(code) >> 1;                      // scalar from here on
+        // the sample-gradient operands of listed pair e (its list entry `code` read a step ahead) for my column and channels: always
+        // issued (a pair past the end, a column or a pooled row that does not exist gets the out-of-range bit: zeros, no
+        // traffic), so the loads in flight are countable.  A dead row's scalar offset must not be negative: the range check
+        // subtracts it from the buffer size, and the out-of-range bit of the vector offset would land in range again.
+        auto issue = [&](float4 (&q)[NQ], int e, int code) {
+            const int pair = (2 * base + __builtin_amdgcn_readfirstlane(code)) >> 1;        // scalar from here on
             const int r = pair / AH, ah = pair - r * AH;
+#if defined(RAB_CLOCKS) && defined(RAB_ABL) && (RAB_ABL & 2)      // tools/micro/rab_clock.hip only: no loads (every request out of range)
+            const bool live = false;
+#else
             const bool live = e < n;
-            if (AVG) {                  // the (<= 4) pooled cells whose 2x2 window holds the sample, raster order
+#endif
+            if (AVG) {                  // the two pooled rows of the sample's 2x2 window, my pooled column
                 const bool d0 = !(live && ah >= 1), d1 = !(live && ah < PH);
-                // (a dead row's scalar offset must not be negative: the range check subtracts it from the buffer size, and the
-                // out-of-range bit of the vector offset would land in range again)
                 const unsigned b0 = d0 ? 0u : (unsigned)(((r * PH + ah - 1) * PW) * C) * 4u, b1 = d1 ? 0u : (unsigned)(((r * PH + ah) * PW) * C) * 4u;
-                q[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(gr, d0 ? 0x80000000u : lcol0, b0, 0));
-                q[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(gr, d0 ? 0x80000000u : lcol1, b0, 0));
-                q[2] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(gr, d1 ? 0x80000000u : lcol0, b1, 0));
-                q[3] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(gr, d1 ? 0x80000000u : lcol1, b1, 0));
+                q[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(gr, lcol | (d0 ? 0x80000000u : 0u), b0, 0));
+                q[1] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(gr, lcol | (d1 ? 0x80000000u : 0u), b1, 0));
             } else {
-                q[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(gr, live ? lcol1 : 0x80000000u, (unsigned)(((r * PH + ah) * PW) * C) * 4u, 0));
+                q[0] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(gr, lcol | (live ? 0u : 0x80000000u),
+                                                                                         live ? (unsigned)(((r * PH + ah) * PW) * C) * 4u : 0u, 0));
             }
         };
         auto process = [&](const float4 (&q)[NQ], const TapRec2 rec) {     // a listed pair: my column's two taps
             float4 v = q[0];
-            if (AVG) {                  // avg_pool2d backward: the windows summed in raster order; grad / 4 (exact) is in the weights
-#pragma unroll
-                for (int d = 1; d < 4; ++d) { v.x += q[d].x; v.y += q[d].y; v.z += q[d].z; v.w += q[d].w; }
+            if (AVG) {                  // avg_pool2d backward: my pooled column's two rows + the left column's (grad / 4 is in the weights)
+                v.x += q[1].x; v.y += q[1].y; v.z += q[1].z; v.w += q[1].w;
+                const float4 l = rab_row_shr2(v);
+                v.x = l.x + v.x; v.y = l.y + v.y; v.z = l.z + v.z; v.w = l.w + v.w;
             }
             const int meta = __builtin_amdgcn_readfirstlane(rec.meta), nr = (meta >> 8) & 255, round = rec.meta & 255;
             float4* pl = (float4*)((char*)rowbuf + ((rec.off & 0xFFFFu) ^ lxor));
             float4* pr = (float4*)((char*)rowbuf + ((rec.off >> 16) ^ lxor));
             const float4 tl = make_float4(v.x * rec.wl, v.y * rec.wl, v.z * rec.wl, v.w * rec.wl);
             const float4 tr = make_float4(v.x * rec.wr, v.y * rec.wr, v.z * rec.wr, v.w * rec.wr);
-            if (meta >> 16) {           // no column's right cell is another column's left cell (and one round): both cells read at once
-                float4 a = *pl, c = *pr;
-                a.x += tl.x; a.y += tl.y; a.z += tl.z; a.w += tl.w;
-                c.x += tr.x; c.y += tr.y; c.z += tr.z; c.w += tr.w;
+#if defined(RAB_CLOCKS) && defined(RAB_ABL) && (RAB_ABL & 1)      // tools/micro/rab_clock.hip only: no read-add-write (results wrong)
+            if (tl.x + tr.y == 12345.678f) *pl = tl;
+            return;
+#endif
+            if (nr == 1) {
+                // one round (every box at least 8 cells wide, i.e. 128 pixels): the pair's cells are distinct except where a
+                // column's right cell IS the next column's left cell -- that tap is handed to the next column in registers
+                // (DPP again) and added with its left tap, so every cell is touched by ONE lane: both reads at once, one LDS
+                // round trip per pair, and a chained column costs one read-add-write instead of two
+                const float4 trp = rab_row_shr2(tr);
+                float4 a = *pl;
+                if (rec.meta & (1 << 24)) { a.x += tl.x + trp.x; a.y += tl.y + trp.y; a.z += tl.z + trp.z; a.w += tl.w + trp.w; }
+                else { a.x += tl.x; a.y += tl.y; a.z += tl.z; a.w += tl.w; }
+                if (!(rec.meta & (1 << 25))) {
+                    float4 c = *pr;
+                    c.x += tr.x; c.y += tr.y; c.z += tr.z; c.w += tr.w;
+                    *pr = c;
+                }
                 *pl = a;
-                *pr = c;
                 return;
             }
             for (int s = 0; s < nr; ++s) {
@@ -718,8 +756,14 @@ roi_align_bwd_row2_kernel(const float* __restrict__ gout, const float* __restric
                 }
             }
         };
-        float4 q0[NQ], q1[NQ], q2[NQ], q3[NQ];
-        if (n > 0) { issue(q0, 0, entry(0)); issue(q1, 1, entry(min(1, n - 1))); issue(q2, 2, entry(min(2, n - 1))); issue(q3, 3, entry(min(3, n - 1))); }
+        float4 q[RB2_DEPTH][NQ];
+        if (n > 0) {
+#pragma unroll
+            for (int k = 0; k < RB2_DEPTH; ++k) issue(q[k], k, list[min(k, n - 1)]);
+        }
+        if (base == 0) {        // the row buffer is cleared under the first requests' round trip (a barrier follows before its first use)
+            for (int i = threadIdx.x; i < (W + 2) * 32; i += 256) ((float4*)rowbuf)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         for (int e0 = 0; e0 < n; e0 += RB2_CHUNK) {
             RAB_T(c_r0);
             {       // ---- the chunk's tap records: thread = (pair of the chunk, sample column)
@@ -727,7 +771,7 @@ roi_align_bwd_row2_kernel(const float* __restrict__ gout, const float* __restric
                 int cell = W;           // (the bin rows W, W + 1)
                 float wl = 0.f, wr = 0.f;
                 if (e < n && sx < AW) {
-                    const int code = entry(e), pair = code >> 1;
+                    const int code = 2 * base + (int)list[e], pair = code >> 1;
                     const int r = pair / AH, ah = pair - r * AH;
                     const float* roi = rois + 5 * (long long)r;
                     const AxisGeom qr = ra_axis(roi[2], roi[4], scale, H, AH, ah);
@@ -744,42 +788,37 @@ roi_align_bwd_row2_kernel(const float* __restrict__ gout, const float* __restric
                     if (sx >= k && c == cell && cell < W) ++round;
                 }
                 // does my right cell belong to the next column as its left cell?  (then the pair's taps are added left, then right)
-                const int nxt = __shfl_down(cell, 1, 8);
-                int chained = sx < 7 && cell < W && nxt == cell + 1;
-                int nr = round + 1;                              // over the pair's 8 threads: the most rounds, any chained
+                const int nxt = __shfl_down(cell, 1, 8), prv = __shfl_up(cell, 1, 8);
+                const int give = sx < 7 && cell < W && nxt == cell + 1;          // my right tap goes to the next column's lane
+                const int take = sx > 0 && cell < W && prv + 1 == cell;          // the previous column's right tap comes to mine
+                int nr = round + 1;                              // over the pair's 8 threads: the most rounds
 #pragma unroll
-                for (int m = 1; m < 8; m <<= 1) {
-                    nr = max(nr, __shfl_xor(nr, m, 8));
-                    chained |= __shfl_xor(chained, m, 8);
-                }
-                const int indep = nr == 1 && !chained;           // one round, nothing chained
+                for (int m = 1; m < 8; m <<= 1) nr = max(nr, __shfl_xor(nr, m, 8));
                 TapRec2 rec;
-                rec.off = (unsigned)(cell * 512 + ((cell & 3) << 7)) | ((unsigned)((cell + 1) * 512 + (((cell + 1) & 3) << 7)) << 16);
+                rec.off = (unsigned)(cell * 512 + ((cell & 7) << 5)) | ((unsigned)((cell + 1) * 512 + (((cell + 1) & 7) << 5)) << 16);
                 rec.wl = AVG ? wl * 0.25f : wl; rec.wr = AVG ? wr * 0.25f : wr;
-                rec.meta = round | (nr << 8) | (indep << 16);
+                rec.meta = round | (nr << 8) | (take << 24) | (give << 25);
                 s_rec[u][sx] = rec;
             }
             __syncthreads();
             RAB_T(c_r1);
             const int ne = min(RB2_CHUNK, n - e0);
-            // four pairs in flight per wave; no wave waits for another.  A step's LDS reads that do not depend on it -- the NEXT
+            // eight pairs in flight per wave; no wave waits for another.  A step's LDS reads that do not depend on it -- the NEXT
             // pair's record, the list entry of the pair requested next -- are issued in front of the step's read-add-write, so
             // they share its round trip (the LDS returns in order) instead of heading chains of their own
             TapRec2 rec = s_rec[0][sxl];
-            int code = entry(min(e0 + 4, n - 1));
-            auto step = [&](float4 (&q)[NQ], int u) {
-                const TapRec2 recn = s_rec[min(u + 1, RB2_CHUNK - 1)][sxl];
-                const int coden = entry(min(e0 + u + 5, n - 1));
-                if (u < ne) process(q, rec);
-                issue(q, e0 + u + 4, code);
-                rec = recn;
-                code = coden;
-            };
-            for (int u = 0; u < ne; u += 4) {
-                step(q0, u);
-                step(q1, u + 1);
-                step(q2, u + 2);
-                step(q3, u + 3);
+            int code = list[min(e0 + RB2_DEPTH, n - 1)];
+            for (int u0 = 0; u0 < ne; u0 += RB2_DEPTH) {
+#pragma unroll
+                for (int k = 0; k < RB2_DEPTH; ++k) {
+                    const int u = u0 + k;
+                    const TapRec2 recn = s_rec[min(u + 1, RB2_CHUNK - 1)][sxl];
+                    const int coden = list[min(e0 + u + RB2_DEPTH + 1, n - 1)];
+                    if (u < ne) process(q[k], rec);
+                    issue(q[k], e0 + u + RB2_DEPTH, code);
+                    rec = recn;
+                    code = coden;
+                }
             }
             __syncthreads();            // the records (and, at the end of a segment, the list) are rewritten next
             RAB_T(c_r2);
@@ -791,7 +830,7 @@ roi_align_bwd_row2_kernel(const float* __restrict__ gout, const float* __restric
     float* o = gfeat + (((long long)b * H + h) * W) * C + (chunk << 7);
     for (int i = threadIdx.x; i < W * 32; i += 256) {
         const int x = i >> 5, c4 = i & 31;
-        *(float4*)(o + (long long)x * C + 4 * c4) = ((const float4*)rowbuf)[x * 32 + ((((c4 >> 3) ^ (x & 3)) << 3) | (c4 & 7))];
+        *(float4*)(o + (long long)x * C + 4 * c4) = ((const float4*)rowbuf)[x * 32 + (c4 ^ ((x & 7) << 1))];
     }
 #ifdef RAB_CLOCKS
     if (threadIdx.x == 0 && blockIdx.x < 8192) {
