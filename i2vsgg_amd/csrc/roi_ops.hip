@@ -614,31 +614,41 @@ __device__ inline float4 rab_row_shr2(float4 v) {           // lane i <- lane i 
     return o;
 }
 
-template <int AVG, int P7>
+template <int AVG, int P7, int GROUPS>
 __global__ void __launch_bounds__(256, 4)
 roi_align_bwd_row2_kernel(const float* __restrict__ gout, const float* __restrict__ rois, float* __restrict__ gfeat, int R, int PH_,
                           int PW_, float scale, int B, int C, int H, int W) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* rowbuf = lds;                                                    // [W + 2][32 slots of 4 channels]: cell x, 4-channel group j (wave j >> 3) in
-                                                                            // slot j ^ ((x & 7) << 1): the eight cells x two groups of a 16-lane access
-                                                                            // cover the 64 banks; rows W, W + 1: a bin for taps outside the map
+    // GROUPS = 1: the workgroup owns 128 channels, a wave 32 of them, every wave walks the whole list.
+    // GROUPS = 2: the workgroup owns 64 channels in TWO row buffers; the listed pairs are dealt to two groups of two waves (even /
+    // odd list index), each adding into ITS buffer, and the store adds the two (buffer 0 + buffer 1: a fixed order).  A
+    // workgroup's pairs form one dependent chain per wave (~1000 cycles per pair, 40+ pairs on a crowded row) and a launch that
+    // fits the chip at once waits for its longest chain: two groups halve it (one frame: 15.8 -> 13.5 us).  A launch of several
+    // rounds is bound by the sum instead, and twice the workgroups pay the list and the records twice (four frames: 30.1 -> 32.8
+    // us): the host picks by the launch's size.
+    // [GROUPS][W + 2][128 / GROUPS channels]: cell x, 4-channel group j (wave-in-group j >> 3) in slot j ^ ((x & 7) << 1) -- the
+    // cells of a 16-lane access spread over the banks; rows W, W + 1: a bin for taps outside the map
+    constexpr int CHB = 512 / GROUPS, WPG = 4 / GROUPS;            // bytes of a cell in one buffer; waves per group
+    float* rowbuf = lds;
     unsigned short* list = (unsigned short*)(rowbuf + (size_t)(W + 2) * 128);       // [4][256] per-wave sublists, then compacted to [n]
     __shared__ int s_cnt[2][4];
     __shared__ __attribute__((aligned(16))) TapRec2 s_rec[RB2_CHUNK][8];
     const int PH = P7 ? 7 : PH_, PW = P7 ? 7 : PW_;
     const int AH = PH + AVG, AW = PW + AVG;
     const int n_pairs = R * AH;
-    const int nchunk = C >> 7;
+    const int nchunk = C / (128 / GROUPS);
     const int chunk = blockIdx.x % nchunk, b = (blockIdx.x / nchunk) % B, hk = blockIdx.x / (nchunk * B);
     const int h = (hk & 1) ? H / 2 - 1 - (hk >> 1) : H / 2 + (hk >> 1);    // rows from the middle of the map outwards (longest lists first)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sxl = (lane >> 1) & 7, c4g = ((lane >> 4) << 1) | (lane & 1);        // my sample column; my 4 of the wave's 32 channels
+    const int grp = wave / WPG, wch = wave % WPG;                                   // my group (list index mod GROUPS); my 32 of the buffer's channels
     constexpr int NQ = AVG ? 2 : 1;
     const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gout), 0, 0x7FFFFFFCu, 0x00020000);
     // loop constants of a lane: the byte offset of my channels in my pooled column (the out-of-range bit where it does not exist),
     // the XOR that turns a record's cell offset into my slot of the cell
-    const unsigned lcol = (sxl < AW && sxl < PW) ? ((unsigned)(sxl * C) + (unsigned)((chunk << 7) + (wave << 5) + (c4g << 2))) * 4u : 0x80000000u;
-    const unsigned lxor = (unsigned)(((wave << 3) | c4g) << 4);
+    const unsigned lcol = (sxl < AW && sxl < PW) ? ((unsigned)(sxl * C) + (unsigned)(chunk * (128 / GROUPS) + (wch << 5) + (c4g << 2))) * 4u : 0x80000000u;
+    const unsigned lxor = (unsigned)(((wch << 3) | c4g) << 4);
+    char* const mybuf = (char*)rowbuf + (size_t)grp * (W + 2) * CHB;
 #ifdef RAB_CLOCKS
     unsigned long long c_list = 0, c_rec = 0, c_add = 0, c_n = 0;
 #endif
@@ -720,8 +730,8 @@ roi_align_bwd_row2_kernel(const float* __restrict__ gout, const float* __restric
                 v.x = l.x + v.x; v.y = l.y + v.y; v.z = l.z + v.z; v.w = l.w + v.w;
             }
             const int meta = __builtin_amdgcn_readfirstlane(rec.meta), nr = (meta >> 8) & 255, round = rec.meta & 255;
-            float4* pl = (float4*)((char*)rowbuf + ((rec.off & 0xFFFFu) ^ lxor));
-            float4* pr = (float4*)((char*)rowbuf + ((rec.off >> 16) ^ lxor));
+            float4* pl = (float4*)(mybuf + ((rec.off & 0xFFFFu) ^ lxor));
+            float4* pr = (float4*)(mybuf + ((rec.off >> 16) ^ lxor));
             const float4 tl = make_float4(v.x * rec.wl, v.y * rec.wl, v.z * rec.wl, v.w * rec.wl);
             const float4 tr = make_float4(v.x * rec.wr, v.y * rec.wr, v.z * rec.wr, v.w * rec.wr);
 #if defined(RAB_CLOCKS) && defined(RAB_ABL) && (RAB_ABL & 1)      // tools/micro/rab_clock.hip only: no read-add-write (results wrong)
@@ -757,9 +767,9 @@ roi_align_bwd_row2_kernel(const float* __restrict__ gout, const float* __restric
             }
         };
         float4 q[RB2_DEPTH][NQ];
-        if (n > 0) {
+        if (n > 0) {            // my group's first pairs: list entries grp, grp + GROUPS, ...
 #pragma unroll
-            for (int k = 0; k < RB2_DEPTH; ++k) issue(q[k], k, list[min(k, n - 1)]);
+            for (int k = 0; k < RB2_DEPTH; ++k) issue(q[k], GROUPS * k + grp, list[min(GROUPS * k + grp, n - 1)]);
         }
         if (base == 0) {        // the row buffer is cleared under the first requests' round trip (a barrier follows before its first use)
             for (int i = threadIdx.x; i < (W + 2) * 32; i += 256) ((float4*)rowbuf)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -795,7 +805,7 @@ roi_align_bwd_row2_kernel(const float* __restrict__ gout, const float* __restric
 #pragma unroll
                 for (int m = 1; m < 8; m <<= 1) nr = max(nr, __shfl_xor(nr, m, 8));
                 TapRec2 rec;
-                rec.off = (unsigned)(cell * 512 + ((cell & 7) << 5)) | ((unsigned)((cell + 1) * 512 + (((cell + 1) & 7) << 5)) << 16);
+                rec.off = (unsigned)(cell * CHB + ((cell & 7) << 5)) | ((unsigned)((cell + 1) * CHB + (((cell + 1) & 7) << 5)) << 16);
                 rec.wl = AVG ? wl * 0.25f : wl; rec.wr = AVG ? wr * 0.25f : wr;
                 rec.meta = round | (nr << 8) | (take << 24) | (give << 25);
                 s_rec[u][sx] = rec;
@@ -803,19 +813,20 @@ roi_align_bwd_row2_kernel(const float* __restrict__ gout, const float* __restric
             __syncthreads();
             RAB_T(c_r1);
             const int ne = min(RB2_CHUNK, n - e0);
-            // eight pairs in flight per wave; no wave waits for another.  A step's LDS reads that do not depend on it -- the NEXT
-            // pair's record, the list entry of the pair requested next -- are issued in front of the step's read-add-write, so
-            // they share its round trip (the LDS returns in order) instead of heading chains of their own
-            TapRec2 rec = s_rec[0][sxl];
-            int code = list[min(e0 + RB2_DEPTH, n - 1)];
-            for (int u0 = 0; u0 < ne; u0 += RB2_DEPTH) {
+            // my group's pairs of the chunk (u = grp, grp + GROUPS, ...), RB2_DEPTH of them in flight per wave; no wave waits for
+            // another.  A step's LDS reads that do not depend on it -- the NEXT pair's record, the list entry of the pair
+            // requested next -- are issued in front of the step's read-add-write, so they share its round trip (the LDS returns
+            // in order) instead of heading chains of their own
+            TapRec2 rec = s_rec[grp][sxl];
+            int code = list[min(e0 + GROUPS * RB2_DEPTH + grp, n - 1)];
+            for (int u0 = 0; u0 < ne; u0 += GROUPS * RB2_DEPTH) {
 #pragma unroll
                 for (int k = 0; k < RB2_DEPTH; ++k) {
-                    const int u = u0 + k;
-                    const TapRec2 recn = s_rec[min(u + 1, RB2_CHUNK - 1)][sxl];
-                    const int coden = list[min(e0 + u + RB2_DEPTH + 1, n - 1)];
+                    const int u = u0 + GROUPS * k + grp;
+                    const TapRec2 recn = s_rec[min(u + GROUPS, RB2_CHUNK - 1)][sxl];
+                    const int coden = list[min(e0 + u + GROUPS * RB2_DEPTH + GROUPS, n - 1)];
                     if (u < ne) process(q[k], rec);
-                    issue(q[k], e0 + u + RB2_DEPTH, code);
+                    issue(q[k], e0 + u + GROUPS * RB2_DEPTH, code);
                     rec = recn;
                     code = coden;
                 }
@@ -827,10 +838,14 @@ roi_align_bwd_row2_kernel(const float* __restrict__ gout, const float* __restric
     }
     __syncthreads();
     RAB_T(c_st0);
-    float* o = gfeat + (((long long)b * H + h) * W) * C + (chunk << 7);
-    for (int i = threadIdx.x; i < W * 32; i += 256) {
-        const int x = i >> 5, c4 = i & 31;
-        *(float4*)(o + (long long)x * C + 4 * c4) = ((const float4*)rowbuf)[x * 32 + (c4 ^ ((x & 7) << 1))];
+    constexpr int C4B = 32 / GROUPS;            // 4-channel groups of a cell in one buffer
+    float* o = gfeat + (((long long)b * H + h) * W) * C + chunk * (128 / GROUPS);
+    const float4* buf1 = (const float4*)rowbuf + (size_t)(W + 2) * C4B;
+    for (int i = threadIdx.x; i < W * C4B; i += 256) {
+        const int x = i / C4B, c4 = i % C4B, at = x * C4B + (c4 ^ ((x & 7) << 1));
+        float4 a = ((const float4*)rowbuf)[at];
+        if (GROUPS == 2) { const float4 c = buf1[at]; a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w; }
+        *(float4*)(o + (long long)x * C + 4 * c4) = a;
     }
 #ifdef RAB_CLOCKS
     if (threadIdx.x == 0 && blockIdx.x < 8192) {
@@ -1203,20 +1218,28 @@ extern "C" int32_t i2v_roi_align_bwd_gather(const float* gout, const float* rois
     I2V_CHECK_ARG((long long)B * H * (C / 128) < (1ll << 31), "roi_align_bwd_gather: grid too large");
     I2V_CHECK_ARG((long long)R * PH * PW * C * 4 < (1ll << 31), "roi_align_bwd_gather: grad_out beyond the 2 GiB a 32-bit buffer offset reaches");
     hipStream_t st = (hipStream_t)stream;
+    // the second form with one pair group per workgroup (128 channels) or two (64 channels, half the dependent chain): two where
+    // the launch fits the chip at once (its time is then its longest list's), one where it runs in rounds (the sum counts)
+    const bool two = form2 && (long long)B * H * (C / 64) <= 4ll * 256;       // four workgroups on each of the 256 CUs
     static bool once = [] {
         (void)hipFuncSetAttribute((const void*)roi_align_bwd_row_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
         (void)hipFuncSetAttribute((const void*)roi_align_bwd_row_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
         (void)hipFuncSetAttribute((const void*)roi_align_bwd_row_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
-        (void)hipFuncSetAttribute((const void*)roi_align_bwd_row2_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
-        (void)hipFuncSetAttribute((const void*)roi_align_bwd_row2_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
-        (void)hipFuncSetAttribute((const void*)roi_align_bwd_row2_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
+        (void)hipFuncSetAttribute((const void*)roi_align_bwd_row2_kernel<0, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
+        (void)hipFuncSetAttribute((const void*)roi_align_bwd_row2_kernel<1, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
+        (void)hipFuncSetAttribute((const void*)roi_align_bwd_row2_kernel<1, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
+        (void)hipFuncSetAttribute((const void*)roi_align_bwd_row2_kernel<0, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
+        (void)hipFuncSetAttribute((const void*)roi_align_bwd_row2_kernel<1, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
+        (void)hipFuncSetAttribute((const void*)roi_align_bwd_row2_kernel<1, 1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 60 * 1024);
         return true;
     }();
     (void)once;
-    const dim3 grid(B * H * (C / 128));
-    if (form2 && avg && PH == 7 && PW == 7) roi_align_bwd_row2_kernel<1, 1><<<grid, 256, lds, st>>>(gout, rois, gfeat, R, PH, PW, scale, B, C, H, W);
-    else if (form2 && avg) roi_align_bwd_row2_kernel<1, 0><<<grid, 256, lds, st>>>(gout, rois, gfeat, R, PH, PW, scale, B, C, H, W);
-    else if (form2) roi_align_bwd_row2_kernel<0, 0><<<grid, 256, lds, st>>>(gout, rois, gfeat, R, PH, PW, scale, B, C, H, W);
+    const dim3 grid(B * H * (C / 128)), grid2(B * H * (C / 64));
+    const int p7 = avg && PH == 7 && PW == 7;
+#define RAB2(A, P, G, GRID) roi_align_bwd_row2_kernel<A, P, G><<<GRID, 256, lds, st>>>(gout, rois, gfeat, R, PH, PW, scale, B, C, H, W)
+    if (form2 && two) { if (p7) RAB2(1, 1, 2, grid2); else if (avg) RAB2(1, 0, 2, grid2); else RAB2(0, 0, 2, grid2); }
+    else if (form2) { if (p7) RAB2(1, 1, 1, grid); else if (avg) RAB2(1, 0, 1, grid); else RAB2(0, 0, 1, grid); }
+#undef RAB2
     else if (avg && PH == 7 && PW == 7) roi_align_bwd_row_kernel<1, 1><<<grid, 256, lds, st>>>(gout, rois, gfeat, R, PH, PW, scale, B, C, H, W);
     else if (avg) roi_align_bwd_row_kernel<1, 0><<<grid, 256, lds, st>>>(gout, rois, gfeat, R, PH, PW, scale, B, C, H, W);
     else roi_align_bwd_row_kernel<0, 0><<<grid, 256, lds, st>>>(gout, rois, gfeat, R, PH, PW, scale, B, C, H, W);

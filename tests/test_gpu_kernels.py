@@ -160,6 +160,15 @@ def test_roi_align_bwd_gather_is_deterministic_and_equals_the_scatter(ops, oracl
     assert O.ROIALIGN_BWD_GATHER
     g1, g2 = run(), run()
     assert torch.equal(g1, g2)                                           # no atomics: the same bits every time
+    # round 5's form of the gather (I2V_TUNE_ROIALIGN_BWD = 0: lane = channel x cell parity, staged batches) against round 6's
+    # (waves that own channel slices, 16-byte read-add-writes, pooled columns loaded once): the same sums in another order
+    from i2vsgg_amd._lib import TUNE, lib
+    assert lib.i2v_get_tuning(TUNE["I2V_ROIALIGN_BWD"]) == 1 and lib.i2v_set_tuning(TUNE["I2V_ROIALIGN_BWD"], 0) == 0
+    try:
+        g5, g5b = run(), run()
+    finally:
+        lib.i2v_set_tuning(TUNE["I2V_ROIALIGN_BWD"], 1)
+    assert torch.equal(g5, g5b) and float((g1 - g5).abs().max()) <= 2e-6 * float(np.abs(ref).max())
     monkeypatch.setattr(O, "ROIALIGN_BWD_GATHER", False)
     sc = run()                                                           # the atomic scatter
     scale = float(np.abs(ref).max())
@@ -1327,7 +1336,8 @@ KNOBS = [("I2V_CONV_SPEC", 1), ("I2V_CONV_SPEC", 2), ("I2V_SPLIT_TARGET", 3), ("
          ("I2V_WGRAD_V2", 3), ("I2V_WINO_ROWS", -1), ("I2V_WINO_ROWS", 3), ("I2V_ROIPOOL_C128", 0), ("I2V_CONV_GEMM", 0),
          ("I2V_STAGGER", 4), ("I2V_ROIALIGN_COLS", 0), ("I2V_ROIALIGN_COLS", 1), ("I2V_WGRAD_PER_CU", 2), ("I2V_WGRAD_XCD", 0), ("I2V_GEMM_PERSIST", 2),
          ("I2V_WGRAD_PRIO", 2), ("I2V_STREAM_TILE", 0), ("I2V_GEMM_X3", 1), ("I2V_KGROUPS", 1), ("I2V_KGROUPS", 2), ("I2V_GEMM_DMA", 0),
-         ("I2V_GEMM_DMA", 2), ("I2V_SPLIT_ATOMICS", 0), ("I2V_WGRAD_ORDERED_GFLOP", 0), ("I2V_WGRAD_DMA", 0)]
+         ("I2V_GEMM_DMA", 2), ("I2V_SPLIT_ATOMICS", 0), ("I2V_WGRAD_ORDERED_GFLOP", 0), ("I2V_WGRAD_DMA", 0),
+         ("I2V_ROIALIGN_BWD", 0)]
 
 
 def test_every_tuning_knob_keeps_the_results(ops):
@@ -1349,6 +1359,7 @@ def test_every_tuning_knob_keeps_the_results(ops):
                                             np.sort(rng.uniform(0, 600, (48, 2, 2)).astype(np.float32), 1).reshape(48, 4)[:, [0, 2, 1, 3]]], 1)).to(DEV)
     xc = cl(t(2, 1024, 38, 63))
     x2, w2, r2 = cl(t(2, 64, 75, 125)), cl(t(256, 64, 1, 1) / 8), cl(t(2, 256, 75, 125))
+    gra = cl(t(48, 1024, 7, 7))
 
     def run():
         out = {}
@@ -1363,6 +1374,9 @@ def test_every_tuning_knob_keeps_the_results(ops):
         out["expand"] = ops.conv2d(x2, w2, sc, sh, r2, 1, 0, relu=True)          # K = 64 over 18750 rows: the HBM-bound tile rule
         out["roi_pool"] = ops.roi_pool(xc, rois, 7, 7, 1.0 / 16, out_nchw=False)
         out["roi_align"] = ops.roi_align(xc, rois, 7, 7, 1.0 / 16)
+        xg = xc.detach().clone().requires_grad_()
+        ops.roi_align(xg, rois, 7, 7, 1.0 / 16).backward(gra)
+        out["roi_align_bwd"] = xg.grad
         return {k: v.clone() for k, v in out.items()}
 
     base = run()
@@ -1385,7 +1399,7 @@ def test_every_tuning_knob_keeps_the_results(ops):
             err = _rel_err(got[k].cpu().numpy(), base[k].cpu().numpy())
             assert err < tol, (name, value, k, err)
     again = run()
-    for k in ("pointwise", "strided", "winograd", "roi_pool", "roi_align"):      # the launches without split-K atomics
+    for k in ("pointwise", "strided", "winograd", "roi_pool", "roi_align", "roi_align_bwd"):      # the launches without split-K atomics
         assert torch.equal(again[k], base[k]), k          # the knobs are back at their defaults
 
 
