@@ -335,7 +335,7 @@ def train_variant(a, net, loader, iters_per_epoch, dev, rank, world):
             opt.step()
             if loss is None:
                 continue
-            acc, n_acc = acc + float(loss), n_acc + 1
+            acc, n_acc = acc + float(loss.detach()), n_acc + 1
             if (it + 1) % a.disp_interval == 0 and rank == 0 and n_acc:
                 print("[session %d][epoch %2d][iter %4d/%4d] loss: %.4f, vrd_lr: %.2e, %.1f frames/s (eager, variant head)" % (
                     a.session, epoch, it + 1, iters_per_epoch, acc / n_acc, opt.lr_of("vrd.fc7.fc.weight"),
