@@ -657,17 +657,19 @@ roi_align_bwd_row2_kernel(const float* __restrict__ gout, const float* __restric
         const int sp = (base / RAB_SEG) & 1;
         RAB_T(c_l0);
         int cnt = 0;
-        {       // ---- the list of this segment (roi_align_bwd_row_kernel's: per-wave sublists, a ballot and a running count, ONE barrier)
+        {       // ---- the list of this segment (roi_align_bwd_row_kernel's: per-wave sublists, a ballot and a running count, ONE barrier).
+                // The candidates are dealt to the waves in blocks of 64 (block 4 k + wave): rois usually arrive frame by frame, and
+                // with 256 consecutive candidates per wave ONE wave did the whole frame's row geometry (fp64) while three idled
             float f0[4], y1[4], y2[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int i = min(base + 256 * wave + 64 * k + lane, n_pairs - 1);
+                const int i = min(base + 64 * (4 * k + wave) + lane, n_pairs - 1);
                 const float* roi = rois + 5 * (long long)(i / AH);
                 f0[k] = roi[0]; y1[k] = roi[2]; y2[k] = roi[4];
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int il = 256 * wave + 64 * k + lane, i = base + il;
+                const int il = 64 * (4 * k + wave) + lane, i = base + il;
                 int hit = 0, dy = 0;
                 if (i < n_pairs && (int)f0[k] == b) {
                     const AxisGeom q = ra_axis(y1[k], y2[k], scale, H, AH, i % AH);
