@@ -61,6 +61,9 @@ cases = [("4096^3", 4096, 4096, 4096, False, 10), ("layer3 conv1, 4 frames", 957
          ("layer3 conv3, 2 frames (+res)", 4788, 256, 1024, True, 30), ("layer3 conv1, 2 frames", 4788, 1024, 256, False, 30),
          ("layer3 conv3, 1 frame (+res)", 2394, 256, 1024, True, 30), ("layer3 conv1, 1 frame", 2394, 1024, 256, False, 30),
          ("layer2 conv3, 1 frame (+res)", 9375, 128, 512, True, 30), ("layer2 conv1, 1 frame", 9375, 512, 128, False, 30),
+         # the stage-split step runs every backbone kernel over BOTH frames of a minibatch (round 6)
+         ("layer2 conv3, 2 frames (+res)", 18750, 128, 512, True, 30), ("layer2 conv1, 2 frames", 18750, 512, 128, False, 30),
+         ("layer1 conv3, 2 frames (+res)", 75000, 64, 256, True, 30), ("layer1 conv1, 2 frames", 75000, 256, 64, False, 30),
          # the relation head's fc6 forward: 128 rows against the 822 MB filter (streams from HBM), in an ordered context as in the step
          ("fc6 forward (ordered ctx)", 128, 50176, 4096, False, 10)]
 only = sys.argv[1:]
