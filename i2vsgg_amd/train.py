@@ -463,6 +463,38 @@ class _FrameSet:
         self.graphs = {}              # back size key -> graph (or False)
 
 
+class _StagePipeline:
+    """Host-side twin of the three head-input slots of the stage-split schedule (in -> mid -> cur): which minibatch each holds and
+    which one the head trained last.  No device state: ``tests/test_host_logic.py`` drives it on the CPU.
+
+    A minibatch reaches the head two calls after it was staged.  ``prime()`` fills every slot with the minibatch staged first, so a
+    resident minibatch is trained by every call; once a NEWER minibatch waits behind one the head has already trained, the next
+    call runs no head (``bubble``) -- in a loop that stages before every call that is exactly its second call."""
+
+    def __init__(self):
+        self.inp = self.mid = self.cur = 0
+        self.last_trained = -1
+
+    def staged(self):
+        self.inp += 1
+
+    def prime(self):
+        self.mid = self.cur = self.inp
+        self.last_trained = -1
+
+    @property
+    def bubble(self):
+        return self.cur <= self.last_trained and max(self.mid, self.inp) > self.cur
+
+    def call(self):
+        """One call of the step: -> the minibatch its head trains, or None for a bubble; the slots advance."""
+        head = None if self.bubble else self.cur
+        if head is not None:
+            self.last_trained = head
+        self.cur, self.mid = self.mid, self.inp
+        return head
+
+
 class SGGEmbStep:
     """One step of trainval_net_SGG_emb.py:189-255 (pre_det) as a replayable object.
 
@@ -549,8 +581,7 @@ class SGGEmbStep:
         # host-side twins of the three head-input slots (which minibatch each holds) and of what the head has trained: with
         # the backbone cut by stage a batch reaches the head two calls after its stage(); in a loop that stages a new batch
         # before every call the second call would find the FIRST batch in ``cur`` again -- that call runs no head (``bubble``)
-        self._id_inp = self._id_mid = self._id_cur = 0
-        self._last_trained, self.n_bubbles = -1, 0
+        self._pipe, self.n_bubbles = _StagePipeline(), 0
         self._mid_key = None          # key of the frame set whose front-half output ``mid_next`` holds
         self.mid_next_flat = self.mid_cur_flat = None
         self.mid_slot = None
@@ -584,8 +615,7 @@ class SGGEmbStep:
         trained while a newer one waits behind it in the pipeline -- the call advances the backbone halves only and its return
         value is stale (``n_bubbles`` counts them).  In a loop that stages before every call that is the second call; a resident
         minibatch (nothing newer staged) is trained by every call."""
-        return bool(self._pipelined and self.stage_split and self._id_cur <= self._last_trained
-                    and max(self._id_mid, self._id_inp) > self._id_cur)
+        return bool(self._pipelined and self.stage_split and self._pipe.bubble)
 
     # ------------------------------------------------------------------ compatibility views
     @property
@@ -729,7 +759,7 @@ class SGGEmbStep:
         if fs.fh is not None:
             host["extent"][:] = (fs.fh, fs.fw)
         self.inp.write_host(host)
-        self._id_inp += 1
+        self._pipe.staged()
         self._staged = key
         first = not self.primed and self.cur is not None and not self._pipelined
         if first and not getattr(self, "_filled", False):
@@ -977,8 +1007,7 @@ class SGGEmbStep:
                 self.mid_cur_flat.copy_(self.mid_next_flat)
                 self._back(fs, self.ctx_bb)
                 self._mid_key = self._fmap_key = fs.key
-                self._id_mid = self._id_cur = self._id_inp
-                self._last_trained = -1
+                self._pipe.prime()
             else:
                 self.cur.buf.copy_(self.inp.buf)
                 self._backbone(fs)
@@ -1158,11 +1187,10 @@ class SGGEmbStep:
         try:
             if self._graphs_on and self._pipelined and self.stage_split:
                 self._measure(fs)
-                if self.bubble:
+                if self._pipe.call() is None:
                     self._fill_call(fs)              # the pipeline fills: both backbone halves, no head
                     self.n_bubbles += 1
                 else:
-                    self._last_trained = self._id_cur
                     fb_key = self._mid_key
                     if fs.graphs.get(fb_key) is None:
                         self._capture_frames(fs)     # first sight of this (front size, back size) pair
@@ -1175,7 +1203,6 @@ class SGGEmbStep:
                     else:
                         self._body_overlapped(fs)    # this pair could not be captured: the same schedule on eager launches
                     self._fmap_key, self._mid_key = fb_key, fs.key
-                self._id_cur, self._id_mid = self._id_mid, self._id_inp      # the slots moved (inside the graph / the fill call)
             elif self._graphs_on:
                 if fs.graph is None:
                     self._capture_frames(fs)         # first sight of this frame size (or the graphs were invalidated)

@@ -477,3 +477,47 @@ def test_block_backward_protocol_wiring():
     assert not layer4[0].in_relu and layer4[1].in_relu and layer4[-1]._next == []
     # no submodule was registered by the wiring: the state_dict keys stay the reference's
     assert not any("_next" in k for k in base.state_dict())
+
+
+def test_stage_pipeline_bookkeeping_trains_every_minibatch_once():
+    """train._StagePipeline, the host-side twin of SGGEmbStep's three head-input slots (round 6: the backbone beside the head cut
+    by stage, a minibatch reaches the head two calls after its stage()): a loop that stages before every call trains every
+    minibatch exactly once, in order, with ONE call that runs no head (its second); a resident minibatch is trained by every call;
+    a minibatch staged into a pipeline of trained ones arrives after two bubbles; ``train.run_staged`` drives any of it."""
+    import torch
+    from i2vsgg_amd import train
+
+    class Step:                                  # SGGEmbStep's calling protocol around the real bookkeeping object
+        def __init__(self):
+            self.pipe, self.trained, self.n_bubbles = train._StagePipeline(), [], 0
+            self.pipe.staged()                   # the first minibatch, staged before capture()
+            self.pipe.prime()
+
+        bubble = property(lambda self: self.pipe.bubble)
+
+        def stage(self):
+            self.pipe.staged()
+
+        def __call__(self):
+            head = self.pipe.call()
+            if head is None:
+                self.n_bubbles += 1
+                return torch.tensor(-1.0)
+            self.trained.append(head)
+            return torch.tensor(float(head))
+
+    st = Step()                                  # (a) resident: every call trains minibatch 1, none is a bubble
+    for _ in range(5):
+        assert not st.bubble
+        st()
+    assert st.trained == [1] * 5 and st.n_bubbles == 0
+    st.stage()                                   # (b) a new minibatch into a pipeline of trained ones: two bubbles, then it trains
+    assert [st.bubble, float(st()), st.bubble, float(st()), st.bubble, float(st())] == [True, -1.0, True, -1.0, False, 2.0]
+    st = Step()                                  # (c) the staging loop
+    keep = torch.zeros(7)
+    train.run_staged(st, [st.stage] * 6, keep)
+    assert st.trained == [1, 2, 3, 4, 5, 6, 7] and keep.tolist() == [1, 2, 3, 4, 5, 6, 7] and st.n_bubbles == 1
+    for _ in range(3):                           # ... and the last minibatch stays resident behind it
+        assert not st.bubble
+        st()
+    assert st.trained[-3:] == [7, 7, 7]
