@@ -135,14 +135,15 @@ def test_roi_align_bwd(ops, oracle, C, H, W, B, avg):
         np.testing.assert_allclose(feat.grad.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("C,H,W,B,R", [(1024, 38, 63, 4, 32), (128, 19, 32, 2, 9), (256, 50, 67, 1, 40)])
+@pytest.mark.parametrize("C,H,W,B,R", [(1024, 38, 63, 4, 32), (128, 19, 32, 2, 9), (256, 50, 67, 1, 40), (128, 19, 32, 2, 300)])
 @pytest.mark.parametrize("avg", [True, False])
 def test_roi_align_bwd_gather_is_deterministic_and_equals_the_scatter(ops, oracle, monkeypatch, C, H, W, B, R, avg):
     """Round 4: the backward of RoIAlign(Avg) as a gather (i2v_roi_align_bwd_gather: NHWC in and out, C % 128 == 0) -- every
     element of the gradient map written once, contributions summed in the serial order of roi_align_kernel.cu:94-143 run as a
     loop (roi, sample row, sample column ascending), no atomics, no zero-fill.  Against the C restatement of that loop, against
     the atomic scatter it replaces, and twice for the same bits; 4 frames x 32 ROIs at full size (8192 samples: four list
-    passes per workgroup), ROIs of every size incl. sub-cell ones (all 64 samples of a ROI on one map row) and ones outside."""
+    passes per workgroup), ROIs of every size incl. sub-cell ones (all 64 samples of a ROI on one map row) and ones outside;
+    2 x 300 ROIs on a small map (five list passes, lists of more than a hundred pairs per row: several record chunks)."""
     from i2vsgg_amd import ops as O
     cops, _ = oracle
     rng = np.random.default_rng(C + H + R)
