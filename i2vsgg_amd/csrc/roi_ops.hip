@@ -585,7 +585,8 @@ roi_align_bwd_row_kernel(const float* __restrict__ gout, const float* __restrict
 //   * a wave owns 32 channels of the row buffer for the whole launch and a lane is (sample column, 4 channels): a pair's two
 //     taps per column are two 16-byte read-add-writes, 1 + 4 LDS instructions per (pair, wave); nothing is handed between waves
 //     but the tap records, made once per chunk of 32 listed pairs (one record per thread, one barrier);
-//   * the sample gradients go from grad_out to registers, eight pairs in flight per wave.  With the 2x2 mean a sample is the
+//   * the sample gradients go from grad_out to registers, two pairs in flight per wave (deeper is slower: more registers and
+//     dead requests behind the end of a 13-pair list buy nothing).  With the 2x2 mean a sample is the
 //     sum of a 2x2 window of pooled cells, and the windows of neighbouring sample columns share a pooled column: a lane loads
 //     ITS pooled column only (two 16-byte loads: the window's rows) and takes the left column's row sum from the lane two to
 //     its left (DPP row_shr:2 -- the 16 lanes of a DPP row hold all eight columns of two channel groups).  Loading all four
@@ -594,16 +595,23 @@ roi_align_bwd_row_kernel(const float* __restrict__ gout, const float* __restrict
 //   * everything of a pair that is wave-uniform (roi, sample row, the byte offsets of its pooled rows) is scalar arithmetic on a
 //     list entry read one step ahead and rides in the scalar offset of the loads; the per-lane part is a loop constant;
 //   * sample columns of a narrow box may share a cell: a record carries the ROUND its column is added in (columns of one round
-//     have distinct cells; one round unless a bin is narrower than a cell).  In a one-round pair a right tap that lands on the
-//     next column's left cell is handed to that column's lane (DPP) and added with its left tap: every cell has one lane, the
-//     pair is one LDS round trip.  The sums keep a fixed order: pair, round, left tap before right tap.
+//     have distinct cells; one round unless a bin is narrower than a cell).  The sums keep a fixed order: pair, round, left tap
+//     before right tap (a column's right cell is often the next column's left cell: the left taps of a round are all stored
+//     before its right taps are read).  Two refinements measured no gain and are not in the kernel (tools/micro/rab_clock.hip,
+//     same box): handing such a right tap to the neighbour's lane by DPP so that a pair is ONE LDS round trip (1 % slower), and
+//     summing the pairs of one box in registers before a single read-add-write (30.8 against 30.8 us).  What a pair costs
+//     (~1200 cycles per wave, sixteen waves per CU) is the bytes it brings into registers -- 2 KB of gradients through the
+//     vector L1 and 3 KB of records and cells from the LDS, ~64 bytes per clock and CU between them -- not a dependent chain.
 // A sample gradient is now (g(ah-1, aw-1) + g(ah, aw-1)) + (g(ah-1, aw) + g(ah, aw)) with the mean's 1/4 (exact) folded into
 // the tap weights -- columns first, where the scatter and round 5's gather add in raster order: <= 1 ulp of the sample.
 constexpr int RB2_CHUNK = 32;           // listed pairs whose tap records are made together (8 threads per pair)
-constexpr int RB2_DEPTH = 4;            // pairs in flight per wave
+#if defined(RAB_CLOCKS) && defined(RAB_DEPTH)          // tools/micro/rab_clock.hip only
+constexpr int RB2_DEPTH = RAB_DEPTH;
+#else
+constexpr int RB2_DEPTH = 2;            // pairs in flight per wave (same box, 4 x 32: depth 1 35.0 us, 2 32.9, 4 34.2, 8 36.4)
+#endif
 struct TapRec2 { unsigned off; float wl, wr; int meta; };   // row-buffer byte offsets of the two taps' cells (left | right << 16; slot 0's),
-                                                             // their weights, round | rounds of the pair << 8 | takes the previous column's right tap << 24
-                                                             // | gives its right tap to the next column << 25
+                                                             // their weights, round | rounds of the pair << 8
 
 __device__ inline float4 rab_row_shr2(float4 v) {           // lane i <- lane i - 2 of its 16-lane DPP row (zeros shifted in)
     float4 o;
@@ -740,23 +748,6 @@ roi_align_bwd_row2_kernel(const float* __restrict__ gout, const float* __restric
             if (tl.x + tr.y == 12345.678f) *pl = tl;
             return;
 #endif
-            if (nr == 1) {
-                // one round (every box at least 8 cells wide, i.e. 128 pixels): the pair's cells are distinct except where a
-                // column's right cell IS the next column's left cell -- that tap is handed to the next column in registers
-                // (DPP again) and added with its left tap, so every cell is touched by ONE lane: both reads at once, one LDS
-                // round trip per pair, and a chained column costs one read-add-write instead of two
-                const float4 trp = rab_row_shr2(tr);
-                float4 a = *pl;
-                if (rec.meta & (1 << 24)) { a.x += tl.x + trp.x; a.y += tl.y + trp.y; a.z += tl.z + trp.z; a.w += tl.w + trp.w; }
-                else { a.x += tl.x; a.y += tl.y; a.z += tl.z; a.w += tl.w; }
-                if (!(rec.meta & (1 << 25))) {
-                    float4 c = *pr;
-                    c.x += tr.x; c.y += tr.y; c.z += tr.z; c.w += tr.w;
-                    *pr = c;
-                }
-                *pl = a;
-                return;
-            }
             for (int s = 0; s < nr; ++s) {
                 if (round == s) {
                     float4 a = *pl;
@@ -800,16 +791,13 @@ roi_align_bwd_row2_kernel(const float* __restrict__ gout, const float* __restric
                     if (sx >= k && c == cell && cell < W) ++round;
                 }
                 // does my right cell belong to the next column as its left cell?  (then the pair's taps are added left, then right)
-                const int nxt = __shfl_down(cell, 1, 8), prv = __shfl_up(cell, 1, 8);
-                const int give = sx < 7 && cell < W && nxt == cell + 1;          // my right tap goes to the next column's lane
-                const int take = sx > 0 && cell < W && prv + 1 == cell;          // the previous column's right tap comes to mine
                 int nr = round + 1;                              // over the pair's 8 threads: the most rounds
 #pragma unroll
                 for (int m = 1; m < 8; m <<= 1) nr = max(nr, __shfl_xor(nr, m, 8));
                 TapRec2 rec;
                 rec.off = (unsigned)(cell * CHB + ((cell & 7) << 5)) | ((unsigned)((cell + 1) * CHB + (((cell + 1) & 7) << 5)) << 16);
                 rec.wl = AVG ? wl * 0.25f : wl; rec.wr = AVG ? wr * 0.25f : wr;
-                rec.meta = round | (nr << 8) | (take << 24) | (give << 25);
+                rec.meta = round | (nr << 8);
                 s_rec[u][sx] = rec;
             }
             __syncthreads();
