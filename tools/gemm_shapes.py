@@ -14,6 +14,7 @@ from i2vsgg_amd import ops  # noqa: E402
 from i2vsgg_amd._lib import lib  # noqa: E402
 
 DEV = "cuda:0"
+CHAINS = int(os.environ.get("CHAINS", "3"))        # co-running copies of the launch (the relation step: 3 branches; the detector step: 2)
 TILES = ["128x128", "128x64", "96x64", "80x64", "64x64", "32x64"]
 blocker = torch.randn(8192, 8192, device=DEV)
 
@@ -64,6 +65,11 @@ cases = [("4096^3", 4096, 4096, 4096, False, 10), ("layer3 conv1, 4 frames", 957
          # the stage-split step runs every backbone kernel over BOTH frames of a minibatch (round 6)
          ("layer2 conv3, 2 frames (+res)", 18750, 128, 512, True, 30), ("layer2 conv1, 2 frames", 18750, 512, 128, False, 30),
          ("layer1 conv3, 2 frames (+res)", 75000, 64, 256, True, 30), ("layer1 conv1, 2 frames", 75000, 256, 64, False, 30),
+         # configs[2]: a domain's 4 frames per launch, two branches (CHAINS=2)
+         ("layer3 conv3, 4 frames (+res)", 9576, 256, 1024, True, 30),
+         ("layer2 conv3, 4 frames (+res)", 37500, 128, 512, True, 20), ("layer2 conv1, 4 frames", 37500, 512, 128, False, 20),
+         ("layer1 conv3, 4 frames (+res)", 150000, 64, 256, True, 20), ("layer1 conv1, 4 frames", 150000, 256, 64, False, 20),
+         ("layer4 conv3, 128 rois 7x7 (+res)", 6272, 512, 2048, True, 30), ("layer4 conv1, 128 rois 7x7", 6272, 2048, 512, False, 30),
          # the relation head's fc6 forward: 128 rows against the 822 MB filter (streams from HBM), in an ordered context as in the step
          ("fc6 forward (ordered ctx)", 128, 50176, 4096, False, 10)]
 only = sys.argv[1:]
@@ -72,7 +78,7 @@ for name, M, K, N, res, reps in cases:
         continue
     fl = 2.0 * M * N * K
     ops_ = []
-    for c in range(3):
+    for c in range(CHAINS):
         # uniform [-1, 1) operands, the convention of /opt/skills/guides (what the lab uses too): the clock the chip holds
         # depends on the data, so rates measured on other distributions do not compare
         x = torch.rand(M, K, 1, 1, device=DEV) * 2 - 1
@@ -89,12 +95,12 @@ for name, M, K, N, res, reps in cases:
             with ctx, torch.no_grad():
                 ops.conv2d(x, w, sc, sh, r, 1, 0, relu=True)
         return fn
-    fns = [make(c) for c in range(3)]
+    fns = [make(c) for c in range(CHAINS)]
     print("== %s  M %d K %d N %d (%.2f GFLOP)" % (name, M, K, N, fl * 1e-9), flush=True)
     for t in [-1] + list(range(len(TILES))):
         lib.i2v_conv_set_tile(t if t >= 0 else -1)
         a = alone(fns[0], reps)
         c3 = corun(fns, reps)
-        print("   tile %-8s alone %8.2f us %6.1f TF | 3 chains %8.2f us/launch %6.1f TF" % (
-            TILES[t] if t >= 0 else "model", a, fl / a / 1e6, c3, fl / c3 / 1e6), flush=True)
+        print("   tile %-8s alone %8.2f us %6.1f TF | %d chains %8.2f us/launch %6.1f TF" % (
+            TILES[t] if t >= 0 else "model", a, fl / a / 1e6, CHAINS, c3, fl / c3 / 1e6), flush=True)
     lib.i2v_conv_set_tile(-1)
