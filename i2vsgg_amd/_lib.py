@@ -135,13 +135,13 @@ lib = _load()
 TUNE = {"I2V_CONV_SPEC": 0, "I2V_SPLIT_TARGET": 1, "I2V_SPLIT_TARGET_SKINNY": 2, "I2V_SPLIT_BELOW": 3, "I2V_SPLIT_ATOMICS": 4,
         "I2V_BIG_FC_TILE": 5, "I2V_WGRAD_V2": 6, "I2V_WGRAD_FUSED_TILE": 7, "I2V_WINO_ROWS": 8, "I2V_ROIPOOL_C128": 9, "I2V_CONV_GEMM": 10, "I2V_STAGGER": 11, "I2V_ROIALIGN_COLS": 12, "I2V_WGRAD_PER_CU": 13, "I2V_WGRAD_XCD": 14, "I2V_FC_FOLD": 15, "I2V_GEMM_X3": 16,
         "I2V_GEMM_PERSIST": 17, "I2V_WGRAD_PRIO": 18, "I2V_STREAM_TILE": 19, "I2V_KGROUPS": 20, "I2V_WGRAD_ORDERED_GFLOP": 21, "I2V_GEMM_DMA": 22,
-        "I2V_WGRAD_DMA": 23, "I2V_ROIALIGN_BWD": 24}
+        "I2V_WGRAD_DMA": 23, "I2V_ROIALIGN_BWD": 24, "I2V_NMS_SCAN": 25}
 # The knobs the environment may set (README.md has the table): the ones a deployment has a reason to move.  The rest of TUNE is
 # reachable through lib.i2v_set_tuning (tests, tools): I2V_ROIALIGN_COLS, I2V_WGRAD_V2, I2V_CONV_GEMM, ... select older forms of
 # kernels; I2V_CONV_SPEC, I2V_STAGGER, I2V_FC_FOLD, I2V_GEMM_X3, I2V_GEMM_PERSIST, I2V_WGRAD_PRIO are the reserved indices of
 # experiment kernels that left the library in round 6 (the library refuses any value but "off").
 ENV_TUNE = ("I2V_SPLIT_ATOMICS", "I2V_SPLIT_TARGET", "I2V_SPLIT_TARGET_SKINNY", "I2V_SPLIT_BELOW", "I2V_BIG_FC_TILE",
-            "I2V_WGRAD_FUSED_TILE", "I2V_WGRAD_PER_CU", "I2V_KGROUPS", "I2V_WGRAD_ORDERED_GFLOP", "I2V_WINO_ROWS", "I2V_GEMM_DMA", "I2V_WGRAD_DMA", "I2V_ROIALIGN_BWD")
+            "I2V_WGRAD_FUSED_TILE", "I2V_WGRAD_PER_CU", "I2V_KGROUPS", "I2V_WGRAD_ORDERED_GFLOP", "I2V_WINO_ROWS", "I2V_GEMM_DMA", "I2V_WGRAD_DMA", "I2V_ROIALIGN_BWD", "I2V_NMS_SCAN")
 # Settled A/B switches of rounds 1-5 that no longer read the environment (their comments in ops.py / train.py name the module
 # attribute that replaced them).  A run that still sets one would measure the default without knowing (round-5 advice): say so.
 RETIRED_ENV = ("I2V_WINOGRAD_TRAIN", "I2V_BLOCK_FUSED", "I2V_WINOGRAD_WGRAD", "I2V_KEEP_V", "I2V_WGRAD_BRANCH", "I2V_ISD_BATCHED",

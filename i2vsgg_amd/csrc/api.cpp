@@ -23,7 +23,7 @@ int g_i2v_tuning[I2V_TUNE_COUNT] = {
     /* BIG_FC_TILE */ 1, /* WGRAD_V2 */ 1, /* WGRAD_FUSED_TILE */ 128, /* WINO_ROWS */ 0, /* ROIPOOL_C128 */ 1,
     /* CONV_GEMM */ 1, /* STAGGER */ 0, /* ROIALIGN_COLS */ 2, /* WGRAD_PER_CU */ 4, /* WGRAD_XCD */ 1,
     /* FC_FOLD */ 0, /* GEMM_X3 */ 0, /* GEMM_PERSIST */ 0, /* WGRAD_PRIO */ 0, /* STREAM_TILE */ 1,
-    /* KGROUPS */ 0, /* WGRAD_ORDERED_GFLOP */ 1000000, /* GEMM_DMA */ 1, /* WGRAD_DMA */ 1, /* ROIALIGN_BWD */ 1,
+    /* KGROUPS */ 0, /* WGRAD_ORDERED_GFLOP */ 1000000, /* GEMM_DMA */ 1, /* WGRAD_DMA */ 1, /* ROIALIGN_BWD */ 1, /* NMS_SCAN */ 2,
 };
 
 extern "C" int32_t i2v_build_flags(void) {

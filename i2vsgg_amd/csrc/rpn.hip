@@ -443,6 +443,215 @@ nms_scan_pipelined_kernel(const unsigned long long* __restrict__ mask, int n, in
     if (threadIdx.x == 0) num_out[img] = s_count;
 }
 
+// Round 6 (the one algorithmic experiment round 5's review left open, as a serial resolve instead of a fixed-point iteration):
+// the scan in SUPER-BLOCKS of 1024 rows whose 1024 x 1024 triangle of the mask (16 words per row, 128 KB) sits in LDS.  The
+// pipelined kernel above pays two workgroup barriers, a fetch and a fold per 64 rows (~2k cycles, 188 times for 12000 boxes);
+// here ONE wave walks the sixteen 64-row blocks of a super-block with everything it needs in LDS and registers -- the
+// verdict words of the super-block's own columns live in its lanes (lane w = word w), a block's rows are resolved in scalar
+// registers as before, the rows just kept are folded into those lanes by one LDS read each -- and the workgroup meets twice per
+// 1024 rows: to fold the kept rows' words for LATER columns into the ``removed`` bitmap (kept rows only, from the mask in
+// global memory: sixteen waves, a 64-row block each) and to bring the next triangle in (requested a super-block ahead, into
+// registers).  The same greedy order, row by row: bit-exact by construction.
+constexpr int SUPER_ROWS = 1024, SUPER_WORDS = 16, NMS_SWEEPS = 48;
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+nms_scan_super_kernel(const unsigned long long* __restrict__ mask, int n, int nblk, int max_keep,
+                      int* __restrict__ keep_out, int* __restrict__ num_out, int fixed_point) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long tri[];       // [1024][16]
+    __shared__ unsigned long long removed[64 * SCAN_PIPE_WORDS + SUPER_WORDS + 1];
+    __shared__ unsigned long long s_kept[SUPER_WORDS];
+    __shared__ int s_count;
+    const int img = blockIdx.x;
+    const unsigned long long* M = mask + (long long)img * n * nblk;
+    int* keep = keep_out + (long long)img * n;
+    for (int i = threadIdx.x; i < 64 * SCAN_PIPE_WORDS + SUPER_WORDS + 1; i += SCAN_THREADS) removed[i] = 0;
+    if (threadIdx.x == 0) s_count = 0;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int limit = max_keep > 0 ? max_keep : n;
+    const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc((void*)M, 0, (unsigned)((long long)n * nblk * 8), 0x00020000);
+    const int nsuper = (n + SUPER_ROWS - 1) / SUPER_ROWS;
+    // the triangle of super-block sb, 16 of its 16384 words per thread: pass p brings rows 64 p .. 64 p + 63, a thread one word of
+    // one row (16 lanes = one row's 128 contiguous bytes: four cache lines per wave instruction.  One ROW per thread -- 64 lines
+    // per instruction -- made the fetch 8 of a super-block's 12.5 us).  Words left of the row's own block were never written by
+    // nms_mask_kernel (below the diagonal), words past the end of the row do not exist: both read as zero (the 2 GiB bit); a
+    // row past n falls off the descriptor by itself
+    unsigned long long tw[SUPER_WORDS];
+    auto fetch_tri = [&](int sb) {
+        const int w = (int)threadIdx.x & (SUPER_WORDS - 1), wa = sb * SUPER_WORDS + w;
+#pragma unroll
+        for (int p = 0; p < SUPER_ROWS / 64; ++p) {
+            const int row = sb * SUPER_ROWS + 64 * p + ((int)threadIdx.x >> 4), rb = row >> 6;
+            const unsigned dead = (row < n && wa >= rb && wa < nblk) ? 0u : 0x80000000u;
+            tw[p] = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(mrs, ((unsigned)(row * nblk + wa) * 8u) | dead, 0, 0));
+        }
+    };
+    fetch_tri(0);
+    __syncthreads();                                         // ``removed`` is clear
+    for (int sb = 0; sb < nsuper; ++sb) {
+        const int r0 = sb * SUPER_ROWS, w0 = sb * SUPER_WORDS;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0): my row's words, requested a super-block ago
+#pragma unroll
+        for (int p = 0; p < SUPER_ROWS / 64; ++p) tri[(64 * p) * SUPER_WORDS + threadIdx.x] = tw[p];
+        __syncthreads();
+        if (sb + 1 < nsuper) fetch_tri(sb + 1);              // lands while this super-block is resolved
+        // ---- fixed-point resolve (round 5's review: "cluster-NMS"): keep <- alive & ~OR_{j kept} row_j, from keep = alive, until it
+        // stops moving.  A row's verdict is final once the rows before it are (induction from row 0), so the fixed point is the
+        // greedy keep set, reached after as many sweeps as the longest suppress-release chain in the 1024 rows is deep; a sweep is
+        // 16 LDS reads per thread, two shuffles and one LDS atomic per 16 lanes.  The serial resolve a kept row at a time costs
+        // ~190 cycles of one wave's dependent scalar instructions per KEPT row (2000 of them: the 182 us of either scan kernel).
+        // Not settled after NMS_SWEEPS sweeps: the serial resolve below does the super-block (same answer, by construction).
+        int settled = 0;
+        if (fixed_point) {
+            __shared__ unsigned long long s_alive[SUPER_WORDS], s_keepw[SUPER_WORDS], s_supp[SUPER_WORDS];
+            __shared__ int s_changed;
+            if (threadIdx.x < SUPER_WORDS) {
+                const int rb = w0 + (int)threadIdx.x;
+                unsigned long long a = 0ull;
+                if (rb < nblk) {
+                    a = ~removed[rb];
+                    const int valid = n - rb * 64;
+                    if (valid < 64) a &= (1ull << valid) - 1ull;
+                }
+                s_alive[threadIdx.x] = a; s_keepw[threadIdx.x] = a; s_supp[threadIdx.x] = 0ull;
+            }
+            __syncthreads();
+            const int w = threadIdx.x & (SUPER_WORDS - 1), g = threadIdx.x >> 4;         // my word; my 16 rows (16 g .. 16 g + 15)
+            for (int sweep = 0; sweep < fixed_point; ++sweep) {
+                const unsigned kb = (unsigned)(s_keepw[g >> 2] >> ((g & 3) * 16)) & 0xFFFFu;
+                unsigned long long acc = 0ull;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned long long v = tri[(16 * g + r) * SUPER_WORDS + w];
+                    acc |= ((kb >> r) & 1u) ? v : 0ull;
+                }
+                acc |= __shfl_xor(acc, 16);
+                acc |= __shfl_xor(acc, 32);
+                if (lane < SUPER_WORDS && acc) atomicOr(&s_supp[w], acc);
+                if (threadIdx.x == 0) s_changed = 0;
+                __syncthreads();
+                if (threadIdx.x < SUPER_WORDS) {
+                    const unsigned long long nk = s_alive[threadIdx.x] & ~s_supp[threadIdx.x];
+                    if (nk != s_keepw[threadIdx.x]) s_changed = 1;
+                    s_keepw[threadIdx.x] = nk;
+                    s_supp[threadIdx.x] = 0ull;
+                }
+                __syncthreads();
+                if (!s_changed) { settled = 1; break; }
+            }
+            if (settled) {
+                // the keep list: rows in order, cut at the limit
+                const int count0 = s_count;
+                int before = 0;
+                for (int q = 0; q < wave; ++q) before += __popcll(s_keepw[q]);
+                const unsigned long long mine = s_keepw[wave];
+                const int rank = before + __popcll(mine & ((1ull << lane) - 1ull));
+                const bool k = ((mine >> lane) & 1ull) && count0 + rank < limit;
+                __syncthreads();                             // everyone has read s_count / s_keepw
+                if (k) keep[count0 + rank] = r0 + 64 * wave + lane;
+                const unsigned long long cut = __ballot(k);
+                if (lane == 0) s_kept[wave] = cut;
+                if (threadIdx.x == 0) {
+                    int total = 0;
+                    for (int q = 0; q < SUPER_WORDS; ++q) total += __popcll(s_keepw[q]);
+                    s_count = min(limit, count0 + total);
+                }
+            }
+        }
+        if (!settled && wave == 0) {
+            // the verdicts on this super-block's columns so far: lane w holds word w0 + w
+            unsigned long long rem = lane < SUPER_WORDS ? removed[min(w0 + lane, nblk)] : 0ull;
+            int count = __builtin_amdgcn_readfirstlane(s_count);
+            for (int q = 0; q < SUPER_WORDS && r0 + 64 * q < n; ++q) {
+                const int rb = w0 + q;
+                unsigned long long cur = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(rem >> 32), q) << 32) |
+                                         (unsigned)__builtin_amdgcn_readlane((int)(unsigned)rem, q);
+                const int valid = min(64, n - rb * 64);
+                if (valid < 64) cur |= ~0ull << valid;
+                const unsigned long long dq = tri[(64 * q + lane) * SUPER_WORDS + q];       // my row's diagonal word
+                const unsigned dlo = (unsigned)dq, dhi = (unsigned)(dq >> 32);
+                unsigned long long kept = 0, todo = ~cur;
+                const int count0 = count;
+                while (todo && count < limit) {              // serial greedy resolve in scalar registers (as the pipelined kernel's)
+                    const int i = __builtin_ctzll(todo);
+                    const unsigned long long d = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, i) << 32) |
+                                                 (unsigned)__builtin_amdgcn_readlane((int)dlo, i);
+                    kept |= 1ull << i;
+                    ++count;
+                    cur |= d;
+                    todo = ~cur & ~((2ull << i) - 1ull);
+                }
+                if ((kept >> lane) & 1ull) keep[count0 + __popcll(kept & ((1ull << lane) - 1ull))] = rb * 64 + lane;
+                if (lane == 0) s_kept[q] = kept;
+                // the kept rows' words for the REST of this super-block's columns: one LDS read per row, all issued before the
+                // first is used (lane w reads word w; words up to q are zero or already applied)
+                unsigned long long k2 = kept;
+                while (k2) {
+                    unsigned long long v[8];
+                    int m = 0;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        v[u] = 0ull;
+                        if (k2) {
+                            const int i = __builtin_ctzll(k2);
+                            k2 &= k2 - 1ull;
+                            v[u] = tri[(64 * q + i) * SUPER_WORDS + (lane & (SUPER_WORDS - 1))];
+                            ++m;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) rem |= v[u];
+                    (void)m;
+                }
+                if (count >= limit) {                        // the blocks behind keep nothing
+                    for (int q2 = q + 1; q2 < SUPER_WORDS; ++q2) if (lane == 0) s_kept[q2] = 0ull;
+                    break;
+                }
+            }
+            for (int q2 = (n - r0 + 63) / 64; q2 < SUPER_WORDS; ++q2) if (lane == 0 && q2 >= 0) s_kept[q2] = 0ull;
+            if (lane == 0) s_count = count;
+        }
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane(s_count) >= limit || sb + 1 == nsuper) break;
+        // fold: the kept rows of block w0 + wave, their words for the columns after this super-block (kept rows only; sixteen
+        // rows' loads in flight per pass), OR-ed in registers and added to the bitmap once per wave
+        {
+            unsigned long long kk = uniform64(s_kept[wave]);
+            unsigned long long acc[SCAN_PIPE_WORDS];
+            unsigned past[SCAN_PIPE_WORDS];
+#pragma unroll
+            for (int c = 0; c < SCAN_PIPE_WORDS; ++c) { acc[c] = 0ull; past[c] = (w0 + SUPER_WORDS + lane + 64 * c < nblk) ? 0u : 0x80000000u; }
+            while (kk) {
+                unsigned long long v[8][SCAN_PIPE_WORDS];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                    for (int c = 0; c < SCAN_PIPE_WORDS; ++c) v[u][c] = 0ull;
+                    if (kk) {
+                        const int i = __builtin_ctzll(kk);
+                        kk &= kk - 1ull;
+                        const unsigned off = (unsigned)((r0 + 64 * wave + i) * nblk + w0 + SUPER_WORDS + lane) * 8u;
+#pragma unroll
+                        for (int c = 0; c < SCAN_PIPE_WORDS; ++c)
+                            if (w0 + SUPER_WORDS + 64 * c < nblk)
+                                v[u][c] = __builtin_bit_cast(unsigned long long, __builtin_amdgcn_raw_buffer_load_b64(mrs, (off | past[c]) + 512u * c, 0, 0));
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int c = 0; c < SCAN_PIPE_WORDS; ++c) acc[c] |= v[u][c];
+            }
+#pragma unroll
+            for (int c = 0; c < SCAN_PIPE_WORDS; ++c) {
+                const int j = w0 + SUPER_WORDS + lane + 64 * c;
+                if (j < nblk && acc[c]) atomicOr(&removed[j], acc[c]);
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) num_out[img] = s_count;
+}
+
 // ------------------------------------------------------------------ emit rois
 __global__ void write_rois(const float* __restrict__ dets, const int* __restrict__ src_idx,
                            const int* __restrict__ keep, const int* __restrict__ num, int n_top, int post,
@@ -534,7 +743,15 @@ int launch_nms(const float* dets, int n_img, int n, float thresh, int max_keep, 
                unsigned long long* mask, hipStream_t st) {
     const int nblk = (n + 63) / 64;
     nms_mask_kernel<<<dim3(nblk, i2v_cdiv(nblk, NMS_MASK_WAVES), n_img), 64 * NMS_MASK_WAVES, 0, st>>>(dets, n, nblk, thresh, mask);
-    if (nblk - 1 <= 64 * SCAN_PIPE_WORDS)
+    static bool once = [] {
+        (void)hipFuncSetAttribute((const void*)nms_scan_super_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SUPER_ROWS * SUPER_WORDS * 8);
+        return true;
+    }();
+    (void)once;
+    if (nblk - 1 <= 64 * SCAN_PIPE_WORDS && g_i2v_tuning[I2V_TUNE_NMS_SCAN] && (long long)n * nblk * 8 < (1ll << 31))
+        nms_scan_super_kernel<<<n_img, SCAN_THREADS, SUPER_ROWS * SUPER_WORDS * 8, st>>>(mask, n, nblk, max_keep, keep, num,
+                                                                                         g_i2v_tuning[I2V_TUNE_NMS_SCAN] < 2 ? 0 : g_i2v_tuning[I2V_TUNE_NMS_SCAN] == 2 ? NMS_SWEEPS : g_i2v_tuning[I2V_TUNE_NMS_SCAN]);
+    else if (nblk - 1 <= 64 * SCAN_PIPE_WORDS)
         nms_scan_pipelined_kernel<<<n_img, SCAN_THREADS, 0, st>>>(mask, n, nblk, max_keep, keep, num);
     else
         nms_scan_kernel<<<n_img, SCAN_THREADS, 0, st>>>(mask, n, nblk, max_keep, keep, num);

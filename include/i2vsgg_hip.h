@@ -272,7 +272,8 @@ size_t  i2v_conv_split_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t 
 #define I2V_TUNE_GEMM_DMA            22   /* how the pointwise / plain-GEMM kernel stages its operand tiles (round 6).  0: global -> registers -> ds_write_b128 (rounds 2-5).  1: LDS-DMA (buffer_load ... lds, the column swizzle on the source address), 32-k stages, same LDS image.  2: LDS-DMA with 16-k stages (64-byte LDS rows): half the LDS per workgroup, twice the barriers.  Bit-equal results in all three */
 #define I2V_TUNE_WGRAD_DMA           23   /* staging of the second-generation filter-gradient kernel on pointwise / linear problems (round 6).  0: global -> registers -> transposing ds_write_b128.  1: LDS-DMA into the [pixel][column] image, the group swizzle on the source column.  Bit-equal */
 #define I2V_TUNE_ROIALIGN_BWD        24   /* the gather form of the RoIAlign backward (round 6).  1: a wave owns 32 channels of the row buffer, a lane = (sample column, 4 channels), gradients from grad_out to registers, 16-byte read-add-writes.  0: round 5's form (lane = channel x cell parity, gradients and tap records staged in LDS per batch of four pairs) */
-#define I2V_TUNE_COUNT               25
+#define I2V_TUNE_NMS_SCAN            25   /* the greedy scan of NMS for up to 12288 boxes (round 6).  2 (default): super-blocks of 1024 rows whose triangle of the mask sits in LDS, resolved by fixed-point sweeps (keep <- alive & ~OR of the kept rows' words, from keep = alive: exact at its fixed point, a few sweeps), a serial resolve for a super-block that has not settled after 48 sweeps; a value v > 2: the same with v sweeps at most.  1: the super-blocks with the serial resolve only.  0: round 5's scan (64-row blocks, two barriers each).  The same keep lists in every mode */
+#define I2V_TUNE_COUNT               26
 /* Keys CONV_SPEC (> 0), STAGGER, FC_FOLD, GEMM_X3, GEMM_PERSIST, WGRAD_PRIO belonged to kernel variants that were measured and lost
  * (DESIGN_HISTORY.md) and left the library in round 6: I2V_ERR_UNSUPPORTED for any value but "off"; the indices stay reserved. */
 int32_t i2v_set_tuning(int32_t key, int32_t value);

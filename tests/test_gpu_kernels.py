@@ -247,26 +247,44 @@ def test_roi_pool_fwd_bwd(ops, oracle, C, H, W, B):
 
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 300, 1000, 6000, 12000])
 def test_nms_keep_matches_reference_golden(ops, gold, n):
+    """The 36 keep lists of the reference's nms_cpu (uniform and clustered boxes, thresholds 0.7 / 0.3), bit for bit, in every
+    form of the scan (I2V_TUNE_NMS_SCAN): 2 = round 6's default (1024-row super-blocks resolved by fixed-point sweeps), 3 = the
+    same with three sweeps at most (clustered super-blocks fall back to the serial resolve: both paths in one launch),
+    1 = super-blocks with the serial resolve, 0 = round 5's 64-row scan."""
+    from i2vsgg_amd._lib import TUNE, lib
     g = gold("nms_keep")
-    for clustered in (False, True):
-        dets = syn.tie_free_dets(1000 + n, n, clustered=clustered)
-        dt = torch.from_numpy(dets).to(DEV)
-        for th in (0.7, 0.3):
-            ref = g["n%d_%s_t%02d" % (n, "c" if clustered else "u", int(th * 10))]
-            keep, num = ops.nms_sorted(dt, th)
-            k = int(num.item())
-            assert k == ref.size
-            assert np.array_equal(keep[0, :k].cpu().numpy(), ref)
+    assert lib.i2v_get_tuning(TUNE["I2V_NMS_SCAN"]) == 2
+    try:
+        for mode in (2, 3, 1, 0):
+            assert lib.i2v_set_tuning(TUNE["I2V_NMS_SCAN"], mode) == 0
+            for clustered in (False, True):
+                dets = syn.tie_free_dets(1000 + n, n, clustered=clustered)
+                dt = torch.from_numpy(dets).to(DEV)
+                for th in (0.7, 0.3):
+                    ref = g["n%d_%s_t%02d" % (n, "c" if clustered else "u", int(th * 10))]
+                    keep, num = ops.nms_sorted(dt, th)
+                    k = int(num.item())
+                    assert k == ref.size, (mode, clustered, th)
+                    assert np.array_equal(keep[0, :k].cpu().numpy(), ref), (mode, clustered, th)
+    finally:
+        lib.i2v_set_tuning(TUNE["I2V_NMS_SCAN"], 2)
 
 
 def test_nms_batched_early_exit_and_empty(ops, oracle):
     cops, _ = oracle
     dets = np.stack([syn.tie_free_dets(77 + i, 3000, clustered=bool(i % 2)) for i in range(3)])
-    keep, num = ops.nms_sorted(torch.from_numpy(dets).to(DEV), 0.7, max_keep=300)
-    for i in range(3):
-        ref = cops.nms_sorted(dets[i], 0.7)[:300]
-        assert int(num[i]) == ref.size
-        assert np.array_equal(keep[i, :ref.size].cpu().numpy(), ref)
+    from i2vsgg_amd._lib import TUNE, lib
+    try:
+        for mode in (2, 3, 1, 0):                         # (every form of the scan: test_nms_keep_matches_reference_golden)
+            lib.i2v_set_tuning(TUNE["I2V_NMS_SCAN"], mode)
+            for cap in (300, 1100, 17):                   # the cut inside the first super-block, inside the second, inside the first rows
+                keep, num = ops.nms_sorted(torch.from_numpy(dets).to(DEV), 0.7, max_keep=cap)
+                for i in range(3):
+                    ref = cops.nms_sorted(dets[i], 0.7)[:cap]
+                    assert int(num[i]) == ref.size, (mode, cap, i)
+                    assert np.array_equal(keep[i, :ref.size].cpu().numpy(), ref), (mode, cap, i)
+    finally:
+        lib.i2v_set_tuning(TUNE["I2V_NMS_SCAN"], 2)
     keep, num = ops.nms_sorted(torch.zeros((0, 5), device=DEV), 0.7)
     assert int(num.item()) == 0
 
