@@ -72,7 +72,7 @@ def _rois_f32(rois):
 ROIALIGN_BWD_GATHER = True     # False (tests set it): the atomic scatter of round 1, which still serves NCHW / narrow maps
 # kernel name -> launches per op, for the profiling tools (bench.py roi_nms_case, tools/roi_nms_pmc_summary.py)
 ROIALIGN_BWD_KERNELS = {"roi_align_bwd_row2_kernel": 1}     # (I2V_TUNE_ROIALIGN_BWD = 0 runs roi_align_bwd_row_kernel, round 5's form)
-NMS_KERNELS = {"nms_mask_kernel": 1, "nms_scan_pipelined_kernel": 1}
+NMS_KERNELS = {"nms_mask_kernel": 1, "nms_scan_super_kernel": 1}      # (I2V_TUNE_NMS_SCAN = 0: nms_scan_pipelined_kernel, round 5's scan)
 
 
 class _RoIAlignFn(torch.autograd.Function):
