@@ -443,20 +443,23 @@ nms_scan_pipelined_kernel(const unsigned long long* __restrict__ mask, int n, in
     if (threadIdx.x == 0) num_out[img] = s_count;
 }
 
-// Round 6 (the one algorithmic experiment round 5's review left open, as a serial resolve instead of a fixed-point iteration):
-// the scan in SUPER-BLOCKS of 1024 rows whose 1024 x 1024 triangle of the mask (16 words per row, 128 KB) sits in LDS.  The
-// pipelined kernel above pays two workgroup barriers, a fetch and a fold per 64 rows (~2k cycles, 188 times for 12000 boxes);
-// here ONE wave walks the sixteen 64-row blocks of a super-block with everything it needs in LDS and registers -- the
-// verdict words of the super-block's own columns live in its lanes (lane w = word w), a block's rows are resolved in scalar
-// registers as before, the rows just kept are folded into those lanes by one LDS read each -- and the workgroup meets twice per
-// 1024 rows: to fold the kept rows' words for LATER columns into the ``removed`` bitmap (kept rows only, from the mask in
-// global memory: sixteen waves, a 64-row block each) and to bring the next triangle in (requested a super-block ahead, into
-// registers).  The same greedy order, row by row: bit-exact by construction.
+// Round 6 (the one algorithmic experiment round 5's review left open): the scan in SUPER-BLOCKS of 1024 rows whose 1024 x 1024
+// triangle of the mask (16 words per row, 128 KB) sits in LDS.  The workgroup meets a handful of times per 1024 rows instead of
+// twice per 64: to resolve the super-block, to fold the kept rows' words for LATER columns into the ``removed`` bitmap (kept rows
+// only, from the mask in global memory: sixteen waves, a 64-row block each) and to bring the next triangle in (requested a
+// super-block ahead, into registers).
+//   ``fixed_point`` > 0 (the default): the super-block is resolved by fixed-point sweeps over the triangle, at most that many;
+//   ``fixed_point`` = 0, or a super-block that has not settled: ONE wave walks the sixteen 64-row blocks serially -- the verdict
+//   words of the super-block's own columns live in its lanes (lane w = word w), a block's rows are resolved in scalar registers
+//   as in the pipelined kernel, the rows just kept are folded into those lanes by one LDS read each.  Alone this form is no
+//   faster than the pipelined kernel (181.8 against 185.2 us): what the scan costs is the resolve's ~190 cycles of dependent
+//   scalar instructions per KEPT row, not the barriers, the fetch or the fold.
+// Either way the greedy keep set, row by row: bit-exact.
 constexpr int SUPER_ROWS = 1024, SUPER_WORDS = 16, NMS_SWEEPS = 48;
 
 __global__ void __launch_bounds__(SCAN_THREADS)
 nms_scan_super_kernel(const unsigned long long* __restrict__ mask, int n, int nblk, int max_keep,
-                      int* __restrict__ keep_out, int* __restrict__ num_out, int fixed_point) {
+                      int* __restrict__ keep_out, int* __restrict__ num_out, int fixed_point /* sweeps at most; 0: serial resolve */) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long tri[];       // [1024][16]
     __shared__ unsigned long long removed[64 * SCAN_PIPE_WORDS + SUPER_WORDS + 1];
     __shared__ unsigned long long s_kept[SUPER_WORDS];
